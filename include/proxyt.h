@@ -1,0 +1,205 @@
+/*
+ * proxyt.h -- C ABI of libproxyt_hip.so, the MI355X (gfx950) implementation of
+ * ProxyTransformation's point-cloud preshaping hot path.
+ *
+ * The reference has no native code and no FFI of its own (setup.py:108
+ * ext_modules=[]); its native arithmetic is reached through pytorch3d / ATen.
+ * Each entry point below names the reference interface it replaces, with
+ * PRE = embodiedscan/models/necks/preshape_norm_reverse_drop.py.
+ *
+ * Conventions
+ *   - every pointer is a CALLER-OWNED DEVICE pointer (HIP memory of the current
+ *     device) unless marked [host]; the library never allocates or frees device
+ *     memory and keeps no global mutable state besides a thread-local error string;
+ *   - all tensors are dense, row-major, fp32 unless a type is given; index tensors
+ *     are int32 on this side of the ABI (the reference's int64 -1-padded layout is
+ *     kept: -1 = padding);
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); work is only
+ *     enqueued, no entry point synchronises the host;
+ *   - return 0 on success, a negative PTX_E* code otherwise; ptx_last_error()
+ *     returns a message for the calling thread.
+ */
+#ifndef PROXYT_H_
+#define PROXYT_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTX_ABI_VERSION 1
+
+#define PTX_OK          0
+#define PTX_EINVAL     -1   /* bad shape / null pointer / unsupported size */
+#define PTX_ELAUNCH    -2   /* HIP launch or runtime error */
+#define PTX_ENOSPACE   -3   /* workspace / prep buffer too small */
+
+/* Static shape of one forward (PRE:282-330 constructor values + input sizes). */
+typedef struct PtxShape {
+    int32_t B;          /* scenes in this call                                  */
+    int32_t N;          /* points per scene (all equal: torch.cat at PRE:427)   */
+    int32_t grid_size;  /* gs; M = gs^3 grid clusters (PRE:290)                 */
+    int32_t K;          /* num_sub slots per cluster (PRE:291)                  */
+    int32_t Mt;         /* M - int(0.3*M) clusters kept by padding count (PRE:374-376) */
+    int32_t Mk;         /* int(M*(1-dynamic_drop_radio)) kept clusters (PRE:389)       */
+    int32_t L;          /* text proxies                                          */
+    int32_t V;          /* image proxies (views)                                 */
+    int32_t C;          /* embed_dim (256)                                       */
+    int32_t heads;      /* num_heads (8)                                         */
+    int32_t hidden;     /* int(C*mlp_radio) (1024)                               */
+    int32_t in_dim;     /* image feature channels (512)                          */
+    int32_t hw;         /* img_spacial_dim^2 (225)                               */
+    float   radius;     /* 3.0 (PRE:23)                                          */
+    float   margin;     /* 4.0 (PRE:23)                                          */
+    float   bn_eps;     /* 1e-5                                                  */
+    float   ln_eps;     /* 1e-5                                                  */
+} PtxShape;
+
+/* Conv2d(6,256,1)+BatchNorm2d(256) of OffsetNetwork / SimplifiedPointNet (PRE:72-76, 112-116). */
+typedef struct PtxSlotMlp {
+    const float *conv_w;   /* (256,6)  */
+    const float *conv_b;   /* (256)    */
+    const float *bn_w, *bn_b, *bn_mean, *bn_var;   /* (256) each, running stats */
+} PtxSlotMlp;
+
+/* One ProxyBlock + the LayerNorm applied after it (PRE:259-276, 441-443, 450-452). */
+typedef struct PtxBlock {
+    const float *norm1_w, *norm1_b;                 /* (C)                      */
+    const float *pb_bias;                           /* (1,Mk,4,4)  PRE:199      */
+    const float *pc_bias;                           /* (1,Mk,s,1)  PRE:200      */
+    const float *pr_bias;                           /* (1,Mk,1,s)  PRE:201      */
+    const float *qkv_w;                             /* (3C,C)      PRE:187      */
+    const float *qkv_b;                             /* (3C) or NULL (qkv_bias=False) */
+    const float *pp_w, *pp_b;                       /* proxy_proj (C,C),(C)     */
+    const float *proj_w, *proj_b;                   /* (C,C),(C)                */
+    const float *norm2_w, *norm2_b;                 /* (C)                      */
+    const float *fc1_w, *fc1_b;                     /* (hidden,C),(hidden)      */
+    const float *fc2_w, *fc2_b;                     /* (C,hidden),(C)           */
+    const float *out_norm_w, *out_norm_b;           /* text_norm[i] / img_norm[i] */
+} PtxBlock;
+
+/* BatchNorm1d in eval mode (PRE:329-330). */
+typedef struct PtxBn1d { const float *w, *b, *mean, *var; } PtxBn1d;
+
+/* Raw reference-layout parameters: pointers straight into the nn.Module's storage. */
+typedef struct PtxWeights {
+    PtxSlotMlp   offset;            /* get_deformable_cluster.get_offsets.mlp     */
+    const float *offset_map_w;      /* ...get_offsets.channel_mapper.weight (3,256) */
+    PtxSlotMlp   encoder;           /* simple_encoder.mlp                         */
+    const float *cm_w, *cm_b;       /* channel_mapper Conv2d(in_dim,C,1)  PRE:304 */
+    const float *pos;               /* attn_pool2d.positional_embedding (hw+1,C)  */
+    const float *q_w, *q_b, *k_w, *k_b, *v_w, *v_b, *c_w, *c_b;   /* PRE:148-151 */
+    const float *norm_img_w, *norm_img_b;
+    PtxBlock     text;              /* textformer[-1] + text_norm[-1] */
+    PtxBlock     img;               /* imgformer[-1]  + img_norm[-1]              */
+    const float *text_trans_w, *text_trans_b;      /* Linear(C,3)  PRE:326       */
+    const float *img_trans_w, *img_trans_b;        /* Linear(C,9)  PRE:327       */
+    PtxBn1d      text_trans_norm, img_trans_norm;  /* PRE:329-330                */
+} PtxWeights;
+
+int         ptx_abi_version(void);
+const char *ptx_last_error(void);
+
+/* Bytes of the parameter-only tables derived once per set of weights (folded
+ * BatchNorm scale/shift, per-slot bias tables PRE:212-215, folded attention-pool
+ * matrices) and of the per-call scratch.  Both buffers are caller-owned. */
+size_t ptx_prep_bytes(const PtxShape *s);
+size_t ptx_workspace_bytes(const PtxShape *s);
+
+/* Build the derived tables in `prep`.  lin = torch.linspace(0,1,gs) (gs floats, device);
+ * it is uploaded by the caller because torch's two-sided linspace formula is part of
+ * the reference's arithmetic (PRE:41).  Re-run after any parameter changes. */
+int ptx_prepare(const PtxShape *s, const PtxWeights *w, const float *lin,
+                void *prep, size_t prep_bytes, void *stream);
+
+/* ------------------------------------------------------------------ stage entry points
+ * Each mirrors one reference function so it can be parity-tested on its own. */
+
+/* PRE:37-48 init_uniform_cluster_center: per-scene min/max + gs^3 grid centres.
+ * minmax (B,2,3): [b][0]=min, [b][1]=max.  centers (B,M,3). */
+int ptx_grid_centers(const float *points, int B, int N, const float *lin, int gs, float margin,
+                     float *minmax, float *centers, void *workspace, size_t ws_bytes, void *stream);
+
+/* pytorch3d.ops.ball_query(p1=centers, p2=points, K, radius) as called at PRE:56 / PRE:65:
+ * first K points in index order with dist2 < radius^2 (fp32, no FMA).
+ * idx (B,M,K) int32 pad -1; cluster (B,M,K,3) gathered xyz pad 0.0 (masked_gather,
+ * PRE:627-672); pad_count (B,M) int32 = #(idx==-1) (PRE:372), may be NULL. */
+int ptx_ball_query(const float *centers, const float *points, int B, int M, int N, int K,
+                   float radius, int32_t *idx, float *cluster, int32_t *pad_count, void *stream);
+
+/* OffsetNetwork.forward + tanh*margin + add + clamp, PRE:58-62, 87-107.
+ * centers_in (B,M,3), cluster (B,M,K,3), minmax (B,2,3) -> centers_out (B,M,3);
+ * offsets_out (B,M,3) = tanh(raw)*margin, may be NULL. */
+int ptx_offset_net(const PtxShape *s, const PtxWeights *w, const void *prep,
+                   const float *centers_in, const float *cluster, const float *minmax,
+                   float *centers_out, float *offsets_out, void *stream);
+
+/* dynamic_cluster_dropout, PRE:352-420, argsort tie-break pinned to stable ascending.
+ * order_override (B,Mt) int32 or NULL: test-only replay of a captured argsort.
+ * Outputs: order (B,Mt), picks (B,Kd) FPS positions, keep (B,Mk) positions,
+ * kcenter (B,Mk,3), kcluster (B,Mk,K,3), kidx (B,Mk,K), drop_idx (B,Kd*K);
+ * tag (B,N) uint32 must be zero on entry: low 31 bits <- 1 + last (m,k) slot that owns the
+ * point (pt_replace's last-writer rule, PRE:478-495), bit 31 <- point is dropped
+ * (remove_points_by_index, PRE:516-523). */
+int ptx_select_clusters(const PtxShape *s, const int32_t *idx, const float *centers,
+                        const float *cluster, const int32_t *pad_count,
+                        const int32_t *order_override,
+                        int32_t *order, int32_t *picks, int32_t *keep,
+                        float *kcenter, float *kcluster, int32_t *kidx, int32_t *drop_idx,
+                        uint32_t *tag, void *stream);
+
+/* SimplifiedPointNet.forward, PRE:126-142 -> point_proxy (B,Mk,C). */
+int ptx_pointnet(const PtxShape *s, const PtxWeights *w, const void *prep, const float *kcenter,
+                 const float *kcluster, float *point_proxy, void *stream);
+
+/* get_img_proxy, PRE:335-342 (1x1 conv + AttentionPool2d token 0 + LayerNorm)
+ * img_feat (B,V,in_dim,hw) -> img_proxy (B,V,C). */
+int ptx_img_proxy(const PtxShape *s, const PtxWeights *w, const void *prep, const float *img_feat,
+                  float *img_proxy, void *workspace, size_t ws_bytes, void *stream);
+
+/* ProxyBlock (eval) + trailing LayerNorm + Linear head + BatchNorm1d(eval):
+ * which = 0: textformer[-1] -> translate (B,Mk,3)   PRE:441-446
+ * which = 1: imgformer[-1]  -> transform (B,Mk,9)   PRE:450-455
+ * proxy (B,Lp,C); mask (B,Lp) uint8 (1 = valid token) or NULL; guide (B,Mk,C) optional
+ * copy of the normed block output (may be NULL). */
+int ptx_proxy_block(const PtxShape *s, const PtxWeights *w, const void *prep, int which,
+                    const float *point_proxy, const float *proxy, int Lp, const uint8_t *mask,
+                    float *head_out, float *guide, void *workspace, size_t ws_bytes, void *stream);
+
+/* Per-cluster affine (PRE:459-462) + pt_replace (PRE:472-498) WITHOUT the drop:
+ * new_points (B,N,3) = points with every owned point replaced by
+ * T_j (p - c_j) + c_j + t_j, j = owning kept cluster (tag from ptx_select_clusters). */
+int ptx_affine_scatter(const PtxShape *s, const float *points, const uint32_t *tag,
+                       const float *kcenter, const float *translate, const float *transform,
+                       float *new_points, void *stream);
+
+/* affine + pt_replace + remove_points_by_index (PRE:459-467, 501-525), order preserving.
+ * out (B,N,3) capacity; counts (B) int32 = surviving points per scene (device). */
+int ptx_affine_compact(const PtxShape *s, const float *points, const uint32_t *tag,
+                       const float *kcenter, const float *translate, const float *transform,
+                       float *out, int32_t *counts, void *workspace, size_t ws_bytes, void *stream);
+
+/* Whole forward, PRE:424-469, enqueued on `stream` (an internal second stream forks the
+ * image branch).  text_mask (B,L) uint8, 1 = valid.  out (B,N,3) capacity, counts (B) int32.
+ * debug (optional, may be NULL): struct of device pointers that receive intermediates. */
+typedef struct PtxDebug {
+    float *centers0, *cluster1, *offsets, *centers, *cluster2;
+    int32_t *idx2, *pad_count, *order, *picks, *keep, *kidx, *drop_idx;
+    float *kcenter, *kcluster, *point_proxy, *img_proxy, *text_guide, *img_guide;
+    float *translate, *transform;
+    uint32_t *tag;
+} PtxDebug;
+
+int ptx_forward(const PtxShape *s, const PtxWeights *w, const void *prep, const float *lin,
+                const float *points, const float *text_feats, const uint8_t *text_mask,
+                const float *img_feat, const int32_t *order_override,
+                const float *centers_override,
+                float *out, int32_t *counts, void *workspace, size_t ws_bytes,
+                const PtxDebug *debug, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PROXYT_H_ */

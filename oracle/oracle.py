@@ -1,0 +1,331 @@
+"""CPU oracle for the preshape hot path -- TEST INFRASTRUCTURE ONLY.
+
+This file is the checker, never the product: only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+it.  ``proxytransformation_amd`` must not (tests/test_layout.py enforces that).
+
+It restates ``ProxyTransformationNormReverse.forward``
+(PRE = embodiedscan/models/necks/preshape_norm_reverse_drop.py:424-469 of the
+reference) as a flat function over a ``state_dict``:
+
+* index-producing steps (grid centres, ball query, cluster selection + FPS,
+  scatter ownership, point removal) run in plain C: ``oracle/ptx_oracle.c``;
+* the floating-point networks (offset net, PointNet, attention pooling, proxy
+  blocks, heads) are a torch-CPU fp32 reference written with ``torch.nn.functional``.
+
+Pinning: ``tests/test_oracle_golden.py`` checks every intermediate this module
+returns against ``tests/golden/*.npz``, which were captured from the reference
+file itself (see tests/golden/gen_golden.py).  pytorch3d's ball-query
+arithmetic is third-party and un-vendored: **parity unpinned** for that op
+(details in the header of ptx_oracle.c and in DESIGN.md).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+RADIUS = 3.0        # PRE:23 (not configurable from the registry config)
+MARGIN = 4.0        # PRE:23
+EMPTY_DROP = 0.3    # PRE:352
+BN_EPS = 1e-5
+LN_EPS = 1e-5
+
+
+def build_lib(force: bool = False) -> str:
+    """Compile oracle/ptx_oracle.c with the committed Makefile; returns the .so path."""
+    so = os.path.join(_HERE, "libptx_oracle.so")
+    src = os.path.join(_HERE, "ptx_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", _HERE, "-B", "libptx_oracle.so"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib() -> ctypes.CDLL:
+    global _LIB
+    if _LIB is None:
+        _LIB = ctypes.CDLL(build_lib())
+    return _LIB
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _f32(x) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(x, dtype=np.float32))
+
+
+def _i64(x) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(x, dtype=np.int64))
+
+
+# --------------------------------------------------------------------------
+# C-backed index steps
+# --------------------------------------------------------------------------
+def grid_centers(points: np.ndarray, gs: int, margin: float = MARGIN):
+    """PRE:33-51.  linspace comes from torch."""
+    points = _f32(points)
+    B, N, _ = points.shape
+    lin = torch.linspace(0, 1, gs).numpy().astype(np.float32)
+    M = gs ** 3
+    centers = np.empty((B, M, 3), np.float32)
+    mn = np.empty((B, 3), np.float32)
+    mx = np.empty((B, 3), np.float32)
+    lib().oracle_grid_centers(_p(points), B, N, _p(lin), gs, ctypes.c_float(margin),
+                              _p(centers), _p(mn), _p(mx))
+    return centers, mn, mx
+
+
+def ball_query(centers: np.ndarray, points: np.ndarray, K: int, radius: float = RADIUS,
+               want_scanned: bool = False):
+    """pytorch3d.ops.ball_query(p1=centers, p2=points, K, radius) -> idx, gathered xyz."""
+    centers, points = _f32(centers), _f32(points)
+    B, M, _ = centers.shape
+    N = points.shape[1]
+    idx = np.empty((B, M, K), np.int64)
+    cluster = np.empty((B, M, K, 3), np.float32)
+    scanned = np.empty((B, M), np.int32) if want_scanned else None
+    lib().oracle_ball_query(_p(centers), _p(points), B, M, N, K, ctypes.c_float(radius),
+                            _p(idx), _p(cluster), _p(scanned) if want_scanned else None)
+    return (idx, cluster, scanned) if want_scanned else (idx, cluster)
+
+
+def fps(pts: np.ndarray, Kd: int) -> np.ndarray:
+    pts = _f32(pts)
+    B, P, _ = pts.shape
+    picks = np.empty((B, Kd), np.int64)
+    lib().oracle_fps(_p(pts), B, P, Kd, _p(picks))
+    return picks
+
+
+def select_clusters(idx: np.ndarray, centers: np.ndarray, Mt: int, Mk: int,
+                    order_override: Optional[np.ndarray] = None):
+    """PRE:352-420 -> dict(pad_counts, order, picks, keep) (positions, see ptx_oracle.c)."""
+    idx, centers = _i64(idx), _f32(centers)
+    B, M, K = idx.shape
+    Kd = Mt - Mk
+    pad = np.empty((B, M), np.int64)
+    order = np.empty((B, Mt), np.int64)
+    picks = np.empty((B, Kd), np.int64)
+    keep = np.empty((B, Mk), np.int64)
+    ov = _i64(order_override) if order_override is not None else None
+    lib().oracle_select_clusters(_p(idx), _p(centers), B, M, K, Mt, Mk,
+                                 _p(ov) if ov is not None else None,
+                                 _p(pad), _p(order), _p(picks), _p(keep))
+    return dict(pad_counts=pad, order=order, picks=picks, keep=keep)
+
+
+def pt_replace(points: np.ndarray, idx: np.ndarray, newc: np.ndarray) -> np.ndarray:
+    out = _f32(points).copy()
+    idx, newc = _i64(idx), _f32(newc)
+    B, N, _ = out.shape
+    _, Mk, K = idx.shape
+    lib().oracle_pt_replace(_p(out), _p(idx), _p(newc), B, N, Mk, K)
+    return out
+
+
+def remove_points(points: np.ndarray, drop_idx: np.ndarray):
+    points, drop_idx = _f32(points), _i64(drop_idx)
+    B, N, _ = points.shape
+    Nd = drop_idx.shape[1]
+    out = np.empty_like(points)
+    counts = np.empty((B,), np.int64)
+    lib().oracle_remove_points(_p(points), _p(drop_idx), B, N, Nd, _p(out), _p(counts))
+    return [out[b, :counts[b]].copy() for b in range(B)]
+
+
+# --------------------------------------------------------------------------
+# torch-CPU fp32 reference for the floating-point networks
+# --------------------------------------------------------------------------
+def _t(x) -> torch.Tensor:
+    return x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x))
+
+
+def _slot_mlp(sd, prefix: str, center: torch.Tensor, cluster: torch.Tensor) -> torch.Tensor:
+    """Shared front of OffsetNetwork / SimplifiedPointNet (PRE:93-100, 131-138):
+    per-slot 6 -> 256 point-wise conv + BatchNorm(eval) + ReLU -> (B,M,K,256)."""
+    rel = cluster - center[:, :, None, :]
+    pad = (cluster == 0).all(dim=-1)                  # padded slot <=> xyz all zero (PRE:94)
+    rel = torch.where(pad[..., None], torch.zeros_like(rel), rel)
+    x = torch.cat([rel, cluster], dim=-1)             # (B,M,K,6)
+    w = sd[prefix + ".mlp.0.weight"].reshape(-1, 6)
+    h = F.linear(x, w, sd[prefix + ".mlp.0.bias"])
+    h = F.batch_norm(h.permute(0, 3, 1, 2), sd[prefix + ".mlp.1.running_mean"],
+                     sd[prefix + ".mlp.1.running_var"], sd[prefix + ".mlp.1.weight"],
+                     sd[prefix + ".mlp.1.bias"], training=False, eps=BN_EPS)
+    return F.relu(h).permute(0, 2, 3, 1)
+
+
+def offset_net(sd, center, cluster) -> torch.Tensor:
+    """OffsetNetwork.forward, PRE:87-107 -> raw offsets (B,M,3) (before tanh)."""
+    pre = "get_deformable_cluster.get_offsets"
+    h = _slot_mlp(sd, pre, center, cluster).mean(dim=2)            # mean over K (PRE:102)
+    return F.linear(h, sd[pre + ".channel_mapper.weight"].reshape(3, -1))
+
+
+def point_encoder(sd, center, cluster) -> torch.Tensor:
+    """SimplifiedPointNet.forward, PRE:126-142 -> (B,M',256); max over all K slots."""
+    return _slot_mlp(sd, "simple_encoder", center, cluster).max(dim=2)[0]
+
+
+def img_proxy(sd, img_feat: torch.Tensor, heads: int) -> torch.Tensor:
+    """get_img_proxy + AttentionPool2d, PRE:335-342, 154-177 -> (B,V,C).
+
+    Written in the 'all queries' form of the reference (token 0 returned)."""
+    B, V, Cin, H, W = img_feat.shape
+    x = img_feat.reshape(B * V, Cin, H * W).permute(0, 2, 1)       # (BV, HW, Cin)
+    C = sd["channel_mapper.weight"].shape[0]
+    x = F.linear(x, sd["channel_mapper.weight"].reshape(C, Cin), sd["channel_mapper.bias"])
+    x = torch.cat([x.mean(dim=1, keepdim=True), x], dim=1)         # prepend mean token
+    x = x + sd["attn_pool2d.positional_embedding"][None]
+    q = F.linear(x, sd["attn_pool2d.q_proj.weight"], sd["attn_pool2d.q_proj.bias"])
+    k = F.linear(x, sd["attn_pool2d.k_proj.weight"], sd["attn_pool2d.k_proj.bias"])
+    v = F.linear(x, sd["attn_pool2d.v_proj.weight"], sd["attn_pool2d.v_proj.bias"])
+    T = x.shape[1]
+    hd = C // heads
+    q = q.reshape(-1, T, heads, hd).transpose(1, 2) * hd ** -0.5
+    k = k.reshape(-1, T, heads, hd).transpose(1, 2)
+    v = v.reshape(-1, T, heads, hd).transpose(1, 2)
+    a = torch.softmax(q @ k.transpose(-1, -2), dim=-1) @ v          # (BV,h,T,hd)
+    a = a.transpose(1, 2).reshape(-1, T, C)
+    out = F.linear(a, sd["attn_pool2d.c_proj.weight"], sd["attn_pool2d.c_proj.bias"])[:, 0]
+    out = F.layer_norm(out, (C,), sd["norm_img.weight"], sd["norm_img.bias"], LN_EPS)
+    return out.reshape(B, V, C)
+
+
+def slot_bias(sd, pre: str, C: int) -> torch.Tensor:
+    """Per-kept-slot learned bias of ProxyAttention, PRE:212-215 -> (M',C)."""
+    s = int(C ** 0.5)
+    b1 = F.interpolate(sd[pre + ".pb_bias"], size=(s, s), mode="bilinear")
+    n = b1.shape[1]
+    return b1.reshape(n, -1) + (sd[pre + ".pc_bias"] + sd[pre + ".pr_bias"]).reshape(n, -1)
+
+
+def proxy_block(sd, pre: str, x: torch.Tensor, proxy: torch.Tensor,
+                mask: Optional[torch.Tensor], heads: int) -> Dict[str, torch.Tensor]:
+    """One ProxyBlock in eval mode (dropout / drop-path are identity), PRE:206-257, 273-276."""
+    B, n, C = x.shape
+    L = proxy.shape[1]
+    hd = C // heads
+    scale = hd ** -0.5
+    xn = F.layer_norm(x, (C,), sd[pre + ".norm1.weight"], sd[pre + ".norm1.bias"], LN_EPS)
+    xb = xn + slot_bias(sd, pre + ".attn", C)[None]
+    qkv = F.linear(xb, sd[pre + ".attn.qkv.weight"], sd.get(pre + ".attn.qkv.bias"))
+    q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    pt = F.linear(proxy, sd[pre + ".attn.proxy_proj.weight"], sd[pre + ".attn.proxy_proj.bias"])
+
+    def split(t, rows):
+        return t.reshape(B, rows, heads, hd).permute(0, 2, 1, 3)
+    q, k, v, pt = split(q, n), split(k, n), split(v, n), split(pt, L)
+    pa = torch.softmax((pt * scale) @ k.transpose(-2, -1), dim=-1)      # proxy as query, no mask
+    pv = pa @ v                                                          # (B,h,L,hd)
+    qa = (q * scale) @ pt.transpose(-2, -1)                              # (B,h,n,L)
+    if mask is not None:
+        qa = qa.masked_fill(~mask[:, None, None, :], -1e9)               # PRE:243-247
+    o = (torch.softmax(qa, dim=-1) @ pv).transpose(1, 2).reshape(B, n, C)
+    attn_out = F.linear(o, sd[pre + ".attn.proj.weight"], sd[pre + ".attn.proj.bias"])
+    x1 = x + attn_out
+    xn2 = F.layer_norm(x1, (C,), sd[pre + ".norm2.weight"], sd[pre + ".norm2.bias"], LN_EPS)
+    h = F.gelu(F.linear(xn2, sd[pre + ".mlp.fc1.weight"], sd[pre + ".mlp.fc1.bias"]))
+    x2 = x1 + F.linear(h, sd[pre + ".mlp.fc2.weight"], sd[pre + ".mlp.fc2.bias"])
+    return dict(qkv=qkv, pt=pt, pv=pv, attn=o, x1=x1, out=x2)
+
+
+def _bn1d_eval(sd, pre: str, x: torch.Tensor) -> torch.Tensor:
+    """BatchNorm1d over the channel (last) dim of (B,m,c) in eval mode, PRE:446, 455."""
+    return F.batch_norm(x.transpose(-2, -1), sd[pre + ".running_mean"], sd[pre + ".running_var"],
+                        sd[pre + ".weight"], sd[pre + ".bias"], training=False,
+                        eps=BN_EPS).transpose(-2, -1)
+
+
+# --------------------------------------------------------------------------
+# full forward
+# --------------------------------------------------------------------------
+def forward(sd_np: Dict[str, np.ndarray], *, grid_size: int, dynamic_drop_radio: float,
+            num_sub: int, num_heads: int, text_blocks: int, img_blocks: int,
+            points: np.ndarray, text_feats: np.ndarray, text_mask: np.ndarray,
+            img_feat: np.ndarray, order_override: Optional[np.ndarray] = None,
+            centers_override: Optional[np.ndarray] = None, stop_after: Optional[str] = None,
+            num_threads: Optional[int] = None) -> Dict[str, object]:
+    """Eval-mode forward of the reference module; returns every intermediate.
+
+    ``order_override`` replays a captured ``sorted_indices[:, :Mt]``;
+    ``centers_override`` injects the clamped centres of ball query #2.
+    """
+    if num_threads is not None:
+        torch.set_num_threads(num_threads)
+    sd = {k: _t(v) for k, v in sd_np.items()}
+    gs, K = grid_size, num_sub
+    M = gs ** 3
+    Mt = M - int(M * EMPTY_DROP)
+    Mk = int(M * (1 - dynamic_drop_radio))
+    out: Dict[str, object] = {}
+    pts = _f32(points)
+    B, N, _ = pts.shape
+
+    with torch.no_grad():
+        centers0, mn, mx = grid_centers(pts, gs)
+        _, cluster1 = ball_query(centers0, pts, K)                         # PRE:56
+        raw = offset_net(sd, _t(centers0), _t(cluster1))                   # PRE:58
+        offsets = raw.tanh() * MARGIN                                      # PRE:59
+        newc = _t(centers0) + offsets                                      # PRE:61
+        clamped = torch.max(torch.min(newc, _t(mx)[:, None]), _t(mn)[:, None])   # PRE:62
+        if centers_override is not None:
+            clamped = _t(_f32(centers_override))
+        idx2, cluster2 = ball_query(clamped.numpy(), pts, K)               # PRE:65
+        out.update(centers0=centers0, mn=mn, mx=mx, cluster1=cluster1, offsets=offsets.numpy(),
+                   centers=clamped.numpy(), idx2=idx2, cluster2=cluster2)
+        if stop_after == "cluster":
+            return out
+
+        sel = select_clusters(idx2, clamped.numpy(), Mt, Mk, order_override)
+        order, picks, keep = sel["order"], sel["picks"], sel["keep"]
+        bidx = np.arange(B)[:, None]
+        keep_src = order[bidx, keep]                                       # original cluster ids
+        pick_src = order[bidx, picks]
+        kcenter = clamped.numpy()[bidx, keep_src]
+        kcluster = cluster2[bidx, keep_src]
+        kidx = idx2[bidx, keep_src]
+        drop_idx = idx2[bidx, pick_src].reshape(B, -1)                     # PRE:417-418
+        out.update(pad_counts=sel["pad_counts"], order=order, picks=picks, keep=keep,
+                   keep_src=keep_src, pick_src=pick_src, kcenter=kcenter, kcluster=kcluster,
+                   kidx=kidx, drop_idx=drop_idx)
+        if stop_after == "select":
+            return out
+
+        pp = point_encoder(sd, _t(kcenter), _t(kcluster))                  # PRE:437
+        tb = proxy_block(sd, f"textformer.{text_blocks - 1}", pp, _t(_f32(text_feats)),
+                         _t(np.asarray(text_mask, bool)), num_heads)       # PRE:441-442 (H8)
+        C = pp.shape[-1]
+        tg = F.layer_norm(tb["out"], (C,), sd[f"text_norm.{text_blocks - 1}.weight"],
+                          sd[f"text_norm.{text_blocks - 1}.bias"], LN_EPS)
+        translate = _bn1d_eval(sd, "text_trans_norm",
+                               F.linear(tg, sd["text_trans.weight"], sd["text_trans.bias"]))
+        ip = img_proxy(sd, _t(_f32(img_feat)), num_heads)                  # PRE:449
+        ib = proxy_block(sd, f"imgformer.{img_blocks - 1}", pp, ip, None, num_heads)
+        ig = F.layer_norm(ib["out"], (C,), sd[f"img_norm.{img_blocks - 1}.weight"],
+                          sd[f"img_norm.{img_blocks - 1}.bias"], LN_EPS)
+        transform = _bn1d_eval(sd, "img_trans_norm",
+                               F.linear(ig, sd["img_trans.weight"], sd["img_trans.bias"]))
+        T = transform.reshape(B, Mk, 3, 3)
+        c = _t(kcenter)[:, :, None, :]
+        newcl = (T @ (_t(kcluster) - c).transpose(-2, -1)).transpose(-2, -1) + c \
+            + translate[:, :, None, :]                                     # PRE:459-462
+        out.update(point_proxy=pp.numpy(), img_proxy=ip.numpy(), text_guide=tg.numpy(),
+                   img_guide=ig.numpy(), translate=translate.numpy(),
+                   transform=transform.numpy(), new_clusters=newcl.numpy(),
+                   text_block=tb, img_block=ib)
+        new_points = pt_replace(pts, kidx, newcl.numpy())                  # PRE:465
+        out["new_points"] = new_points
+        out["outputs"] = remove_points(new_points, drop_idx)               # PRE:467
+    return out

@@ -1,0 +1,112 @@
+"""ctypes binding of ``libproxyt_hip.so`` (C ABI declared in ``include/proxyt.h``).
+
+The library is the product: there is no CPU or PyTorch fallback.  Importing this
+module never touches the GPU; :func:`lib` raises ``RuntimeError`` with build
+instructions if the shared object is missing, and every ``ptx_*`` call that
+returns a negative code raises ``RuntimeError`` carrying ``ptx_last_error()``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libproxyt_hip.so")
+ABI_VERSION = 1
+
+c_float_p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
+
+
+class PtxShape(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("B", "N", "grid_size", "K", "Mt", "Mk", "L", "V", "C", "heads", "hidden",
+                 "in_dim", "hw")] + \
+               [(n, C.c_float) for n in ("radius", "margin", "bn_eps", "ln_eps")]
+
+
+class PtxSlotMlp(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("conv_w", "conv_b", "bn_w", "bn_b", "bn_mean", "bn_var")]
+
+
+class PtxBlock(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("norm1_w", "norm1_b", "pb_bias", "pc_bias", "pr_bias", "qkv_w", "qkv_b",
+                 "pp_w", "pp_b", "proj_w", "proj_b", "norm2_w", "norm2_b",
+                 "fc1_w", "fc1_b", "fc2_w", "fc2_b", "out_norm_w", "out_norm_b")]
+
+
+class PtxBn1d(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("w", "b", "mean", "var")]
+
+
+class PtxWeights(C.Structure):
+    _fields_ = [("offset", PtxSlotMlp), ("offset_map_w", C.c_void_p), ("encoder", PtxSlotMlp),
+                ("cm_w", C.c_void_p), ("cm_b", C.c_void_p), ("pos", C.c_void_p)] + \
+               [(n, C.c_void_p) for n in ("q_w", "q_b", "k_w", "k_b", "v_w", "v_b", "c_w", "c_b",
+                                          "norm_img_w", "norm_img_b")] + \
+               [("text", PtxBlock), ("img", PtxBlock)] + \
+               [(n, C.c_void_p) for n in ("text_trans_w", "text_trans_b", "img_trans_w", "img_trans_b")] + \
+               [("text_trans_norm", PtxBn1d), ("img_trans_norm", PtxBn1d)]
+
+
+DEBUG_FIELDS = ("centers0", "cluster1", "offsets", "centers", "cluster2",
+                "idx2", "pad_count", "order", "picks", "keep", "kidx", "drop_idx",
+                "kcenter", "kcluster", "point_proxy", "img_proxy", "text_guide", "img_guide",
+                "translate", "transform", "tag")
+
+
+class PtxDebug(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in DEBUG_FIELDS]
+
+
+# name -> (restype, argtypes); must list every symbol declared in include/proxyt.h
+_P, _I, _F, _Z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+_SH, _W = C.POINTER(PtxShape), C.POINTER(PtxWeights)
+SIGNATURES = {
+    "ptx_abi_version": (C.c_int, []),
+    "ptx_last_error": (C.c_char_p, []),
+    "ptx_prep_bytes": (_Z, [_SH]),
+    "ptx_workspace_bytes": (_Z, [_SH]),
+    "ptx_prepare": (_I, [_SH, _W, _P, _P, _Z, _P]),
+    "ptx_grid_centers": (_I, [_P, _I, _I, _P, _I, _F, _P, _P, _P, _Z, _P]),
+    "ptx_ball_query": (_I, [_P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P]),
+    "ptx_offset_net": (_I, [_SH, _W, _P, _P, _P, _P, _P, _P, _P]),
+    "ptx_select_clusters": (_I, [_SH] + [_P] * 14),
+    "ptx_pointnet": (_I, [_SH, _W, _P, _P, _P, _P, _P]),
+    "ptx_img_proxy": (_I, [_SH, _W, _P, _P, _P, _P, _Z, _P]),
+    "ptx_proxy_block": (_I, [_SH, _W, _P, _I, _P, _P, _I, _P, _P, _P, _P, _Z, _P]),
+    "ptx_affine_scatter": (_I, [_SH, _P, _P, _P, _P, _P, _P, _P]),
+    "ptx_affine_compact": (_I, [_SH, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "ptx_forward": (_I, [_SH, _W, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z,
+                         C.POINTER(PtxDebug), _P]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load (once) and type the shared library; fail loudly if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension is the only implementation of this "
+            "path (no CPU fallback). Build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C proxytransformation_amd/csrc`.")
+    handle = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(handle, name)          # AttributeError if the symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    got = handle.ptx_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError(f"libproxyt_hip.so ABI {got} != binding ABI {ABI_VERSION}")
+    _lib = handle
+    return handle
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().ptx_last_error()
+        raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")

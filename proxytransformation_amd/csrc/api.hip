@@ -1,0 +1,530 @@
+// extern "C" surface of libproxyt_hip.so (include/proxyt.h) and the forward driver.
+#include <cmath>
+#include <cstring>
+#include <mutex>
+
+#include "common.h"
+
+namespace ptx {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static inline float attn_scale(int hd) { return (float)(1.0 / std::sqrt((double)hd)); }   // head_dim ** -0.5
+
+int validate_shape(const PtxShape &s)
+{
+    const long M = (long)s.grid_size * s.grid_size * s.grid_size;
+    PTX_REQUIRE(s.B >= 1 && s.N >= 1, "shape: B=%d N=%d", s.B, s.N);
+    PTX_REQUIRE(s.grid_size >= 1 && M <= (1 << 20), "shape: grid_size=%d", s.grid_size);
+    PTX_REQUIRE(s.K >= 1 && s.K <= 63, "shape: num_sub K=%d must be in [1,63]", s.K);
+    PTX_REQUIRE(s.Mk >= 1 && s.Mk <= s.Mt && s.Mt <= M, "shape: need 1 <= Mk=%d <= Mt=%d <= M=%ld", s.Mk, s.Mt, M);
+    PTX_REQUIRE(s.C == kSlotHidden, "shape: embed_dim=%d; this build supports 256 (SimplifiedPointNet width, PRE:302)", s.C);
+    PTX_REQUIRE(s.heads >= 1 && s.heads <= 8 && s.C % s.heads == 0 && s.C / s.heads == 32,
+                "shape: heads=%d; head_dim must be 32", s.heads);
+    int sd = 1;
+    while (sd * sd < s.C) ++sd;
+    PTX_REQUIRE(sd * sd == s.C, "shape: embed_dim=%d is not a perfect square (PRE:196)", s.C);
+    PTX_REQUIRE(s.hidden >= 4 && s.hidden % 4 == 0, "shape: hidden=%d", s.hidden);
+    PTX_REQUIRE(s.in_dim >= 64 && s.in_dim % 64 == 0, "shape: in_dim=%d must be a multiple of 64", s.in_dim);
+    PTX_REQUIRE(s.hw >= 1 && s.L >= 1 && s.V >= 1, "shape: hw=%d L=%d V=%d", s.hw, s.L, s.V);
+    PTX_REQUIRE((long)s.Mk * s.K < (1l << 31) - 1, "shape: Mk*K overflows the ownership tag");
+    return PTX_OK;
+}
+
+PrepLayout prep_layout(const PtxShape &s)
+{
+    PrepLayout P{};
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t r = o; o += align_up(n, 64); return r; };   // 256-B granules
+    P.hd = s.C / s.heads;
+    P.KT1 = s.in_dim + s.hw + 1;
+    P.KT2p = (int)align_up((size_t)s.in_dim + s.hw + 1, 4);
+    P.off_ab = take(2 * kSlotHidden); P.enc_ab = take(2 * kSlotHidden);
+    P.ttn_ab = take(6); P.itn_ab = take(18);
+    P.posb_t = take((size_t)s.Mk * s.C); P.posb_i = take((size_t)s.Mk * s.C);
+    P.x0b = take(s.C);
+    P.wqkv0 = take((size_t)3 * s.C * s.C); P.bqkv0 = take((size_t)3 * s.C);
+    P.t1 = take((size_t)s.heads * P.KT1 * P.hd);
+    P.t2 = take((size_t)s.heads * P.hd * P.KT2p);
+    P.total = o;
+    return P;
+}
+
+WsLayout ws_layout(const PtxShape &s)
+{
+    WsLayout L{};
+    const PrepLayout P = prep_layout(s);
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o += align_up(bytes, 256); return r; };
+    const size_t B = s.B, N = s.N, K = s.K, C = s.C;
+    const size_t M = (size_t)s.grid_size * s.grid_size * s.grid_size;
+    const size_t Mk = s.Mk, Mt = s.Mt, Kd = s.Mt - s.Mk;
+    const size_t nimg = B * s.V, Lp = s.L > s.V ? s.L : s.V, R = B * Mk;
+    L.zero_begin = o;
+    L.mm_enc = take(B * 6 * 4);
+    L.tag = take(B * N * 4);
+    L.zero_bytes = o - L.zero_begin;
+    L.minmax = take(B * 6 * 4);
+    L.centers0 = take(B * M * 3 * 4); L.cluster1 = take(B * M * K * 3 * 4);
+    L.offsets = take(B * M * 3 * 4);  L.centers = take(B * M * 3 * 4);
+    L.idx2 = take(B * M * K * 4);     L.cluster2 = take(B * M * K * 3 * 4);
+    L.pad_count = take(B * M * 4);
+    L.order = take(B * Mt * 4); L.picks = take(B * (Kd ? Kd : 1) * 4); L.keep = take(B * Mk * 4);
+    L.kcenter = take(B * Mk * 3 * 4); L.kcluster = take(B * Mk * K * 3 * 4); L.kidx = take(B * Mk * K * 4);
+    L.drop_idx = take(B * (Kd ? Kd : 1) * K * 4);
+    L.tile_counts = take(B * (size_t)cdiv(s.N, kTilePts) * 4);
+    L.point_proxy = take(R * C * 4);
+    for (int i = 0; i < 2; ++i) L.x_in[i] = take(R * C * 4);
+    L.fm = take(nimg * s.in_dim * 4); L.x0 = take(nimg * C * 4); L.qkv0 = take(nimg * 3 * C * 4);
+    L.we = take(nimg * s.heads * (size_t)P.KT1 * 4); L.gbuf = take(nimg * s.heads * (size_t)P.KT2p * 4);
+    L.obuf = take(nimg * C * 4); L.cbuf = take(nimg * C * 4); L.img_proxy = take(nimg * C * 4);
+    for (int i = 0; i < 2; ++i) {
+        L.qkv[i] = take(R * 3 * C * 4); L.pt[i] = take(B * Lp * C * 4); L.pv[i] = take(B * Lp * C * 4);
+        L.ao[i] = take(R * C * 4); L.x1[i] = take(R * C * 4); L.xn2[i] = take(R * C * 4);
+        L.hbuf[i] = take(R * (size_t)s.hidden * 4); L.x2[i] = take(R * C * 4); L.guide[i] = take(R * C * 4);
+        L.head[i] = take(R * 9 * 4);
+    }
+    L.total = o;
+    return L;
+}
+
+// ---- second stream for the image branch (the only process-wide state; lazily created) -------
+struct SideStream { hipStream_t st = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+static std::mutex g_side_mu;
+static SideStream g_side[16];
+
+static int side_stream(SideStream **out)
+{
+    int dev = 0;
+    PTX_HIP(hipGetDevice(&dev));
+    PTX_REQUIRE(dev >= 0 && dev < 16, "device %d out of range", dev);
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    SideStream &s = g_side[dev];
+    if (s.st == nullptr) {
+        PTX_HIP(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
+        PTX_HIP(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming));
+        PTX_HIP(hipEventCreateWithFlags(&s.join, hipEventDisableTiming));
+    }
+    *out = &s;
+    return PTX_OK;
+}
+
+template <typename T>
+static inline T *at(void *base, size_t off) { return reinterpret_cast<T *>(static_cast<char *>(base) + off); }
+
+// ---- image chain ---------------------------------------------------------------------------------
+static int run_img_proxy(const PtxShape &s, const PtxWeights &w, const float *prep, const float *img,
+                         float *img_proxy, void *ws, hipStream_t st)
+{
+    const PrepLayout P = prep_layout(s);
+    const WsLayout L = ws_layout(s);
+    const int nimg = s.B * s.V, C = s.C, hd = P.hd;
+    float *fm = at<float>(ws, L.fm), *x0 = at<float>(ws, L.x0), *qkv0 = at<float>(ws, L.qkv0);
+    float *we = at<float>(ws, L.we), *gbuf = at<float>(ws, L.gbuf), *obuf = at<float>(ws, L.obuf);
+    float *cbuf = at<float>(ws, L.cbuf);
+    PTX_TRY(launch_img_mean(img, nimg, s.in_dim, s.hw, fm, st));
+    {   // x0 = Wc mean(f) + (bc + pos_0)
+        GemmBatch g{}; g.n = 1;
+        g.p[0] = GemmProb{fm, w.cm_w, x0, prep + P.x0b, nullptr, nullptr, nullptr,
+                          nimg, C, s.in_dim, s.in_dim, s.in_dim, C, 0, 0, 0, EPI_NONE};
+        PTX_TRY(launch_gemm(g, st));
+    }
+    {   // [q | k0 | v0] of token 0
+        GemmBatch g{}; g.n = 1;
+        g.p[0] = GemmProb{x0, prep + P.wqkv0, qkv0, prep + P.bqkv0, nullptr, nullptr, nullptr,
+                          nimg, 3 * C, C, C, C, 3 * C, 0, 0, 0, EPI_NONE};
+        PTX_TRY(launch_gemm(g, st));
+    }
+    {   // per head: [w_h | e_h] = q_h T1_h^T
+        GemmBatch g{}; g.n = s.heads;
+        for (int h = 0; h < s.heads; ++h)
+            g.p[h] = GemmProb{qkv0 + h * hd, prep + P.t1 + (size_t)h * P.KT1 * hd, we + (size_t)h * P.KT1,
+                              nullptr, nullptr, nullptr, nullptr, nimg, P.KT1, hd, 3 * C, hd,
+                              s.heads * P.KT1, 0, 0, 0, EPI_NONE};
+        PTX_TRY(launch_gemm(g, st));
+    }
+    PTX_TRY(launch_img_scores(img, we, qkv0, nimg, s.in_dim, s.hw, s.heads, C, P.KT1, P.KT2p,
+                              attn_scale(hd), gbuf, st));
+    PTX_TRY(launch_img_gather(img, nimg, s.in_dim, s.hw, s.heads, P.KT2p, gbuf, st));
+    {   // per head: o_h = [g_h | a_h] T2_h^T + a_h(0) v0_h + bv_h
+        GemmBatch g{}; g.n = s.heads;
+        for (int h = 0; h < s.heads; ++h)
+            g.p[h] = GemmProb{gbuf + (size_t)h * P.KT2p, prep + P.t2 + (size_t)h * hd * P.KT2p, obuf + h * hd,
+                              w.v_b + h * hd, nullptr, gbuf + (size_t)h * P.KT2p + s.in_dim,
+                              qkv0 + 2 * C + h * hd, nimg, hd, P.KT2p, s.heads * P.KT2p, P.KT2p, C,
+                              0, s.heads * P.KT2p, 3 * C, EPI_NONE};
+        PTX_TRY(launch_gemm(g, st));
+    }
+    {   // c_proj
+        GemmBatch g{}; g.n = 1;
+        g.p[0] = GemmProb{obuf, w.c_w, cbuf, w.c_b, nullptr, nullptr, nullptr,
+                          nimg, C, C, C, C, C, 0, 0, 0, EPI_NONE};
+        PTX_TRY(launch_gemm(g, st));
+    }
+    LnBatch lb{}; lb.n = 1; lb.C = C; lb.eps = s.ln_eps;
+    lb.p[0] = LnProb{cbuf, img_proxy, w.norm_img_w, w.norm_img_b, nullptr, nimg, 1};
+    PTX_TRY(launch_ln_rows(lb, st));
+    return PTX_OK;
+}
+
+// ---- proxy blocks (one or both branches in the same launches) --------------------------------------
+struct Branch {
+    const PtxBlock *blk; const float *x_in; const float *proxy; int Lp; const uint8_t *mask;
+    const float *head_w, *head_b, *head_ab; int nout; float *head_out; float *guide; int slot;
+};
+
+static int run_blocks(const PtxShape &s, const Branch *br, int nb, const float *point_proxy, void *ws,
+                      hipStream_t st)
+{
+    const WsLayout L = ws_layout(s);
+    const int C = s.C, R = s.B * s.Mk;
+    {   // qkv = Linear(C,3C)(LN1(x)+bias) (PRE:221);  proxy_tokens = proxy_proj(proxy) (PRE:223)
+        GemmBatch g{}; g.n = 2 * nb;
+        for (int i = 0; i < nb; ++i) {
+            const int sl = br[i].slot;
+            g.p[2 * i] = GemmProb{br[i].x_in, br[i].blk->qkv_w, at<float>(ws, L.qkv[sl]), br[i].blk->qkv_b,
+                                  nullptr, nullptr, nullptr, R, 3 * C, C, C, C, 3 * C, 0, 0, 0, EPI_NONE};
+            g.p[2 * i + 1] = GemmProb{br[i].proxy, br[i].blk->pp_w, at<float>(ws, L.pt[sl]), br[i].blk->pp_b,
+                                      nullptr, nullptr, nullptr, s.B * br[i].Lp, C, C, C, C, C, 0, 0, 0, EPI_NONE};
+        }
+        PTX_TRY(launch_gemm(g, st));
+    }
+    AttnBatch a{}; a.n = nb; a.B = s.B; a.heads = s.heads; a.scale = attn_scale(C / s.heads);
+    for (int i = 0; i < nb; ++i) {   // proxy as query (PRE:232-238): no mask
+        const int sl = br[i].slot;
+        float *qkv = at<float>(ws, L.qkv[sl]);
+        a.p[i] = AttnProb{at<float>(ws, L.pt[sl]), qkv + C, qkv + 2 * C, at<float>(ws, L.pv[sl]), nullptr,
+                          br[i].Lp, s.Mk, C, 3 * C, 3 * C, C,
+                          (long)br[i].Lp * C, (long)s.Mk * 3 * C, (long)s.Mk * 3 * C, (long)br[i].Lp * C};
+    }
+    PTX_TRY(launch_attn32(a, st));
+    for (int i = 0; i < nb; ++i) {   // proxy as key (PRE:241-250): padded text tokens masked
+        const int sl = br[i].slot;
+        float *qkv = at<float>(ws, L.qkv[sl]);
+        a.p[i] = AttnProb{qkv, at<float>(ws, L.pt[sl]), at<float>(ws, L.pv[sl]), at<float>(ws, L.ao[sl]),
+                          br[i].mask, s.Mk, br[i].Lp, 3 * C, C, C, C,
+                          (long)s.Mk * 3 * C, (long)br[i].Lp * C, (long)br[i].Lp * C, (long)s.Mk * C};
+    }
+    PTX_TRY(launch_attn32(a, st));
+    {   // x1 = x + proj(attn) (PRE:255, 274)
+        GemmBatch g{}; g.n = nb;
+        for (int i = 0; i < nb; ++i) {
+            const int sl = br[i].slot;
+            g.p[i] = GemmProb{at<float>(ws, L.ao[sl]), br[i].blk->proj_w, at<float>(ws, L.x1[sl]),
+                              br[i].blk->proj_b, point_proxy, nullptr, nullptr, R, C, C, C, C, C, C, 0, 0, EPI_NONE};
+        }
+        PTX_TRY(launch_gemm(g, st));
+    }
+    {   // norm2 (PRE:275)
+        LnBatch lb{}; lb.n = nb; lb.C = C; lb.eps = s.ln_eps;
+        for (int i = 0; i < nb; ++i) {
+            const int sl = br[i].slot;
+            lb.p[i] = LnProb{at<float>(ws, L.x1[sl]), at<float>(ws, L.xn2[sl]), br[i].blk->norm2_w,
+                             br[i].blk->norm2_b, nullptr, R, 1};
+        }
+        PTX_TRY(launch_ln_rows(lb, st));
+    }
+    {   // fc1 + GELU(erf)
+        GemmBatch g{}; g.n = nb;
+        for (int i = 0; i < nb; ++i) {
+            const int sl = br[i].slot;
+            g.p[i] = GemmProb{at<float>(ws, L.xn2[sl]), br[i].blk->fc1_w, at<float>(ws, L.hbuf[sl]),
+                              br[i].blk->fc1_b, nullptr, nullptr, nullptr, R, s.hidden, C, C, C, s.hidden,
+                              0, 0, 0, EPI_GELU};
+        }
+        PTX_TRY(launch_gemm(g, st));
+    }
+    {   // x2 = x1 + fc2(h)
+        GemmBatch g{}; g.n = nb;
+        for (int i = 0; i < nb; ++i) {
+            const int sl = br[i].slot;
+            g.p[i] = GemmProb{at<float>(ws, L.hbuf[sl]), br[i].blk->fc2_w, at<float>(ws, L.x2[sl]),
+                              br[i].blk->fc2_b, at<float>(ws, L.x1[sl]), nullptr, nullptr, R, C, s.hidden,
+                              s.hidden, s.hidden, C, C, 0, 0, EPI_NONE};
+        }
+        PTX_TRY(launch_gemm(g, st));
+    }
+    HeadBatch hb{}; hb.n = nb; hb.C = C; hb.eps = s.ln_eps;
+    for (int i = 0; i < nb; ++i) {
+        const int sl = br[i].slot;
+        hb.p[i] = HeadProb{at<float>(ws, L.x2[sl]), br[i].blk->out_norm_w, br[i].blk->out_norm_b,
+                           br[i].head_w, br[i].head_b, br[i].head_ab, br[i].head_out, br[i].guide, R, br[i].nout};
+    }
+    PTX_TRY(launch_heads(hb, st));
+    return PTX_OK;
+}
+
+static Branch make_branch(const PtxShape &s, const PtxWeights &w, const float *prep, int which,
+                          const float *x_in, const float *proxy, int Lp, const uint8_t *mask,
+                          float *head_out, float *guide)
+{
+    const PrepLayout P = prep_layout(s);
+    Branch b{};
+    b.blk = which == 0 ? &w.text : &w.img;
+    b.x_in = x_in; b.proxy = proxy; b.Lp = Lp; b.mask = mask;
+    b.head_w = which == 0 ? w.text_trans_w : w.img_trans_w;
+    b.head_b = which == 0 ? w.text_trans_b : w.img_trans_b;
+    b.head_ab = prep + (which == 0 ? P.ttn_ab : P.itn_ab);
+    b.nout = which == 0 ? 3 : 9;
+    b.head_out = head_out; b.guide = guide; b.slot = which;
+    return b;
+}
+
+static int check_bufs(const PtxShape *s, const void *ws, size_t ws_bytes)
+{
+    PTX_REQUIRE(s != nullptr, "null shape");
+    PTX_TRY(validate_shape(*s));
+    PTX_REQUIRE(ws != nullptr, "null workspace");
+    const size_t need = ws_layout(*s).total;
+    if (ws_bytes < need) { set_error("workspace too small: %zu < %zu bytes", ws_bytes, need); return PTX_ENOSPACE; }
+    PTX_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 255) == 0, "workspace must be 256-byte aligned");
+    return PTX_OK;
+}
+
+}  // namespace ptx
+
+using namespace ptx;
+
+extern "C" {
+
+int ptx_abi_version(void) { return PTX_ABI_VERSION; }
+const char *ptx_last_error(void) { return g_err; }
+
+size_t ptx_prep_bytes(const PtxShape *s)
+{
+    if (s == nullptr || validate_shape(*s) != PTX_OK) return 0;
+    return prep_layout(*s).total * sizeof(float);
+}
+
+size_t ptx_workspace_bytes(const PtxShape *s)
+{
+    if (s == nullptr || validate_shape(*s) != PTX_OK) return 0;
+    return ws_layout(*s).total;
+}
+
+int ptx_prepare(const PtxShape *s, const PtxWeights *w, const float *lin, void *prep, size_t prep_bytes,
+                void *stream)
+{
+    (void)lin;
+    PTX_REQUIRE(s && w && prep, "ptx_prepare: null argument");
+    PTX_TRY(validate_shape(*s));
+    if (prep_bytes < prep_layout(*s).total * sizeof(float)) { set_error("prep buffer too small"); return PTX_ENOSPACE; }
+    return run_prepare(*s, *w, static_cast<float *>(prep), static_cast<hipStream_t>(stream));
+}
+
+int ptx_grid_centers(const float *points, int B, int N, const float *lin, int gs, float margin,
+                     float *minmax, float *centers, void *workspace, size_t ws_bytes, void *stream)
+{
+    // stage API for PRE:37-48 only: the ball query is skipped by asking for K = 0 hits.
+    PTX_REQUIRE(points && lin && minmax && centers && workspace, "ptx_grid_centers: null argument");
+    PTX_REQUIRE(ws_bytes >= (size_t)B * 6 * 4, "ptx_grid_centers: workspace needs %d bytes", B * 24);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    uint32_t *enc = static_cast<uint32_t *>(workspace);
+    PTX_HIP(hipMemsetAsync(enc, 0, (size_t)B * 6 * 4, st));
+    PTX_TRY(launch_minmax(points, B, N, enc, st));
+    return launch_ball_query(nullptr, enc, lin, gs, margin, minmax, centers, points, B, gs * gs * gs, N, 0,
+                             0.0f, nullptr, nullptr, nullptr, st);
+}
+
+int ptx_ball_query(const float *centers, const float *points, int B, int M, int N, int K, float radius,
+                   int32_t *idx, float *cluster, int32_t *pad_count, void *stream)
+{
+    PTX_REQUIRE(centers && points && idx && cluster, "ptx_ball_query: null argument");
+    PTX_REQUIRE(B >= 1 && M >= 1 && N >= 1 && K >= 1, "ptx_ball_query: B=%d M=%d N=%d K=%d", B, M, N, K);
+    return launch_ball_query(centers, nullptr, nullptr, 0, 0.0f, nullptr, nullptr, points, B, M, N, K, radius,
+                             idx, cluster, pad_count, static_cast<hipStream_t>(stream));
+}
+
+int ptx_offset_net(const PtxShape *s, const PtxWeights *w, const void *prep, const float *centers_in,
+                   const float *cluster, const float *minmax, float *centers_out, float *offsets_out,
+                   void *stream)
+{
+    PTX_REQUIRE(s && w && prep && centers_in && cluster && minmax && centers_out, "ptx_offset_net: null argument");
+    PTX_TRY(validate_shape(*s));
+    const PrepLayout P = prep_layout(*s);
+    const int M = s->grid_size * s->grid_size * s->grid_size;
+    return launch_offset_net(static_cast<const float *>(prep) + P.off_ab, w->offset, w->offset_map_w, centers_in,
+                             cluster, minmax, s->B * M, M, s->K, s->margin, centers_out, offsets_out,
+                             static_cast<hipStream_t>(stream));
+}
+
+int ptx_select_clusters(const PtxShape *s, const int32_t *idx, const float *centers, const float *cluster,
+                        const int32_t *pad_count, const int32_t *order_override, int32_t *order,
+                        int32_t *picks, int32_t *keep, float *kcenter, float *kcluster, int32_t *kidx,
+                        int32_t *drop_idx, uint32_t *tag, void *stream)
+{
+    PTX_REQUIRE(s && idx && centers && cluster && pad_count && order && picks && keep && kcenter && kcluster &&
+                kidx && drop_idx, "ptx_select_clusters: null argument");
+    PTX_TRY(validate_shape(*s));
+    return launch_select(*s, idx, centers, cluster, pad_count, order_override, order, picks, keep, kcenter,
+                         kcluster, kidx, drop_idx, tag, static_cast<hipStream_t>(stream));
+}
+
+int ptx_pointnet(const PtxShape *s, const PtxWeights *w, const void *prep, const float *kcenter,
+                 const float *kcluster, float *point_proxy, void *stream)
+{
+    PTX_REQUIRE(s && w && prep && kcenter && kcluster && point_proxy, "ptx_pointnet: null argument");
+    PTX_TRY(validate_shape(*s));
+    const PrepLayout P = prep_layout(*s);
+    return launch_pointnet(static_cast<const float *>(prep) + P.enc_ab, w->encoder, kcenter, kcluster,
+                           s->B * s->Mk, s->Mk, s->K, point_proxy, nullptr, nullptr, nullptr, nullptr, nullptr,
+                           nullptr, s->ln_eps, static_cast<hipStream_t>(stream));
+}
+
+int ptx_img_proxy(const PtxShape *s, const PtxWeights *w, const void *prep, const float *img_feat,
+                  float *img_proxy, void *workspace, size_t ws_bytes, void *stream)
+{
+    PTX_REQUIRE(w && prep && img_feat && img_proxy, "ptx_img_proxy: null argument");
+    PTX_TRY(check_bufs(s, workspace, ws_bytes));
+    return run_img_proxy(*s, *w, static_cast<const float *>(prep), img_feat, img_proxy, workspace,
+                         static_cast<hipStream_t>(stream));
+}
+
+int ptx_proxy_block(const PtxShape *s, const PtxWeights *w, const void *prep, int which,
+                    const float *point_proxy, const float *proxy, int Lp, const uint8_t *mask,
+                    float *head_out, float *guide, void *workspace, size_t ws_bytes, void *stream)
+{
+    PTX_REQUIRE(w && prep && point_proxy && proxy && head_out, "ptx_proxy_block: null argument");
+    PTX_REQUIRE(which == 0 || which == 1, "ptx_proxy_block: which=%d", which);
+    PTX_TRY(check_bufs(s, workspace, ws_bytes));
+    PTX_REQUIRE(Lp >= 1 && Lp <= (s->L > s->V ? s->L : s->V), "ptx_proxy_block: Lp=%d exceeds max(L,V)", Lp);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const PrepLayout P = prep_layout(*s);
+    const WsLayout L = ws_layout(*s);
+    const float *pf = static_cast<const float *>(prep);
+    const PtxBlock &blk = which == 0 ? w->text : w->img;
+    float *x_in = at<float>(workspace, L.x_in[which]);
+    LnBatch lb{}; lb.n = 1; lb.C = s->C; lb.eps = s->ln_eps;     // norm1 + per-slot bias (PRE:274, 215-217)
+    lb.p[0] = LnProb{point_proxy, x_in, blk.norm1_w, blk.norm1_b, pf + (which == 0 ? P.posb_t : P.posb_i),
+                     s->B * s->Mk, s->Mk};
+    PTX_TRY(launch_ln_rows(lb, st));
+    Branch br = make_branch(*s, *w, pf, which, x_in, proxy, Lp, mask, head_out, guide);
+    return run_blocks(*s, &br, 1, point_proxy, workspace, st);
+}
+
+int ptx_affine_scatter(const PtxShape *s, const float *points, const uint32_t *tag, const float *kcenter,
+                       const float *translate, const float *transform, float *new_points, void *stream)
+{
+    PTX_REQUIRE(s && points && tag && kcenter && translate && transform && new_points, "ptx_affine_scatter: null argument");
+    PTX_TRY(validate_shape(*s));
+    return launch_affine(*s, points, tag, kcenter, translate, transform, new_points, nullptr, nullptr, false,
+                         static_cast<hipStream_t>(stream));
+}
+
+int ptx_affine_compact(const PtxShape *s, const float *points, const uint32_t *tag, const float *kcenter,
+                       const float *translate, const float *transform, float *out, int32_t *counts,
+                       void *workspace, size_t ws_bytes, void *stream)
+{
+    PTX_REQUIRE(points && tag && kcenter && translate && transform && out && counts, "ptx_affine_compact: null argument");
+    PTX_TRY(check_bufs(s, workspace, ws_bytes));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int32_t *tc = at<int32_t>(workspace, ws_layout(*s).tile_counts);
+    PTX_TRY(launch_tile_count(tag, s->B, s->N, tc, st));
+    return launch_affine(*s, points, tag, kcenter, translate, transform, out, counts, tc, true, st);
+}
+
+#define PTX_DBG(field, src, bytes)                                                                         do {                                                                                                       if (debug && debug->field)                                                                                 PTX_HIP(hipMemcpyAsync(debug->field, src, bytes, hipMemcpyDeviceToDevice, st));                } while (0)
+
+int ptx_forward(const PtxShape *s, const PtxWeights *w, const void *prep, const float *lin,
+                const float *points, const float *text_feats, const uint8_t *text_mask,
+                const float *img_feat, const int32_t *order_override, const float *centers_override,
+                float *out, int32_t *counts, void *workspace, size_t ws_bytes, const PtxDebug *debug,
+                void *stream)
+{
+    PTX_REQUIRE(w && prep && lin && points && text_feats && img_feat && out && counts, "ptx_forward: null argument");
+    PTX_TRY(check_bufs(s, workspace, ws_bytes));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const PtxShape &S = *s;
+    const PrepLayout P = prep_layout(S);
+    const WsLayout L = ws_layout(S);
+    const float *pf = static_cast<const float *>(prep);
+    void *ws = workspace;
+    const int M = S.grid_size * S.grid_size * S.grid_size, B = S.B, K = S.K, Kd = S.Mt - S.Mk;
+
+    // ---- fork: the image branch only depends on img_feat (PRE:449)
+    SideStream *side = nullptr;
+    PTX_TRY(side_stream(&side));
+    PTX_HIP(hipEventRecord(side->fork, st));
+    PTX_HIP(hipStreamWaitEvent(side->st, side->fork, 0));
+    float *img_proxy = at<float>(ws, L.img_proxy);
+    PTX_TRY(run_img_proxy(S, *w, pf, img_feat, img_proxy, ws, side->st));
+    PTX_HIP(hipEventRecord(side->join, side->st));
+
+    // ---- clustering (PRE:430)
+    uint32_t *mm_enc = at<uint32_t>(ws, L.mm_enc), *tag = at<uint32_t>(ws, L.tag);
+    float *minmax = at<float>(ws, L.minmax), *centers0 = at<float>(ws, L.centers0);
+    float *cluster1 = at<float>(ws, L.cluster1), *offsets = at<float>(ws, L.offsets);
+    float *centers = at<float>(ws, L.centers), *cluster2 = at<float>(ws, L.cluster2);
+    int32_t *idx2 = at<int32_t>(ws, L.idx2), *pad_count = at<int32_t>(ws, L.pad_count);
+    PTX_HIP(hipMemsetAsync(at<char>(ws, L.zero_begin), 0, L.zero_bytes, st));
+    PTX_TRY(launch_minmax(points, B, S.N, mm_enc, st));
+    // ball query #1 on the unclamped grid centres; only the gathered xyz is used (PRE:56, Q3)
+    PTX_TRY(launch_ball_query(nullptr, mm_enc, lin, S.grid_size, S.margin, minmax, centers0, points, B, M, S.N,
+                              K, S.radius, idx2, cluster1, nullptr, st));
+    PTX_TRY(launch_offset_net(pf + P.off_ab, w->offset, w->offset_map_w, centers0, cluster1, minmax, B * M, M,
+                              K, S.margin, centers, offsets, st));
+    if (centers_override)
+        PTX_HIP(hipMemcpyAsync(centers, centers_override, (size_t)B * M * 3 * 4, hipMemcpyDeviceToDevice, st));
+    PTX_TRY(launch_ball_query(centers, nullptr, nullptr, 0, 0.0f, nullptr, nullptr, points, B, M, S.N, K,
+                              S.radius, idx2, cluster2, pad_count, st));                      // PRE:65
+
+    // ---- dynamic cluster dropout (PRE:433)
+    int32_t *order = at<int32_t>(ws, L.order), *picks = at<int32_t>(ws, L.picks), *keep = at<int32_t>(ws, L.keep);
+    float *kcenter = at<float>(ws, L.kcenter), *kcluster = at<float>(ws, L.kcluster);
+    int32_t *kidx = at<int32_t>(ws, L.kidx), *drop_idx = at<int32_t>(ws, L.drop_idx);
+    PTX_TRY(launch_select(S, idx2, centers, cluster2, pad_count, order_override, order, picks, keep, kcenter,
+                          kcluster, kidx, drop_idx, tag, st));
+    int32_t *tile_counts = at<int32_t>(ws, L.tile_counts);
+    PTX_TRY(launch_tile_count(tag, B, S.N, tile_counts, st));
+
+    // ---- point proxies (PRE:437) + norm1 / slot bias of both blocks
+    float *point_proxy = at<float>(ws, L.point_proxy);
+    float *xin_t = at<float>(ws, L.x_in[0]), *xin_i = at<float>(ws, L.x_in[1]);
+    PTX_TRY(launch_pointnet(pf + P.enc_ab, w->encoder, kcenter, kcluster, B * S.Mk, S.Mk, K, point_proxy,
+                            &w->text, &w->img, pf + P.posb_t, pf + P.posb_i, xin_t, xin_i, S.ln_eps, st));
+
+    // ---- join, then both proxy blocks + heads in shared launches (PRE:440-455)
+    PTX_HIP(hipStreamWaitEvent(st, side->join, 0));
+    float *translate = at<float>(ws, L.head[0]), *transform = at<float>(ws, L.head[1]);
+    float *guide_t = (debug && debug->text_guide) ? at<float>(ws, L.guide[0]) : nullptr;
+    float *guide_i = (debug && debug->img_guide) ? at<float>(ws, L.guide[1]) : nullptr;
+    Branch br[2] = {make_branch(S, *w, pf, 0, xin_t, text_feats, S.L, text_mask, translate, guide_t),
+                    make_branch(S, *w, pf, 1, xin_i, img_proxy, S.V, nullptr, transform, guide_i)};
+    PTX_TRY(run_blocks(S, br, 2, point_proxy, ws, st));
+
+    // ---- submanifold reshape + scatter + drop (PRE:459-467)
+    PTX_TRY(launch_affine(S, points, tag, kcenter, translate, transform, out, counts, tile_counts, true, st));
+
+    PTX_DBG(centers0, centers0, (size_t)B * M * 3 * 4);
+    PTX_DBG(cluster1, cluster1, (size_t)B * M * K * 3 * 4);
+    PTX_DBG(offsets, offsets, (size_t)B * M * 3 * 4);
+    PTX_DBG(centers, centers, (size_t)B * M * 3 * 4);
+    PTX_DBG(cluster2, cluster2, (size_t)B * M * K * 3 * 4);
+    PTX_DBG(idx2, idx2, (size_t)B * M * K * 4);
+    PTX_DBG(pad_count, pad_count, (size_t)B * M * 4);
+    PTX_DBG(order, order, (size_t)B * S.Mt * 4);
+    PTX_DBG(picks, picks, (size_t)B * Kd * 4);
+    PTX_DBG(keep, keep, (size_t)B * S.Mk * 4);
+    PTX_DBG(kidx, kidx, (size_t)B * S.Mk * K * 4);
+    PTX_DBG(drop_idx, drop_idx, (size_t)B * Kd * K * 4);
+    PTX_DBG(kcenter, kcenter, (size_t)B * S.Mk * 3 * 4);
+    PTX_DBG(kcluster, kcluster, (size_t)B * S.Mk * K * 3 * 4);
+    PTX_DBG(point_proxy, point_proxy, (size_t)B * S.Mk * S.C * 4);
+    PTX_DBG(img_proxy, img_proxy, (size_t)B * S.V * S.C * 4);
+    PTX_DBG(text_guide, guide_t, (size_t)B * S.Mk * S.C * 4);
+    PTX_DBG(img_guide, guide_i, (size_t)B * S.Mk * S.C * 4);
+    PTX_DBG(translate, translate, (size_t)B * S.Mk * 3 * 4);
+    PTX_DBG(transform, transform, (size_t)B * S.Mk * 9 * 4);
+    PTX_DBG(tag, tag, (size_t)B * S.N * 4);
+    return PTX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,143 @@
+// Proxy attention (PRE:230-250) on the matrix cores, head_dim = 32.
+//
+// One kernel serves both contractions of ProxyAttention:
+//   proxy as query : O = softmax_n((P*scale) K^T) V          queries = proxies, keys = cluster tokens
+//   proxy as key   : O = softmax_L(mask((Q*scale) P^T)) PV   queries = tokens, keys = proxies
+// One wave owns 32 query rows of one (scene, head) and streams the keys in tiles of 32 with an
+// online softmax.  Everything stays in registers:
+//   S^T = K Q^T      v_mfma_f32_32x32x2_f32, A = key rows, B = query rows -> lane owns ONE query
+//                    (col = lane & 31) and 16 of the 32 key scores of the tile, so the row
+//                    max / sum of the softmax are in-lane reductions plus one xor-32 exchange;
+//   O^T += V^T P^T   A = V^T (lane = output dim), B = the probabilities exactly where the first
+//                    MFMA left them (key index of step s, half hh = (s&3) + 8*(s>>2) + 4*hh),
+//                    so P never moves between lanes and the running rescale is per lane.
+// fp32 in / fp32 accumulate: this is the parity configuration.
+#include "common.h"
+
+namespace ptx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int HD = 32;
+
+__global__ __launch_bounds__(256) void k_attn32(AttnBatch ab)
+{
+    const AttnProb &p = ab.p[blockIdx.z];
+    const int lane = lane_id();
+    const int qt = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int q0 = qt * 32;
+    if (q0 >= p.nq) return;
+    const int b = blockIdx.y / ab.heads, h = blockIdx.y - b * ab.heads;
+    const int li = lane & 31, hh = lane >> 5;
+    const float *Q = p.Q + (size_t)b * p.sQ + h * HD;
+    const float *Kp = p.K + (size_t)b * p.sK + h * HD;
+    const float *Vp = p.V + (size_t)b * p.sV + h * HD;
+    const uint8_t *mask = p.mask ? p.mask + (size_t)b * p.nk : nullptr;
+
+    // B operand of S^T: this lane's query row, dims hh*16 .. hh*16+15, pre-scaled (PRE:232, 241)
+    float qf[16];
+    {
+        const int qi = q0 + li;
+        if (qi < p.nq) {
+            const float4 *src = reinterpret_cast<const float4 *>(Q + (size_t)qi * p.ldq + hh * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 t = src[i];
+                qf[4 * i] = t.x * ab.scale; qf[4 * i + 1] = t.y * ab.scale;
+                qf[4 * i + 2] = t.z * ab.scale; qf[4 * i + 3] = t.w * ab.scale;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) qf[i] = 0.0f;
+        }
+    }
+    float m_run = -INFINITY, l_run = 0.0f;
+    f32x16 o;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[i] = 0.0f;
+
+    for (int k0 = 0; k0 < p.nk; k0 += 32) {
+        // A operand of S^T: key row k0 + li, dims hh*16 .. +15
+        float kf[16];
+        {
+            const int ki = k0 + li;
+            if (ki < p.nk) {
+                const float4 *src = reinterpret_cast<const float4 *>(Kp + (size_t)ki * p.ldk + hh * 16);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 t = src[i];
+                    kf[4 * i] = t.x; kf[4 * i + 1] = t.y; kf[4 * i + 2] = t.z; kf[4 * i + 3] = t.w;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) kf[i] = 0.0f;
+            }
+        }
+        // A operand of O^T: V[key(s,hh)][li]
+        float vf[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int key = k0 + (s & 3) + 8 * (s >> 2) + 4 * hh;
+            vf[s] = key < p.nk ? Vp[(size_t)key * p.ldv + li] : 0.0f;
+        }
+        f32x16 sc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sc[i] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[s], sc, 0, 0, 0);
+        // sc[r] = score(key = k0 + (r&3) + 8*(r>>2) + 4*hh, query = q0 + li)
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            float v = sc[r];
+            if (key >= p.nk) v = -INFINITY;
+            else if (mask && mask[key] == 0) v = -1e9f;               // masked_fill(-1e9), PRE:247
+            sc[r] = v;
+            tmax = fmaxf(tmax, v);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);                       // finite: tile 0 has a valid key
+        const float alpha = expf(m_run - m_new);
+        float psum = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float e = expf(sc[r] - m_new); sc[r] = e; psum += e; }
+        psum += __shfl_xor(psum, 32, 64);
+        l_run = fmaf(l_run, alpha, psum);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[i] *= alpha;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) o = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[s], sc[s], o, 0, 0, 0);
+        m_run = m_new;
+    }
+    // o[r] = O^T[d = (r&3) + 8*(r>>2) + 4*hh][query = li]
+    const int qi = q0 + li;
+    if (qi < p.nq) {
+        const float inv = 1.0f / l_run;
+        float *dst = p.O + (size_t)b * p.sO + (size_t)qi * p.ldo + h * HD;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 t = make_float4(o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+            *reinterpret_cast<float4 *>(dst + 8 * g + 4 * hh) = t;
+        }
+    }
+}
+
+int launch_attn32(const AttnBatch &ab, hipStream_t st)
+{
+    int nqmax = 0;
+    for (int g = 0; g < ab.n; ++g) {
+        const AttnProb &p = ab.p[g];
+        PTX_REQUIRE(p.Q && p.K && p.V && p.O, "attention: null operand in group %d", g);
+        PTX_REQUIRE(p.nk >= 1, "attention: no keys in group %d", g);
+        PTX_REQUIRE(p.ldq % 4 == 0 && p.ldk % 4 == 0 && p.ldo % 4 == 0 && p.sQ % 4 == 0 &&
+                    p.sK % 4 == 0 && p.sO % 4 == 0, "attention: strides must be multiples of 4 floats");
+        nqmax = p.nq > nqmax ? p.nq : nqmax;
+    }
+    if (nqmax == 0) return PTX_OK;
+    hipLaunchKernelGGL(k_attn32, dim3(cdiv(cdiv(nqmax, 32), 4), ab.B * ab.heads, ab.n), dim3(256), 0, st, ab);
+    PTX_LAUNCHED("k_attn32");
+    return PTX_OK;
+}
+
+}  // namespace ptx

@@ -1,0 +1,640 @@
+// Clustering and apply kernels of the preshape path (gfx950, wave64).
+//
+//   k_minmax        PRE:37-38   per-scene bbox (HBM-bound streaming read, 12 B/point)
+//   k_ball_query    PRE:56,65   pytorch3d.ops.ball_query: first K in index order, r = 3
+//                               (+ PRE:41-48 grid centres when GRID)
+//   k_slot_net      PRE:87-107 / 126-142 OffsetNetwork / SimplifiedPointNet, one wave per cluster
+//   k_select        PRE:352-420 padding-count ordering, FPS, keep list, gathers, ownership tags
+//   k_tile_count / k_affine     PRE:459-467, 472-525 affine + last-writer scatter + ordered drop
+//
+// Build with -ffp-contract=off: squared distances decide integer results and must be
+// ((dx*dx)+dy*dy)+dz*dz exactly; they additionally use __f*_rn intrinsics.
+#include "common.h"
+
+namespace ptx {
+
+// ------------------------------------------------------------------------------ min / max
+// mm_enc[b][0..2] = ~ord(min_d)   (so that atomicMax over a zeroed word yields the minimum)
+// mm_enc[b][3..5] =  ord(max_d)
+__global__ __launch_bounds__(256) void k_minmax(const float *__restrict__ points, int N,
+                                                uint32_t *__restrict__ mm_enc)
+{
+    const int b = blockIdx.y;
+    const float *p = points + (size_t)b * N * 3;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nth = gridDim.x * blockDim.x;
+    const bool vec = ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(p) & 15) == 0);
+    if (vec) {
+        // 4 points = 12 floats = 3 float4 per step
+        const float4 *p4 = reinterpret_cast<const float4 *>(p);
+        const int nq = N >> 2;
+        for (int q = tid; q < nq; q += nth) {
+            float4 a = p4[3 * q], c = p4[3 * q + 1], e = p4[3 * q + 2];
+            // a = x0 y0 z0 x1 | c = y1 z1 x2 y2 | e = z2 x3 y3 z3
+            float xs[4] = {a.x, a.w, c.z, e.y}, ys[4] = {a.y, c.x, c.w, e.z}, zs[4] = {a.z, c.y, e.x, e.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                lo[0] = fminf(lo[0], xs[i]); hi[0] = fmaxf(hi[0], xs[i]);
+                lo[1] = fminf(lo[1], ys[i]); hi[1] = fmaxf(hi[1], ys[i]);
+                lo[2] = fminf(lo[2], zs[i]); hi[2] = fmaxf(hi[2], zs[i]);
+            }
+        }
+    } else {
+        for (int i = tid; i < N; i += nth) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                float v = p[(size_t)i * 3 + d];
+                lo[d] = fminf(lo[d], v); hi[d] = fmaxf(hi[d], v);
+            }
+        }
+    }
+    __shared__ float red[4][6];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { lo[d] = wave_min(lo[d]); hi[d] = wave_max(hi[d]); }
+    const int w = threadIdx.x >> 6;
+    if (lane_id() == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { red[w][d] = lo[d]; red[w][3 + d] = hi[d]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int d = threadIdx.x;
+        float v = red[0][d];
+        for (int i = 1; i < 4; ++i) v = d < 3 ? fminf(v, red[i][d]) : fmaxf(v, red[i][d]);
+        if (d < 3) { if (v != INFINITY) atomicMax(&mm_enc[b * 6 + d], ~f2ord(v)); }
+        else       { if (v != -INFINITY) atomicMax(&mm_enc[b * 6 + d], f2ord(v)); }
+    }
+}
+
+int launch_minmax(const float *points, int B, int N, uint32_t *mm_enc, hipStream_t st)
+{
+    int per_scene = cdiv(N, 256 * 16);
+    if (per_scene < 1) per_scene = 1;
+    if (per_scene > 256) per_scene = 256;
+    hipLaunchKernelGGL(k_minmax, dim3(per_scene, B), dim3(256), 0, st, points, N, mm_enc);
+    PTX_LAUNCHED("k_minmax");
+    return PTX_OK;
+}
+
+// ------------------------------------------------------------------------------ ball query
+// One wave per centre; lanes test 64 consecutive points at a time, a ballot + prefix popcount
+// keeps hits in index order, the wave stops as soon as it has K hits.  All waves of a launch
+// walk the same short prefix of the point array, which stays in L2.
+constexpr int kBqUnroll = 4;   // 256 points per outer step
+
+template <bool GRID>
+__global__ __launch_bounds__(256) void k_ball_query(
+    const float *__restrict__ centers, const uint32_t *__restrict__ mm_enc,
+    const float *__restrict__ lin, int gs, float margin, float *__restrict__ minmax_out,
+    float *__restrict__ centers_out, const float *__restrict__ points, int BM, int M, int N, int K,
+    float radius, int32_t *__restrict__ idx, float *__restrict__ cluster,
+    int32_t *__restrict__ pad_count)
+{
+    const int lane = lane_id();
+    const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (w >= BM) return;
+    const int b = w / M, m = w - b * M;
+    float cx, cy, cz;
+    if (GRID) {
+        // PRE:48: (min + margin) + lin * ((max - min) - 2*margin), python operator order
+        float mn[3], mx[3], c[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { mn[d] = ord2f(~mm_enc[b * 6 + d]); mx[d] = ord2f(mm_enc[b * 6 + 3 + d]); }
+        const int ijk[3] = {m / (gs * gs), (m / gs) % gs, m % gs};   // meshgrid 'ij' (PRE:44)
+        const float two_margin = __fmul_rn(2.0f, margin);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            float base = __fadd_rn(mn[d], margin);
+            float span = __fsub_rn(__fsub_rn(mx[d], mn[d]), two_margin);
+            c[d] = __fadd_rn(base, __fmul_rn(lin[ijk[d]], span));
+        }
+        cx = c[0]; cy = c[1]; cz = c[2];
+        if (lane < 3) centers_out[(size_t)w * 3 + lane] = c[lane];
+        if (m == 0 && lane < 3) { minmax_out[b * 6 + lane] = mn[lane]; minmax_out[b * 6 + 3 + lane] = mx[lane]; }
+    } else {
+        cx = centers[(size_t)w * 3 + 0]; cy = centers[(size_t)w * 3 + 1]; cz = centers[(size_t)w * 3 + 2];
+    }
+    const float r2 = __fmul_rn(radius, radius);
+    const float *p = points + (size_t)b * N * 3;
+    int32_t *oi = idx + (size_t)w * K;
+    float *oc = cluster + (size_t)w * K * 3;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int count = 0;
+    for (int base = 0; base < N && count < K; base += 64 * kBqUnroll) {
+        float px[kBqUnroll], py[kBqUnroll], pz[kBqUnroll];
+#pragma unroll
+        for (int u = 0; u < kBqUnroll; ++u) {
+            const int j = base + u * 64 + lane;
+            if (j < N) { px[u] = p[(size_t)j * 3]; py[u] = p[(size_t)j * 3 + 1]; pz[u] = p[(size_t)j * 3 + 2]; }
+            else       { px[u] = py[u] = pz[u] = 0.0f; }
+        }
+#pragma unroll
+        for (int u = 0; u < kBqUnroll; ++u) {
+            if (count < K) {                                   // wave-uniform
+                const int j = base + u * 64 + lane;
+                const float d2 = dist2_nofma(cx, cy, cz, px[u], py[u], pz[u]);
+                const bool hit = (j < N) && (d2 < r2);          // strict <
+                const unsigned long long mask = __ballot(hit);
+                const int pos = count + __popcll(mask & lt);
+                if (hit && pos < K) {
+                    oi[pos] = j;
+                    oc[pos * 3] = px[u]; oc[pos * 3 + 1] = py[u]; oc[pos * 3 + 2] = pz[u];
+                }
+                count += __popcll(mask);
+            }
+        }
+    }
+    if (count > K) count = K;
+    for (int k = count + lane; k < K; k += 64) {               // masked_gather padding (PRE:664-671)
+        oi[k] = -1;
+        oc[k * 3] = 0.0f; oc[k * 3 + 1] = 0.0f; oc[k * 3 + 2] = 0.0f;
+    }
+    if (pad_count != nullptr && lane == 0) pad_count[w] = K - count;
+}
+
+int launch_ball_query(const float *centers, const uint32_t *mm_enc, const float *lin, int gs,
+                      float margin, float *minmax_out, float *centers_out, const float *points,
+                      int B, int M, int N, int K, float radius, int32_t *idx, float *cluster,
+                      int32_t *pad_count, hipStream_t st)
+{
+    const int BM = B * M;
+    const dim3 grid(cdiv(BM, 4)), block(256);
+    if (centers == nullptr) {
+        hipLaunchKernelGGL(k_ball_query<true>, grid, block, 0, st, nullptr, mm_enc, lin, gs, margin,
+                           minmax_out, centers_out, points, BM, M, N, K, radius, idx, cluster, pad_count);
+    } else {
+        hipLaunchKernelGGL(k_ball_query<false>, grid, block, 0, st, centers, nullptr, nullptr, 0, 0.0f,
+                           nullptr, nullptr, points, BM, M, N, K, radius, idx, cluster, pad_count);
+    }
+    PTX_LAUNCHED("k_ball_query");
+    return PTX_OK;
+}
+
+// ------------------------------------------------------------------------------ slot networks
+// Shared front of OffsetNetwork (PRE:87-107) and SimplifiedPointNet (PRE:126-142):
+//   x_k = [rel_k (zeroed on padded slots), p_k]  (6)      PRE:93-99
+//   h_k = relu(alpha * (W x_k + b) + beta)       (256)    Conv2d 1x1 + eval BatchNorm2d + ReLU
+// One wave per cluster, lane owns channels lane, lane+64, lane+128, lane+192; the K slot inputs
+// are produced by lanes 0..K-1 and broadcast through v_readlane (SGPR operands of the FMAs).
+// MODE 0: mean_K -> 256->3 map -> tanh*margin -> add -> clamp  (PRE:59-62, 102-103)
+// MODE 1: max_K  -> point_proxy (+ LayerNorm1 + per-slot bias for both ProxyBlocks, PRE:274, 212-217)
+struct SlotNetArgs {
+    const float *ab;                  // (2,256) alpha, beta
+    const float *conv_w, *conv_b;     // (256,6), (256)
+    const float *center, *cluster;    // (BM,3), (BM,K,3)
+    int BM, Mper, K;
+    // MODE 0
+    const float *map_w; const float *minmax; float margin; float *centers_out; float *offsets_out;
+    // MODE 1
+    float *proxy; const float *n1w[2]; const float *n1b[2]; const float *posb[2]; float *xin[2];
+    float ln_eps;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_slot_net(SlotNetArgs a)
+{
+    const int lane = lane_id();
+    const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (w >= a.BM) return;
+    float wt[4][6], bs[4], al[4], be[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = lane + 64 * q;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) wt[q][i] = a.conv_w[c * 6 + i];
+        bs[q] = a.conv_b[c]; al[q] = a.ab[c]; be[q] = a.ab[kSlotHidden + c];
+    }
+    const float cx = a.center[(size_t)w * 3], cy = a.center[(size_t)w * 3 + 1], cz = a.center[(size_t)w * 3 + 2];
+    // lane k (< K) prepares slot k
+    float x[6] = {0, 0, 0, 0, 0, 0};
+    if (lane < a.K) {
+        const float *pk = a.cluster + ((size_t)w * a.K + lane) * 3;
+        const float px = pk[0], py = pk[1], pz = pk[2];
+        const bool pad = (px == 0.0f) && (py == 0.0f) && (pz == 0.0f);     // PRE:94 / PRE:132
+        x[0] = pad ? 0.0f : px - cx; x[1] = pad ? 0.0f : py - cy; x[2] = pad ? 0.0f : pz - cz;
+        x[3] = px; x[4] = py; x[5] = pz;
+    }
+    float acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = MODE == 0 ? 0.0f : -INFINITY;
+    for (int k = 0; k < a.K; ++k) {
+        float s[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) s[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x[i]), k));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float h = bs[q];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) h = fmaf(wt[q][i], s[i], h);
+            h = fmaxf(fmaf(h, al[q], be[q]), 0.0f);
+            acc[q] = MODE == 0 ? acc[q] + h : fmaxf(acc[q], h);
+        }
+    }
+    if (MODE == 0) {
+        const float invK = 1.0f / (float)a.K;
+        float o[3] = {0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float hm = acc[q] * invK;
+            const int c = lane + 64 * q;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) o[j] = fmaf(a.map_w[j * kSlotHidden + c], hm, o[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) o[j] = wave_sum(o[j]);
+        if (lane < 3) {
+            const int b = w / a.Mper;
+            const float cen = lane == 0 ? cx : (lane == 1 ? cy : cz);
+            const float raw = lane == 0 ? o[0] : (lane == 1 ? o[1] : o[2]);
+            const float off = tanhf(raw) * a.margin;                              // PRE:59
+            const float mn = a.minmax[b * 6 + lane], mx = a.minmax[b * 6 + 3 + lane];
+            const float nc = fmaxf(fminf(cen + off, mx), mn);                     // PRE:61-62
+            a.centers_out[(size_t)w * 3 + lane] = nc;
+            if (a.offsets_out) a.offsets_out[(size_t)w * 3 + lane] = off;
+        }
+    } else {
+        float *pr = a.proxy + (size_t)w * kSlotHidden;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pr[lane + 64 * q] = acc[q];
+        // LayerNorm1 (PRE:274) + per-slot bias (PRE:215-217) for the text / image ProxyBlock
+        float mean = wave_sum(acc[0] + acc[1] + acc[2] + acc[3]) * (1.0f / kSlotHidden);
+        float var = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const float d = acc[q] - mean; var = fmaf(d, d, var); }
+        var = wave_sum(var) * (1.0f / kSlotHidden);
+        const float rstd = 1.0f / sqrtf(var + a.ln_eps);
+        const int j = w % a.Mper;                                                  // kept-slot position (Q9)
+#pragma unroll
+        for (int br = 0; br < 2; ++br) {
+            if (a.xin[br] == nullptr) continue;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = lane + 64 * q;
+                const float xn = (acc[q] - mean) * rstd * a.n1w[br][c] + a.n1b[br][c];
+                a.xin[br][(size_t)w * kSlotHidden + c] = xn + a.posb[br][(size_t)j * kSlotHidden + c];
+            }
+        }
+    }
+}
+
+int launch_offset_net(const float *ab, const PtxSlotMlp &mlp, const float *map_w,
+                      const float *centers_in, const float *cluster, const float *minmax,
+                      int BM, int M, int K, float margin, float *centers_out, float *offsets_out,
+                      hipStream_t st)
+{
+    SlotNetArgs a{};
+    a.ab = ab; a.conv_w = mlp.conv_w; a.conv_b = mlp.conv_b; a.center = centers_in; a.cluster = cluster;
+    a.BM = BM; a.Mper = M; a.K = K; a.map_w = map_w; a.minmax = minmax; a.margin = margin;
+    a.centers_out = centers_out; a.offsets_out = offsets_out;
+    hipLaunchKernelGGL(k_slot_net<0>, dim3(cdiv(BM, 4)), dim3(256), 0, st, a);
+    PTX_LAUNCHED("k_slot_net<offset>");
+    return PTX_OK;
+}
+
+int launch_pointnet(const float *ab, const PtxSlotMlp &mlp, const float *kcenter,
+                    const float *kcluster, int BM, int Mk, int K, float *point_proxy,
+                    const PtxBlock *blk_t, const PtxBlock *blk_i, const float *posb_t,
+                    const float *posb_i, float *xin_t, float *xin_i, float ln_eps, hipStream_t st)
+{
+    SlotNetArgs a{};
+    a.ab = ab; a.conv_w = mlp.conv_w; a.conv_b = mlp.conv_b; a.center = kcenter; a.cluster = kcluster;
+    a.BM = BM; a.Mper = Mk; a.K = K; a.proxy = point_proxy; a.ln_eps = ln_eps;
+    if (blk_t && xin_t) { a.n1w[0] = blk_t->norm1_w; a.n1b[0] = blk_t->norm1_b; a.posb[0] = posb_t; a.xin[0] = xin_t; }
+    if (blk_i && xin_i) { a.n1w[1] = blk_i->norm1_w; a.n1b[1] = blk_i->norm1_b; a.posb[1] = posb_i; a.xin[1] = xin_i; }
+    hipLaunchKernelGGL(k_slot_net<1>, dim3(cdiv(BM, 4)), dim3(256), 0, st, a);
+    PTX_LAUNCHED("k_slot_net<pointnet>");
+    return PTX_OK;
+}
+
+// ------------------------------------------------------------------------------ cluster selection
+// One work-group per scene, everything after the loads lives in LDS / registers.
+//  1. stable counting sort of clusters by padding count (keys 0..K), first Mt   PRE:372-385
+//  2. FPS over the re-ordered centres, Kd = Mt - Mk picks, start 0, first max   PRE:393
+//  3. keep = ascending positions not picked, first Mk                           PRE:395-408
+//  4. gathers + drop_idx                                                        PRE:411-418
+//  5. ownership / drop tags for pt_replace and remove_points_by_index          PRE:478-495, 516-523
+struct SelectArgs {
+    const int32_t *idx; const float *centers; const float *cluster; const int32_t *pad_count;
+    const int32_t *order_override;
+    int32_t *order, *picks, *keep; float *kcenter, *kcluster; int32_t *kidx, *drop_idx; uint32_t *tag;
+    int M, K, Mt, Mk, Kd, N;
+};
+
+template <int P>   // points per thread in the FPS loop (blockDim.x * P >= Mt)
+__global__ __launch_bounds__(256) void k_select(SelectArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int T = blockDim.x, tid = threadIdx.x, lane = lane_id(), wid = tid >> 6, nw = T >> 6;
+    const int b = blockIdx.x;
+    const int M = a.M, K = a.K, Mt = a.Mt, Mk = a.Mk, Kd = a.Kd;
+    // LDS carve
+    int *s_order = reinterpret_cast<int *>(smem);                 // Mt
+    float *sx = reinterpret_cast<float *>(s_order + Mt);          // Mt each
+    float *sy = sx + Mt, *sz = sy + Mt;
+    int *s_flag = reinterpret_cast<int *>(sz + Mt);               // Mt: 1 = picked by FPS
+    int *s_keep = s_flag + Mt;                                    // Mk
+    int *s_picks = s_keep + Mk;                                   // Kd
+    int *s_hist = s_picks + (Kd > 0 ? Kd : 1);                    // 64
+    float *s_redv = reinterpret_cast<float *>(s_hist + 64);       // 2*4
+    int *s_redi = reinterpret_cast<int *>(s_redv + 8);            // 2*4
+
+    const int32_t *pc = a.pad_count + (size_t)b * M;
+    // ---- 1. ordering
+    if (a.order_override != nullptr) {
+        for (int t = tid; t < Mt; t += T) s_order[t] = a.order_override[(size_t)b * Mt + t];
+        __syncthreads();
+    } else {
+        if (tid < 64) s_hist[tid] = 0;
+        __syncthreads();
+        for (int m = tid; m < M; m += T) atomicAdd(&s_hist[pc[m]], 1);
+        __syncthreads();
+        if (wid == 0) {
+            // lane v holds the next free position of bucket v (K + 1 <= 64 buckets)
+            int cnt = s_hist[lane];
+            int incl = cnt;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { int n = __shfl_up(incl, o, 64); if (lane >= o) incl += n; }
+            int base = incl - cnt;
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            for (int m0 = 0; m0 < M; m0 += 64) {
+                const int m = m0 + lane;
+                const bool valid = m < M;
+                const int c = valid ? pc[m] : -1;
+                unsigned long long remaining = __ballot(valid);
+                while (remaining) {
+                    const int leader = __ffsll((long long)remaining) - 1;
+                    const int v = __shfl(c, leader, 64);
+                    const bool mine = valid && c == v;
+                    const unsigned long long match = __ballot(mine);
+                    const int start = __shfl(base, v, 64);
+                    const int pos = start + __popcll(match & lt);
+                    if (mine && pos < Mt) s_order[pos] = m;
+                    if (lane == v) base += __popcll(match);
+                    remaining &= ~match;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (int t = tid; t < Mt; t += T) {
+        const int src = s_order[t];
+        a.order[(size_t)b * Mt + t] = src;
+        const float *c = a.centers + ((size_t)b * M + src) * 3;
+        sx[t] = c[0]; sy[t] = c[1]; sz[t] = c[2];
+        s_flag[t] = 0;
+    }
+    __syncthreads();
+
+    // ---- 2. farthest point sampling (sequential in k, parallel over points)
+    float px[P], py[P], pz[P], mind[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const int t = tid + i * T;
+        if (t < Mt) { px[i] = sx[t]; py[i] = sy[t]; pz[i] = sz[t]; } else { px[i] = py[i] = pz[i] = 0.0f; }
+        mind[i] = INFINITY;
+    }
+    int last = 0;
+    if (tid == 0 && Kd > 0) s_picks[0] = 0;
+    const int kn = Kd < Mt ? Kd : Mt;                                            // PRE:595
+    for (int k = 1; k < kn; ++k) {
+        const float lx = sx[last], ly = sy[last], lz = sz[last];
+        float bv = -1.0f; int bi = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const int t = tid + i * T;
+            if (t < Mt) {
+                const float d2 = dist2_nofma(lx, ly, lz, px[i], py[i], pz[i]);
+                const float mnv = fminf(mind[i], d2);                            // PRE:609
+                mind[i] = mnv;
+                if (mnv > bv) { bv = mnv; bi = t; }                              // t ascending in i: first max
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        const int par = k & 1;
+        if (lane == 0) { s_redv[par * 4 + wid] = bv; s_redi[par * 4 + wid] = bi; }
+        __syncthreads();
+        bv = s_redv[par * 4]; bi = s_redi[par * 4];
+        for (int ww = 1; ww < nw; ++ww) {
+            const float ov = s_redv[par * 4 + ww]; const int oi = s_redi[par * 4 + ww];
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        last = bi;                                                               // PRE:613 argmax, first max
+        if (tid == 0) s_picks[k] = last;
+    }
+    __syncthreads();
+    for (int k = tid; k < Kd; k += T) {
+        const int pk = k < kn ? s_picks[k] : -1;
+        a.picks[(size_t)b * Kd + k] = pk;
+        if (pk >= 0) s_flag[pk] = 1;            // duplicates write the same value
+    }
+    __syncthreads();
+
+    // ---- 3. keep list: ascending positions that were not picked, first Mk (PRE:400-406)
+    if (wid == 0) {
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        int n = 0;
+        for (int t0 = 0; t0 < Mt && n < Mk; t0 += 64) {
+            const int t = t0 + lane;
+            const bool kp = t < Mt && s_flag[t] == 0;
+            const unsigned long long mask = __ballot(kp);
+            const int pos = n + __popcll(mask & lt);
+            if (kp && pos < Mk) s_keep[pos] = t;
+            n += __popcll(mask);
+        }
+    }
+    __syncthreads();
+
+    // ---- 4/5. gathers, drop list, tags
+    uint32_t *tag = a.tag ? a.tag + (size_t)b * a.N : nullptr;
+    for (int j = tid; j < Mk; j += T) {
+        const int t = s_keep[j];
+        a.keep[(size_t)b * Mk + j] = t;
+        a.kcenter[((size_t)b * Mk + j) * 3] = sx[t];
+        a.kcenter[((size_t)b * Mk + j) * 3 + 1] = sy[t];
+        a.kcenter[((size_t)b * Mk + j) * 3 + 2] = sz[t];
+    }
+    for (int e = tid; e < Mk * K; e += T) {
+        const int j = e / K, k = e - j * K;
+        const int src = s_order[s_keep[j]];
+        const int id = a.idx[((size_t)b * M + src) * K + k];
+        a.kidx[(size_t)b * Mk * K + e] = id;
+        const float *cp = a.cluster + (((size_t)b * M + src) * K + k) * 3;
+        float *op = a.kcluster + ((size_t)b * Mk * K + e) * 3;
+        op[0] = cp[0]; op[1] = cp[1]; op[2] = cp[2];
+        if (tag && id >= 0) atomicMax(&tag[id], (uint32_t)(e + 1));              // last (m,k) writer wins
+    }
+    // every owner atomic of this scene has completed (vmcnt(0) + barrier) before a drop bit is
+    // OR-ed in, so a dropped point keeps its owner in the low 31 bits
+    __syncthreads();
+    for (int e = tid; e < Kd * K; e += T) {
+        const int kk = e / K, k = e - kk * K;
+        const int pk = kk < kn ? s_picks[kk] : -1;
+        int id = -1;
+        if (pk >= 0) id = a.idx[((size_t)b * M + s_order[pk]) * K + k];
+        a.drop_idx[(size_t)b * Kd * K + e] = id;
+        if (tag && id >= 0) atomicOr(&tag[id], 0x80000000u);
+    }
+}
+
+static size_t select_lds_bytes(const PtxShape &s)
+{
+    const int Kd = s.Mt - s.Mk;
+    return sizeof(int) * ((size_t)s.Mt * 5 + s.Mk + (Kd > 0 ? Kd : 1) + 64 + 16);
+}
+
+int launch_select(const PtxShape &s, const int32_t *idx, const float *centers, const float *cluster,
+                  const int32_t *pad_count, const int32_t *order_override, int32_t *order,
+                  int32_t *picks, int32_t *keep, float *kcenter, float *kcluster, int32_t *kidx,
+                  int32_t *drop_idx, uint32_t *tag, hipStream_t st)
+{
+    SelectArgs a{idx, centers, cluster, pad_count, order_override, order, picks, keep, kcenter,
+                 kcluster, kidx, drop_idx, tag, s.grid_size * s.grid_size * s.grid_size, s.K, s.Mt,
+                 s.Mk, s.Mt - s.Mk, s.N};
+    const size_t lds = select_lds_bytes(s);
+    PTX_REQUIRE(lds <= 160 * 1024, "select: Mt=%d needs %zu B of LDS (> 160 KiB)", s.Mt, lds);
+    const int per = cdiv(s.Mt, 256);
+    const dim3 grid(s.B), block(256);
+#define PTX_SEL(P_)                                                                          \
+    do {                                                                                     \
+        if (lds > 64 * 1024)                                                                 \
+            PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_select<P_>),       \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(k_select<P_>, grid, block, lds, st, a);                           \
+    } while (0)
+    if (per <= 2) PTX_SEL(2);
+    else if (per <= 6) PTX_SEL(6);
+    else if (per <= 12) PTX_SEL(12);
+    else if (per <= 24) PTX_SEL(24);
+    else { set_error("select: Mt=%d too large (max %d)", s.Mt, 256 * 24); return PTX_EINVAL; }
+#undef PTX_SEL
+    PTX_LAUNCHED("k_select");
+    return PTX_OK;
+}
+
+// ------------------------------------------------------------------------------ apply
+// tag word per point: bit 31 = dropped (PRE:516-523), low 31 bits = 1 + owning flat (m,k) slot
+// (last writer in flat order, PRE:495 single-thread semantics), 0 = untouched.
+__global__ __launch_bounds__(256) void k_tile_count(const uint32_t *__restrict__ tag, int N,
+                                                    int32_t *__restrict__ tile_counts)
+{
+    const int b = blockIdx.y, tile = blockIdx.x;
+    const uint32_t *tg = tag + (size_t)b * N;
+    int c = 0;
+#pragma unroll
+    for (int r = 0; r < kTilePts / 256; ++r) {
+        const int n = tile * kTilePts + r * 256 + threadIdx.x;
+        if (n < N) c += (tg[n] >> 31) == 0;
+    }
+    c = wave_sum(c);
+    __shared__ int red[4];
+    if (lane_id() == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_counts[b * gridDim.x + tile] = red[0] + red[1] + red[2] + red[3];
+}
+
+int launch_tile_count(const uint32_t *tag, int B, int N, int32_t *tile_counts, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_tile_count, dim3(cdiv(N, kTilePts), B), dim3(256), 0, st, tag, N, tile_counts);
+    PTX_LAUNCHED("k_tile_count");
+    return PTX_OK;
+}
+
+struct AffineArgs {
+    const float *points; const uint32_t *tag; const float *kcenter, *translate, *transform;
+    float *out; int32_t *counts; const int32_t *tile_counts; int N, Mk, K;
+};
+
+template <bool COMPACT>
+__global__ __launch_bounds__(256) void k_affine(AffineArgs a)
+{
+    const int b = blockIdx.y, tile = blockIdx.x, ntiles = gridDim.x;
+    const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
+    const uint32_t *tg = a.tag + (size_t)b * a.N;
+    const float *pts = a.points + (size_t)b * a.N * 3;
+    float *out = a.out + (size_t)b * a.N * 3;
+    constexpr int R = kTilePts / 256;
+    __shared__ int s_cnt[R][4];
+    __shared__ int s_base;
+    int base = 0;
+    if (COMPACT) {
+        int acc = 0;
+        for (int t = tid; t < tile; t += 256) acc += a.tile_counts[b * ntiles + t];
+        acc = wave_sum(acc);
+        if (lane == 0) s_cnt[0][wid] = acc;
+        __syncthreads();
+        if (tid == 0) s_base = s_cnt[0][0] + s_cnt[0][1] + s_cnt[0][2] + s_cnt[0][3];
+        __syncthreads();
+        base = s_base;
+        __syncthreads();
+    }
+    float v[R][3]; bool keep[R]; unsigned long long bal[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int n = tile * kTilePts + r * 256 + tid;
+        keep[r] = false;
+        if (n < a.N) {
+            const uint32_t t = tg[n];
+            float x = pts[(size_t)n * 3], y = pts[(size_t)n * 3 + 1], z = pts[(size_t)n * 3 + 2];
+            keep[r] = !COMPACT || (t >> 31) == 0;
+            const uint32_t own = t & 0x7fffffffu;
+            if (own != 0 && keep[r]) {
+                const int j = (int)(own - 1) / a.K;
+                const float *c = a.kcenter + ((size_t)b * a.Mk + j) * 3;
+                const float *T = a.transform + ((size_t)b * a.Mk + j) * 9;
+                const float *tr = a.translate + ((size_t)b * a.Mk + j) * 3;
+                const float dx = x - c[0], dy = y - c[1], dz = z - c[2];
+                // (T (p-c)^T)^T + c + t     PRE:462
+                const float rx = fmaf(T[2], dz, fmaf(T[1], dy, T[0] * dx));
+                const float ry = fmaf(T[5], dz, fmaf(T[4], dy, T[3] * dx));
+                const float rz = fmaf(T[8], dz, fmaf(T[7], dy, T[6] * dx));
+                x = (rx + c[0]) + tr[0]; y = (ry + c[1]) + tr[1]; z = (rz + c[2]) + tr[2];
+            }
+            v[r][0] = x; v[r][1] = y; v[r][2] = z;
+        }
+        bal[r] = __ballot(keep[r]);
+        if (COMPACT && lane == 0) s_cnt[r][wid] = __popcll(bal[r]);
+    }
+    if (!COMPACT) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int n = tile * kTilePts + r * 256 + tid;
+            if (n < a.N) { out[(size_t)n * 3] = v[r][0]; out[(size_t)n * 3 + 1] = v[r][1]; out[(size_t)n * 3 + 2] = v[r][2]; }
+        }
+        return;
+    }
+    __syncthreads();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int run = base;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int before = 0;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) before += ww < wid ? s_cnt[r][ww] : 0;
+        if (keep[r]) {
+            const size_t pos = (size_t)(run + before + __popcll(bal[r] & lt));
+            out[pos * 3] = v[r][0]; out[pos * 3 + 1] = v[r][1]; out[pos * 3 + 2] = v[r][2];
+        }
+        run += s_cnt[r][0] + s_cnt[r][1] + s_cnt[r][2] + s_cnt[r][3];
+    }
+    if (tile == ntiles - 1 && tid == 0) a.counts[b] = run;
+}
+
+int launch_affine(const PtxShape &s, const float *points, const uint32_t *tag, const float *kcenter,
+                  const float *translate, const float *transform, float *out, int32_t *counts,
+                  const int32_t *tile_counts, bool compact, hipStream_t st)
+{
+    AffineArgs a{points, tag, kcenter, translate, transform, out, counts, tile_counts, s.N, s.Mk, s.K};
+    const dim3 grid(cdiv(s.N, kTilePts), s.B), block(256);
+    if (compact) hipLaunchKernelGGL(k_affine<true>, grid, block, 0, st, a);
+    else         hipLaunchKernelGGL(k_affine<false>, grid, block, 0, st, a);
+    PTX_LAUNCHED("k_affine");
+    return PTX_OK;
+}
+
+}  // namespace ptx

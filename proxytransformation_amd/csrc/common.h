@@ -1,0 +1,191 @@
+// Internal helpers shared by the gfx950 translation units of libproxyt_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/proxyt.h"
+
+namespace ptx {
+
+void set_error(const char *fmt, ...);
+
+#define PTX_REQUIRE(cond, ...)                                   \
+    do {                                                         \
+        if (!(cond)) {                                           \
+            ::ptx::set_error(__VA_ARGS__);                       \
+            return PTX_EINVAL;                                   \
+        }                                                        \
+    } while (0)
+
+#define PTX_HIP(expr)                                                              \
+    do {                                                                           \
+        hipError_t e_ = (expr);                                                    \
+        if (e_ != hipSuccess) {                                                    \
+            ::ptx::set_error("%s failed: %s", #expr, hipGetErrorString(e_));       \
+            return PTX_ELAUNCH;                                                    \
+        }                                                                          \
+    } while (0)
+
+#define PTX_LAUNCHED(name)                                                         \
+    do {                                                                           \
+        hipError_t e_ = hipGetLastError();                                         \
+        if (e_ != hipSuccess) {                                                    \
+            ::ptx::set_error("launch %s failed: %s", name, hipGetErrorString(e_)); \
+            return PTX_ELAUNCH;                                                    \
+        }                                                                          \
+    } while (0)
+
+#define PTX_TRY(expr)                 \
+    do {                              \
+        int rc_ = (expr);             \
+        if (rc_ != PTX_OK) return rc_;\
+    } while (0)
+
+constexpr int kWave = 64;
+constexpr int kSlotHidden = 256;   // OffsetNetwork / SimplifiedPointNet width is hard-coded (PRE:31,302)
+constexpr int kTilePts = 2048;     // points per compaction tile
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- device helpers -------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// order-preserving float <-> uint32 (larger float <=> larger uint)
+__device__ __forceinline__ uint32_t f2ord(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+// squared distance exactly as pytorch3d's CPU loops accumulate it: ((dx*dx)+dy*dy)+dz*dz,
+// one rounding per operation, never contracted into an FMA.
+__device__ __forceinline__ float dist2_nofma(float ax, float ay, float az, float bx, float by, float bz) {
+    float dx = __fsub_rn(ax, bx), dy = __fsub_rn(ay, by), dz = __fsub_rn(az, bz);
+    return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
+// ---- parameter-only tables (ptx_prepare) ------------------------------------
+struct PrepLayout {
+    // all offsets in floats from the start of `prep`
+    size_t off_ab, enc_ab;          // (2,256): alpha, beta of the folded eval BatchNorm2d
+    size_t ttn_ab, itn_ab;          // (2,3), (2,9) BatchNorm1d alpha/beta
+    size_t posb_t, posb_i;          // (Mk,C) per-slot bias tables (PRE:212-215)
+    size_t x0b;                     // (C)  channel_mapper.bias + pos[0]
+    size_t wqkv0, bqkv0;            // (3C,C), (3C): [q;k;v] projections of token 0
+    size_t t1;                      // (heads, KT1, hd): scale * [WkWc | K-proj of (bc+pos_i)]
+    size_t t2;                      // (heads, hd, KT2p): [WvWc | V-proj of (bc+pos_i)] (transposed)
+    size_t total;                   // floats
+    int KT1, KT2p, hd;
+};
+PrepLayout prep_layout(const PtxShape &s);
+
+// ---- per-call scratch ---------------------------------------------------------
+struct WsLayout {
+    // byte offsets from the start of the workspace
+    size_t zero_begin, zero_bytes;  // region cleared by one memset per call
+    size_t mm_enc;                  // (B,6) uint32 encoded min / max
+    size_t tag;                     // (B,N) uint32
+    size_t minmax, centers0, cluster1, offsets, centers, idx2, cluster2, pad_count;
+    size_t order, picks, keep, kcenter, kcluster, kidx, drop_idx, tile_counts;
+    size_t point_proxy, x_in[2];    // x_in: LN1(x)+slot bias per branch (B*Mk,C)
+    size_t fm, x0, qkv0, we, gbuf, obuf, cbuf, img_proxy;
+    size_t qkv[2], pt[2], pv[2], ao[2], x1[2], xn2[2], hbuf[2], x2[2], guide[2], head[2];
+    size_t total;
+};
+WsLayout ws_layout(const PtxShape &s);
+
+int validate_shape(const PtxShape &s);
+
+// ---- grouped NT GEMM (gemm.hip) --------------------------------------------------
+enum : int { EPI_NONE = 0, EPI_GELU = 1 };
+struct GemmProb {
+    const float *A; const float *W; float *C;
+    const float *bias;      // (N) or null
+    const float *res;       // residual (R,N) ld = ldres, or null
+    const float *rs;        // per-row scalar, element r*rs_stride, or null
+    const float *ad;        // addend (R,N) ld = ldad, multiplied by rs
+    int R, N, K, lda, ldw, ldc, ldres, rs_stride, ldad, epi;
+};
+constexpr int kMaxGroups = 8;
+struct GemmBatch { GemmProb p[kMaxGroups]; int n; };
+int launch_gemm(const GemmBatch &gb, hipStream_t st);
+
+struct LnProb { const float *x; float *y; const float *w; const float *b; const float *add; int R, add_rows; };
+struct LnBatch { LnProb p[2]; int n; int C; float eps; };
+int launch_ln_rows(const LnBatch &lb, hipStream_t st);
+
+struct HeadProb {
+    const float *x; const float *nw; const float *nb;   // rows (R,C), LayerNorm weight/bias
+    const float *hw; const float *hb;                   // Linear (nout,C), (nout)
+    const float *ab;                                    // (2,nout) BatchNorm1d alpha, beta
+    float *out; float *guide; int R, nout;
+};
+struct HeadBatch { HeadProb p[2]; int n; int C; float eps; };
+int launch_heads(const HeadBatch &hb, hipStream_t st);
+
+// ---- proxy attention (attn.hip) -----------------------------------------------------
+struct AttnProb {
+    const float *Q, *K, *V; float *O; const uint8_t *mask;   // mask (B,nk), 1 = valid, or null
+    int nq, nk, ldq, ldk, ldv, ldo;
+    long sQ, sK, sV, sO;                                     // per-scene strides (elements)
+};
+struct AttnBatch { AttnProb p[2]; int n; int B, heads; float scale; };
+int launch_attn32(const AttnBatch &ab, hipStream_t st);
+
+// ---- clustering / apply (cluster.hip) ---------------------------------------------------
+int launch_minmax(const float *points, int B, int N, uint32_t *mm_enc, hipStream_t st);
+int launch_ball_query(const float *centers, const uint32_t *mm_enc, const float *lin, int gs,
+                      float margin, float *minmax_out, float *centers_out, const float *points,
+                      int B, int M, int N, int K, float radius, int32_t *idx, float *cluster,
+                      int32_t *pad_count, hipStream_t st);
+int launch_offset_net(const float *ab, const PtxSlotMlp &mlp, const float *map_w,
+                      const float *centers_in, const float *cluster, const float *minmax,
+                      int BM, int M, int K, float margin, float *centers_out, float *offsets_out,
+                      hipStream_t st);
+int launch_pointnet(const float *ab, const PtxSlotMlp &mlp, const float *kcenter,
+                    const float *kcluster, int BM, int Mk, int K, float *point_proxy,
+                    const PtxBlock *blk_t, const PtxBlock *blk_i, const float *posb_t,
+                    const float *posb_i, float *xin_t, float *xin_i, float ln_eps, hipStream_t st);
+int launch_select(const PtxShape &s, const int32_t *idx, const float *centers, const float *cluster,
+                  const int32_t *pad_count, const int32_t *order_override, int32_t *order,
+                  int32_t *picks, int32_t *keep, float *kcenter, float *kcluster, int32_t *kidx,
+                  int32_t *drop_idx, uint32_t *tag, hipStream_t st);
+int launch_tile_count(const uint32_t *tag, int B, int N, int32_t *tile_counts, hipStream_t st);
+int launch_affine(const PtxShape &s, const float *points, const uint32_t *tag, const float *kcenter,
+                  const float *translate, const float *transform, float *out, int32_t *counts,
+                  const int32_t *tile_counts, bool compact, hipStream_t st);
+
+// ---- image proxy (imgproxy.hip) ------------------------------------------------------------
+int launch_img_mean(const float *img, int nimg, int in_dim, int hw, float *fm, hipStream_t st);
+int launch_img_scores(const float *img, const float *we, const float *qkv0, int nimg, int in_dim,
+                      int hw, int heads, int C, int KT1, int KT2p, float scale, float *gbuf,
+                      hipStream_t st);
+int launch_img_gather(const float *img, int nimg, int in_dim, int hw, int heads, int KT2p,
+                      float *gbuf, hipStream_t st);
+
+// ---- prep (prep.hip) ----------------------------------------------------------------------------
+int run_prepare(const PtxShape &s, const PtxWeights &w, float *prep, hipStream_t st);
+
+}  // namespace ptx

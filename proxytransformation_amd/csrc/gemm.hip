@@ -1,0 +1,197 @@
+// fp32 matrix-core kernels of the proxy blocks and the folded attention pool.
+//
+//   k_gemm_nt   C[r][n] = sum_k A[r][k] * W[n][k]  (+bias, GELU, residual, row-scaled addend)
+//               grouped: blockIdx.z selects one of up to 8 problems (text / image branch,
+//               or the 8 heads of the folded AttentionPool2d tables).
+//               v_mfma_f32_32x32x2_f32: exact fp32 (parity config), 64x64 tile per
+//               4-wave work-group, each wave one 32x32 accumulator.
+//   k_ln_rows   LayerNorm over the channel dim, one wave per row (PRE:275 norm2, PRE:340 norm_img)
+//   k_heads     trailing LayerNorm + Linear(C,3|9) + eval BatchNorm1d (PRE:443-446, 452-455)
+#include "common.h"
+
+namespace ptx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 64, BN = 64, BK = 16, LDT = BK + 4;   // LDT*4 B = 80 B rows: 16-B aligned
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__global__ __launch_bounds__(256) void k_gemm_nt(GemmBatch gb)
+{
+    const GemmProb &pr = gb.p[blockIdx.z];
+    const int row0 = blockIdx.y * BM, col0 = blockIdx.x * BN;
+    if (row0 >= pr.R || col0 >= pr.N) return;
+    __shared__ __attribute__((aligned(16))) float As[BM][LDT];
+    __shared__ __attribute__((aligned(16))) float Ws[BN][LDT];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    const int li = lane & 31, hh = lane >> 5;
+    // staging assignment: thread -> (row = tid/4, 4 consecutive k at (tid%4)*4)
+    const int sr = tid >> 2, sk = (tid & 3) * 4;
+    const float *Ap = pr.A + (size_t)(row0 + sr) * pr.lda + sk;
+    const float *Wp = pr.W + (size_t)(col0 + sr) * pr.ldw + sk;
+    const bool a_ok = (row0 + sr) < pr.R, w_ok = (col0 + sr) < pr.N;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    for (int k0 = 0; k0 < pr.K; k0 += BK) {
+        float4 av = make_float4(0.f, 0.f, 0.f, 0.f), wv = av;
+        if (k0 + sk < pr.K) {                                   // K % 4 == 0 is validated by the host
+            if (a_ok) av = *reinterpret_cast<const float4 *>(Ap + k0);
+            if (w_ok) wv = *reinterpret_cast<const float4 *>(Wp + k0);
+        }
+        __syncthreads();                                        // previous tile fully consumed
+        *reinterpret_cast<float4 *>(&As[sr][sk]) = av;
+        *reinterpret_cast<float4 *>(&Ws[sr][sk]) = wv;
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            // lane half hh owns k = kk*8 + hh*4 .. +3 of this group for both operands, so the
+            // two k-values an MFMA consumes (one per half) are consistent between A and B
+            const float4 a4 = *reinterpret_cast<const float4 *>(&As[wr * 32 + li][kk * 8 + hh * 4]);
+            const float4 b4 = *reinterpret_cast<const float4 *>(&Ws[wc * 32 + li][kk * 8 + hh * 4]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+        }
+    }
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const int n = col0 + wc * 32 + li;
+    if (n >= pr.N) return;
+    const float bias = pr.bias ? pr.bias[n] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = row0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (row < pr.R) {
+            float v = acc[r] + bias;
+            if (pr.epi == EPI_GELU) v = gelu_erf(v);
+            if (pr.rs) v = fmaf(pr.rs[(size_t)row * pr.rs_stride], pr.ad[(size_t)row * pr.ldad + n], v);
+            if (pr.res) v += pr.res[(size_t)row * pr.ldres + n];
+            pr.C[(size_t)row * pr.ldc + n] = v;
+        }
+    }
+}
+
+int launch_gemm(const GemmBatch &gb, hipStream_t st)
+{
+    PTX_REQUIRE(gb.n >= 1 && gb.n <= kMaxGroups, "gemm: %d groups", gb.n);
+    int tm = 0, tn = 0;
+    for (int g = 0; g < gb.n; ++g) {
+        const GemmProb &p = gb.p[g];
+        PTX_REQUIRE(p.A && p.W && p.C, "gemm: null operand in group %d", g);
+        PTX_REQUIRE(p.K % 4 == 0 && p.lda % 4 == 0 && p.ldw % 4 == 0,
+                    "gemm: K=%d lda=%d ldw=%d must be multiples of 4", p.K, p.lda, p.ldw);
+        PTX_REQUIRE(((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.W)) & 15) == 0,
+                    "gemm: operands of group %d are not 16-byte aligned", g);
+        PTX_REQUIRE(p.rs == nullptr || p.ad != nullptr, "gemm: row scale without addend");
+        if (cdiv(p.R, BM) > tm) tm = cdiv(p.R, BM);
+        if (cdiv(p.N, BN) > tn) tn = cdiv(p.N, BN);
+    }
+    if (tm == 0 || tn == 0) return PTX_OK;
+    hipLaunchKernelGGL(k_gemm_nt, dim3(tn, tm, gb.n), dim3(256), 0, st, gb);
+    PTX_LAUNCHED("k_gemm_nt");
+    return PTX_OK;
+}
+
+// ------------------------------------------------------------------------------ LayerNorm rows
+// one wave per row; C is a multiple of 64 and at most 512 (8 values per lane)
+constexpr int kMaxPerLane = 8;
+
+__device__ __forceinline__ void ln_row(const float *x, int C, float eps, float (&v)[kMaxPerLane],
+                                       float &mean, float &rstd)
+{
+    const int lane = lane_id();
+    float s = 0.0f;
+#pragma unroll
+    for (int q = 0; q < kMaxPerLane; ++q) {
+        const int c = lane + 64 * q;
+        v[q] = c < C ? x[c] : 0.0f;
+        s += v[q];
+    }
+    mean = wave_sum(s) / (float)C;
+    float var = 0.0f;
+#pragma unroll
+    for (int q = 0; q < kMaxPerLane; ++q) {
+        const int c = lane + 64 * q;
+        const float d = c < C ? v[q] - mean : 0.0f;
+        var = fmaf(d, d, var);
+    }
+    rstd = 1.0f / sqrtf(wave_sum(var) / (float)C + eps);
+}
+
+__global__ __launch_bounds__(256) void k_ln_rows(LnBatch lb)
+{
+    const LnProb &p = lb.p[blockIdx.y];
+    const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (row >= p.R) return;
+    float v[kMaxPerLane], mean, rstd;
+    ln_row(p.x + (size_t)row * lb.C, lb.C, lb.eps, v, mean, rstd);
+    const int lane = lane_id();
+#pragma unroll
+    for (int q = 0; q < kMaxPerLane; ++q) {
+        const int c = lane + 64 * q;
+        if (c < lb.C) {
+            float y = (v[q] - mean) * rstd * p.w[c] + p.b[c];
+            if (p.add) y += p.add[(size_t)(row % p.add_rows) * lb.C + c];
+            p.y[(size_t)row * lb.C + c] = y;
+        }
+    }
+}
+
+int launch_ln_rows(const LnBatch &lb, hipStream_t st)
+{
+    PTX_REQUIRE(lb.C % 64 == 0 && lb.C <= 64 * kMaxPerLane, "layer norm: C=%d unsupported", lb.C);
+    int rmax = 0;
+    for (int g = 0; g < lb.n; ++g) rmax = lb.p[g].R > rmax ? lb.p[g].R : rmax;
+    if (rmax == 0) return PTX_OK;
+    hipLaunchKernelGGL(k_ln_rows, dim3(cdiv(rmax, 4), lb.n), dim3(256), 0, st, lb);
+    PTX_LAUNCHED("k_ln_rows");
+    return PTX_OK;
+}
+
+// ------------------------------------------------------------------------------ heads
+__global__ __launch_bounds__(256) void k_heads(HeadBatch hb)
+{
+    const HeadProb &p = hb.p[blockIdx.y];
+    const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (row >= p.R) return;
+    float v[kMaxPerLane], mean, rstd;
+    ln_row(p.x + (size_t)row * hb.C, hb.C, hb.eps, v, mean, rstd);
+    const int lane = lane_id();
+#pragma unroll
+    for (int q = 0; q < kMaxPerLane; ++q) {
+        const int c = lane + 64 * q;
+        if (c < hb.C) {
+            v[q] = (v[q] - mean) * rstd * p.nw[c] + p.nb[c];
+            if (p.guide) p.guide[(size_t)row * hb.C + c] = v[q];
+        } else v[q] = 0.0f;
+    }
+    for (int o = 0; o < p.nout; ++o) {
+        float s = 0.0f;
+#pragma unroll
+        for (int q = 0; q < kMaxPerLane; ++q) {
+            const int c = lane + 64 * q;
+            if (c < hb.C) s = fmaf(p.hw[(size_t)o * hb.C + c], v[q], s);
+        }
+        s = wave_sum(s);
+        if (lane == 0) {
+            const float y = s + p.hb[o];
+            p.out[(size_t)row * p.nout + o] = fmaf(y, p.ab[o], p.ab[p.nout + o]);   // eval BatchNorm1d
+        }
+    }
+}
+
+int launch_heads(const HeadBatch &hb, hipStream_t st)
+{
+    PTX_REQUIRE(hb.C % 64 == 0 && hb.C <= 64 * kMaxPerLane, "heads: C=%d unsupported", hb.C);
+    int rmax = 0;
+    for (int g = 0; g < hb.n; ++g) rmax = hb.p[g].R > rmax ? hb.p[g].R : rmax;
+    if (rmax == 0) return PTX_OK;
+    hipLaunchKernelGGL(k_heads, dim3(cdiv(rmax, 4), hb.n), dim3(256), 0, st, hb);
+    PTX_LAUNCHED("k_heads");
+    return PTX_OK;
+}
+
+}  // namespace ptx

@@ -1,0 +1,126 @@
+// Parameter-only tables (run once per set of weights by ptx_prepare, never on the per-scene
+// path): folded eval-mode BatchNorm scale/shift, the per-slot bias tables of ProxyAttention
+// (PRE:212-215), and the products that fold Conv2d(512,256,1) into AttentionPool2d's key /
+// value projections (see imgproxy.hip).  One thread per output element: clarity over speed.
+#include "common.h"
+
+namespace ptx {
+
+// eval BatchNorm as ATen applies it: alpha = w / sqrt(var + eps), beta = b - mean * alpha
+__global__ void k_prep_bn(const float *w, const float *b, const float *mean, const float *var,
+                          int n, float eps, float *ab)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float alpha = w[i] / sqrtf(var[i] + eps);
+    ab[i] = alpha;
+    ab[n + i] = b[i] - mean[i] * alpha;
+}
+
+// bias[j][y*s+x] = bilinear(pb[j] 4x4 -> s x s, align_corners=False)[y][x] + pc[j][y] + pr[j][x]
+__global__ void k_prep_posbias(const float *pb, const float *pc, const float *pr, int Mk, int s,
+                               float *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Mk * s * s) return;
+    const int j = i / (s * s), yx = i - j * s * s, y = yx / s, x = yx - y * s;
+    const float sc = 4.0f / (float)s;
+    float sy = sc * ((float)y + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
+    float sx = sc * ((float)x + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < 3 ? 1 : 0), x1 = x0 + (x0 < 3 ? 1 : 0);
+    const float ly1 = sy - (float)y0, ly0 = 1.f - ly1, lx1 = sx - (float)x0, lx0 = 1.f - lx1;
+    const float *p = pb + (size_t)j * 16;
+    const float v = ly0 * (lx0 * p[y0 * 4 + x0] + lx1 * p[y0 * 4 + x1]) +
+                    ly1 * (lx0 * p[y1 * 4 + x0] + lx1 * p[y1 * 4 + x1]);
+    out[i] = v + (pc[(size_t)j * s + y] + pr[(size_t)j * s + x]);
+}
+
+__global__ void k_prep_qkv0(const float *qw, const float *kw, const float *vw, const float *qb,
+                            const float *cb, const float *pos, int C, float *wqkv0, float *bqkv0,
+                            float *x0b)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 3 * C * C) {
+        const int part = i / (C * C), r = i - part * C * C;
+        wqkv0[i] = part == 0 ? qw[r] : (part == 1 ? kw[r] : vw[r]);
+    }
+    if (i < 3 * C) bqkv0[i] = i < C ? qb[i] : 0.0f;
+    if (i < C) x0b[i] = cb[i] + pos[i];
+}
+
+// T1[h][t][d], t < in_dim : scale * sum_j Wk[h*hd+d][j] * Wc[j][t]
+//              t = in_dim+i: scale * sum_j Wk[h*hd+d][j] * (bc[j] + pos[i][j])   (i = 0 unused: 0)
+__global__ void k_prep_t1(const float *kw, const float *cw, const float *cb, const float *pos, int C,
+                          int in_dim, int hw, int heads, float scale, float *t1)
+{
+    const int hd = C / heads, KT1 = in_dim + hw + 1;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= heads * KT1 * hd) return;
+    const int h = i / (KT1 * hd), rem = i - h * KT1 * hd, t = rem / hd, d = rem - t * hd;
+    const float *wk = kw + (size_t)(h * hd + d) * C;
+    float s = 0.0f;
+    if (t < in_dim) {
+        for (int j = 0; j < C; ++j) s = fmaf(wk[j], cw[(size_t)j * in_dim + t], s);
+    } else if (t > in_dim) {
+        const float *pi = pos + (size_t)(t - in_dim) * C;
+        for (int j = 0; j < C; ++j) s = fmaf(wk[j], cb[j] + pi[j], s);
+    }
+    t1[i] = s * scale;
+}
+
+// T2[h][d][t], t < in_dim : sum_j Wv[h*hd+d][j] * Wc[j][t]
+//              t = in_dim+i: sum_j Wv[h*hd+d][j] * (bc[j] + pos[i][j]) for 1 <= i <= hw, else 0
+__global__ void k_prep_t2(const float *vw, const float *cw, const float *cb, const float *pos, int C,
+                          int in_dim, int hw, int heads, int KT2p, float *t2)
+{
+    const int hd = C / heads;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= heads * hd * KT2p) return;
+    const int h = i / (hd * KT2p), rem = i - h * hd * KT2p, d = rem / KT2p, t = rem - d * KT2p;
+    const float *wv = vw + (size_t)(h * hd + d) * C;
+    float s = 0.0f;
+    if (t < in_dim) {
+        for (int j = 0; j < C; ++j) s = fmaf(wv[j], cw[(size_t)j * in_dim + t], s);
+    } else if (t > in_dim && t <= in_dim + hw) {
+        const float *pi = pos + (size_t)(t - in_dim) * C;
+        for (int j = 0; j < C; ++j) s = fmaf(wv[j], cb[j] + pi[j], s);
+    }
+    t2[i] = s;
+}
+
+int run_prepare(const PtxShape &s, const PtxWeights &w, float *prep, hipStream_t st)
+{
+    const PrepLayout P = prep_layout(s);
+    const int C = s.C, T = 256;
+    hipLaunchKernelGGL(k_prep_bn, dim3(1), dim3(T), 0, st, w.offset.bn_w, w.offset.bn_b,
+                       w.offset.bn_mean, w.offset.bn_var, kSlotHidden, s.bn_eps, prep + P.off_ab);
+    hipLaunchKernelGGL(k_prep_bn, dim3(1), dim3(T), 0, st, w.encoder.bn_w, w.encoder.bn_b,
+                       w.encoder.bn_mean, w.encoder.bn_var, kSlotHidden, s.bn_eps, prep + P.enc_ab);
+    hipLaunchKernelGGL(k_prep_bn, dim3(1), dim3(T), 0, st, w.text_trans_norm.w, w.text_trans_norm.b,
+                       w.text_trans_norm.mean, w.text_trans_norm.var, 3, s.bn_eps, prep + P.ttn_ab);
+    hipLaunchKernelGGL(k_prep_bn, dim3(1), dim3(T), 0, st, w.img_trans_norm.w, w.img_trans_norm.b,
+                       w.img_trans_norm.mean, w.img_trans_norm.var, 9, s.bn_eps, prep + P.itn_ab);
+    PTX_LAUNCHED("k_prep_bn");
+    int sd = 1;
+    while (sd * sd < C) ++sd;
+    const int nb = s.Mk * C;
+    hipLaunchKernelGGL(k_prep_posbias, dim3(cdiv(nb, T)), dim3(T), 0, st, w.text.pb_bias, w.text.pc_bias,
+                       w.text.pr_bias, s.Mk, sd, prep + P.posb_t);
+    hipLaunchKernelGGL(k_prep_posbias, dim3(cdiv(nb, T)), dim3(T), 0, st, w.img.pb_bias, w.img.pc_bias,
+                       w.img.pr_bias, s.Mk, sd, prep + P.posb_i);
+    PTX_LAUNCHED("k_prep_posbias");
+    hipLaunchKernelGGL(k_prep_qkv0, dim3(cdiv(3 * C * C, T)), dim3(T), 0, st, w.q_w, w.k_w, w.v_w, w.q_b,
+                       w.cm_b, w.pos, C, prep + P.wqkv0, prep + P.bqkv0, prep + P.x0b);
+    PTX_LAUNCHED("k_prep_qkv0");
+    const float scale = 1.0f / sqrtf((float)P.hd);
+    hipLaunchKernelGGL(k_prep_t1, dim3(cdiv(s.heads * P.KT1 * P.hd, T)), dim3(T), 0, st, w.k_w, w.cm_w,
+                       w.cm_b, w.pos, C, s.in_dim, s.hw, s.heads, scale, prep + P.t1);
+    PTX_LAUNCHED("k_prep_t1");
+    hipLaunchKernelGGL(k_prep_t2, dim3(cdiv(s.heads * P.hd * P.KT2p, T)), dim3(T), 0, st, w.v_w, w.cm_w,
+                       w.cm_b, w.pos, C, s.in_dim, s.hw, s.heads, P.KT2p, prep + P.t2);
+    PTX_LAUNCHED("k_prep_t2");
+    return PTX_OK;
+}
+
+}  // namespace ptx

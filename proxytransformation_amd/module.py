@@ -1,0 +1,346 @@
+"""``ProxyTransformationNormReverse`` for MI355X: the reference's registry entry,
+constructor, ``state_dict`` layout and ``forward`` contract, executed by the
+hand-written HIP kernels of ``libproxyt_hip.so`` through a ctypes C ABI.
+
+Reference: embodiedscan/models/necks/preshape_norm_reverse_drop.py (PRE)
+  * class + registration          PRE:280-281
+  * constructor arguments         PRE:282-285 (kept verbatim, including the
+                                  ``dynamic_drop_radio`` / ``mlp_radio`` / ``img_spacial_dim`` spellings)
+  * parameter names / shapes      PRE:22-330 (checkpoints of the reference load unchanged)
+  * forward(points, text_dict, img_feat) -> list of (N_i', 3) tensors    PRE:424-469
+  * caller                        detectors/sparse_featfusion_grounder_preshape.py:95, 385
+
+The torch modules declared below are *parameter containers only* -- none of their
+``forward`` methods is ever called.  All arithmetic of the path runs in HIP; if the
+extension is missing, or the inputs are not on a GPU, ``forward`` raises.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _abi
+from .registry import MODELS
+
+__all__ = ["ProxyTransformationNormReverse"]
+
+_RADIUS, _MARGIN = 3.0, 4.0          # PRE:23 (fixed, not reachable from the config)
+_EMPTY_DROP = 0.3                    # PRE:352
+_SLOT_WIDTH = 256                    # PRE:31, PRE:302 (hard-coded in the reference)
+
+
+# --------------------------------------------------------------------------- containers
+class _Holder(nn.Module):
+    """A module that only owns parameters / sub-modules (never called)."""
+
+    def forward(self, *a, **k):  # pragma: no cover - guard
+        raise RuntimeError("parameter container: the HIP path does not call torch sub-modules")
+
+
+def _slot_mlp(hidden: int) -> nn.Sequential:
+    # Conv2d(6,hidden,1) + BatchNorm2d + ReLU                         PRE:72-76 / PRE:112-116
+    return nn.Sequential(nn.Conv2d(6, hidden, 1), nn.BatchNorm2d(hidden), nn.ReLU())
+
+
+class _OffsetNetwork(_Holder):                                        # PRE:69-78
+    def __init__(self, hidden: int):
+        super().__init__()
+        self.mlp = _slot_mlp(hidden)
+        self.channel_mapper = nn.Conv1d(hidden, 3, kernel_size=1, bias=False)
+
+
+class _DeformablePointCluster(_Holder):                               # PRE:22-31
+    def __init__(self, hidden: int):
+        super().__init__()
+        self.get_offsets = _OffsetNetwork(hidden)
+
+
+class _SimplifiedPointNet(_Holder):                                   # PRE:109-117
+    def __init__(self, hidden: int):
+        super().__init__()
+        self.mlp = _slot_mlp(hidden)
+
+
+class _AttentionPool2d(_Holder):                                      # PRE:144-152
+    def __init__(self, spacial_dim: int, dim: int):
+        super().__init__()
+        self.positional_embedding = nn.Parameter(torch.randn(spacial_dim ** 2 + 1, dim) / dim ** 0.5)
+        self.k_proj = nn.Linear(dim, dim)
+        self.q_proj = nn.Linear(dim, dim)
+        self.v_proj = nn.Linear(dim, dim)
+        self.c_proj = nn.Linear(dim, dim)
+
+
+class _ProxyAttention(_Holder):                                       # PRE:179-204
+    def __init__(self, dim: int, kept: int, qkv_bias: bool):
+        super().__init__()
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proxy_proj = nn.Linear(dim, dim)
+        self.proj = nn.Linear(dim, dim)
+        s = int(dim ** 0.5)
+        self.pb_bias = nn.Parameter(torch.zeros(1, kept, 4, 4))
+        self.pc_bias = nn.Parameter(torch.zeros(1, kept, s, 1))
+        self.pr_bias = nn.Parameter(torch.zeros(1, kept, 1, s))
+        for p in (self.pb_bias, self.pc_bias, self.pr_bias):
+            nn.init.trunc_normal_(p, std=.02, a=-.04, b=.04)
+
+
+class _Mlp(_Holder):                                                   # timm Mlp: fc1, fc2
+    def __init__(self, dim: int, hidden: int):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+
+class _ProxyBlock(_Holder):                                            # PRE:259-271
+    def __init__(self, dim: int, hidden: int, kept: int, qkv_bias: bool):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn = _ProxyAttention(dim, kept, qkv_bias)
+        self.norm2 = nn.LayerNorm(dim)
+        self.mlp = _Mlp(dim, hidden)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+# --------------------------------------------------------------------------- the module
+@MODELS.register_module()
+class ProxyTransformationNormReverse(nn.Module):
+    """Drop-in for the reference neck of the same name (see module docstring)."""
+
+    def __init__(self, embed_dim=256, num_heads=8, n_points=100000, grid_size=4, text_blocks=1,
+                 img_blocks=1, dynamic_drop_radio=0.8, mlp_radio=4, qkv_bias=False, drop_rate=0.2,
+                 attn_drop_rate=0.2, drop_path_rate=0.2, act_layer=nn.GELU, norm_layer=nn.LayerNorm,
+                 num_sub=30, drop_radio=0.2, input_dim=512, img_spacial_dim=15):
+        super().__init__()
+        if act_layer is not nn.GELU or norm_layer is not nn.LayerNorm:
+            raise NotImplementedError("the HIP path implements act_layer=nn.GELU, norm_layer=nn.LayerNorm")
+        self.embed_dim = embed_dim
+        self.num_heads = num_heads
+        self.grid_size = grid_size
+        self.num_cluster = grid_size ** 3
+        self.num_sub = num_sub or n_points // self.num_cluster               # PRE:291
+        self.input_dim = input_dim
+        self.img_spacial_dim = img_spacial_dim
+        self.drop_radio = drop_radio
+        self.text_blocks = text_blocks
+        self.img_blocks = img_blocks
+        self.dynamic_drop_radio = dynamic_drop_radio
+        self.mlp_hidden = int(embed_dim * mlp_radio)
+        self.drop_rate, self.attn_drop_rate, self.drop_path_rate = drop_rate, attn_drop_rate, drop_path_rate
+        kept = int(self.num_cluster * (1 - dynamic_drop_radio))              # PRE:195
+        self.real_cluster_num = kept
+
+        self.get_deformable_cluster = _DeformablePointCluster(_SLOT_WIDTH)
+        self.simple_encoder = _SimplifiedPointNet(_SLOT_WIDTH)
+        self.channel_mapper = nn.Conv2d(input_dim, embed_dim, kernel_size=1)
+        self.attn_pool2d = _AttentionPool2d(img_spacial_dim, embed_dim)
+        self.norm_img = nn.LayerNorm(embed_dim)
+        self.textformer = nn.ModuleList(
+            [_ProxyBlock(embed_dim, self.mlp_hidden, kept, qkv_bias) for _ in range(text_blocks)])
+        self.text_norm = nn.ModuleList([nn.LayerNorm(embed_dim) for _ in range(text_blocks)])
+        self.imgformer = nn.ModuleList(
+            [_ProxyBlock(embed_dim, self.mlp_hidden, kept, qkv_bias) for _ in range(img_blocks)])
+        self.img_norm = nn.ModuleList([nn.LayerNorm(embed_dim) for _ in range(img_blocks)])
+        self.text_trans = nn.Linear(embed_dim, 3)
+        self.img_trans = nn.Linear(embed_dim, 9)
+        self.text_trans_norm = nn.BatchNorm1d(3)
+        self.img_trans_norm = nn.BatchNorm1d(9)
+
+        # host-side caches (not part of the state_dict)
+        self._wkey = None
+        self._wstruct: Optional[_abi.PtxWeights] = None
+        self._prep: Optional[torch.Tensor] = None
+        self._lin: Optional[torch.Tensor] = None
+        self._ws: Dict[tuple, torch.Tensor] = {}
+        # test-only hooks: replay a captured argsort / inject clamped centres
+        self._order_override: Optional[torch.Tensor] = None
+        self._centers_override: Optional[torch.Tensor] = None
+
+    # ------------------------------------------------------------------ reference-named helpers
+    def get_text_proxy(self, text_dict):                                       # PRE:332-333
+        return text_dict.values()
+
+    # ------------------------------------------------------------------ shape / weights plumbing
+    def _shape(self, B: int, N: int, L: int, V: int) -> _abi.PtxShape:
+        M = self.num_cluster
+        return _abi.PtxShape(B=B, N=N, grid_size=self.grid_size, K=self.num_sub,
+                             Mt=M - int(M * _EMPTY_DROP), Mk=self.real_cluster_num, L=L, V=V,
+                             C=self.embed_dim, heads=self.num_heads, hidden=self.mlp_hidden,
+                             in_dim=self.input_dim, hw=self.img_spacial_dim ** 2,
+                             radius=_RADIUS, margin=_MARGIN, bn_eps=self.text_trans_norm.eps,
+                             ln_eps=self.norm_img.eps)
+
+    def _weights_key(self):
+        return tuple((t.data_ptr(), t._version) for t in self.state_dict(keep_vars=True).values())
+
+    def _block_struct(self, blk: _ProxyBlock, out_norm: nn.LayerNorm) -> _abi.PtxBlock:
+        a = blk.attn
+        return _abi.PtxBlock(
+            norm1_w=_ptr(blk.norm1.weight), norm1_b=_ptr(blk.norm1.bias),
+            pb_bias=_ptr(a.pb_bias), pc_bias=_ptr(a.pc_bias), pr_bias=_ptr(a.pr_bias),
+            qkv_w=_ptr(a.qkv.weight), qkv_b=_ptr(a.qkv.bias),
+            pp_w=_ptr(a.proxy_proj.weight), pp_b=_ptr(a.proxy_proj.bias),
+            proj_w=_ptr(a.proj.weight), proj_b=_ptr(a.proj.bias),
+            norm2_w=_ptr(blk.norm2.weight), norm2_b=_ptr(blk.norm2.bias),
+            fc1_w=_ptr(blk.mlp.fc1.weight), fc1_b=_ptr(blk.mlp.fc1.bias),
+            fc2_w=_ptr(blk.mlp.fc2.weight), fc2_b=_ptr(blk.mlp.fc2.bias),
+            out_norm_w=_ptr(out_norm.weight), out_norm_b=_ptr(out_norm.bias))
+
+    @staticmethod
+    def _slot_struct(seq: nn.Sequential) -> _abi.PtxSlotMlp:
+        conv, bn = seq[0], seq[1]
+        return _abi.PtxSlotMlp(conv_w=_ptr(conv.weight), conv_b=_ptr(conv.bias), bn_w=_ptr(bn.weight),
+                               bn_b=_ptr(bn.bias), bn_mean=_ptr(bn.running_mean), bn_var=_ptr(bn.running_var))
+
+    @staticmethod
+    def _bn_struct(bn: nn.BatchNorm1d) -> _abi.PtxBn1d:
+        return _abi.PtxBn1d(w=_ptr(bn.weight), b=_ptr(bn.bias), mean=_ptr(bn.running_mean),
+                            var=_ptr(bn.running_var))
+
+    def _ensure_prepared(self, shape: _abi.PtxShape, device: torch.device, stream: int):
+        """(Re)build the weight-pointer struct and the parameter-only tables when any
+        parameter storage or version changed (load_state_dict, .to(), optimiser step ...)."""
+        key = (self._weights_key(), str(device), shape.Mk)
+        if key == self._wkey:
+            return
+        for name, t in self.state_dict(keep_vars=True).items():
+            if t.device != device:
+                raise RuntimeError(f"parameter {name} is on {t.device}, inputs are on {device}")
+            if t.is_floating_point() and (t.dtype != torch.float32 or not t.is_contiguous()):
+                raise RuntimeError(f"parameter {name} must be contiguous float32 (got {t.dtype})")
+        ap = self.attn_pool2d
+        # only the last block of each list reaches the output (PRE:441-443, 450-452)
+        w = _abi.PtxWeights(
+            offset=self._slot_struct(self.get_deformable_cluster.get_offsets.mlp),
+            offset_map_w=_ptr(self.get_deformable_cluster.get_offsets.channel_mapper.weight),
+            encoder=self._slot_struct(self.simple_encoder.mlp),
+            cm_w=_ptr(self.channel_mapper.weight), cm_b=_ptr(self.channel_mapper.bias),
+            pos=_ptr(ap.positional_embedding),
+            q_w=_ptr(ap.q_proj.weight), q_b=_ptr(ap.q_proj.bias), k_w=_ptr(ap.k_proj.weight),
+            k_b=_ptr(ap.k_proj.bias), v_w=_ptr(ap.v_proj.weight), v_b=_ptr(ap.v_proj.bias),
+            c_w=_ptr(ap.c_proj.weight), c_b=_ptr(ap.c_proj.bias),
+            norm_img_w=_ptr(self.norm_img.weight), norm_img_b=_ptr(self.norm_img.bias),
+            text=self._block_struct(self.textformer[-1], self.text_norm[-1]),
+            img=self._block_struct(self.imgformer[-1], self.img_norm[-1]),
+            text_trans_w=_ptr(self.text_trans.weight), text_trans_b=_ptr(self.text_trans.bias),
+            img_trans_w=_ptr(self.img_trans.weight), img_trans_b=_ptr(self.img_trans.bias),
+            text_trans_norm=self._bn_struct(self.text_trans_norm),
+            img_trans_norm=self._bn_struct(self.img_trans_norm))
+        lib = _abi.lib()
+        nbytes = lib.ptx_prep_bytes(ctypes.byref(shape))
+        if nbytes == 0:
+            raise RuntimeError("unsupported configuration: " + lib.ptx_last_error().decode())
+        prep = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        # torch.linspace is part of the reference's arithmetic (PRE:41)
+        lin = torch.linspace(0, 1, self.grid_size, device="cpu").to(device)
+        _abi.check(lib.ptx_prepare(ctypes.byref(shape), ctypes.byref(w), lin.data_ptr(),
+                                   prep.data_ptr(), nbytes, stream), "ptx_prepare")
+        self._wstruct, self._prep, self._lin, self._wkey = w, prep, lin, key
+
+    def _workspace(self, shape: _abi.PtxShape, device: torch.device) -> torch.Tensor:
+        key = (shape.B, shape.N, shape.L, shape.V, str(device))
+        ws = self._ws.get(key)
+        if ws is None:
+            nbytes = _abi.lib().ptx_workspace_bytes(ctypes.byref(shape))
+            if nbytes == 0:
+                raise RuntimeError("unsupported configuration: " + _abi.lib().ptx_last_error().decode())
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            self._ws = {key: ws}          # one live workspace per module
+        return ws
+
+    # ------------------------------------------------------------------ forward
+    def _check_inputs(self, points, text_dict, img_feat):
+        if self.training:
+            raise NotImplementedError(
+                "train-mode forward (batch-stat BatchNorm, dropout, autograd) is not built yet; "
+                "call .eval() -- see DESIGN.md 'next'")
+        if not isinstance(points, (list, tuple)) or len(points) == 0:
+            raise ValueError("points must be a non-empty list of (N,3) tensors")
+        pts = torch.stack([p for p in points], dim=0)        # RuntimeError on unequal N, like torch.cat (PRE:427)
+        if pts.dim() != 3 or pts.shape[-1] != 3:
+            raise RuntimeError(f"points must be (N,3) per scene, got {tuple(pts.shape[1:])}")
+        if not pts.is_cuda:
+            raise RuntimeError("ProxyTransformationNormReverse (HIP) needs GPU tensors: there is no CPU path")
+        text_feats, text_mask = self.get_text_proxy(text_dict)   # positional unpack (PRE:440)
+        B, N, _ = pts.shape
+        if text_feats.shape[0] != B or text_feats.shape[-1] != self.embed_dim:
+            raise RuntimeError(f"text_feats must be ({B},L,{self.embed_dim}), got {tuple(text_feats.shape)}")
+        if tuple(text_mask.shape) != tuple(text_feats.shape[:2]):
+            raise RuntimeError("text_token_mask must be (B,L)")
+        hw = self.img_spacial_dim
+        if img_feat.dim() != 5 or img_feat.shape[0] != B or img_feat.shape[2] != self.input_dim \
+                or img_feat.shape[3] != hw or img_feat.shape[4] != hw:
+            raise RuntimeError(f"img_feat must be ({B},V,{self.input_dim},{hw},{hw}), got {tuple(img_feat.shape)}")
+        assert self.real_cluster_num >= 1                        # PRE:209
+        pts = pts.to(torch.float32).contiguous()
+        text_feats = text_feats.to(torch.float32).contiguous()
+        mask_u8 = text_mask.to(torch.uint8).contiguous()
+        img = img_feat.to(torch.float32).contiguous()
+        return pts, text_feats, mask_u8, img
+
+    def _run(self, points, text_dict, img_feat, debug: bool):
+        pts, text_feats, mask_u8, img = self._check_inputs(points, text_dict, img_feat)
+        dev = pts.device
+        B, N, _ = pts.shape
+        shape = self._shape(B, N, text_feats.shape[1], img.shape[1])
+        lib = _abi.lib()
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            self._ensure_prepared(shape, dev, stream)
+            ws = self._workspace(shape, dev)
+            out = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
+            counts = torch.empty((B,), dtype=torch.int32, device=dev)
+            dbg_struct, dbg = None, {}
+            if debug:
+                dbg = self._alloc_debug(shape, dev)
+                dbg_struct = _abi.PtxDebug(**{k: v.data_ptr() for k, v in dbg.items()})
+            oo = self._order_override
+            co = self._centers_override
+            if oo is not None:
+                oo = oo.to(device=dev, dtype=torch.int32).contiguous()
+            if co is not None:
+                co = co.to(device=dev, dtype=torch.float32).contiguous()
+            _abi.check(lib.ptx_forward(
+                ctypes.byref(shape), ctypes.byref(self._wstruct), self._prep.data_ptr(),
+                self._lin.data_ptr(), pts.data_ptr(), text_feats.data_ptr(), mask_u8.data_ptr(),
+                img.data_ptr(), _ptr(oo), _ptr(co), out.data_ptr(), counts.data_ptr(),
+                ws.data_ptr(), ws.numel(), ctypes.byref(dbg_struct) if dbg_struct else None, stream),
+                "ptx_forward")
+            n_keep = counts.cpu().tolist()               # the one host sync of the path (list lengths)
+        outs = [out[b, :n_keep[b]] for b in range(B)]
+        return outs, dbg
+
+    def _alloc_debug(self, s: _abi.PtxShape, dev) -> Dict[str, torch.Tensor]:
+        M, K, Kd = self.num_cluster, s.K, s.Mt - s.Mk
+        f32, i32 = torch.float32, torch.int32
+        spec = dict(
+            centers0=((s.B, M, 3), f32), cluster1=((s.B, M, K, 3), f32), offsets=((s.B, M, 3), f32),
+            centers=((s.B, M, 3), f32), cluster2=((s.B, M, K, 3), f32), idx2=((s.B, M, K), i32),
+            pad_count=((s.B, M), i32), order=((s.B, s.Mt), i32), picks=((s.B, Kd), i32),
+            keep=((s.B, s.Mk), i32), kidx=((s.B, s.Mk, K), i32), drop_idx=((s.B, Kd * K), i32),
+            kcenter=((s.B, s.Mk, 3), f32), kcluster=((s.B, s.Mk, K, 3), f32),
+            point_proxy=((s.B, s.Mk, s.C), f32), img_proxy=((s.B, s.V, s.C), f32),
+            text_guide=((s.B, s.Mk, s.C), f32), img_guide=((s.B, s.Mk, s.C), f32),
+            translate=((s.B, s.Mk, 3), f32), transform=((s.B, s.Mk, 9), f32),
+            tag=((s.B, s.N), torch.int32))
+        return {k: torch.empty(shp, dtype=dt, device=dev) for k, (shp, dt) in spec.items()}
+
+    def forward(self, points: List[torch.Tensor], text_dict: dict, img_feat: torch.Tensor):
+        """points: list of B (N,3) fp32 GPU tensors; text_dict.values() -> (text_feats (B,L,C),
+        text_token_mask (B,L) bool, True = valid); img_feat (B,V,input_dim,H,W).
+        Returns a list of B tensors (N_i',3): transformed points, dropped points removed,
+        original order preserved (PRE:424-469)."""
+        return self._run(points, text_dict, img_feat, debug=False)[0]
+
+    @torch.no_grad()
+    def forward_debug(self, points, text_dict, img_feat):
+        """forward + every intermediate the C ABI can export (tests / parity only)."""
+        outs, dbg = self._run(points, text_dict, img_feat, debug=True)
+        dbg["outputs"] = outs
+        return dbg

@@ -1,0 +1,321 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors in this directory from the reference itself.
+
+Runs ONLY in the build container (needs /root/reference); the .npz files it
+writes are data (inputs + expected outputs) and are committed, this script is
+committed with them, and nothing under tests/ reads /root/reference at test time.
+
+How the reference is run:
+  * preshape_norm_reverse_drop.py (PRE) is loaded by path, untouched;
+  * its three missing imports are replaced by stand-ins registered in sys.modules:
+      - embodiedscan.registry.MODELS: register_module()/build() only;
+      - timm.models.layers: Mlp (fc1-act-drop1-fc2-drop2), DropPath, trunc_normal_;
+      - pytorch3d.ops.sample_farthest_points -> PRE's OWN in-file statement
+        ``sample_farthest_points_naive`` (PRE:527-625, "Same Args/Returns");
+      - pytorch3d.ops.ball_query -> a torch restatement of the published
+        pytorch3d CPU algorithm (first K in index order with dist2 < r*r, idx pad -1),
+        written with separate fp32 mul/add tensor ops (no FMA) and gathering through
+        PRE's own ``masked_gather`` (PRE:627-672).  pytorch3d is not vendored in the
+        reference, so this op's arithmetic is "parity unpinned" (see DESIGN.md).
+  * model.eval(), torch.set_num_threads(1) (index_put_ with duplicate targets is only
+    deterministic single-threaded), fp32.
+  * ``torch.argsort`` inside PRE is unstable and ties are the norm: each case
+    is run twice -- as shipped (the permutation torch 2.10 CPU happens to return is
+    recorded) and with argsort forced stable at harness level (PRE untouched).  The
+    stable run is the pinned production semantics.
+
+Usage:  python tests/golden/gen_golden.py
+"""
+from __future__ import annotations
+
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+REF = "/root/reference/embodiedscan/models/necks/preshape_norm_reverse_drop.py"
+
+from proxytransformation_amd.synth import PreshapeConfig, fill_state_dict, make_scene_batch  # noqa: E402
+
+CAPTURE = {}
+
+
+# ----------------------------------------------------------------------------- stand-ins
+class _Registry:
+    def __init__(self):
+        self.d = {}
+
+    def register_module(self):
+        def deco(cls):
+            self.d[cls.__name__] = cls
+            return cls
+        return deco
+
+    def build(self, cfg):
+        cfg = dict(cfg)
+        return self.d[cfg.pop("type")](**cfg)
+
+
+class Mlp(nn.Module):          # timm.models.layers.Mlp surface used at PRE:271
+    def __init__(self, in_features, hidden_features=None, out_features=None,
+                 act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features or in_features)
+        self.act = act_layer()
+        self.drop1 = nn.Dropout(drop)
+        self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
+        self.drop2 = nn.Dropout(drop)
+
+    def forward(self, x):
+        return self.drop2(self.fc2(self.drop1(self.act(self.fc1(x)))))
+
+
+class DropPath(nn.Module):     # identity in eval mode
+    def __init__(self, p=0.):
+        super().__init__()
+        self.p = p
+
+    def forward(self, x):
+        if not self.training or self.p == 0.:
+            return x
+        keep = 1 - self.p
+        m = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+        return x * m / keep
+
+
+def trunc_normal_(t, std=1.):
+    return nn.init.trunc_normal_(t, std=std, a=-2 * std, b=2 * std)
+
+
+def _install_standins():
+    reg = _Registry()
+    es = types.ModuleType("embodiedscan")
+    esr = types.ModuleType("embodiedscan.registry")
+    esr.MODELS = reg
+    timm = types.ModuleType("timm")
+    tm = types.ModuleType("timm.models")
+    tml = types.ModuleType("timm.models.layers")
+    tml.Mlp, tml.DropPath, tml.trunc_normal_ = Mlp, DropPath, trunc_normal_
+    p3 = types.ModuleType("pytorch3d")
+    p3o = types.ModuleType("pytorch3d.ops")
+    p3o.ball_query = lambda *a, **k: _ball_query(*a, **k)
+    p3o.sample_farthest_points = lambda *a, **k: _fps(*a, **k)
+    sys.modules.update({"embodiedscan": es, "embodiedscan.registry": esr, "timm": timm,
+                        "timm.models": tm, "timm.models.layers": tml,
+                        "pytorch3d": p3, "pytorch3d.ops": p3o})
+    return reg
+
+
+PRE = None
+
+
+def _ball_query(p1, p2, lengths1=None, lengths2=None, K=500, radius=0.2, return_nn=True):
+    """torch restatement of pytorch3d's ball_query_cpu.cpp (see module docstring)."""
+    B, M, _ = p1.shape
+    N = p2.shape[1]
+    r2 = torch.tensor(float(radius), dtype=torch.float32) * torch.tensor(float(radius), dtype=torch.float32)
+    idx = torch.full((B, M, K), -1, dtype=torch.int64)
+    dists = torch.zeros((B, M, K), dtype=p1.dtype)
+    chunk = 64
+    for b in range(B):
+        for m0 in range(0, M, chunk):
+            c = p1[b, m0:m0 + chunk]                                   # (c,3)
+            d0 = c[:, None, 0] - p2[b, None, :, 0]
+            d1 = c[:, None, 1] - p2[b, None, :, 1]
+            d2_ = c[:, None, 2] - p2[b, None, :, 2]
+            acc = d0 * d0                                              # 0 + dx*dx == dx*dx
+            acc = acc + d1 * d1
+            acc = acc + d2_ * d2_
+            hit = acc < r2
+            rank = hit.cumsum(dim=1) - 1                                # slot of each hit
+            sel = hit & (rank < K)
+            mm, jj = sel.nonzero(as_tuple=True)
+            idx[b, m0 + mm, rank[mm, jj]] = jj
+            dists[b, m0 + mm, rank[mm, jj]] = acc[mm, jj]
+    nn_ = PRE.masked_gather(p2, idx)
+    CAPTURE.setdefault("bq", []).append((p1.clone(), idx.clone(), nn_.clone()))
+    return dists, idx, nn_
+
+
+def _fps(points, lengths=None, K=50, random_start_point=False):
+    pts, idx = PRE.sample_farthest_points_naive(points, lengths, K, random_start_point)
+    CAPTURE["fps_in"] = points.clone()
+    CAPTURE["fps_idx"] = idx.clone()
+    return pts, idx
+
+
+# ----------------------------------------------------------------------------- cases
+CASES = [
+    # cfg1 shape (BASELINE.json configs[0]) with B=2 so the masked scene (index 1) exists
+    PreshapeConfig("g1_cfg1", B=2, N=20000, grid_size=8, dynamic_drop_radio=0.875,
+                   L=16, V=4, seed_base=1000),
+    # sparse scene: ~26 points per ball -> padded slots, padding-count ordering matters,
+    # 2+2 blocks so "only the last block is live"  is exercised
+    PreshapeConfig("g2_sparse", B=2, N=300, grid_size=4, dynamic_drop_radio=0.5,
+                   L=8, V=2, text_blocks=2, img_blocks=2, seed_base=7100),
+    # small room: every side < 2*margin -> the grid inverts and centres are clamped onto
+    # the bbox; many coincident centres, FPS ties
+    PreshapeConfig("g3_room", B=1, N=5000, grid_size=4, dynamic_drop_radio=0.5,
+                   L=5, V=3, extent=(7.0, 5.0, 3.0), seed_base=7300),
+]
+
+
+def run_case(reg, cfg: PreshapeConfig):
+    torch.manual_seed(0)
+    model = reg.build(dict(type="ProxyTransformationNormReverse", **cfg.module_kwargs()))
+    sd_np = fill_state_dict(model.state_dict())
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+    model.eval()
+    pts, text, mask, img = make_scene_batch(cfg)
+    tpts = [torch.from_numpy(pts[b].copy()) for b in range(cfg.B)]
+    text_dict = {"text_feats": torch.from_numpy(text), "text_token_mask": torch.from_numpy(mask)}
+    timg = torch.from_numpy(img)
+
+    hooks = {}
+
+    def hook(name):
+        def fn(mod, inp, outp):
+            hooks[name] = outp
+        return fn
+
+    hs = [model.get_deformable_cluster.get_offsets.register_forward_hook(hook("offset_raw")),
+          model.simple_encoder.register_forward_hook(hook("point_proxy")),
+          model.norm_img.register_forward_hook(hook("img_proxy")),
+          model.text_norm[-1].register_forward_hook(hook("text_guide")),
+          model.img_norm[-1].register_forward_hook(hook("img_guide")),
+          model.text_trans_norm.register_forward_hook(hook("translate_t")),
+          model.img_trans_norm.register_forward_hook(hook("transform_t")),
+          model.textformer[-1].register_forward_hook(hook("text_block")),
+          model.imgformer[-1].register_forward_hook(hook("img_block"))]
+
+    # dynamic_cluster_dropout's own results are not visible through module hooks
+    orig_drop = model.dynamic_cluster_dropout
+    drop_out = {}
+
+    def wrapped_drop(cluster, center, idx, empty_drop=0.3):
+        r = orig_drop(cluster, center, idx, empty_drop)
+        drop_out.update(new_cluster=r[0], new_center=r[1], new_idx=r[2], drop_idx=r[3])
+        return r
+    model.dynamic_cluster_dropout = wrapped_drop
+
+    orig_replace = PRE.pt_replace
+    replaced = {}
+
+    def wrapped_replace(p2, idx, cluster):
+        replaced["new_clusters"] = cluster.clone()
+        r = orig_replace(p2, idx, cluster)
+        replaced["new_points"] = r.clone()
+        return r
+    PRE.pt_replace = wrapped_replace
+
+    real_argsort = torch.argsort
+    results = {}
+    for mode in ("shipped", "stable"):
+        CAPTURE.clear()
+        captured_sorted = {}
+
+        def argsort(x, dim=-1, descending=False, stable=False):
+            r = real_argsort(x, dim=dim, descending=descending, stable=(mode == "stable"))
+            captured_sorted["sorted"] = r.clone()
+            captured_sorted["pad_counts"] = x.clone()
+            return r
+        torch.argsort = argsort
+        try:
+            torch.set_num_threads(1)
+            with torch.no_grad():
+                outs = model(tpts, text_dict, timg)
+        finally:
+            torch.argsort = real_argsort
+        results[mode] = dict(
+            outs=[o.numpy().copy() for o in outs],
+            sorted=captured_sorted["sorted"].numpy().copy(),
+            pad_counts=captured_sorted["pad_counts"].numpy().copy(),
+            bq=[(a.numpy().copy(), b.numpy().copy(), c.numpy().copy()) for a, b, c in CAPTURE["bq"]],
+            fps_idx=CAPTURE["fps_idx"].numpy().copy(),
+            hooks={k: (v.detach().numpy().copy()) for k, v in hooks.items()},
+            drop={k: v.numpy().copy() for k, v in drop_out.items()},
+            replaced={k: v.numpy().copy() for k, v in replaced.items()},
+        )
+    PRE.pt_replace = orig_replace
+    for h in hs:
+        h.remove()
+
+    st, sh = results["stable"], results["shipped"]
+    Mt = cfg.Mt
+    save = dict(
+        # ---- inputs
+        points=pts, text_feats=text, text_mask=mask, img_feat=img,
+        cfg=np.array([cfg.B, cfg.N, cfg.grid_size, cfg.L, cfg.V, cfg.embed_dim, cfg.num_heads,
+                      cfg.num_sub, cfg.text_blocks, cfg.img_blocks], np.int64),
+        dynamic_drop_radio=np.float64(cfg.dynamic_drop_radio),
+        extent=np.asarray(cfg.extent, np.float64), seed_base=np.int64(cfg.seed_base),
+        # ---- clustering (identical in both modes up to the argsort)
+        centers0=st["bq"][0][0], cluster1=st["bq"][0][2],
+        offset_raw=st["hooks"]["offset_raw"],
+        centers=st["bq"][1][0], idx2=st["bq"][1][1], cluster2=st["bq"][1][2],
+        pad_counts=st["pad_counts"],
+        # ---- stable (production pin)
+        order_stable=st["sorted"][:, :Mt], fps_stable=st["fps_idx"],
+        kcluster_stable=st["drop"]["new_cluster"], kcenter_stable=st["drop"]["new_center"],
+        kidx_stable=st["drop"]["new_idx"], drop_idx_stable=st["drop"]["drop_idx"],
+        point_proxy_stable=st["hooks"]["point_proxy"], img_proxy=st["hooks"]["img_proxy"],
+        text_guide_stable=st["hooks"]["text_guide"], img_guide_stable=st["hooks"]["img_guide"],
+        text_block_stable=st["hooks"]["text_block"], img_block_stable=st["hooks"]["img_block"],
+        translate_stable=st["hooks"]["translate_t"].transpose(0, 2, 1),
+        transform_stable=st["hooks"]["transform_t"].transpose(0, 2, 1),
+        new_clusters_stable=st["replaced"]["new_clusters"],
+        new_points_stable=st["replaced"]["new_points"],
+        # ---- as shipped (torch 2.10 CPU unstable argsort), replayed through order_override
+        order_shipped=sh["sorted"][:, :Mt], fps_shipped=sh["fps_idx"],
+        kidx_shipped=sh["drop"]["new_idx"], drop_idx_shipped=sh["drop"]["drop_idx"],
+        translate_shipped=sh["hooks"]["translate_t"].transpose(0, 2, 1),
+        transform_shipped=sh["hooks"]["transform_t"].transpose(0, 2, 1),
+        new_points_shipped=sh["replaced"]["new_points"],
+    )
+    for b in range(cfg.B):
+        save[f"out_stable_{b}"] = st["outs"][b]
+        save[f"out_shipped_{b}"] = sh["outs"][b]
+    # boundary-safety report: smallest |dist2 - r^2| over scanned candidates of
+    # ball query #2, so end-to-end GPU tests know whether membership may legitimately flip
+    c2, i2 = st["bq"][1][0], st["bq"][1][1]
+    margins = []
+    for b in range(cfg.B):
+        best = np.inf
+        for m in range(c2.shape[1]):
+            last = i2[b, m].max()
+            stop = (last + 1) if (i2[b, m] >= 0).all() else cfg.N
+            d = c2[b, m][None, :] - pts[b, :stop]
+            d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+            best = min(best, float(np.abs(d2 - np.float32(9.0)).min()))
+        margins.append(best)
+    save["bq2_boundary_margin"] = np.asarray(margins, np.float64)
+    path = os.path.join(HERE, cfg.name + ".npz")
+    np.savez_compressed(path, **save)
+    n_par = sum(int(np.prod(v.shape)) for k, v in sd_np.items())
+    print(f"{cfg.name}: params={n_par} outs={[o.shape for o in st['outs']]} "
+          f"order_equal={np.array_equal(st['sorted'], sh['sorted'])} "
+          f"margin={margins} -> {os.path.getsize(path) / 1e6:.2f} MB")
+
+
+def main():
+    global PRE
+    reg = _install_standins()
+    spec = importlib.util.spec_from_file_location("pre_ref", REF)
+    PRE = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(PRE)
+    only = sys.argv[1:]
+    for cfg in CASES:
+        if only and cfg.name not in only:
+            continue
+        run_case(reg, cfg)
+
+
+if __name__ == "__main__":
+    main()

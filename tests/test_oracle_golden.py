@@ -1,0 +1,74 @@
+"""Pin the CPU oracle (oracle/) against the golden vectors captured from the reference file
+itself (tests/golden/gen_golden.py).  Integer results must be bit-identical; float results
+are compared at tolerances far below the 1e-4 coordinate tolerance of the north star."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests.util import GOLDEN_CASES, assert_close, build_module, golden_cfg, load_golden, oracle_kwargs
+
+
+def _run(name, mode, inject_centers=True):
+    g = load_golden(name)
+    cfg = golden_cfg(g)
+    _, sd = build_module(cfg)
+    out = oracle.forward(
+        sd, **oracle_kwargs(cfg), points=g["points"], text_feats=g["text_feats"],
+        text_mask=g["text_mask"], img_feat=g["img_feat"],
+        order_override=g["order_shipped"] if mode == "shipped" else None,
+        centers_override=g["centers"] if inject_centers else None, num_threads=1)
+    return g, cfg, out
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_clustering_matches_reference(name):
+    g, cfg, out = _run(name, "stable", inject_centers=False)
+    # grid centres are bit-exact, gathered clusters are copies
+    assert np.array_equal(out["centers0"], g["centers0"])
+    assert np.array_equal(out["cluster1"], g["cluster1"])
+    # offset net: same math, different summation order
+    assert_close(out["centers"], g["centers"], atol=2e-5, what="clamped centres")
+    # golden scenes are boundary-safe (margin recorded by the generator), so membership is identical
+    assert g["bq2_boundary_margin"].min() > 1e-4
+    assert np.array_equal(out["idx2"], g["idx2"])
+    assert np.array_equal(out["cluster2"], g["cluster2"])
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+@pytest.mark.parametrize("mode", ["stable", "shipped"])
+def test_selection_and_outputs_match_reference(name, mode):
+    g, cfg, out = _run(name, mode)
+    assert np.array_equal(out["idx2"], g["idx2"])
+    assert np.array_equal(out["pad_counts"], g["pad_counts"])
+    assert np.array_equal(out["order"], g[f"order_{mode}"])          # stable counting sort == torch stable argsort
+    assert np.array_equal(out["picks"], g[f"fps_{mode}"])            # FPS == PRE's sample_farthest_points_naive
+    assert np.array_equal(out["kidx"], g[f"kidx_{mode}"])
+    assert np.array_equal(out["drop_idx"], g[f"drop_idx_{mode}"])
+    assert_close(out["translate"], g[f"translate_{mode}"], atol=2e-5, rtol=1e-5, what="translate")
+    assert_close(out["transform"], g[f"transform_{mode}"], atol=2e-5, rtol=1e-5, what="transform")
+    assert_close(out["new_points"], g[f"new_points_{mode}"], atol=5e-5, what="new_points")
+    for b in range(cfg.B):
+        ref = g[f"out_{mode}_{b}"]
+        assert out["outputs"][b].shape == ref.shape                  # same points dropped
+        assert_close(out["outputs"][b], ref, atol=5e-5, what=f"output {b}")
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_float_stages_match_reference(name):
+    g, cfg, out = _run(name, "stable")
+    assert np.array_equal(out["kcluster"], g["kcluster_stable"])
+    assert np.array_equal(out["kcenter"], g["kcenter_stable"])
+    assert_close(out["point_proxy"], g["point_proxy_stable"], atol=1e-5, rtol=1e-5, what="point_proxy")
+    assert_close(out["img_proxy"].reshape(g["img_proxy"].shape), g["img_proxy"], atol=2e-5, rtol=1e-5,
+                 what="img_proxy")
+    assert_close(out["text_block"]["out"].numpy(), g["text_block_stable"], atol=5e-5, rtol=1e-5, what="text block")
+    assert_close(out["img_block"]["out"].numpy(), g["img_block_stable"], atol=5e-5, rtol=1e-5, what="img block")
+    assert_close(out["text_guide"], g["text_guide_stable"], atol=2e-5, rtol=1e-5, what="text_guide")
+    assert_close(out["img_guide"], g["img_guide_stable"], atol=2e-5, rtol=1e-5, what="img_guide")
+    assert_close(out["new_clusters"], g["new_clusters_stable"], atol=5e-5, what="new_clusters")
+
+
+def test_unstable_argsort_really_differs():
+    """the as-shipped permutation is not the stable one, so both modes are exercised."""
+    g = load_golden("g1_cfg1")
+    assert not np.array_equal(g["order_stable"], g["order_shipped"])
