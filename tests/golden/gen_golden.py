@@ -304,6 +304,21 @@ def run_case(reg, cfg: PreshapeConfig):
           f"margin={margins} -> {os.path.getsize(path) / 1e6:.2f} MB")
 
 
+def write_manifest(reg):
+    """Key / shape / dtype manifest of the reference module's state_dict (data, not code)."""
+    import json
+    entries = []
+    for kwargs in (dict(), dict(n_points=100000, grid_size=12, text_blocks=3, img_blocks=3,
+                                dynamic_drop_radio=0.6, num_sub=30),            # CFG:41
+                   dict(grid_size=8, dynamic_drop_radio=0.5, qkv_bias=True)):
+        model = reg.build(dict(type="ProxyTransformationNormReverse", **kwargs))
+        entries.append(dict(kwargs=kwargs, tensors=[[k, list(v.shape), str(v.dtype)]
+                                                    for k, v in model.state_dict().items()]))
+    with open(os.path.join(HERE, "state_dict_manifest.json"), "w") as f:
+        json.dump(entries, f, indent=0)
+    print("manifest:", [len(e["tensors"]) for e in entries], "tensors")
+
+
 def main():
     global PRE
     reg = _install_standins()
@@ -311,6 +326,8 @@ def main():
     PRE = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(PRE)
     only = sys.argv[1:]
+    if not only or "manifest" in only:
+        write_manifest(reg)
     for cfg in CASES:
         if only and cfg.name not in only:
             continue
