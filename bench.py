@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Throughput of the preshape hot path on MI355X: scenes/sec at 1/2/4/8 GPUs.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A *step* is one eval forward of ``ProxyTransformationNormReverse`` over this rank's batch of
+synthetic scenes (BASELINE.json configs[1] shape: 100k points, 8^3 grid -> 256 kept clusters,
+64 text + 196 image proxies, d = 256; 4 scenes per GPU = the per-GPU shard of configs[2]).
+Inputs are resident in HBM before the timed region; the step ends when the list of output
+tensors exists (this includes the path's single host sync for the per-scene lengths).
+Scenes are sharded by scene id with no data-path collective (weak scaling).
+
+Rank 0 prints ONE JSON line.  Extra objects:
+  roofline      dominant kernel (k_img_scores, one streaming read of img_feat): algorithmic
+                bytes per launch / average launch duration, timed with HIP events recorded by
+                the library on the kernel's own stream during the timed steps
+  cpu_baseline  the CPU oracle (torch CPU fp32 + C ball query / FPS, "port") on this box's
+                host cores, same workload, bounded sample (rank 0, N = 1 only)
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from proxytransformation_amd import MODELS, _abi                                   # noqa: E402
+from proxytransformation_amd.synth import CONFIGS, fill_state_dict, make_scene_batch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--scenes-per-gpu", type=int, default=None)
+    ap.add_argument("--time-kernel", default="k_img_scores", help="launch site timed for the roofline object")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-scenes", type=int, default=None, help="scenes in the CPU baseline sample")
+    ap.add_argument("--breakdown", action="store_true", help="print per-kernel event timings to stderr")
+    return ap.parse_args()
+
+
+def build_module(cfg, device):
+    mod = MODELS.build(dict(type="ProxyTransformationNormReverse", **cfg.module_kwargs()))
+    sd = fill_state_dict(mod.state_dict())
+    mod.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return mod.eval().to(device), sd
+
+
+def kernel_id(lib, name):
+    names = [lib.ptx_kernel_name(i).decode() for i in range(lib.ptx_kernel_count())]
+    if name not in names:
+        raise SystemExit(f"--time-kernel must be one of {names}")
+    return names.index(name), names
+
+
+def algorithmic_bytes(cfg, B, name):
+    """Algorithmic HBM bytes one launch of `name` must move (kernel table)."""
+    img = B * cfg.V * cfg.input_dim * cfg.img_spacial_dim ** 2 * 4
+    table = {
+        "k_img_mean": img, "k_img_scores": img, "k_img_gather": img,
+        "k_minmax": B * cfg.N * 12,
+        "k_affine<compact>": B * cfg.N * (12 + 4 + 12),
+        "k_tile_count": B * cfg.N * 4,
+    }
+    return table.get(name)
+
+
+def cpu_baseline(cfg, sd, n_scenes):
+    """Time the CPU oracle (the checker, here only as the reported baseline) on a bounded sample."""
+    from oracle import oracle
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    pts, text, mask, img = make_scene_batch(cfg, scene_ids=range(n_scenes))
+    kw = dict(grid_size=cfg.grid_size, dynamic_drop_radio=cfg.dynamic_drop_radio, num_sub=cfg.num_sub,
+              num_heads=cfg.num_heads, text_blocks=cfg.text_blocks, img_blocks=cfg.img_blocks,
+              points=pts, text_feats=text, text_mask=mask, img_feat=img)
+    oracle.forward(sd, **kw)                                   # warm-up (lib load, thread pools)
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        oracle.forward(sd, **kw)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > 12.0 or reps >= 20:
+            break
+    return dict(value=round(n_scenes * reps / el, 4), unit="scenes/s", cores=cores, kind="port",
+                sample=f"{reps} forwards of {n_scenes} {cfg.name}-shape scenes on {cores} host threads "
+                       f"({el:.1f} s); oracle/oracle.py: torch-CPU fp32 + single-thread C ball query/FPS")
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path to measure)"
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    cfg = CONFIGS[args.config]
+    B = args.scenes_per_gpu or cfg.B
+    scene_ids = range(rank * B, rank * B + B)                  # weak scaling: B scenes per GPU
+    mod, sd = build_module(cfg, device)
+    pts, text, mask, img = make_scene_batch(cfg, scene_ids=scene_ids)
+    points = [torch.from_numpy(p).to(device) for p in pts]
+    text_dict = {"text_feats": torch.from_numpy(text).to(device),
+                 "text_token_mask": torch.from_numpy(mask).to(device)}
+    img_feat = torch.from_numpy(img).to(device)
+    lib = _abi.lib()
+    kid, names = kernel_id(lib, args.time_kernel)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            outs = mod(points, text_dict, img_feat)
+        n_out = sum(int(o.shape[0]) for o in outs) if args.warmup else None
+        lib.ptx_timing_select(kid)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            outs = mod(points, text_dict, img_feat)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        launches, total_ms = ctypes.c_int(0), ctypes.c_float(0.0)
+        lib.ptx_timing_read(ctypes.byref(launches), ctypes.byref(total_ms))
+        lib.ptx_timing_select(-1)
+
+        breakdown = None
+        if args.breakdown and rank == 0:
+            breakdown = {}
+            for i, nm in enumerate(names):
+                lib.ptx_timing_select(i)
+                for _ in range(5):
+                    mod(points, text_dict, img_feat)
+                torch.cuda.synchronize()
+                n_, ms_ = ctypes.c_int(0), ctypes.c_float(0.0)
+                lib.ptx_timing_read(ctypes.byref(n_), ctypes.byref(ms_))
+                breakdown[nm] = round(1e3 * ms_.value / max(n_.value, 1), 2)
+            lib.ptx_timing_select(-1)
+            print("per-kernel us/launch:", json.dumps(breakdown), file=sys.stderr)
+
+    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        total_scenes = world * B * args.steps
+        abytes = algorithmic_bytes(cfg, B, args.time_kernel)
+        roof = None
+        if launches.value > 0 and abytes:
+            avg_s = total_ms.value / launches.value / 1e3
+            ach = abytes / avg_s / 1e9
+            roof = dict(bound="hbm", kernel=args.time_kernel, achieved=round(ach, 1), peak=HBM_PEAK_GBS,
+                        unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
+                        avg_launch_us=round(avg_s * 1e6, 2), launches=launches.value,
+                        algorithmic_bytes_per_launch=abytes)
+        line = dict(metric="scenes/sec (100k pts, 256 clusters, 64 proxies)", value=round(total_scenes / elapsed, 2),
+                    unit="scenes/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                    ms_per_step=round(1e3 * elapsed / args.steps, 4), higher_is_better=True, scaling="weak",
+                    vs_baseline=None, dtype="f32", data="synthetic",
+                    config=dict(workload=f"{cfg.name}: N={cfg.N} pts, gs={cfg.grid_size}->M'={cfg.M_keep} kept clusters, "
+                                         f"L={cfg.L} text + V={cfg.V} image proxies, d={cfg.embed_dim}, eval forward",
+                                scenes_per_gpu=B, global_scenes_per_step=world * B, sharding="by scene, no collective",
+                                img_feat_dtype="f32", surviving_points_per_step=n_out),
+                    roofline=roof)
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(cfg, sd, args.cpu_scenes or min(B, 2))
+            except Exception as e:                               # the baseline must never sink the GPU number
+                line["cpu_baseline"] = dict(value=None, error=repr(e))
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -102,6 +102,16 @@ typedef struct PtxWeights {
 int         ptx_abi_version(void);
 const char *ptx_last_error(void);
 
+/* Per-kernel timing of ptx_forward for roofline measurement (bench.py): select ONE launch
+ * site by id (0 .. ptx_kernel_count()-1, -1 = off); every later ptx_forward brackets that
+ * launch with HIP events recorded on the stream the kernel runs on.  ptx_timing_read()
+ * waits for the recorded events and returns launches and summed milliseconds [host pointers],
+ * then clears the record.  Do not enable while a stream capture is active. */
+int         ptx_kernel_count(void);
+const char *ptx_kernel_name(int kid);
+int         ptx_timing_select(int kid);
+int         ptx_timing_read(int *launches, float *total_ms);
+
 /* Bytes of the parameter-only tables derived once per set of weights (folded
  * BatchNorm scale/shift, per-slot bias tables PRE:212-215, folded attention-pool
  * matrices) and of the per-call scratch.  Both buffers are caller-owned. */

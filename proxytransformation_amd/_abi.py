@@ -66,6 +66,10 @@ _SH, _W = C.POINTER(PtxShape), C.POINTER(PtxWeights)
 SIGNATURES = {
     "ptx_abi_version": (C.c_int, []),
     "ptx_last_error": (C.c_char_p, []),
+    "ptx_kernel_count": (C.c_int, []),
+    "ptx_kernel_name": (C.c_char_p, [_I]),
+    "ptx_timing_select": (_I, [_I]),
+    "ptx_timing_read": (_I, [C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     "ptx_prep_bytes": (_Z, [_SH]),
     "ptx_workspace_bytes": (_Z, [_SH]),
     "ptx_prepare": (_I, [_SH, _W, _P, _P, _Z, _P]),

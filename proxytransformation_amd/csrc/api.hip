@@ -2,6 +2,8 @@
 #include <cmath>
 #include <cstring>
 #include <mutex>
+#include <utility>
+#include <vector>
 
 #include "common.h"
 
@@ -16,6 +18,49 @@ void set_error(const char *fmt, ...)
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+// ---- optional per-kernel timing (bench.py's roofline leg) -----------------------------------------
+// One launch site of the forward can be bracketed by HIP events recorded on the stream the kernel
+// is launched on; ptx_timing_read() returns launches and summed milliseconds.  Off by default.
+static const char *const kKernelNames[] = {
+    "memset", "k_minmax", "k_ball_query<grid>", "k_slot_net<offset>", "k_ball_query", "k_select",
+    "k_tile_count", "k_slot_net<pointnet>", "k_img_mean", "k_gemm_nt[x0]", "k_gemm_nt[qkv0]",
+    "k_gemm_nt[we]", "k_img_scores", "k_img_gather", "k_gemm_nt[o]", "k_gemm_nt[c_proj]",
+    "k_ln_rows[norm_img]", "k_gemm_nt[qkv+proxy_proj]", "k_attn32[proxy_as_query]",
+    "k_attn32[proxy_as_key]", "k_gemm_nt[proj]", "k_ln_rows[norm2]", "k_gemm_nt[fc1]", "k_gemm_nt[fc2]",
+    "k_heads", "k_affine<compact>"};
+enum Kid : int {
+    KID_MEMSET = 0, KID_MINMAX, KID_BQ1, KID_OFFSET, KID_BQ2, KID_SELECT, KID_TILECOUNT, KID_POINTNET,
+    KID_IMG_MEAN, KID_IMG_X0, KID_IMG_QKV0, KID_IMG_WE, KID_IMG_SCORES, KID_IMG_GATHER, KID_IMG_O, KID_IMG_C,
+    KID_IMG_LN, KID_BLK_QKV, KID_BLK_ATTN_A, KID_BLK_ATTN_B, KID_BLK_PROJ, KID_BLK_LN2, KID_BLK_FC1,
+    KID_BLK_FC2, KID_BLK_HEADS, KID_AFFINE, KID_COUNT};
+static_assert(sizeof(kKernelNames) / sizeof(kKernelNames[0]) == KID_COUNT, "kernel name table");
+
+struct TimingState {
+    std::mutex mu;
+    int selected = -1;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    size_t used = 0;
+};
+static TimingState g_timing;
+
+struct Timed {
+    hipEvent_t stop = nullptr; hipStream_t st;
+    Timed(int kid, hipStream_t s) : st(s) {
+        if (g_timing.selected != kid) return;
+        std::lock_guard<std::mutex> lk(g_timing.mu);
+        if (g_timing.used == g_timing.pool.size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+            g_timing.pool.emplace_back(a, b);
+        }
+        auto &pr = g_timing.pool[g_timing.used++];
+        (void)hipEventRecord(pr.first, st);
+        stop = pr.second;
+    }
+    ~Timed() { if (stop) (void)hipEventRecord(stop, st); }
+};
+#define PTX_TIMED(kid, st, call) do { ::ptx::Timed t_(kid, st); PTX_TRY(call); } while (0)
 
 static inline float attn_scale(int hd) { return (float)(1.0 / std::sqrt((double)hd)); }   // head_dim ** -0.5
 
@@ -130,18 +175,18 @@ static int run_img_proxy(const PtxShape &s, const PtxWeights &w, const float *pr
     float *fm = at<float>(ws, L.fm), *x0 = at<float>(ws, L.x0), *qkv0 = at<float>(ws, L.qkv0);
     float *we = at<float>(ws, L.we), *gbuf = at<float>(ws, L.gbuf), *obuf = at<float>(ws, L.obuf);
     float *cbuf = at<float>(ws, L.cbuf);
-    PTX_TRY(launch_img_mean(img, nimg, s.in_dim, s.hw, fm, st));
+    PTX_TIMED(KID_IMG_MEAN, st, launch_img_mean(img, nimg, s.in_dim, s.hw, fm, st));
     {   // x0 = Wc mean(f) + (bc + pos_0)
         GemmBatch g{}; g.n = 1;
         g.p[0] = GemmProb{fm, w.cm_w, x0, prep + P.x0b, nullptr, nullptr, nullptr,
                           nimg, C, s.in_dim, s.in_dim, s.in_dim, C, 0, 0, 0, EPI_NONE};
-        PTX_TRY(launch_gemm(g, st));
+        PTX_TIMED(KID_IMG_X0, st, launch_gemm(g, st));
     }
     {   // [q | k0 | v0] of token 0
         GemmBatch g{}; g.n = 1;
         g.p[0] = GemmProb{x0, prep + P.wqkv0, qkv0, prep + P.bqkv0, nullptr, nullptr, nullptr,
                           nimg, 3 * C, C, C, C, 3 * C, 0, 0, 0, EPI_NONE};
-        PTX_TRY(launch_gemm(g, st));
+        PTX_TIMED(KID_IMG_QKV0, st, launch_gemm(g, st));
     }
     {   // per head: [w_h | e_h] = q_h T1_h^T
         GemmBatch g{}; g.n = s.heads;
@@ -149,11 +194,11 @@ static int run_img_proxy(const PtxShape &s, const PtxWeights &w, const float *pr
             g.p[h] = GemmProb{qkv0 + h * hd, prep + P.t1 + (size_t)h * P.KT1 * hd, we + (size_t)h * P.KT1,
                               nullptr, nullptr, nullptr, nullptr, nimg, P.KT1, hd, 3 * C, hd,
                               s.heads * P.KT1, 0, 0, 0, EPI_NONE};
-        PTX_TRY(launch_gemm(g, st));
+        PTX_TIMED(KID_IMG_WE, st, launch_gemm(g, st));
     }
-    PTX_TRY(launch_img_scores(img, we, qkv0, nimg, s.in_dim, s.hw, s.heads, C, P.KT1, P.KT2p,
-                              attn_scale(hd), gbuf, st));
-    PTX_TRY(launch_img_gather(img, nimg, s.in_dim, s.hw, s.heads, P.KT2p, gbuf, st));
+    PTX_TIMED(KID_IMG_SCORES, st, launch_img_scores(img, we, qkv0, nimg, s.in_dim, s.hw, s.heads, C, P.KT1,
+                                                    P.KT2p, attn_scale(hd), gbuf, st));
+    PTX_TIMED(KID_IMG_GATHER, st, launch_img_gather(img, nimg, s.in_dim, s.hw, s.heads, P.KT2p, gbuf, st));
     {   // per head: o_h = [g_h | a_h] T2_h^T + a_h(0) v0_h + bv_h
         GemmBatch g{}; g.n = s.heads;
         for (int h = 0; h < s.heads; ++h)
@@ -161,17 +206,17 @@ static int run_img_proxy(const PtxShape &s, const PtxWeights &w, const float *pr
                               w.v_b + h * hd, nullptr, gbuf + (size_t)h * P.KT2p + s.in_dim,
                               qkv0 + 2 * C + h * hd, nimg, hd, P.KT2p, s.heads * P.KT2p, P.KT2p, C,
                               0, s.heads * P.KT2p, 3 * C, EPI_NONE};
-        PTX_TRY(launch_gemm(g, st));
+        PTX_TIMED(KID_IMG_O, st, launch_gemm(g, st));
     }
     {   // c_proj
         GemmBatch g{}; g.n = 1;
         g.p[0] = GemmProb{obuf, w.c_w, cbuf, w.c_b, nullptr, nullptr, nullptr,
                           nimg, C, C, C, C, C, 0, 0, 0, EPI_NONE};
-        PTX_TRY(launch_gemm(g, st));
+        PTX_TIMED(KID_IMG_C, st, launch_gemm(g, st));
     }
     LnBatch lb{}; lb.n = 1; lb.C = C; lb.eps = s.ln_eps;
     lb.p[0] = LnProb{cbuf, img_proxy, w.norm_img_w, w.norm_img_b, nullptr, nimg, 1};
-    PTX_TRY(launch_ln_rows(lb, st));
+    PTX_TIMED(KID_IMG_LN, st, launch_ln_rows(lb, st));
     return PTX_OK;
 }
 
@@ -195,7 +240,7 @@ static int run_blocks(const PtxShape &s, const Branch *br, int nb, const float *
             g.p[2 * i + 1] = GemmProb{br[i].proxy, br[i].blk->pp_w, at<float>(ws, L.pt[sl]), br[i].blk->pp_b,
                                       nullptr, nullptr, nullptr, s.B * br[i].Lp, C, C, C, C, C, 0, 0, 0, EPI_NONE};
         }
-        PTX_TRY(launch_gemm(g, st));
+        PTX_TIMED(KID_BLK_QKV, st, launch_gemm(g, st));
     }
     AttnBatch a{}; a.n = nb; a.B = s.B; a.heads = s.heads; a.scale = attn_scale(C / s.heads);
     for (int i = 0; i < nb; ++i) {   // proxy as query (PRE:232-238): no mask
@@ -205,7 +250,7 @@ static int run_blocks(const PtxShape &s, const Branch *br, int nb, const float *
                           br[i].Lp, s.Mk, C, 3 * C, 3 * C, C,
                           (long)br[i].Lp * C, (long)s.Mk * 3 * C, (long)s.Mk * 3 * C, (long)br[i].Lp * C};
     }
-    PTX_TRY(launch_attn32(a, st));
+    PTX_TIMED(KID_BLK_ATTN_A, st, launch_attn32(a, st));
     for (int i = 0; i < nb; ++i) {   // proxy as key (PRE:241-250): padded text tokens masked
         const int sl = br[i].slot;
         float *qkv = at<float>(ws, L.qkv[sl]);
@@ -213,7 +258,7 @@ static int run_blocks(const PtxShape &s, const Branch *br, int nb, const float *
                           br[i].mask, s.Mk, br[i].Lp, 3 * C, C, C, C,
                           (long)s.Mk * 3 * C, (long)br[i].Lp * C, (long)br[i].Lp * C, (long)s.Mk * C};
     }
-    PTX_TRY(launch_attn32(a, st));
+    PTX_TIMED(KID_BLK_ATTN_B, st, launch_attn32(a, st));
     {   // x1 = x + proj(attn) (PRE:255, 274)
         GemmBatch g{}; g.n = nb;
         for (int i = 0; i < nb; ++i) {
@@ -221,7 +266,7 @@ static int run_blocks(const PtxShape &s, const Branch *br, int nb, const float *
             g.p[i] = GemmProb{at<float>(ws, L.ao[sl]), br[i].blk->proj_w, at<float>(ws, L.x1[sl]),
                               br[i].blk->proj_b, point_proxy, nullptr, nullptr, R, C, C, C, C, C, C, 0, 0, EPI_NONE};
         }
-        PTX_TRY(launch_gemm(g, st));
+        PTX_TIMED(KID_BLK_PROJ, st, launch_gemm(g, st));
     }
     {   // norm2 (PRE:275)
         LnBatch lb{}; lb.n = nb; lb.C = C; lb.eps = s.ln_eps;
@@ -230,7 +275,7 @@ static int run_blocks(const PtxShape &s, const Branch *br, int nb, const float *
             lb.p[i] = LnProb{at<float>(ws, L.x1[sl]), at<float>(ws, L.xn2[sl]), br[i].blk->norm2_w,
                              br[i].blk->norm2_b, nullptr, R, 1};
         }
-        PTX_TRY(launch_ln_rows(lb, st));
+        PTX_TIMED(KID_BLK_LN2, st, launch_ln_rows(lb, st));
     }
     {   // fc1 + GELU(erf)
         GemmBatch g{}; g.n = nb;
@@ -240,7 +285,7 @@ static int run_blocks(const PtxShape &s, const Branch *br, int nb, const float *
                               br[i].blk->fc1_b, nullptr, nullptr, nullptr, R, s.hidden, C, C, C, s.hidden,
                               0, 0, 0, EPI_GELU};
         }
-        PTX_TRY(launch_gemm(g, st));
+        PTX_TIMED(KID_BLK_FC1, st, launch_gemm(g, st));
     }
     {   // x2 = x1 + fc2(h)
         GemmBatch g{}; g.n = nb;
@@ -250,7 +295,7 @@ static int run_blocks(const PtxShape &s, const Branch *br, int nb, const float *
                               br[i].blk->fc2_b, at<float>(ws, L.x1[sl]), nullptr, nullptr, R, C, s.hidden,
                               s.hidden, s.hidden, C, C, 0, 0, EPI_NONE};
         }
-        PTX_TRY(launch_gemm(g, st));
+        PTX_TIMED(KID_BLK_FC2, st, launch_gemm(g, st));
     }
     HeadBatch hb{}; hb.n = nb; hb.C = C; hb.eps = s.ln_eps;
     for (int i = 0; i < nb; ++i) {
@@ -258,7 +303,7 @@ static int run_blocks(const PtxShape &s, const Branch *br, int nb, const float *
         hb.p[i] = HeadProb{at<float>(ws, L.x2[sl]), br[i].blk->out_norm_w, br[i].blk->out_norm_b,
                            br[i].head_w, br[i].head_b, br[i].head_ab, br[i].head_out, br[i].guide, R, br[i].nout};
     }
-    PTX_TRY(launch_heads(hb, st));
+    PTX_TIMED(KID_BLK_HEADS, st, launch_heads(hb, st));
     return PTX_OK;
 }
 
@@ -296,6 +341,35 @@ using namespace ptx;
 extern "C" {
 
 int ptx_abi_version(void) { return PTX_ABI_VERSION; }
+
+int ptx_kernel_count(void) { return KID_COUNT; }
+const char *ptx_kernel_name(int kid) { return kid >= 0 && kid < KID_COUNT ? kKernelNames[kid] : nullptr; }
+
+int ptx_timing_select(int kid)
+{
+    PTX_REQUIRE(kid >= -1 && kid < KID_COUNT, "ptx_timing_select: kid=%d", kid);
+    std::lock_guard<std::mutex> lk(g_timing.mu);
+    g_timing.selected = kid;
+    g_timing.used = 0;
+    return PTX_OK;
+}
+
+int ptx_timing_read(int *launches, float *total_ms)
+{
+    PTX_REQUIRE(launches && total_ms, "ptx_timing_read: null argument");
+    std::lock_guard<std::mutex> lk(g_timing.mu);
+    float sum = 0.0f;
+    for (size_t i = 0; i < g_timing.used; ++i) {
+        PTX_HIP(hipEventSynchronize(g_timing.pool[i].second));
+        float ms = 0.0f;
+        PTX_HIP(hipEventElapsedTime(&ms, g_timing.pool[i].first, g_timing.pool[i].second));
+        sum += ms;
+    }
+    *launches = (int)g_timing.used;
+    *total_ms = sum;
+    g_timing.used = 0;
+    return PTX_OK;
+}
 const char *ptx_last_error(void) { return g_err; }
 
 size_t ptx_prep_bytes(const PtxShape *s)
@@ -464,32 +538,33 @@ int ptx_forward(const PtxShape *s, const PtxWeights *w, const void *prep, const 
     float *cluster1 = at<float>(ws, L.cluster1), *offsets = at<float>(ws, L.offsets);
     float *centers = at<float>(ws, L.centers), *cluster2 = at<float>(ws, L.cluster2);
     int32_t *idx2 = at<int32_t>(ws, L.idx2), *pad_count = at<int32_t>(ws, L.pad_count);
-    PTX_HIP(hipMemsetAsync(at<char>(ws, L.zero_begin), 0, L.zero_bytes, st));
-    PTX_TRY(launch_minmax(points, B, S.N, mm_enc, st));
+    { Timed t_(KID_MEMSET, st); PTX_HIP(hipMemsetAsync(at<char>(ws, L.zero_begin), 0, L.zero_bytes, st)); }
+    PTX_TIMED(KID_MINMAX, st, launch_minmax(points, B, S.N, mm_enc, st));
     // ball query #1 on the unclamped grid centres; only the gathered xyz is used (PRE:56, Q3)
-    PTX_TRY(launch_ball_query(nullptr, mm_enc, lin, S.grid_size, S.margin, minmax, centers0, points, B, M, S.N,
-                              K, S.radius, idx2, cluster1, nullptr, st));
-    PTX_TRY(launch_offset_net(pf + P.off_ab, w->offset, w->offset_map_w, centers0, cluster1, minmax, B * M, M,
-                              K, S.margin, centers, offsets, st));
+    PTX_TIMED(KID_BQ1, st, launch_ball_query(nullptr, mm_enc, lin, S.grid_size, S.margin, minmax, centers0, points,
+                                             B, M, S.N, K, S.radius, idx2, cluster1, nullptr, st));
+    PTX_TIMED(KID_OFFSET, st, launch_offset_net(pf + P.off_ab, w->offset, w->offset_map_w, centers0, cluster1,
+                                                minmax, B * M, M, K, S.margin, centers, offsets, st));
     if (centers_override)
         PTX_HIP(hipMemcpyAsync(centers, centers_override, (size_t)B * M * 3 * 4, hipMemcpyDeviceToDevice, st));
-    PTX_TRY(launch_ball_query(centers, nullptr, nullptr, 0, 0.0f, nullptr, nullptr, points, B, M, S.N, K,
-                              S.radius, idx2, cluster2, pad_count, st));                      // PRE:65
+    PTX_TIMED(KID_BQ2, st, launch_ball_query(centers, nullptr, nullptr, 0, 0.0f, nullptr, nullptr, points, B, M,
+                                             S.N, K, S.radius, idx2, cluster2, pad_count, st));   // PRE:65
 
     // ---- dynamic cluster dropout (PRE:433)
     int32_t *order = at<int32_t>(ws, L.order), *picks = at<int32_t>(ws, L.picks), *keep = at<int32_t>(ws, L.keep);
     float *kcenter = at<float>(ws, L.kcenter), *kcluster = at<float>(ws, L.kcluster);
     int32_t *kidx = at<int32_t>(ws, L.kidx), *drop_idx = at<int32_t>(ws, L.drop_idx);
-    PTX_TRY(launch_select(S, idx2, centers, cluster2, pad_count, order_override, order, picks, keep, kcenter,
-                          kcluster, kidx, drop_idx, tag, st));
+    PTX_TIMED(KID_SELECT, st, launch_select(S, idx2, centers, cluster2, pad_count, order_override, order, picks,
+                                            keep, kcenter, kcluster, kidx, drop_idx, tag, st));
     int32_t *tile_counts = at<int32_t>(ws, L.tile_counts);
-    PTX_TRY(launch_tile_count(tag, B, S.N, tile_counts, st));
+    PTX_TIMED(KID_TILECOUNT, st, launch_tile_count(tag, B, S.N, tile_counts, st));
 
     // ---- point proxies (PRE:437) + norm1 / slot bias of both blocks
     float *point_proxy = at<float>(ws, L.point_proxy);
     float *xin_t = at<float>(ws, L.x_in[0]), *xin_i = at<float>(ws, L.x_in[1]);
-    PTX_TRY(launch_pointnet(pf + P.enc_ab, w->encoder, kcenter, kcluster, B * S.Mk, S.Mk, K, point_proxy,
-                            &w->text, &w->img, pf + P.posb_t, pf + P.posb_i, xin_t, xin_i, S.ln_eps, st));
+    PTX_TIMED(KID_POINTNET, st, launch_pointnet(pf + P.enc_ab, w->encoder, kcenter, kcluster, B * S.Mk, S.Mk, K,
+                                                point_proxy, &w->text, &w->img, pf + P.posb_t, pf + P.posb_i, xin_t,
+                                                xin_i, S.ln_eps, st));
 
     // ---- join, then both proxy blocks + heads in shared launches (PRE:440-455)
     PTX_HIP(hipStreamWaitEvent(st, side->join, 0));
@@ -501,7 +576,8 @@ int ptx_forward(const PtxShape *s, const PtxWeights *w, const void *prep, const 
     PTX_TRY(run_blocks(S, br, 2, point_proxy, ws, st));
 
     // ---- submanifold reshape + scatter + drop (PRE:459-467)
-    PTX_TRY(launch_affine(S, points, tag, kcenter, translate, transform, out, counts, tile_counts, true, st));
+    PTX_TIMED(KID_AFFINE, st, launch_affine(S, points, tag, kcenter, translate, transform, out, counts, tile_counts,
+                                            true, st));
 
     PTX_DBG(centers0, centers0, (size_t)B * M * 3 * 4);
     PTX_DBG(cluster1, cluster1, (size_t)B * M * K * 3 * 4);
