@@ -139,6 +139,12 @@ int ptx_grid_centers(const float *points, int B, int N, const float *lin, int gs
 int ptx_ball_query(const float *centers, const float *points, int B, int M, int N, int K,
                    float radius, int32_t *idx, float *cluster, int32_t *pad_count, void *stream);
 
+/* nn.Linear as used throughout ProxyAttention / Mlp (PRE:221, 223, 255; timm Mlp fc1/fc2):
+ * y (rows,n_out) = x (rows,n_in) w^T (n_out,n_in) + bias [-> GELU(erf) if gelu] [+ residual].
+ * fp32 MFMA (v_mfma_f32_32x32x2_f32); n_in % 4 == 0, x and w 16-byte aligned. */
+int ptx_linear(const float *x, const float *w, const float *bias, const float *residual, float *y,
+               int rows, int n_out, int n_in, int gelu, void *stream);
+
 /* OffsetNetwork.forward + tanh*margin + add + clamp, PRE:58-62, 87-107.
  * centers_in (B,M,3), cluster (B,M,K,3), minmax (B,2,3) -> centers_out (B,M,3);
  * offsets_out (B,M,3) = tanh(raw)*margin, may be NULL. */

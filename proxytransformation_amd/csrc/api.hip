@@ -24,14 +24,14 @@ void set_error(const char *fmt, ...)
 // is launched on; ptx_timing_read() returns launches and summed milliseconds.  Off by default.
 static const char *const kKernelNames[] = {
     "memset", "k_minmax", "k_ball_query<grid>", "k_slot_net<offset>", "k_ball_query", "k_select",
-    "k_tile_count", "k_slot_net<pointnet>", "k_img_mean", "k_gemm_nt[x0]", "k_gemm_nt[qkv0]",
+    "k_tile_count", "k_slot_net<pointnet>", "k_img_mean", "k_gemm_nt[qkv0]",
     "k_gemm_nt[we]", "k_img_scores", "k_img_gather", "k_gemm_nt[o]", "k_gemm_nt[c_proj]",
     "k_ln_rows[norm_img]", "k_gemm_nt[qkv+proxy_proj]", "k_attn32[proxy_as_query]",
     "k_attn32[proxy_as_key]", "k_gemm_nt[proj]", "k_ln_rows[norm2]", "k_gemm_nt[fc1]", "k_gemm_nt[fc2]",
     "k_heads", "k_affine<compact>"};
 enum Kid : int {
     KID_MEMSET = 0, KID_MINMAX, KID_BQ1, KID_OFFSET, KID_BQ2, KID_SELECT, KID_TILECOUNT, KID_POINTNET,
-    KID_IMG_MEAN, KID_IMG_X0, KID_IMG_QKV0, KID_IMG_WE, KID_IMG_SCORES, KID_IMG_GATHER, KID_IMG_O, KID_IMG_C,
+    KID_IMG_MEAN, KID_IMG_QKV0, KID_IMG_WE, KID_IMG_SCORES, KID_IMG_GATHER, KID_IMG_O, KID_IMG_C,
     KID_IMG_LN, KID_BLK_QKV, KID_BLK_ATTN_A, KID_BLK_ATTN_B, KID_BLK_PROJ, KID_BLK_LN2, KID_BLK_FC1,
     KID_BLK_FC2, KID_BLK_HEADS, KID_AFFINE, KID_COUNT};
 static_assert(sizeof(kKernelNames) / sizeof(kKernelNames[0]) == KID_COUNT, "kernel name table");
@@ -95,8 +95,7 @@ PrepLayout prep_layout(const PtxShape &s)
     P.off_ab = take(2 * kSlotHidden); P.enc_ab = take(2 * kSlotHidden);
     P.ttn_ab = take(6); P.itn_ab = take(18);
     P.posb_t = take((size_t)s.Mk * s.C); P.posb_i = take((size_t)s.Mk * s.C);
-    P.x0b = take(s.C);
-    P.wqkv0 = take((size_t)3 * s.C * s.C); P.bqkv0 = take((size_t)3 * s.C);
+    P.w3 = take((size_t)3 * s.C * s.in_dim); P.b3 = take((size_t)3 * s.C);
     P.t1 = take((size_t)s.heads * P.KT1 * P.hd);
     P.t2 = take((size_t)s.heads * P.hd * P.KT2p);
     P.total = o;
@@ -128,7 +127,7 @@ WsLayout ws_layout(const PtxShape &s)
     L.tile_counts = take(B * (size_t)cdiv(s.N, kTilePts) * 4);
     L.point_proxy = take(R * C * 4);
     for (int i = 0; i < 2; ++i) L.x_in[i] = take(R * C * 4);
-    L.fm = take(nimg * s.in_dim * 4); L.x0 = take(nimg * C * 4); L.qkv0 = take(nimg * 3 * C * 4);
+    L.fm = take(nimg * s.in_dim * 4); L.qkv0 = take(nimg * 3 * C * 4);
     L.we = take(nimg * s.heads * (size_t)P.KT1 * 4); L.gbuf = take(nimg * s.heads * (size_t)P.KT2p * 4);
     L.obuf = take(nimg * C * 4); L.cbuf = take(nimg * C * 4); L.img_proxy = take(nimg * C * 4);
     for (int i = 0; i < 2; ++i) {
@@ -172,20 +171,14 @@ static int run_img_proxy(const PtxShape &s, const PtxWeights &w, const float *pr
     const PrepLayout P = prep_layout(s);
     const WsLayout L = ws_layout(s);
     const int nimg = s.B * s.V, C = s.C, hd = P.hd;
-    float *fm = at<float>(ws, L.fm), *x0 = at<float>(ws, L.x0), *qkv0 = at<float>(ws, L.qkv0);
+    float *fm = at<float>(ws, L.fm), *qkv0 = at<float>(ws, L.qkv0);
     float *we = at<float>(ws, L.we), *gbuf = at<float>(ws, L.gbuf), *obuf = at<float>(ws, L.obuf);
     float *cbuf = at<float>(ws, L.cbuf);
     PTX_TIMED(KID_IMG_MEAN, st, launch_img_mean(img, nimg, s.in_dim, s.hw, fm, st));
-    {   // x0 = Wc mean(f) + (bc + pos_0)
+    {   // [q | k0 | v0] of token 0 = W3 mean(f) + b3
         GemmBatch g{}; g.n = 1;
-        g.p[0] = GemmProb{fm, w.cm_w, x0, prep + P.x0b, nullptr, nullptr, nullptr,
-                          nimg, C, s.in_dim, s.in_dim, s.in_dim, C, 0, 0, 0, EPI_NONE};
-        PTX_TIMED(KID_IMG_X0, st, launch_gemm(g, st));
-    }
-    {   // [q | k0 | v0] of token 0
-        GemmBatch g{}; g.n = 1;
-        g.p[0] = GemmProb{x0, prep + P.wqkv0, qkv0, prep + P.bqkv0, nullptr, nullptr, nullptr,
-                          nimg, 3 * C, C, C, C, 3 * C, 0, 0, 0, EPI_NONE};
+        g.p[0] = GemmProb{fm, prep + P.w3, qkv0, prep + P.b3, nullptr, nullptr, nullptr,
+                          nimg, 3 * C, s.in_dim, s.in_dim, s.in_dim, 3 * C, 0, 0, 0, EPI_NONE};
         PTX_TIMED(KID_IMG_QKV0, st, launch_gemm(g, st));
     }
     {   // per head: [w_h | e_h] = q_h T1_h^T
@@ -415,6 +408,17 @@ int ptx_ball_query(const float *centers, const float *points, int B, int M, int 
     PTX_REQUIRE(B >= 1 && M >= 1 && N >= 1 && K >= 1, "ptx_ball_query: B=%d M=%d N=%d K=%d", B, M, N, K);
     return launch_ball_query(centers, nullptr, nullptr, 0, 0.0f, nullptr, nullptr, points, B, M, N, K, radius,
                              idx, cluster, pad_count, static_cast<hipStream_t>(stream));
+}
+
+int ptx_linear(const float *x, const float *w, const float *bias, const float *residual, float *y,
+               int rows, int n_out, int n_in, int gelu, void *stream)
+{
+    PTX_REQUIRE(x && w && y, "ptx_linear: null argument");
+    PTX_REQUIRE(rows >= 1 && n_out >= 1 && n_in >= 4, "ptx_linear: rows=%d n_out=%d n_in=%d", rows, n_out, n_in);
+    GemmBatch g{}; g.n = 1;
+    g.p[0] = GemmProb{x, w, y, bias, residual, nullptr, nullptr, rows, n_out, n_in, n_in, n_in, n_out, n_out, 0, 0,
+                      gelu ? EPI_GELU : EPI_NONE};
+    return launch_gemm(g, static_cast<hipStream_t>(stream));
 }
 
 int ptx_offset_net(const PtxShape *s, const PtxWeights *w, const void *prep, const float *centers_in,

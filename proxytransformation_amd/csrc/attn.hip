@@ -22,7 +22,7 @@ constexpr int HD = 32;
 
 __global__ __launch_bounds__(256) void k_attn32(AttnBatch ab)
 {
-    const AttnProb &p = ab.p[blockIdx.z];
+    const AttnProb p = ab.p[blockIdx.z];           // by value: fields live in SGPRs
     const int lane = lane_id();
     const int qt = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     const int q0 = qt * 32;
@@ -56,30 +56,34 @@ __global__ __launch_bounds__(256) void k_attn32(AttnBatch ab)
 #pragma unroll
     for (int i = 0; i < 16; ++i) o[i] = 0.0f;
 
-    for (int k0 = 0; k0 < p.nk; k0 += 32) {
-        // A operand of S^T: key row k0 + li, dims hh*16 .. +15
-        float kf[16];
-        {
-            const int ki = k0 + li;
-            if (ki < p.nk) {
-                const float4 *src = reinterpret_cast<const float4 *>(Kp + (size_t)ki * p.ldk + hh * 16);
+    // key / value fragments of tile k0 (A operands): kf = K[k0 + li][hh*16 .. +15],
+    // vf[s] = V[k0 + key(s,hh)][li] with key(s,hh) = (s&3) + 8*(s>>2) + 4*hh
+    auto load_tile = [&](int k0, float (&kf)[16], float (&vf)[16]) {
+        const int ki = k0 + li;
+        if (ki < p.nk) {
+            const float4 *src = reinterpret_cast<const float4 *>(Kp + (size_t)ki * p.ldk + hh * 16);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float4 t = src[i];
-                    kf[4 * i] = t.x; kf[4 * i + 1] = t.y; kf[4 * i + 2] = t.z; kf[4 * i + 3] = t.w;
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) kf[i] = 0.0f;
+            for (int i = 0; i < 4; ++i) {
+                const float4 t = src[i];
+                kf[4 * i] = t.x; kf[4 * i + 1] = t.y; kf[4 * i + 2] = t.z; kf[4 * i + 3] = t.w;
             }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) kf[i] = 0.0f;
         }
-        // A operand of O^T: V[key(s,hh)][li]
-        float vf[16];
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int key = k0 + (s & 3) + 8 * (s >> 2) + 4 * hh;
             vf[s] = key < p.nk ? Vp[(size_t)key * p.ldv + li] : 0.0f;
         }
+    };
+    float kf[16], vf[16], kn[16], vn[16];
+    load_tile(0, kf, vf);
+    for (int k0 = 0; k0 < p.nk; k0 += 32) {
+        // software pipeline: the next tile's loads are in flight while this tile is consumed
+        // (freshly written K/V come from another XCD's L2 or HBM: ~1 us per dependent round trip)
+        const bool more = k0 + 32 < p.nk;
+        if (more) load_tile(k0 + 32, kn, vn);
         f32x16 sc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) sc[i] = 0.0f;
@@ -109,6 +113,10 @@ __global__ __launch_bounds__(256) void k_attn32(AttnBatch ab)
 #pragma unroll
         for (int s = 0; s < 16; ++s) o = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[s], sc[s], o, 0, 0, 0);
         m_run = m_new;
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { kf[i] = kn[i]; vf[i] = vn[i]; }
+        }
     }
     // o[r] = O^T[d = (r&3) + 8*(r>>2) + 4*hh][query = li]
     const int qi = q0 + li;

@@ -321,11 +321,11 @@ struct SelectArgs {
     int M, K, Mt, Mk, Kd, N;
 };
 
-template <int P>   // points per thread in the FPS loop (blockDim.x * P >= Mt)
+template <int P>   // points per lane of the FPS wave (64 * P >= Mt)
 __global__ __launch_bounds__(256) void k_select(SelectArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int T = blockDim.x, tid = threadIdx.x, lane = lane_id(), wid = tid >> 6, nw = T >> 6;
+    const int T = blockDim.x, tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
     const int b = blockIdx.x;
     const int M = a.M, K = a.K, Mt = a.Mt, Mk = a.Mk, Kd = a.Kd;
     // LDS carve
@@ -336,8 +336,6 @@ __global__ __launch_bounds__(256) void k_select(SelectArgs a)
     int *s_keep = s_flag + Mt;                                    // Mk
     int *s_picks = s_keep + Mk;                                   // Kd
     int *s_hist = s_picks + (Kd > 0 ? Kd : 1);                    // 64
-    float *s_redv = reinterpret_cast<float *>(s_hist + 64);       // 2*4
-    int *s_redi = reinterpret_cast<int *>(s_redv + 8);            // 2*4
 
     const int32_t *pc = a.pad_count + (size_t)b * M;
     // ---- 1. ordering
@@ -386,46 +384,41 @@ __global__ __launch_bounds__(256) void k_select(SelectArgs a)
     }
     __syncthreads();
 
-    // ---- 2. farthest point sampling (sequential in k, parallel over points)
-    float px[P], py[P], pz[P], mind[P];
-#pragma unroll
-    for (int i = 0; i < P; ++i) {
-        const int t = tid + i * T;
-        if (t < Mt) { px[i] = sx[t]; py[i] = sy[t]; pz[i] = sz[t]; } else { px[i] = py[i] = pz[i] = 0.0f; }
-        mind[i] = INFINITY;
-    }
-    int last = 0;
-    if (tid == 0 && Kd > 0) s_picks[0] = 0;
+    // ---- 2. farthest point sampling: sequential in k, so it runs in ONE wave with no barrier.
+    // Lane l keeps points l*P .. l*P+P-1 (blocked: lane order == index order) and their running
+    // minimum distances in registers; per pick: P distance updates, a DPP row-rotate max, one
+    // ballot.  First-max tie-break (PRE:613): in-lane strict '>', across lanes lowest set ballot bit.
     const int kn = Kd < Mt ? Kd : Mt;                                            // PRE:595
-    for (int k = 1; k < kn; ++k) {
-        const float lx = sx[last], ly = sy[last], lz = sz[last];
-        float bv = -1.0f; int bi = 0x7fffffff;
+    if (wid == 0) {
+        // the whole scene waits on this one latency-bound wave while bandwidth-bound kernels of the
+        // image branch share the CU: give it issue priority
+        __builtin_amdgcn_s_setprio(3);
+        float px[P], py[P], pz[P], mind[P];
 #pragma unroll
         for (int i = 0; i < P; ++i) {
-            const int t = tid + i * T;
-            if (t < Mt) {
+            const int t = lane * P + i;
+            if (t < Mt) { px[i] = sx[t]; py[i] = sy[t]; pz[i] = sz[t]; mind[i] = INFINITY; }
+            else        { px[i] = py[i] = pz[i] = 0.0f; mind[i] = -1.0f; }      // never the maximum
+        }
+        int last = 0;
+        if (lane == 0 && Kd > 0) s_picks[0] = 0;
+        for (int k = 1; k < kn; ++k) {
+            const float lx = sx[last], ly = sy[last], lz = sz[last];
+            float bv = -1.0f; int bi = 0;
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
                 const float d2 = dist2_nofma(lx, ly, lz, px[i], py[i], pz[i]);
                 const float mnv = fminf(mind[i], d2);                            // PRE:609
                 mind[i] = mnv;
-                if (mnv > bv) { bv = mnv; bi = t; }                              // t ascending in i: first max
+                if (mnv > bv) { bv = mnv; bi = i; }
             }
+            const float gmax = wave_max_dpp(bv);
+            const unsigned long long who = __ballot(bv == gmax);
+            const int leader = __ffsll((long long)who) - 1;
+            last = leader * P + __builtin_amdgcn_readlane(bi, leader);
+            if (lane == 0) s_picks[k] = last;
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(bv, o, 64);
-            const int oi = __shfl_xor(bi, o, 64);
-            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-        }
-        const int par = k & 1;
-        if (lane == 0) { s_redv[par * 4 + wid] = bv; s_redi[par * 4 + wid] = bi; }
-        __syncthreads();
-        bv = s_redv[par * 4]; bi = s_redi[par * 4];
-        for (int ww = 1; ww < nw; ++ww) {
-            const float ov = s_redv[par * 4 + ww]; const int oi = s_redi[par * 4 + ww];
-            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-        }
-        last = bi;                                                               // PRE:613 argmax, first max
-        if (tid == 0) s_picks[k] = last;
+        __builtin_amdgcn_s_setprio(0);
     }
     __syncthreads();
     for (int k = tid; k < Kd; k += T) {
@@ -498,7 +491,7 @@ int launch_select(const PtxShape &s, const int32_t *idx, const float *centers, c
                  s.Mk, s.Mt - s.Mk, s.N};
     const size_t lds = select_lds_bytes(s);
     PTX_REQUIRE(lds <= 160 * 1024, "select: Mt=%d needs %zu B of LDS (> 160 KiB)", s.Mt, lds);
-    const int per = cdiv(s.Mt, 256);
+    const int per = cdiv(s.Mt, 64);
     const dim3 grid(s.B), block(256);
 #define PTX_SEL(P_)                                                                          \
     do {                                                                                     \
@@ -507,11 +500,11 @@ int launch_select(const PtxShape &s, const int32_t *idx, const float *centers, c
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(k_select<P_>, grid, block, lds, st, a);                           \
     } while (0)
-    if (per <= 2) PTX_SEL(2);
-    else if (per <= 6) PTX_SEL(6);
-    else if (per <= 12) PTX_SEL(12);
-    else if (per <= 24) PTX_SEL(24);
-    else { set_error("select: Mt=%d too large (max %d)", s.Mt, 256 * 24); return PTX_EINVAL; }
+    if (per <= 8) PTX_SEL(8);
+    else if (per <= 16) PTX_SEL(16);
+    else if (per <= 32) PTX_SEL(32);
+    else if (per <= 64) PTX_SEL(64);
+    else { set_error("select: Mt=%d too large (max %d)", s.Mt, 64 * 64); return PTX_EINVAL; }
 #undef PTX_SEL
     PTX_LAUNCHED("k_select");
     return PTX_OK;

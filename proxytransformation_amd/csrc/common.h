@@ -53,23 +53,29 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // ---- device helpers -------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
-template <typename T>
-__device__ __forceinline__ T wave_sum(T v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+// All-lanes wave reductions without LDS traffic: 4 DPP row rotations leave every lane with its
+// 16-lane row result, v_readlane of one lane per row combines the 4 rows on the scalar side.
+#define PTX_ROR_F(v, n) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + (n), 0xf, 0xf, false))
+#define PTX_ROR_I(v, n) __builtin_amdgcn_update_dpp(0, (v), 0x120 + (n), 0xf, 0xf, false)
+#define PTX_LANE_F(v, l) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (l)))
+__device__ __forceinline__ float wave_sum(float v) {
+    v += PTX_ROR_F(v, 8); v += PTX_ROR_F(v, 4); v += PTX_ROR_F(v, 2); v += PTX_ROR_F(v, 1);
+    return (PTX_LANE_F(v, 0) + PTX_LANE_F(v, 16)) + (PTX_LANE_F(v, 32) + PTX_LANE_F(v, 48));
+}
+__device__ __forceinline__ int wave_sum(int v) {
+    v += PTX_ROR_I(v, 8); v += PTX_ROR_I(v, 4); v += PTX_ROR_I(v, 2); v += PTX_ROR_I(v, 1);
+    return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) +
+           (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, PTX_ROR_F(v, 8)); v = fmaxf(v, PTX_ROR_F(v, 4)); v = fmaxf(v, PTX_ROR_F(v, 2)); v = fmaxf(v, PTX_ROR_F(v, 1));
+    return fmaxf(fmaxf(PTX_LANE_F(v, 0), PTX_LANE_F(v, 16)), fmaxf(PTX_LANE_F(v, 32), PTX_LANE_F(v, 48)));
 }
 __device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fminf(v, PTX_ROR_F(v, 8)); v = fminf(v, PTX_ROR_F(v, 4)); v = fminf(v, PTX_ROR_F(v, 2)); v = fminf(v, PTX_ROR_F(v, 1));
+    return fminf(fminf(PTX_LANE_F(v, 0), PTX_LANE_F(v, 16)), fminf(PTX_LANE_F(v, 32), PTX_LANE_F(v, 48)));
 }
-
+__device__ __forceinline__ float wave_max_dpp(float v) { return wave_max(v); }
 // order-preserving float <-> uint32 (larger float <=> larger uint)
 __device__ __forceinline__ uint32_t f2ord(float f) {
     uint32_t u = __float_as_uint(f);
@@ -92,8 +98,7 @@ struct PrepLayout {
     size_t off_ab, enc_ab;          // (2,256): alpha, beta of the folded eval BatchNorm2d
     size_t ttn_ab, itn_ab;          // (2,3), (2,9) BatchNorm1d alpha/beta
     size_t posb_t, posb_i;          // (Mk,C) per-slot bias tables (PRE:212-215)
-    size_t x0b;                     // (C)  channel_mapper.bias + pos[0]
-    size_t wqkv0, bqkv0;            // (3C,C), (3C): [q;k;v] projections of token 0
+    size_t w3, b3;                  // (3C,in_dim), (3C): [q | k0 | v0] of token 0 from the image mean
     size_t t1;                      // (heads, KT1, hd): scale * [WkWc | K-proj of (bc+pos_i)]
     size_t t2;                      // (heads, hd, KT2p): [WvWc | V-proj of (bc+pos_i)] (transposed)
     size_t total;                   // floats
@@ -110,7 +115,7 @@ struct WsLayout {
     size_t minmax, centers0, cluster1, offsets, centers, idx2, cluster2, pad_count;
     size_t order, picks, keep, kcenter, kcluster, kidx, drop_idx, tile_counts;
     size_t point_proxy, x_in[2];    // x_in: LN1(x)+slot bias per branch (B*Mk,C)
-    size_t fm, x0, qkv0, we, gbuf, obuf, cbuf, img_proxy;
+    size_t fm, qkv0, we, gbuf, obuf, cbuf, img_proxy;
     size_t qkv[2], pt[2], pv[2], ao[2], x1[2], xn2[2], hbuf[2], x2[2], guide[2], head[2];
     size_t total;
 };

@@ -13,49 +13,79 @@ namespace ptx {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 64, BN = 64, BK = 16, LDT = BK + 4;   // LDT*4 B = 80 B rows: 16-B aligned
+constexpr int BK = 32, LDT = BK + 4;   // 144-B LDS rows: 16-B aligned, b128 fragment reads conflict-free
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-__global__ __launch_bounds__(256) void k_gemm_nt(GemmBatch gb)
+// TM x TN output tile per work-group, one 32x32 MFMA accumulator per wave ((TM/32)*(TN/32) waves).
+// K loop: BK = 32 per step; the next A/W tiles are fetched into registers while the current
+// ones are consumed from LDS, then stored into the other LDS buffer (one barrier per step).
+template <int TM, int TN>
+__global__ __launch_bounds__((TM / 32) * (TN / 32) * 64) void k_gemm_nt(GemmBatch gb)
 {
-    const GemmProb &pr = gb.p[blockIdx.z];
-    const int row0 = blockIdx.y * BM, col0 = blockIdx.x * BN;
+    constexpr int NT = (TM / 32) * (TN / 32) * 64;     // threads
+    constexpr int AV = TM * (BK / 4) / NT;             // float4 per thread per A tile
+    constexpr int WV = TN * (BK / 4) / NT;
+    const GemmProb pr = gb.p[blockIdx.z];          // by value: fields live in SGPRs, not re-read from kernarg
+    const int row0 = blockIdx.y * TM, col0 = blockIdx.x * TN;
     if (row0 >= pr.R || col0 >= pr.N) return;
-    __shared__ __attribute__((aligned(16))) float As[BM][LDT];
-    __shared__ __attribute__((aligned(16))) float Ws[BN][LDT];
+    __shared__ __attribute__((aligned(16))) float As[2][TM][LDT];
+    __shared__ __attribute__((aligned(16))) float Ws[2][TN][LDT];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wr = wid >> 1, wc = wid & 1;
+    const int wr = wid / (TN / 32), wc = wid % (TN / 32);
     const int li = lane & 31, hh = lane >> 5;
-    // staging assignment: thread -> (row = tid/4, 4 consecutive k at (tid%4)*4)
-    const int sr = tid >> 2, sk = (tid & 3) * 4;
-    const float *Ap = pr.A + (size_t)(row0 + sr) * pr.lda + sk;
-    const float *Wp = pr.W + (size_t)(col0 + sr) * pr.ldw + sk;
-    const bool a_ok = (row0 + sr) < pr.R, w_ok = (col0 + sr) < pr.N;
+    float4 av[AV], wv[WV];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < AV; ++i) {
+            const int e = tid + i * NT, r = e >> 3, kq = (e & 7) * 4;
+            av[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row0 + r < pr.R && k0 + kq < pr.K)         // K % 4 == 0 is validated by the host
+                av[i] = *reinterpret_cast<const float4 *>(pr.A + (size_t)(row0 + r) * pr.lda + k0 + kq);
+        }
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            const int e = tid + i * NT, r = e >> 3, kq = (e & 7) * 4;
+            wv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (col0 + r < pr.N && k0 + kq < pr.K)
+                wv[i] = *reinterpret_cast<const float4 *>(pr.W + (size_t)(col0 + r) * pr.ldw + k0 + kq);
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < AV; ++i) {
+            const int e = tid + i * NT;
+            *reinterpret_cast<float4 *>(&As[buf][e >> 3][(e & 7) * 4]) = av[i];
+        }
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            const int e = tid + i * NT;
+            *reinterpret_cast<float4 *>(&Ws[buf][e >> 3][(e & 7) * 4]) = wv[i];
+        }
+    };
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-    for (int k0 = 0; k0 < pr.K; k0 += BK) {
-        float4 av = make_float4(0.f, 0.f, 0.f, 0.f), wv = av;
-        if (k0 + sk < pr.K) {                                   // K % 4 == 0 is validated by the host
-            if (a_ok) av = *reinterpret_cast<const float4 *>(Ap + k0);
-            if (w_ok) wv = *reinterpret_cast<const float4 *>(Wp + k0);
-        }
-        __syncthreads();                                        // previous tile fully consumed
-        *reinterpret_cast<float4 *>(&As[sr][sk]) = av;
-        *reinterpret_cast<float4 *>(&Ws[sr][sk]) = wv;
-        __syncthreads();
+    const int nk = (pr.K + BK - 1) / BK;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int it = 0; it < nk; ++it) {
+        const int cur = it & 1;
+        if (it + 1 < nk) fetch((it + 1) * BK);
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
             // lane half hh owns k = kk*8 + hh*4 .. +3 of this group for both operands, so the
             // two k-values an MFMA consumes (one per half) are consistent between A and B
-            const float4 a4 = *reinterpret_cast<const float4 *>(&As[wr * 32 + li][kk * 8 + hh * 4]);
-            const float4 b4 = *reinterpret_cast<const float4 *>(&Ws[wc * 32 + li][kk * 8 + hh * 4]);
+            const float4 a4 = *reinterpret_cast<const float4 *>(&As[cur][wr * 32 + li][kk * 8 + hh * 4]);
+            const float4 b4 = *reinterpret_cast<const float4 *>(&Ws[cur][wc * 32 + li][kk * 8 + hh * 4]);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
         }
+        if (it + 1 < nk) stash(cur ^ 1);
+        __syncthreads();
     }
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     const int n = col0 + wc * 32 + li;
@@ -77,7 +107,8 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmBatch gb)
 int launch_gemm(const GemmBatch &gb, hipStream_t st)
 {
     PTX_REQUIRE(gb.n >= 1 && gb.n <= kMaxGroups, "gemm: %d groups", gb.n);
-    int tm = 0, tn = 0;
+    int rmax = 0, nmax = 0;
+    long big_tiles = 0;
     for (int g = 0; g < gb.n; ++g) {
         const GemmProb &p = gb.p[g];
         PTX_REQUIRE(p.A && p.W && p.C, "gemm: null operand in group %d", g);
@@ -86,11 +117,18 @@ int launch_gemm(const GemmBatch &gb, hipStream_t st)
         PTX_REQUIRE(((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.W)) & 15) == 0,
                     "gemm: operands of group %d are not 16-byte aligned", g);
         PTX_REQUIRE(p.rs == nullptr || p.ad != nullptr, "gemm: row scale without addend");
-        if (cdiv(p.R, BM) > tm) tm = cdiv(p.R, BM);
-        if (cdiv(p.N, BN) > tn) tn = cdiv(p.N, BN);
+        rmax = p.R > rmax ? p.R : rmax;
+        nmax = p.N > nmax ? p.N : nmax;
+        big_tiles += (long)cdiv(p.R, 64) * cdiv(p.N, 64);
     }
-    if (tm == 0 || tn == 0) return PTX_OK;
-    hipLaunchKernelGGL(k_gemm_nt, dim3(tn, tm, gb.n), dim3(256), 0, st, gb);
+    if (rmax == 0 || nmax == 0) return PTX_OK;
+    // 64x64 tiles re-use each staged operand twice as often; below ~2 work-groups per CU the
+    // launch is latency-bound and the 4x finer 32x32 decomposition fills the chip instead
+    if (big_tiles >= 512 && nmax > 32) {
+        hipLaunchKernelGGL((k_gemm_nt<64, 64>), dim3(cdiv(nmax, 64), cdiv(rmax, 64), gb.n), dim3(256), 0, st, gb);
+    } else {
+        hipLaunchKernelGGL((k_gemm_nt<32, 32>), dim3(cdiv(nmax, 32), cdiv(rmax, 32), gb.n), dim3(64), 0, st, gb);
+    }
     PTX_LAUNCHED("k_gemm_nt");
     return PTX_OK;
 }
@@ -123,7 +161,7 @@ __device__ __forceinline__ void ln_row(const float *x, int C, float eps, float (
 
 __global__ __launch_bounds__(256) void k_ln_rows(LnBatch lb)
 {
-    const LnProb &p = lb.p[blockIdx.y];
+    const LnProb p = lb.p[blockIdx.y];
     const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (row >= p.R) return;
     float v[kMaxPerLane], mean, rstd;
@@ -154,7 +192,7 @@ int launch_ln_rows(const LnBatch &lb, hipStream_t st)
 // ------------------------------------------------------------------------------ heads
 __global__ __launch_bounds__(256) void k_heads(HeadBatch hb)
 {
-    const HeadProb &p = hb.p[blockIdx.y];
+    const HeadProb p = hb.p[blockIdx.y];
     const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (row >= p.R) return;
     float v[kMaxPerLane], mean, rstd;

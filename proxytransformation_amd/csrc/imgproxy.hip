@@ -16,7 +16,7 @@
 // This file holds the three kernels that touch the image itself (HBM-bound, in_dim*hw*4 B / image):
 //   k_img_mean    f -> mean_p f                      (pass 1)
 //   k_img_scores  s_h(p), softmax -> a_h             (pass 2)
-//   k_img_gather  g_h = sum_p a_h(p) f_p             (pass 3, LDS-transposed)
+//   k_img_gather  g_h = sum_p a_h(p) f_p             (pass 3, v_mfma_f32_16x16x4_f32 from global)
 #include "common.h"
 
 namespace ptx {
@@ -58,49 +58,56 @@ int launch_img_mean(const float *img, int nimg, int in_dim, int hw, float *fm, h
     return PTX_OK;
 }
 
-// One work-group per image.  Wave w owns pixels [64w, 64w+64); every lane walks all channels
-// of its pixel (coalesced 256-B rows), 8 head scores accumulate in registers; w_h comes from LDS.
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-B load at 4-B alignment
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kMaxHeads = 8;
 
+// ---- pass 2: scores + softmax ---------------------------------------------------------------
+// One work-group (4 waves) per image; wave w streams channels [w*in_dim/4, (w+1)*in_dim/4).
+// Lane j owns pixels 4j..4j+3 of EVERY row (one 16-B load per lane and row; rows are hw*4 B
+// apart, so the loads are only 4-B aligned -- global_load_dwordx4 takes that), the hw%4 tail
+// pixels go to the next lanes as dword loads.  The 8 head weights of a row are wave-uniform and
+// arrive through the scalar cache (s_load), so the inner loop is 32 FMAs per 16-B load.
+template <int HEADS>
 __global__ __launch_bounds__(256) void k_img_scores(
     const float *__restrict__ img, const float *__restrict__ we, const float *__restrict__ qkv0,
-    int in_dim, int hw, int heads, int C, int KT1, int KT2p, float scale, float *__restrict__ gbuf)
+    int in_dim, int hw, int C, int KT1, int KT2p, float scale, float *__restrict__ gbuf)
 {
+    constexpr int heads = HEADS;
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float *w_s = sm;                               // [heads][in_dim]
-    float *S = sm + (size_t)heads * in_dim;        // [heads][hw + 1]
-    const int im = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
+    const int hwp = (hw + 3) & ~3;
+    float *red = sm;                               // [4][heads][hwp]
+    float *S = sm + 4 * heads * hwp;               // [heads][hw + 1]
+    const int im = blockIdx.x, tid = threadIdx.x, lane = lane_id();
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float *wim = we + (size_t)im * heads * KT1;
-    for (int i = tid; i < heads * in_dim; i += 256) {
-        const int h = i / in_dim, c = i - h * in_dim;
-        w_s[i] = wim[(size_t)h * KT1 + c];
-    }
-    __syncthreads();
     const float *f = img + (size_t)im * in_dim * hw;
-    for (int p0 = wid * 64; p0 < hw; p0 += 256) {
-        const int p = p0 + lane;
-        const bool ok = p < hw;
-        float acc[kMaxHeads];
+    const int nv4 = hw >> 2, tail = hw & 3;
+    const bool vec = lane < nv4, one = !vec && lane < nv4 + tail;
+    const int poff = vec ? 4 * lane : 4 * nv4 + (lane - nv4);
+    float acc[HEADS][4];
 #pragma unroll
-        for (int h = 0; h < kMaxHeads; ++h) acc[h] = 0.0f;
-        for (int c = 0; c < in_dim; c += 4) {
-            float fv[4];
+    for (int h = 0; h < HEADS; ++h) { acc[h][0] = acc[h][1] = acc[h][2] = acc[h][3] = 0.0f; }
+    const int cper = in_dim / 4, cbeg = wid * cper;
+#pragma unroll 4
+    for (int cc = 0; cc < cper; ++cc) {
+        const int c = cbeg + cc;
+        const float *row = f + (size_t)c * hw + poff;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        if (vec) { const f4u t = *reinterpret_cast<const f4u *>(row); v0 = t.x; v1 = t.y; v2 = t.z; v3 = t.w; }
+        if (one) v0 = row[0];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) fv[u] = ok ? f[(size_t)(c + u) * hw + p] : 0.0f;
-#pragma unroll
-            for (int h = 0; h < kMaxHeads; ++h) {
-                if (h < heads) {
-                    const float4 w4 = *reinterpret_cast<const float4 *>(&w_s[h * in_dim + c]);
-                    acc[h] = fmaf(w4.x, fv[0], acc[h]); acc[h] = fmaf(w4.y, fv[1], acc[h]);
-                    acc[h] = fmaf(w4.z, fv[2], acc[h]); acc[h] = fmaf(w4.w, fv[3], acc[h]);
-                }
-            }
+        for (int h = 0; h < HEADS; ++h) {
+            const float wv = wim[(size_t)h * KT1 + c];           // wave-uniform -> scalar load
+            acc[h][0] = fmaf(wv, v0, acc[h][0]); acc[h][1] = fmaf(wv, v1, acc[h][1]);
+            acc[h][2] = fmaf(wv, v2, acc[h][2]); acc[h][3] = fmaf(wv, v3, acc[h][3]);
         }
-        if (ok) {
+    }
 #pragma unroll
-            for (int h = 0; h < kMaxHeads; ++h)
-                if (h < heads) S[h * (hw + 1) + 1 + p] = acc[h] + wim[(size_t)h * KT1 + in_dim + 1 + p];
-        }
+    for (int h = 0; h < HEADS; ++h) {
+        float *r = red + ((size_t)wid * heads + h) * hwp + poff;
+        if (vec) *reinterpret_cast<float4 *>(r) = make_float4(acc[h][0], acc[h][1], acc[h][2], acc[h][3]);
+        if (one) r[0] = acc[h][0];
     }
     if (tid < heads) {                              // token 0: s_h(0) = scale * q_h . k0_h
         const int hd = C / heads;
@@ -111,7 +118,14 @@ __global__ __launch_bounds__(256) void k_img_scores(
         S[tid * (hw + 1)] = s * scale;
     }
     __syncthreads();
-    for (int h = wid; h < heads; h += 4) {          // softmax over hw + 1 tokens, one wave per head
+    for (int i = tid; i < heads * hw; i += 256) {
+        const int h = i / hw, p = i - h * hw;
+        const float *r = red + (size_t)h * hwp + p;
+        const float s = (r[0] + r[(size_t)heads * hwp]) + (r[(size_t)2 * heads * hwp] + r[(size_t)3 * heads * hwp]);
+        S[h * (hw + 1) + 1 + p] = s + wim[(size_t)h * KT1 + in_dim + 1 + p];
+    }
+    __syncthreads();
+    for (int h = tid >> 6; h < heads; h += 4) {     // softmax over hw + 1 tokens, one wave per head
         const float *sh = S + h * (hw + 1);
         float mx = -INFINITY;
         for (int i = lane; i <= hw; i += 64) mx = fmaxf(mx, sh[i]);
@@ -129,61 +143,67 @@ int launch_img_scores(const float *img, const float *we, const float *qkv0, int 
                       int hw, int heads, int C, int KT1, int KT2p, float scale, float *gbuf,
                       hipStream_t st)
 {
-    PTX_REQUIRE(heads <= kMaxHeads && in_dim % 4 == 0, "img scores: heads=%d in_dim=%d unsupported", heads, in_dim);
-    const size_t lds = sizeof(float) * ((size_t)heads * in_dim + (size_t)heads * (hw + 1));
+    PTX_REQUIRE(heads == kMaxHeads && in_dim % 4 == 0, "img scores: heads=%d in_dim=%d unsupported", heads, in_dim);
+    PTX_REQUIRE((hw >> 2) + (hw & 3) <= 64, "img scores: hw=%d > 252 pixels is not supported", hw);
+    const int hwp = (hw + 3) & ~3;
+    const size_t lds = sizeof(float) * ((size_t)4 * heads * hwp + (size_t)heads * (hw + 1));
     PTX_REQUIRE(lds <= 64 * 1024, "img scores: %zu B of LDS", lds);
-    hipLaunchKernelGGL(k_img_scores, dim3(nimg), dim3(256), lds, st, img, we, qkv0, in_dim, hw, heads,
+    hipLaunchKernelGGL(k_img_scores<kMaxHeads>, dim3(nimg), dim3(256), lds, st, img, we, qkv0, in_dim, hw,
                        C, KT1, KT2p, scale, gbuf);
     PTX_LAUNCHED("k_img_scores");
     return PTX_OK;
 }
 
-// One work-group per (image, 64-channel chunk).  The chunk (64*hw contiguous floats) is staged
-// in LDS with coalesced 16-B loads; lane = channel then reads its row with stride hw (odd for
-// hw = 225 -> conflict-free), wave = pixel quarter, so the attention weights are wave-uniform.
-constexpr int kGatherCh = 64;
+// ---- pass 3: g_h = sum_p a_h(p) f_p on the matrix cores ------------------------------------------
+// G^T (channels x heads) = F (channels x pixels) . A^T (pixels x heads) with v_mfma_f32_16x16x4_f32:
+// a wave owns 16 channel rows; lane (ci = l & 15, kq = l >> 4) loads 16 B = 4 pixels of row ci at
+// pixel 16*kb + 4*kq straight from global (no LDS staging of the image), MFMA step t contracts
+// pixel 16*kb + 4*kq + t; the B operand a_h(p) (h = l & 15, zero for h >= heads) comes from a
+// 7 KB LDS copy of the softmax output.  fp32 in / fp32 accumulate: exact products.
+constexpr int kGatherCh = 64;      // channels per work-group (4 waves x 16)
 
 __global__ __launch_bounds__(256) void k_img_gather(const float *__restrict__ img, int in_dim, int hw,
                                                     int heads, int KT2p, float *__restrict__ gbuf)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float *tile = sm;                                       // [64][hw]
-    float *a_s = sm + (size_t)kGatherCh * hw;               // [hw][8]
-    float *red = a_s + (size_t)hw * kMaxHeads;              // [4][8][64]
+    const int hwp = (hw + 3) & ~3;
+    float *a_s = sm;                                        // [heads][hwp], zero padded
     const int chunks = in_dim / kGatherCh;
     const int im = blockIdx.x / chunks, c0 = (blockIdx.x - im * chunks) * kGatherCh;
     const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
-    const float4 *src = reinterpret_cast<const float4 *>(img + ((size_t)im * in_dim + c0) * hw);
-    float4 *dst = reinterpret_cast<float4 *>(tile);
-    const int n4 = kGatherCh * hw / 4;
-    for (int j = tid; j < n4; j += 256) dst[j] = src[j];
-    for (int i = tid; i < hw * kMaxHeads; i += 256) {
-        const int p = i / kMaxHeads, h = i - p * kMaxHeads;
-        a_s[i] = h < heads ? gbuf[((size_t)im * heads + h) * KT2p + in_dim + 1 + p] : 0.0f;
+    for (int i = tid; i < heads * hwp; i += 256) {
+        const int h = i / hwp, p = i - h * hwp;
+        a_s[i] = p < hw ? gbuf[((size_t)im * heads + h) * KT2p + in_dim + 1 + p] : 0.0f;
     }
     __syncthreads();
-    const int per = (hw + 3) / 4;
-    const int pbeg = wid * per, pend = min(hw, pbeg + per);
-    float acc[kMaxHeads];
-#pragma unroll
-    for (int h = 0; h < kMaxHeads; ++h) acc[h] = 0.0f;
-    const float *row = tile + (size_t)lane * hw;
-    for (int p = pbeg; p < pend; ++p) {
-        const float fv = row[p];
-        const float4 a0 = *reinterpret_cast<const float4 *>(&a_s[p * kMaxHeads]);
-        const float4 a1 = *reinterpret_cast<const float4 *>(&a_s[p * kMaxHeads + 4]);
-        acc[0] = fmaf(a0.x, fv, acc[0]); acc[1] = fmaf(a0.y, fv, acc[1]);
-        acc[2] = fmaf(a0.z, fv, acc[2]); acc[3] = fmaf(a0.w, fv, acc[3]);
-        acc[4] = fmaf(a1.x, fv, acc[4]); acc[5] = fmaf(a1.y, fv, acc[5]);
-        acc[6] = fmaf(a1.z, fv, acc[6]); acc[7] = fmaf(a1.w, fv, acc[7]);
+    const int ci = lane & 15, kq = lane >> 4;
+    const int cb = c0 + wid * 16;
+    const float *row = img + ((size_t)im * in_dim + cb + ci) * hw;
+    const bool live = ci < heads;
+    const float *arow = a_s + (size_t)(live ? ci : 0) * hwp;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int nkb = hw >> 4;
+#pragma unroll 7
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int p0 = 16 * kb + 4 * kq;
+        const f4u fa = *reinterpret_cast<const f4u *>(row + p0);
+        float4 ba = *reinterpret_cast<const float4 *>(arow + p0);
+        if (!live) ba = make_float4(0.f, 0.f, 0.f, 0.f);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.x, ba.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.y, ba.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.z, ba.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.w, ba.w, acc, 0, 0, 0);
     }
-#pragma unroll
-    for (int h = 0; h < kMaxHeads; ++h) red[(wid * kMaxHeads + h) * 64 + lane] = acc[h];
-    __syncthreads();
-    for (int h = wid; h < heads; h += 4) {
-        const float v = red[(0 * kMaxHeads + h) * 64 + lane] + red[(1 * kMaxHeads + h) * 64 + lane] +
-                        red[(2 * kMaxHeads + h) * 64 + lane] + red[(3 * kMaxHeads + h) * 64 + lane];
-        gbuf[((size_t)im * heads + h) * KT2p + c0 + lane] = v;
+    for (int pp = 16 * nkb; pp < hw; pp += 4) {             // pixel tail (1 pixel for 15 x 15)
+        const int p = pp + kq;
+        const float fa = p < hw ? row[p] : 0.0f;
+        const float ba = (p < hw && live) ? arow[p] : 0.0f;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, ba, acc, 0, 0, 0);
+    }
+    // D[row = 4*kq + r][col = l & 15] = G^T[channel cb + 4*kq + r][head l & 15]
+    if (live) {
+        float *dst = gbuf + ((size_t)im * heads + ci) * KT2p + cb + 4 * kq;
+        *reinterpret_cast<float4 *>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
 }
 
@@ -191,12 +211,9 @@ int launch_img_gather(const float *img, int nimg, int in_dim, int hw, int heads,
                       float *gbuf, hipStream_t st)
 {
     PTX_REQUIRE(in_dim % kGatherCh == 0 && heads <= kMaxHeads, "img gather: in_dim=%d heads=%d", in_dim, heads);
-    PTX_REQUIRE((kGatherCh * hw) % 4 == 0, "img gather: hw=%d", hw);
-    const size_t lds = sizeof(float) * ((size_t)kGatherCh * hw + (size_t)hw * kMaxHeads + 4 * kMaxHeads * 64);
-    PTX_REQUIRE(lds <= 160 * 1024, "img gather: %zu B of LDS", lds);
-    if (lds > 64 * 1024)
-        PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_img_gather),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int hwp = (hw + 3) & ~3;
+    const size_t lds = sizeof(float) * (size_t)heads * hwp;
+    PTX_REQUIRE(lds <= 64 * 1024, "img gather: %zu B of LDS", lds);
     hipLaunchKernelGGL(k_img_gather, dim3(nimg * (in_dim / kGatherCh)), dim3(256), lds, st, img, in_dim,
                        hw, heads, KT2p, gbuf);
     PTX_LAUNCHED("k_img_gather");

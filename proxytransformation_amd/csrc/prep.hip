@@ -36,17 +36,26 @@ __global__ void k_prep_posbias(const float *pb, const float *pc, const float *pr
     out[i] = v + (pc[(size_t)j * s + y] + pr[(size_t)j * s + x]);
 }
 
-__global__ void k_prep_qkv0(const float *qw, const float *kw, const float *vw, const float *qb,
-                            const float *cb, const float *pos, int C, float *wqkv0, float *bqkv0,
-                            float *x0b)
+// Token 0 of AttentionPool2d is linear in the image mean (PRE:156-157):
+//   [q | k0 | v0] = [Wq; Wk; Wv] (Wc mean(f) + bc + pos_0) + [bq; 0; 0] = W3 mean(f) + b3
+// W3 (3C, in_dim) = [Wq; Wk; Wv] Wc,  b3 (3C) = [Wq; Wk; Wv] (bc + pos_0) + [bq; 0; 0]
+__global__ void k_prep_w3(const float *qw, const float *kw, const float *vw, const float *qb,
+                          const float *cw, const float *cb, const float *pos, int C, int in_dim,
+                          float *w3, float *b3)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 3 * C * C) {
-        const int part = i / (C * C), r = i - part * C * C;
-        wqkv0[i] = part == 0 ? qw[r] : (part == 1 ? kw[r] : vw[r]);
+    if (i >= 3 * C * (in_dim + 1)) return;
+    const int n = i / (in_dim + 1), c = i - n * (in_dim + 1);
+    const int part = n / C, r = n - part * C;
+    const float *wrow = (part == 0 ? qw : (part == 1 ? kw : vw)) + (size_t)r * C;
+    float s = 0.0f;
+    if (c < in_dim) {
+        for (int j = 0; j < C; ++j) s = fmaf(wrow[j], cw[(size_t)j * in_dim + c], s);
+        w3[(size_t)n * in_dim + c] = s;
+    } else {
+        for (int j = 0; j < C; ++j) s = fmaf(wrow[j], cb[j] + pos[j], s);
+        b3[n] = s + (part == 0 ? qb[r] : 0.0f);
     }
-    if (i < 3 * C) bqkv0[i] = i < C ? qb[i] : 0.0f;
-    if (i < C) x0b[i] = cb[i] + pos[i];
 }
 
 // T1[h][t][d], t < in_dim : scale * sum_j Wk[h*hd+d][j] * Wc[j][t]
@@ -110,10 +119,10 @@ int run_prepare(const PtxShape &s, const PtxWeights &w, float *prep, hipStream_t
     hipLaunchKernelGGL(k_prep_posbias, dim3(cdiv(nb, T)), dim3(T), 0, st, w.img.pb_bias, w.img.pc_bias,
                        w.img.pr_bias, s.Mk, sd, prep + P.posb_i);
     PTX_LAUNCHED("k_prep_posbias");
-    hipLaunchKernelGGL(k_prep_qkv0, dim3(cdiv(3 * C * C, T)), dim3(T), 0, st, w.q_w, w.k_w, w.v_w, w.q_b,
-                       w.cm_b, w.pos, C, prep + P.wqkv0, prep + P.bqkv0, prep + P.x0b);
-    PTX_LAUNCHED("k_prep_qkv0");
-    const float scale = 1.0f / sqrtf((float)P.hd);
+    hipLaunchKernelGGL(k_prep_w3, dim3(cdiv(3 * C * (s.in_dim + 1), T)), dim3(T), 0, st, w.q_w, w.k_w, w.v_w,
+                       w.q_b, w.cm_w, w.cm_b, w.pos, C, s.in_dim, prep + P.w3, prep + P.b3);
+    PTX_LAUNCHED("k_prep_w3");
+    const float scale = (float)(1.0 / sqrt((double)P.hd));                    // head_dim ** -0.5
     hipLaunchKernelGGL(k_prep_t1, dim3(cdiv(s.heads * P.KT1 * P.hd, T)), dim3(T), 0, st, w.k_w, w.cm_w,
                        w.cm_b, w.pos, C, s.in_dim, s.hw, s.heads, scale, prep + P.t1);
     PTX_LAUNCHED("k_prep_t1");
