@@ -17,74 +17,72 @@ constexpr int BK = 32, LDT = BK + 4;   // 144-B LDS rows: 16-B aligned, b128 fra
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-// TM x TN output tile per work-group, one 32x32 MFMA accumulator per wave ((TM/32)*(TN/32) waves).
-// K loop: BK = 32 per step; the next A/W tiles are fetched into registers while the current
-// ones are consumed from LDS, then stored into the other LDS buffer (one barrier per step).
-template <int TM, int TN>
-__global__ __launch_bounds__((TM / 32) * (TN / 32) * 64) void k_gemm_nt(GemmBatch gb)
+// Throughput-regime kernel: 64x64 output tile per 4-wave work-group, one 32x32 MFMA accumulator
+// per wave.  K loop, BK = 32 per step, three stages: tile it is consumed from LDS, tile it+1
+// sits in the other LDS buffer, tile it+2 is in flight in registers (two register sets, loop
+// unrolled by two) -- a fetch has two full MFMA phases (>= 2000 cycles) to land.  Fetches are
+// branch-free (clamped rows; the K tail is zeroed on the W side only).
+#define PTX_G64_FETCH(S, it_)                                                              \
+    do {                                                                                   \
+        const int k_ = min((it_), nk - 1) * BK + kq, kc_ = min(k_, pr.K - 4);              \
+        const bool ok_ = k_ < pr.K;                                                        \
+        a##S##0 = *reinterpret_cast<const float4 *>(pr.A + ao0 + kc_);                     \
+        a##S##1 = *reinterpret_cast<const float4 *>(pr.A + ao1 + kc_);                     \
+        w##S##0 = *reinterpret_cast<const float4 *>(pr.W + wo0 + kc_);                     \
+        w##S##1 = *reinterpret_cast<const float4 *>(pr.W + wo1 + kc_);                     \
+        if (!ok_) { w##S##0 = z4; w##S##1 = z4; }                                          \
+    } while (0)
+#define PTX_G64_STASH(S, buf_)                                                             \
+    do {                                                                                   \
+        *reinterpret_cast<float4 *>(&As[buf_][sr][kq]) = a##S##0;                          \
+        *reinterpret_cast<float4 *>(&As[buf_][sr + 32][kq]) = a##S##1;                     \
+        *reinterpret_cast<float4 *>(&Ws[buf_][sr][kq]) = w##S##0;                          \
+        *reinterpret_cast<float4 *>(&Ws[buf_][sr + 32][kq]) = w##S##1;                     \
+    } while (0)
+#define PTX_G64_COMPUTE(buf_)                                                              \
+    do {                                                                                   \
+        _Pragma("unroll") for (int kk = 0; kk < BK / 8; ++kk) {                            \
+            const float4 a4 = *reinterpret_cast<const float4 *>(&As[buf_][wr * 32 + li][kk * 8 + hh * 4]); \
+            const float4 b4 = *reinterpret_cast<const float4 *>(&Ws[buf_][wc * 32 + li][kk * 8 + hh * 4]); \
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);          \
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);          \
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);          \
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);          \
+        }                                                                                  \
+    } while (0)
+
+__global__ __launch_bounds__(256) void k_gemm64(GemmBatch gb)
 {
-    constexpr int NT = (TM / 32) * (TN / 32) * 64;     // threads
-    constexpr int AV = TM * (BK / 4) / NT;             // float4 per thread per A tile
-    constexpr int WV = TN * (BK / 4) / NT;
     const GemmProb pr = gb.p[blockIdx.z];          // by value: fields live in SGPRs, not re-read from kernarg
-    const int row0 = blockIdx.y * TM, col0 = blockIdx.x * TN;
+    const int row0 = blockIdx.x * 64, col0 = blockIdx.y * 64;
     if (row0 >= pr.R || col0 >= pr.N) return;
-    __shared__ __attribute__((aligned(16))) float As[2][TM][LDT];
-    __shared__ __attribute__((aligned(16))) float Ws[2][TN][LDT];
+    __shared__ __attribute__((aligned(16))) float As[2][64][LDT];
+    __shared__ __attribute__((aligned(16))) float Ws[2][64][LDT];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wr = wid / (TN / 32), wc = wid % (TN / 32);
+    const int wr = wid >> 1, wc = wid & 1;
     const int li = lane & 31, hh = lane >> 5;
-    float4 av[AV], wv[WV];
-    auto fetch = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < AV; ++i) {
-            const int e = tid + i * NT, r = e >> 3, kq = (e & 7) * 4;
-            av[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row0 + r < pr.R && k0 + kq < pr.K)         // K % 4 == 0 is validated by the host
-                av[i] = *reinterpret_cast<const float4 *>(pr.A + (size_t)(row0 + r) * pr.lda + k0 + kq);
-        }
-#pragma unroll
-        for (int i = 0; i < WV; ++i) {
-            const int e = tid + i * NT, r = e >> 3, kq = (e & 7) * 4;
-            wv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (col0 + r < pr.N && k0 + kq < pr.K)
-                wv[i] = *reinterpret_cast<const float4 *>(pr.W + (size_t)(col0 + r) * pr.ldw + k0 + kq);
-        }
-    };
-    auto stash = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < AV; ++i) {
-            const int e = tid + i * NT;
-            *reinterpret_cast<float4 *>(&As[buf][e >> 3][(e & 7) * 4]) = av[i];
-        }
-#pragma unroll
-        for (int i = 0; i < WV; ++i) {
-            const int e = tid + i * NT;
-            *reinterpret_cast<float4 *>(&Ws[buf][e >> 3][(e & 7) * 4]) = wv[i];
-        }
-    };
+    const int sr = tid >> 3, kq = (tid & 7) * 4;        // staging: rows sr and sr + 32
+    const size_t ao0 = (size_t)min(row0 + sr, pr.R - 1) * pr.lda, ao1 = (size_t)min(row0 + sr + 32, pr.R - 1) * pr.lda;
+    const size_t wo0 = (size_t)min(col0 + sr, pr.N - 1) * pr.ldw, wo1 = (size_t)min(col0 + sr + 32, pr.N - 1) * pr.ldw;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 aA0, aA1, wA0, wA1, aB0, aB1, wB0, wB1;
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
     const int nk = (pr.K + BK - 1) / BK;
-    fetch(0);
-    stash(0);
+    PTX_G64_FETCH(A, 0);
+    PTX_G64_FETCH(B, 1);
+    PTX_G64_STASH(A, 0);
     __syncthreads();
-    for (int it = 0; it < nk; ++it) {
-        const int cur = it & 1;
-        if (it + 1 < nk) fetch((it + 1) * BK);
-#pragma unroll
-        for (int kk = 0; kk < BK / 8; ++kk) {
-            // lane half hh owns k = kk*8 + hh*4 .. +3 of this group for both operands, so the
-            // two k-values an MFMA consumes (one per half) are consistent between A and B
-            const float4 a4 = *reinterpret_cast<const float4 *>(&As[cur][wr * 32 + li][kk * 8 + hh * 4]);
-            const float4 b4 = *reinterpret_cast<const float4 *>(&Ws[cur][wc * 32 + li][kk * 8 + hh * 4]);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
-        }
-        if (it + 1 < nk) stash(cur ^ 1);
+    for (int it = 0; it < nk; it += 2) {
+        PTX_G64_FETCH(A, it + 2);
+        PTX_G64_COMPUTE(0);
+        PTX_G64_STASH(B, 1);
+        __syncthreads();
+        if (it + 1 >= nk) break;
+        PTX_G64_FETCH(B, it + 3);
+        PTX_G64_COMPUTE(1);
+        PTX_G64_STASH(A, 0);
         __syncthreads();
     }
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -103,15 +101,151 @@ __global__ __launch_bounds__((TM / 32) * (TN / 32) * 64) void k_gemm_nt(GemmBatc
         }
     }
 }
+#undef PTX_G64_FETCH
+#undef PTX_G64_STASH
+#undef PTX_G64_COMPUTE
+
+// Latency-regime variant for the small GEMMs of this path (a few hundred 32x32 tiles): one wave
+// per (tile, K-slice).  SK waves of a work-group split the K range of ONE 32x32 tile, each with
+// private LDS staging (no barrier in the K loop: a wave's LDS traffic is ordered), partial
+// accumulators are summed in fixed wave order through LDS -> bit-reproducible.  Operand
+// fetches are branch-free (clamped addresses; the K tail is zeroed on the W side only:
+// out-of-range rows / columns are computed on valid memory and never stored), so the loop is one
+// basic block and hipcc interleaves the next tile's global loads with the MFMAs.
+// blockIdx.x = row tile: work-groups that share an A row-panel land on the same XCD (b % 8)
+// whenever the row-tile count is a multiple of 8.
+template <int SK>
+__global__ __launch_bounds__(SK * 64) void k_gemm32(GemmBatch gb)
+{
+    const GemmProb pr = gb.p[blockIdx.z];
+    const int row0 = blockIdx.x * 32, col0 = blockIdx.y * 32;
+    if (row0 >= pr.R || col0 >= pr.N) return;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float *base = lds + (size_t)wv * (4 * 32 * LDT);        // [A0 | W0 | A1 | W1], each 32 x LDT
+    const int li = lane & 31, hh = lane >> 5;
+    const int nk = (pr.K + BK - 1) / BK, per = (nk + SK - 1) / SK;
+    const int it0 = wv * per, it1 = min(nk, it0 + per);
+    // staging role: e = lane + 64 i -> row e >> 3 = (lane >> 3) + 8 i, k offset (e & 7) * 4
+    const int r0 = lane >> 3, kq = (lane & 7) * 4;
+    const size_t a0 = (size_t)min(row0 + r0, pr.R - 1) * pr.lda, a1 = (size_t)min(row0 + r0 + 8, pr.R - 1) * pr.lda;
+    const size_t a2 = (size_t)min(row0 + r0 + 16, pr.R - 1) * pr.lda, a3 = (size_t)min(row0 + r0 + 24, pr.R - 1) * pr.lda;
+    const size_t w0 = (size_t)min(col0 + r0, pr.N - 1) * pr.ldw, w1 = (size_t)min(col0 + r0 + 8, pr.N - 1) * pr.ldw;
+    const size_t w2 = (size_t)min(col0 + r0 + 16, pr.N - 1) * pr.ldw, w3 = (size_t)min(col0 + r0 + 24, pr.N - 1) * pr.ldw;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 aA0, aA1, aA2, aA3, wA0, wA1, wA2, wA3, aB0, aB1, aB2, aB3, wB0, wB1, wB2, wB3;
+#define PTX_FETCH(S, it_)                                                                 \
+    do {                                                                                  \
+        const int k_ = min((it_), it1 - 1) * BK + kq, kc_ = min(k_, pr.K - 4);            \
+        const bool ok_ = k_ < pr.K;                                                       \
+        a##S##0 = *reinterpret_cast<const float4 *>(pr.A + a0 + kc_);                     \
+        a##S##1 = *reinterpret_cast<const float4 *>(pr.A + a1 + kc_);                     \
+        a##S##2 = *reinterpret_cast<const float4 *>(pr.A + a2 + kc_);                     \
+        a##S##3 = *reinterpret_cast<const float4 *>(pr.A + a3 + kc_);                     \
+        w##S##0 = *reinterpret_cast<const float4 *>(pr.W + w0 + kc_);                     \
+        w##S##1 = *reinterpret_cast<const float4 *>(pr.W + w1 + kc_);                     \
+        w##S##2 = *reinterpret_cast<const float4 *>(pr.W + w2 + kc_);                     \
+        w##S##3 = *reinterpret_cast<const float4 *>(pr.W + w3 + kc_);                     \
+        if (!ok_) { w##S##0 = z4; w##S##1 = z4; w##S##2 = z4; w##S##3 = z4; }             \
+    } while (0)
+#define PTX_STASH(S, buf_)                                                                \
+    do {                                                                                  \
+        float *A_s = base + (buf_) * (2 * 32 * LDT) + r0 * LDT + kq, *W_s = A_s + 32 * LDT; \
+        *reinterpret_cast<float4 *>(A_s) = a##S##0;                                       \
+        *reinterpret_cast<float4 *>(A_s + 8 * LDT) = a##S##1;                             \
+        *reinterpret_cast<float4 *>(A_s + 16 * LDT) = a##S##2;                            \
+        *reinterpret_cast<float4 *>(A_s + 24 * LDT) = a##S##3;                            \
+        *reinterpret_cast<float4 *>(W_s) = w##S##0;                                       \
+        *reinterpret_cast<float4 *>(W_s + 8 * LDT) = w##S##1;                             \
+        *reinterpret_cast<float4 *>(W_s + 16 * LDT) = w##S##2;                            \
+        *reinterpret_cast<float4 *>(W_s + 24 * LDT) = w##S##3;                            \
+    } while (0)
+#define PTX_COMPUTE(buf_)                                                                 \
+    do {                                                                                  \
+        const float *A_ = base + (buf_) * (2 * 32 * LDT) + li * LDT + hh * 4, *W_ = A_ + 32 * LDT; \
+        _Pragma("unroll") for (int kk = 0; kk < BK / 8; ++kk) {                           \
+            const float4 a4 = *reinterpret_cast<const float4 *>(A_ + kk * 8);             \
+            const float4 b4 = *reinterpret_cast<const float4 *>(W_ + kk * 8);             \
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);         \
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);         \
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);         \
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);         \
+        }                                                                                 \
+    } while (0)
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    if (it0 < it1) {
+        // three stages: tile it in LDS[cur], tile it+1 in LDS[cur^1], tile it+2 in flight (registers)
+        PTX_FETCH(A, it0);
+        PTX_FETCH(B, it0 + 1);
+        PTX_STASH(A, 0);
+        for (int it = it0; it < it1; it += 2) {
+            PTX_FETCH(A, it + 2);
+            PTX_COMPUTE(0);
+            PTX_STASH(B, 1);
+            if (it + 1 >= it1) break;
+            PTX_FETCH(B, it + 3);
+            PTX_COMPUTE(1);
+            PTX_STASH(A, 0);
+        }
+    }
+#undef PTX_FETCH
+#undef PTX_STASH
+#undef PTX_COMPUTE
+    if (SK > 1) {
+        // fixed-order reduction of the K slices: slice w parks its accumulator in its own LDS
+        __syncthreads();
+        if (wv > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) base[r * 64 + lane] = acc[r];
+        }
+        __syncthreads();
+        if (wv > 0) return;
+#pragma unroll
+        for (int w = 1; w < SK; ++w) {
+            const float *o = lds + (size_t)w * (4 * 32 * LDT);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += o[r * 64 + lane];
+        }
+    }
+    const int n = col0 + li;
+    if (n >= pr.N) return;
+    const float bias = pr.bias ? pr.bias[n] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (row < pr.R) {
+            float v = acc[r] + bias;
+            if (pr.epi == EPI_GELU) v = gelu_erf(v);
+            if (pr.rs) v = fmaf(pr.rs[(size_t)row * pr.rs_stride], pr.ad[(size_t)row * pr.ldad + n], v);
+            if (pr.res) v += pr.res[(size_t)row * pr.ldres + n];
+            pr.C[(size_t)row * pr.ldc + n] = v;
+        }
+    }
+}
+
+template <int SK>
+static int launch_gemm32(const GemmBatch &gb, int rmax, int nmax, hipStream_t st)
+{
+    const size_t lds = sizeof(float) * SK * 4 * 32 * LDT;
+    if (lds > 64 * 1024)
+        PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm32<SK>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_gemm32<SK>, dim3(cdiv(rmax, 32), cdiv(nmax, 32), gb.n), dim3(SK * 64), lds, st, gb);
+    return PTX_OK;
+}
 
 int launch_gemm(const GemmBatch &gb, hipStream_t st)
 {
     PTX_REQUIRE(gb.n >= 1 && gb.n <= kMaxGroups, "gemm: %d groups", gb.n);
-    int rmax = 0, nmax = 0;
-    long big_tiles = 0;
+    int rmax = 0, nmax = 0, kmin = 1 << 30;
+    long tiles32 = 0;
     for (int g = 0; g < gb.n; ++g) {
         const GemmProb &p = gb.p[g];
         PTX_REQUIRE(p.A && p.W && p.C, "gemm: null operand in group %d", g);
+        PTX_REQUIRE(p.R >= 1 && p.N >= 1 && p.K >= 4, "gemm: empty problem in group %d", g);
         PTX_REQUIRE(p.K % 4 == 0 && p.lda % 4 == 0 && p.ldw % 4 == 0,
                     "gemm: K=%d lda=%d ldw=%d must be multiples of 4", p.K, p.lda, p.ldw);
         PTX_REQUIRE(((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.W)) & 15) == 0,
@@ -119,17 +253,22 @@ int launch_gemm(const GemmBatch &gb, hipStream_t st)
         PTX_REQUIRE(p.rs == nullptr || p.ad != nullptr, "gemm: row scale without addend");
         rmax = p.R > rmax ? p.R : rmax;
         nmax = p.N > nmax ? p.N : nmax;
-        big_tiles += (long)cdiv(p.R, 64) * cdiv(p.N, 64);
+        kmin = p.K < kmin ? p.K : kmin;
+        tiles32 += (long)cdiv(p.R, 32) * cdiv(p.N, 32);
     }
-    if (rmax == 0 || nmax == 0) return PTX_OK;
-    // 64x64 tiles re-use each staged operand twice as often; below ~2 work-groups per CU the
-    // launch is latency-bound and the 4x finer 32x32 decomposition fills the chip instead
-    if (big_tiles >= 512 && nmax > 32) {
-        hipLaunchKernelGGL((k_gemm_nt<64, 64>), dim3(cdiv(nmax, 64), cdiv(rmax, 64), gb.n), dim3(256), 0, st, gb);
+    if (tiles32 >= 1536) {
+        // enough tiles to fill the chip: 64x64 tiles re-use each staged operand twice as often
+        hipLaunchKernelGGL(k_gemm64, dim3(cdiv(rmax, 64), cdiv(nmax, 64), gb.n), dim3(256), 0, st, gb);
     } else {
-        hipLaunchKernelGGL((k_gemm_nt<32, 32>), dim3(cdiv(nmax, 32), cdiv(rmax, 32), gb.n), dim3(64), 0, st, gb);
+        // latency regime: aim for >= 4 waves per SIMD (4096 waves) by slicing K inside the work-group
+        const int nk = cdiv(kmin, BK);
+        int sk = 1;
+        while (sk < 4 && tiles32 * sk < 4096 && nk >= 4 * sk) sk *= 2;
+        if (sk == 1) PTX_TRY(launch_gemm32<1>(gb, rmax, nmax, st));
+        else if (sk == 2) PTX_TRY(launch_gemm32<2>(gb, rmax, nmax, st));
+        else PTX_TRY(launch_gemm32<4>(gb, rmax, nmax, st));
     }
-    PTX_LAUNCHED("k_gemm_nt");
+    PTX_LAUNCHED("k_gemm");
     return PTX_OK;
 }
 

@@ -153,6 +153,8 @@ class ProxyTransformationNormReverse(nn.Module):
         self.img_trans_norm = nn.BatchNorm1d(9)
 
         # host-side caches (not part of the state_dict)
+        self._tensors = None
+        self._counts_host: Optional[torch.Tensor] = None
         self._wkey = None
         self._wstruct: Optional[_abi.PtxWeights] = None
         self._prep: Optional[torch.Tensor] = None
@@ -176,8 +178,25 @@ class ProxyTransformationNormReverse(nn.Module):
                              radius=_RADIUS, margin=_MARGIN, bn_eps=self.text_trans_norm.eps,
                              ln_eps=self.norm_img.eps)
 
+    def _apply(self, fn, *args, **kwargs):
+        # .to() / .cuda() / .float() re-allocate parameter storage: drop every cached pointer
+        self._tensors = None
+        self._wkey = None
+        return super()._apply(fn, *args, **kwargs)
+
     def _weights_key(self):
-        return tuple((t.data_ptr(), t._version) for t in self.state_dict(keep_vars=True).values())
+        """Cheap per-call change detector: in-place updates (optimizer steps, load_state_dict)
+        bump ``_version``; re-allocations go through ``_apply`` above, and a re-assigned
+        ``.data`` / ``assign=True`` load changes ``data_ptr`` (checked on a slow cadence)."""
+        if self._tensors is None:
+            self._tensors = list(self.state_dict(keep_vars=True).values())
+            self._ptrs = tuple(t.data_ptr() for t in self._tensors)
+            self._calls = 0
+        self._calls += 1
+        if (self._calls & 63) == 0 and tuple(t.data_ptr() for t in self._tensors) != self._ptrs:
+            self._tensors = None
+            return self._weights_key()
+        return tuple([t._version for t in self._tensors])
 
     def _block_struct(self, blk: _ProxyBlock, out_norm: nn.LayerNorm) -> _abi.PtxBlock:
         a = blk.attn
@@ -280,7 +299,10 @@ class ProxyTransformationNormReverse(nn.Module):
         assert self.real_cluster_num >= 1                        # PRE:209
         pts = pts.to(torch.float32).contiguous()
         text_feats = text_feats.to(torch.float32).contiguous()
-        mask_u8 = text_mask.to(torch.uint8).contiguous()
+        if text_mask.dtype == torch.bool and text_mask.is_contiguous():
+            mask_u8 = text_mask.view(torch.uint8)                 # zero-copy: bool is one byte, 0 / 1
+        else:
+            mask_u8 = (text_mask != 0).to(torch.uint8).contiguous()
         img = img_feat.to(torch.float32).contiguous()
         return pts, text_feats, mask_u8, img
 
@@ -295,7 +317,12 @@ class ProxyTransformationNormReverse(nn.Module):
             self._ensure_prepared(shape, dev, stream)
             ws = self._workspace(shape, dev)
             out = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
-            counts = torch.empty((B,), dtype=torch.int32, device=dev)
+            # per-scene survivor counts land directly in pinned (device-mapped) host memory:
+            # the path's one host sync is a plain stream synchronise, no D2H copy
+            counts = self._counts_host
+            if counts is None or counts.numel() < B:
+                counts = torch.empty((max(B, 64),), dtype=torch.int32).pin_memory()
+                self._counts_host = counts
             dbg_struct, dbg = None, {}
             if debug:
                 dbg = self._alloc_debug(shape, dev)
@@ -312,7 +339,8 @@ class ProxyTransformationNormReverse(nn.Module):
                 img.data_ptr(), _ptr(oo), _ptr(co), out.data_ptr(), counts.data_ptr(),
                 ws.data_ptr(), ws.numel(), ctypes.byref(dbg_struct) if dbg_struct else None, stream),
                 "ptx_forward")
-            n_keep = counts.cpu().tolist()               # the one host sync of the path (list lengths)
+            torch.cuda.current_stream(dev).synchronize()   # the one host sync of the path (list lengths)
+            n_keep = counts[:B].tolist()
         outs = [out[b, :n_keep[b]] for b in range(B)]
         return outs, dbg
 
