@@ -63,51 +63,54 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kMaxHeads = 8;
 
 // ---- pass 2: scores + softmax ---------------------------------------------------------------
-// One work-group (4 waves) per image; wave w streams channels [w*in_dim/4, (w+1)*in_dim/4).
+// One work-group (8 waves) per image; wave w streams channels [w*in_dim/8, (w+1)*in_dim/8).
 // Lane j owns pixels 4j..4j+3 of EVERY row (one 16-B load per lane and row; rows are hw*4 B
-// apart, so the loads are only 4-B aligned -- global_load_dwordx4 takes that), the hw%4 tail
-// pixels go to the next lanes as dword loads.  The 8 head weights of a row are wave-uniform and
-// arrive through the scalar cache (s_load), so the inner loop is 32 FMAs per 16-B load.
+// apart, so the loads are only 4-B aligned -- global_load_dwordx4 takes that); the hw%4 tail
+// pixels are covered by one more lane that re-reads the last 4 pixels, so a row is exactly one
+// load instruction.  The 8 head weights of a row are wave-uniform and arrive through the scalar
+// cache (s_load), so the inner loop is 32 FMAs per 16-B load.
+// Measured alternatives that were NOT faster (r01, MI355X): LDS-broadcast weights instead of
+// s_load, 2 / 4 / 16 waves per image, unroll 2 / 8, explicit register double-buffering, 16-B
+// aligned rows, and (image, 64- or 128-channel chunk) work-groups with a last-arriver reduction
+// (write-through partials + agent-scope counter): the per-chunk hand-off costs more than the
+// 784-images-over-256-CUs imbalance it removes.
+constexpr int kScoreWaves = 8;
+
 template <int HEADS>
-__global__ __launch_bounds__(256) void k_img_scores(
+__global__ __launch_bounds__(kScoreWaves * 64) void k_img_scores(
     const float *__restrict__ img, const float *__restrict__ we, const float *__restrict__ qkv0,
     int in_dim, int hw, int C, int KT1, int KT2p, float scale, float *__restrict__ gbuf)
 {
-    constexpr int heads = HEADS;
+    constexpr int heads = HEADS, NW = kScoreWaves;
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int hwp = (hw + 3) & ~3;
-    float *red = sm;                               // [4][heads][hwp]
-    float *S = sm + 4 * heads * hwp;               // [heads][hw + 1]
-    const int im = blockIdx.x, tid = threadIdx.x, lane = lane_id();
+    float *red = sm;                               // [NW/2][heads][64 lanes x 4]
+    float *S = sm + (NW / 2) * heads * 256;        // [heads][hw + 1]
+    // pass 2 walks the images in the opposite order of pass 1 (what pass 1 streamed last is the
+    // most likely to still sit in the 256 MiB Infinity Cache)
+    const int im = gridDim.x - 1 - blockIdx.x, tid = threadIdx.x, lane = lane_id();
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float *wim = we + (size_t)im * heads * KT1;
     const float *f = img + (size_t)im * in_dim * hw;
     const int nv4 = hw >> 2, tail = hw & 3;
-    const bool vec = lane < nv4, one = !vec && lane < nv4 + tail;
-    const int poff = vec ? 4 * lane : 4 * nv4 + (lane - nv4);
+    const bool edge = tail != 0 && lane == nv4;
+    const bool vec = lane < nv4 || edge;
+    const int poff = edge ? hw - 4 : 4 * lane;
+    const int cfirst = edge ? 4 - tail : 0;        // first valid component of this lane
     float acc[HEADS][4];
 #pragma unroll
     for (int h = 0; h < HEADS; ++h) { acc[h][0] = acc[h][1] = acc[h][2] = acc[h][3] = 0.0f; }
-    const int cper = in_dim / 4, cbeg = wid * cper;
+    const int cper = in_dim / NW, cbeg = wid * cper;
 #pragma unroll 4
     for (int cc = 0; cc < cper; ++cc) {
         const int c = cbeg + cc;
-        const float *row = f + (size_t)c * hw + poff;
         float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-        if (vec) { const f4u t = *reinterpret_cast<const f4u *>(row); v0 = t.x; v1 = t.y; v2 = t.z; v3 = t.w; }
-        if (one) v0 = row[0];
+        if (vec) { const f4u t = *reinterpret_cast<const f4u *>(f + (size_t)c * hw + poff); v0 = t.x; v1 = t.y; v2 = t.z; v3 = t.w; }
 #pragma unroll
         for (int h = 0; h < HEADS; ++h) {
             const float wv = wim[(size_t)h * KT1 + c];           // wave-uniform -> scalar load
             acc[h][0] = fmaf(wv, v0, acc[h][0]); acc[h][1] = fmaf(wv, v1, acc[h][1]);
             acc[h][2] = fmaf(wv, v2, acc[h][2]); acc[h][3] = fmaf(wv, v3, acc[h][3]);
         }
-    }
-#pragma unroll
-    for (int h = 0; h < HEADS; ++h) {
-        float *r = red + ((size_t)wid * heads + h) * hwp + poff;
-        if (vec) *reinterpret_cast<float4 *>(r) = make_float4(acc[h][0], acc[h][1], acc[h][2], acc[h][3]);
-        if (one) r[0] = acc[h][0];
     }
     if (tid < heads) {                              // token 0: s_h(0) = scale * q_h . k0_h
         const int hd = C / heads;
@@ -117,15 +120,38 @@ __global__ __launch_bounds__(256) void k_img_scores(
         for (int d = 0; d < hd; ++d) s = fmaf(q[d], k0[d], s);
         S[tid * (hw + 1)] = s * scale;
     }
-    __syncthreads();
-    for (int i = tid; i < heads * hw; i += 256) {
-        const int h = i / hw, p = i - h * hw;
-        const float *r = red + (size_t)h * hwp + p;
-        const float s = (r[0] + r[(size_t)heads * hwp]) + (r[(size_t)2 * heads * hwp] + r[(size_t)3 * heads * hwp]);
-        S[h * (hw + 1) + 1 + p] = s + wim[(size_t)h * KT1 + in_dim + 1 + p];
+    // fixed-order tree over the NW channel slices: upper half parks, lower half adds
+    // (red is indexed by lane, not by pixel: the edge lane overlaps its neighbour's pixels)
+#pragma unroll
+    for (int half = NW / 2; half >= 1; half >>= 1) {
+        if (wid >= half && wid < 2 * half) {
+#pragma unroll
+            for (int h = 0; h < HEADS; ++h)
+                *reinterpret_cast<float4 *>(red + ((size_t)(wid - half) * heads + h) * 256 + 4 * lane) =
+                    make_float4(acc[h][0], acc[h][1], acc[h][2], acc[h][3]);
+        }
+        __syncthreads();
+        if (wid < half) {
+#pragma unroll
+            for (int h = 0; h < HEADS; ++h) {
+                const float4 t = *reinterpret_cast<const float4 *>(red + ((size_t)wid * heads + h) * 256 + 4 * lane);
+                acc[h][0] += t.x; acc[h][1] += t.y; acc[h][2] += t.z; acc[h][3] += t.w;
+            }
+        }
+        __syncthreads();
+    }
+    if (wid == 0 && vec) {
+#pragma unroll
+        for (int h = 0; h < HEADS; ++h) {
+            float *d = S + h * (hw + 1) + 1 + poff;
+            const float *e = wim + (size_t)h * KT1 + in_dim + 1 + poff;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c >= cfirst) d[c] = acc[h][c] + e[c];
+        }
     }
     __syncthreads();
-    for (int h = tid >> 6; h < heads; h += 4) {     // softmax over hw + 1 tokens, one wave per head
+    for (int h = wid; h < heads; h += NW) {         // softmax over hw + 1 tokens, one wave per head
         const float *sh = S + h * (hw + 1);
         float mx = -INFINITY;
         for (int i = lane; i <= hw; i += 64) mx = fmaxf(mx, sh[i]);
@@ -143,13 +169,12 @@ int launch_img_scores(const float *img, const float *we, const float *qkv0, int 
                       int hw, int heads, int C, int KT1, int KT2p, float scale, float *gbuf,
                       hipStream_t st)
 {
-    PTX_REQUIRE(heads == kMaxHeads && in_dim % 4 == 0, "img scores: heads=%d in_dim=%d unsupported", heads, in_dim);
-    PTX_REQUIRE((hw >> 2) + (hw & 3) <= 64, "img scores: hw=%d > 252 pixels is not supported", hw);
-    const int hwp = (hw + 3) & ~3;
-    const size_t lds = sizeof(float) * ((size_t)4 * heads * hwp + (size_t)heads * (hw + 1));
+    PTX_REQUIRE(heads == kMaxHeads && in_dim % kScoreWaves == 0, "img scores: heads=%d in_dim=%d unsupported", heads, in_dim);
+    PTX_REQUIRE(hw >= 4 && (hw >> 2) + ((hw & 3) ? 1 : 0) <= 64, "img scores: hw=%d (supported: 4..256 pixels)", hw);
+    const size_t lds = sizeof(float) * ((size_t)(kScoreWaves / 2) * heads * 256 + (size_t)heads * (hw + 1));
     PTX_REQUIRE(lds <= 64 * 1024, "img scores: %zu B of LDS", lds);
-    hipLaunchKernelGGL(k_img_scores<kMaxHeads>, dim3(nimg), dim3(256), lds, st, img, we, qkv0, in_dim, hw,
-                       C, KT1, KT2p, scale, gbuf);
+    hipLaunchKernelGGL(k_img_scores<kMaxHeads>, dim3(nimg), dim3(kScoreWaves * 64), lds, st, img, we, qkv0,
+                       in_dim, hw, C, KT1, KT2p, scale, gbuf);
     PTX_LAUNCHED("k_img_scores");
     return PTX_OK;
 }
@@ -182,19 +207,28 @@ __global__ __launch_bounds__(256) void k_img_gather(const float *__restrict__ im
     const bool live = ci < heads;
     const float *arow = a_s + (size_t)(live ? ci : 0) * hwp;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const int nkb = hw >> 4;
-#pragma unroll 7
+    // 32 pixels per step: lane (ci, kq) reads pixels 32*kb + 8*kq .. +7 (two 16-B loads), so the
+    // four kq groups of a row consume one full 128-B line back to back; MFMA step (j, t) contracts
+    // pixel 32*kb + 8*kq + 4*j + t on both operands.
+    const int nkb = hw >> 5;
+#pragma unroll 4
     for (int kb = 0; kb < nkb; ++kb) {
-        const int p0 = 16 * kb + 4 * kq;
-        const f4u fa = *reinterpret_cast<const f4u *>(row + p0);
-        float4 ba = *reinterpret_cast<const float4 *>(arow + p0);
-        if (!live) ba = make_float4(0.f, 0.f, 0.f, 0.f);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.x, ba.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.y, ba.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.z, ba.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.w, ba.w, acc, 0, 0, 0);
+        const int p0 = 32 * kb + 8 * kq;
+        const f4u f0 = *reinterpret_cast<const f4u *>(row + p0);
+        const f4u f1 = *reinterpret_cast<const f4u *>(row + p0 + 4);
+        float4 b0 = *reinterpret_cast<const float4 *>(arow + p0);
+        float4 b1 = *reinterpret_cast<const float4 *>(arow + p0 + 4);
+        if (!live) { b0 = make_float4(0.f, 0.f, 0.f, 0.f); b1 = b0; }
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f0.x, b0.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f0.y, b0.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f0.z, b0.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f0.w, b0.w, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f1.x, b1.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f1.y, b1.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f1.z, b1.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f1.w, b1.w, acc, 0, 0, 0);
     }
-    for (int pp = 16 * nkb; pp < hw; pp += 4) {             // pixel tail (1 pixel for 15 x 15)
+    for (int pp = 32 * nkb; pp < hw; pp += 4) {             // pixel tail (1 pixel for 15 x 15)
         const int p = pp + kq;
         const float fa = p < hw ? row[p] : 0.0f;
         const float ba = (p < hw && live) ? arow[p] : 0.0f;

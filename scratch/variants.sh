@@ -1,0 +1,2 @@
+python -m pytest tests -m gpu -x -q 2>&1 | tail -1
+for v in 0 0; do python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['roofline']['avg_launch_us'])"; done
