@@ -174,6 +174,8 @@ def main():
         total_scenes = world * B * args.steps
         abytes = algorithmic_bytes(cfg, B, args.time_kernel)
         roof = None
+        if launches.value > 0 and not abytes:
+            roof = dict(kernel=args.time_kernel, avg_launch_us=round(total_ms.value / launches.value * 1e3, 2))
         if launches.value > 0 and abytes:
             avg_s = total_ms.value / launches.value / 1e3
             ach = abytes / avg_s / 1e9

@@ -217,23 +217,30 @@ static int run_img_proxy(const PtxShape &s, const PtxWeights &w, const float *pr
 struct Branch {
     const PtxBlock *blk; const float *x_in; const float *proxy; int Lp; const uint8_t *mask;
     const float *head_w, *head_b, *head_ab; int nout; float *head_out; float *guide; int slot;
+    bool late_proxy;     // the proxies of this branch are produced on the side stream (image proxies)
 };
 
+// phase 0: everything; phase 1: only the projections that do not wait for late proxies
+// (qkv of every branch + proxy_proj of the early ones); phase 2: the rest.
 static int run_blocks(const PtxShape &s, const Branch *br, int nb, const float *point_proxy, void *ws,
-                      hipStream_t st)
+                      hipStream_t st, int phase = 0)
 {
     const WsLayout L = ws_layout(s);
     const int C = s.C, R = s.B * s.Mk;
     {   // qkv = Linear(C,3C)(LN1(x)+bias) (PRE:221);  proxy_tokens = proxy_proj(proxy) (PRE:223)
-        GemmBatch g{}; g.n = 2 * nb;
+        GemmBatch g{}; g.n = 0;
         for (int i = 0; i < nb; ++i) {
             const int sl = br[i].slot;
-            g.p[2 * i] = GemmProb{br[i].x_in, br[i].blk->qkv_w, at<float>(ws, L.qkv[sl]), br[i].blk->qkv_b,
-                                  nullptr, nullptr, nullptr, R, 3 * C, C, C, C, 3 * C, 0, 0, 0, EPI_NONE};
-            g.p[2 * i + 1] = GemmProb{br[i].proxy, br[i].blk->pp_w, at<float>(ws, L.pt[sl]), br[i].blk->pp_b,
+            if (phase != 2)
+                g.p[g.n++] = GemmProb{br[i].x_in, br[i].blk->qkv_w, at<float>(ws, L.qkv[sl]), br[i].blk->qkv_b,
+                                      nullptr, nullptr, nullptr, R, 3 * C, C, C, C, 3 * C, 0, 0, 0, EPI_NONE};
+            const bool now = phase == 0 || (phase == 1 && !br[i].late_proxy) || (phase == 2 && br[i].late_proxy);
+            if (now)
+                g.p[g.n++] = GemmProb{br[i].proxy, br[i].blk->pp_w, at<float>(ws, L.pt[sl]), br[i].blk->pp_b,
                                       nullptr, nullptr, nullptr, s.B * br[i].Lp, C, C, C, C, C, 0, 0, 0, EPI_NONE};
         }
-        PTX_TIMED(KID_BLK_QKV, st, launch_gemm(g, st));
+        if (g.n > 0) PTX_TIMED(KID_BLK_QKV, st, launch_gemm(g, st));
+        if (phase == 1) return PTX_OK;
     }
     AttnBatch a{}; a.n = nb; a.B = s.B; a.heads = s.heads; a.scale = attn_scale(C / s.heads);
     for (int i = 0; i < nb; ++i) {   // proxy as query (PRE:232-238): no mask
@@ -312,7 +319,7 @@ static Branch make_branch(const PtxShape &s, const PtxWeights &w, const float *p
     b.head_b = which == 0 ? w.text_trans_b : w.img_trans_b;
     b.head_ab = prep + (which == 0 ? P.ttn_ab : P.itn_ab);
     b.nout = which == 0 ? 3 : 9;
-    b.head_out = head_out; b.guide = guide; b.slot = which;
+    b.head_out = head_out; b.guide = guide; b.slot = which; b.late_proxy = which == 1;
     return b;
 }
 
@@ -570,14 +577,16 @@ int ptx_forward(const PtxShape *s, const PtxWeights *w, const void *prep, const 
                                                 point_proxy, &w->text, &w->img, pf + P.posb_t, pf + P.posb_i, xin_t,
                                                 xin_i, S.ln_eps, st));
 
-    // ---- join, then both proxy blocks + heads in shared launches (PRE:440-455)
-    PTX_HIP(hipStreamWaitEvent(st, side->join, 0));
+    // ---- both proxy blocks + heads in shared launches (PRE:440-455); the input projections that
+    // do not need the image proxies run before the join
     float *translate = at<float>(ws, L.head[0]), *transform = at<float>(ws, L.head[1]);
     float *guide_t = (debug && debug->text_guide) ? at<float>(ws, L.guide[0]) : nullptr;
     float *guide_i = (debug && debug->img_guide) ? at<float>(ws, L.guide[1]) : nullptr;
     Branch br[2] = {make_branch(S, *w, pf, 0, xin_t, text_feats, S.L, text_mask, translate, guide_t),
                     make_branch(S, *w, pf, 1, xin_i, img_proxy, S.V, nullptr, transform, guide_i)};
-    PTX_TRY(run_blocks(S, br, 2, point_proxy, ws, st));
+    PTX_TRY(run_blocks(S, br, 2, point_proxy, ws, st, 1));
+    PTX_HIP(hipStreamWaitEvent(st, side->join, 0));
+    PTX_TRY(run_blocks(S, br, 2, point_proxy, ws, st, 2));
 
     // ---- submanifold reshape + scatter + drop (PRE:459-467)
     PTX_TIMED(KID_AFFINE, st, launch_affine(S, points, tag, kcenter, translate, transform, out, counts, tile_counts,

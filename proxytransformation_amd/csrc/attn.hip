@@ -3,8 +3,11 @@
 // One kernel serves both contractions of ProxyAttention:
 //   proxy as query : O = softmax_n((P*scale) K^T) V          queries = proxies, keys = cluster tokens
 //   proxy as key   : O = softmax_L(mask((Q*scale) P^T)) PV   queries = tokens, keys = proxies
-// One wave owns 32 query rows of one (scene, head) and streams the keys in tiles of 32 with an
-// online softmax.  Everything stays in registers:
+// A work-group owns 32 query rows of one (scene, head); its 4 waves split the key tiles (32 keys
+// each) four ways, every wave runs an online softmax over its share, and the four partial
+// (max, sum, O) triples are merged in fixed wave order through LDS (the chain of dependent
+// tiles, not the arithmetic, is what a launch of this size waits for).  Per wave everything
+// stays in registers:
 //   S^T = K Q^T      v_mfma_f32_32x32x2_f32, A = key rows, B = query rows -> lane owns ONE query
 //                    (col = lane & 31) and 16 of the 32 key scores of the tile, so the row
 //                    max / sum of the softmax are in-lane reductions plus one xor-32 exchange;
@@ -24,9 +27,11 @@ __global__ __launch_bounds__(256) void k_attn32(AttnBatch ab)
 {
     const AttnProb p = ab.p[blockIdx.z];           // by value: fields live in SGPRs
     const int lane = lane_id();
-    const int qt = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    const int q0 = qt * 32;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q0 = blockIdx.x * 32;
     if (q0 >= p.nq) return;
+    const int ntile = (p.nk + 31) >> 5, tper = (ntile + 3) >> 2;
+    const int kbeg = wv * tper * 32, kend = min(p.nk, (wv + 1) * tper * 32);   // this wave's keys
     const int b = blockIdx.y / ab.heads, h = blockIdx.y - b * ab.heads;
     const int li = lane & 31, hh = lane >> 5;
     const float *Q = p.Q + (size_t)b * p.sQ + h * HD;
@@ -78,11 +83,11 @@ __global__ __launch_bounds__(256) void k_attn32(AttnBatch ab)
         }
     };
     float kf[16], vf[16], kn[16], vn[16];
-    load_tile(0, kf, vf);
-    for (int k0 = 0; k0 < p.nk; k0 += 32) {
+    if (kbeg < kend) load_tile(kbeg, kf, vf);
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
         // software pipeline: the next tile's loads are in flight while this tile is consumed
         // (freshly written K/V come from another XCD's L2 or HBM: ~1 us per dependent round trip)
-        const bool more = k0 + 32 < p.nk;
+        const bool more = k0 + 32 < kend;
         if (more) load_tile(k0 + 32, kn, vn);
         f32x16 sc;
 #pragma unroll
@@ -101,7 +106,7 @@ __global__ __launch_bounds__(256) void k_attn32(AttnBatch ab)
             tmax = fmaxf(tmax, v);
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m_run, tmax);                       // finite: tile 0 has a valid key
+        const float m_new = fmaxf(m_run, tmax);                       // finite: every tile has a valid key
         const float alpha = expf(m_run - m_new);
         float psum = 0.0f;
 #pragma unroll
@@ -117,6 +122,34 @@ __global__ __launch_bounds__(256) void k_attn32(AttnBatch ab)
 #pragma unroll
             for (int i = 0; i < 16; ++i) { kf[i] = kn[i]; vf[i] = vn[i]; }
         }
+    }
+    // ---- merge the 4 key slices in fixed order: m = max m_w, O = sum_w O_w exp(m_w - m), l likewise
+    __shared__ float s_ml[3][2][64];
+    __shared__ __attribute__((aligned(16))) float s_o[3][16][64];
+    if (wv > 0) {
+        s_ml[wv - 1][0][lane] = m_run;
+        s_ml[wv - 1][1][lane] = l_run;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_o[wv - 1][r][lane] = o[r];
+    }
+    __syncthreads();
+    if (wv > 0) return;
+    float m_all = m_run;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) m_all = fmaxf(m_all, s_ml[w][0][lane]);
+    {
+        const float a0 = expf(m_run - m_all);                       // wave 0 always owns >= 1 tile
+        l_run *= a0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] *= a0;
+    }
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+        const float mw = s_ml[w][0][lane];
+        const float aw = mw == -INFINITY ? 0.0f : expf(mw - m_all);   // slice without keys
+        l_run = fmaf(s_ml[w][1][lane], aw, l_run);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = fmaf(s_o[w][r][lane], aw, o[r]);
     }
     // o[r] = O^T[d = (r&3) + 8*(r>>2) + 4*hh][query = li]
     const int qi = q0 + li;
@@ -143,7 +176,7 @@ int launch_attn32(const AttnBatch &ab, hipStream_t st)
         nqmax = p.nq > nqmax ? p.nq : nqmax;
     }
     if (nqmax == 0) return PTX_OK;
-    hipLaunchKernelGGL(k_attn32, dim3(cdiv(cdiv(nqmax, 32), 4), ab.B * ab.heads, ab.n), dim3(256), 0, st, ab);
+    hipLaunchKernelGGL(k_attn32, dim3(cdiv(nqmax, 32), ab.B * ab.heads, ab.n), dim3(256), 0, st, ab);
     PTX_LAUNCHED("k_attn32");
     return PTX_OK;
 }

@@ -70,6 +70,15 @@ __global__ __launch_bounds__(256) void k_gemm64(GemmBatch gb)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
     const int nk = (pr.K + BK - 1) / BK;
+    // epilogue operands are requested up front: a dependent ~1 us round trip after the K loop otherwise
+    const int n = col0 + wc * 32 + li;
+    const float bias = (pr.bias && n < pr.N) ? pr.bias[n] : 0.0f;
+    float resv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = row0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        resv[r] = (pr.res && row < pr.R && n < pr.N) ? pr.res[(size_t)row * pr.ldres + n] : 0.0f;
+    }
     PTX_G64_FETCH(A, 0);
     PTX_G64_FETCH(B, 1);
     PTX_G64_STASH(A, 0);
@@ -86,9 +95,7 @@ __global__ __launch_bounds__(256) void k_gemm64(GemmBatch gb)
         __syncthreads();
     }
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-    const int n = col0 + wc * 32 + li;
     if (n >= pr.N) return;
-    const float bias = pr.bias ? pr.bias[n] : 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = row0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -96,7 +103,7 @@ __global__ __launch_bounds__(256) void k_gemm64(GemmBatch gb)
             float v = acc[r] + bias;
             if (pr.epi == EPI_GELU) v = gelu_erf(v);
             if (pr.rs) v = fmaf(pr.rs[(size_t)row * pr.rs_stride], pr.ad[(size_t)row * pr.ldad + n], v);
-            if (pr.res) v += pr.res[(size_t)row * pr.ldres + n];
+            if (pr.res) v += resv[r];
             pr.C[(size_t)row * pr.ldc + n] = v;
         }
     }
@@ -173,6 +180,22 @@ __global__ __launch_bounds__(SK * 64) void k_gemm32(GemmBatch gb)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);         \
         }                                                                                 \
     } while (0)
+    // epilogue operands (used by wave 0 only) are requested up front: a dependent ~1 us round trip
+    // after the K loop otherwise
+    const int n = col0 + li;
+    float bias = 0.0f, resv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) resv[r] = 0.0f;
+    if (wv == 0 && n < pr.N) {
+        if (pr.bias) bias = pr.bias[n];
+        if (pr.res) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (row < pr.R) resv[r] = pr.res[(size_t)row * pr.ldres + n];
+            }
+        }
+    }
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
@@ -210,9 +233,7 @@ __global__ __launch_bounds__(SK * 64) void k_gemm32(GemmBatch gb)
             for (int r = 0; r < 16; ++r) acc[r] += o[r * 64 + lane];
         }
     }
-    const int n = col0 + li;
     if (n >= pr.N) return;
-    const float bias = pr.bias ? pr.bias[n] : 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -220,7 +241,7 @@ __global__ __launch_bounds__(SK * 64) void k_gemm32(GemmBatch gb)
             float v = acc[r] + bias;
             if (pr.epi == EPI_GELU) v = gelu_erf(v);
             if (pr.rs) v = fmaf(pr.rs[(size_t)row * pr.rs_stride], pr.ad[(size_t)row * pr.ldad + n], v);
-            if (pr.res) v += pr.res[(size_t)row * pr.ldres + n];
+            if (pr.res) v += resv[r];
             pr.C[(size_t)row * pr.ldc + n] = v;
         }
     }
@@ -329,44 +350,73 @@ int launch_ln_rows(const LnBatch &lb, hipStream_t st)
 }
 
 // ------------------------------------------------------------------------------ heads
+// One wave handles kHeadRows consecutive rows: the LayerNorm / head weights are loaded once per
+// wave (36 + 8 registers) instead of once per row -- cold, chip-wide shared lines are the cost
+// of this kernel (measured: 12 of 20 us with one row per wave), not its arithmetic.
+constexpr int kHeadRows = 4;
+
 __global__ __launch_bounds__(256) void k_heads(HeadBatch hb)
 {
     const HeadProb p = hb.p[blockIdx.y];
-    const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (row >= p.R) return;
-    float v[kMaxPerLane], mean, rstd;
-    ln_row(p.x + (size_t)row * hb.C, hb.C, hb.eps, v, mean, rstd);
+    const int row0 = __builtin_amdgcn_readfirstlane((blockIdx.x * 4 + (threadIdx.x >> 6)) * kHeadRows);
+    if (row0 >= p.R) return;
     const int lane = lane_id();
+    constexpr int kMaxOut = 9, Q = 4;                      // C = 256: 4 values per lane
+    float hbias = 0.0f, bn_a = 0.0f, bn_b = 0.0f;
+    if (lane < p.nout) { hbias = p.hb[lane]; bn_a = p.ab[lane]; bn_b = p.ab[p.nout + lane]; }
+    float nw[Q], nb[Q], hwt[kMaxOut][Q];
 #pragma unroll
-    for (int q = 0; q < kMaxPerLane; ++q) {
-        const int c = lane + 64 * q;
-        if (c < hb.C) {
-            v[q] = (v[q] - mean) * rstd * p.nw[c] + p.nb[c];
-            if (p.guide) p.guide[(size_t)row * hb.C + c] = v[q];
-        } else v[q] = 0.0f;
-    }
-    for (int o = 0; o < p.nout; ++o) {
-        float s = 0.0f;
+    for (int q = 0; q < Q; ++q) { nw[q] = p.nw[lane + 64 * q]; nb[q] = p.nb[lane + 64 * q]; }
 #pragma unroll
-        for (int q = 0; q < kMaxPerLane; ++q) {
-            const int c = lane + 64 * q;
-            if (c < hb.C) s = fmaf(p.hw[(size_t)o * hb.C + c], v[q], s);
+    for (int o = 0; o < kMaxOut; ++o)
+#pragma unroll
+        for (int q = 0; q < Q; ++q) hwt[o][q] = o < p.nout ? p.hw[(size_t)o * hb.C + lane + 64 * q] : 0.0f;
+    float x[kHeadRows][Q];
+#pragma unroll
+    for (int r = 0; r < kHeadRows; ++r)
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+            x[r][q] = row0 + r < p.R ? p.x[(size_t)(row0 + r) * hb.C + lane + 64 * q] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < kHeadRows; ++r) {
+        const int row = row0 + r;
+        if (row >= p.R) break;                               // wave-uniform
+        const float mean = wave_sum((x[r][0] + x[r][1]) + (x[r][2] + x[r][3])) / (float)hb.C;
+        float var = 0.0f;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { const float d = x[r][q] - mean; var = fmaf(d, d, var); }
+        const float rstd = 1.0f / sqrtf(wave_sum(var) / (float)hb.C + hb.eps);
+        float v[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            v[q] = (x[r][q] - mean) * rstd * nw[q] + nb[q];
+            if (p.guide) p.guide[(size_t)row * hb.C + lane + 64 * q] = v[q];
         }
-        s = wave_sum(s);
-        if (lane == 0) {
-            const float y = s + p.hb[o];
-            p.out[(size_t)row * p.nout + o] = fmaf(y, p.ab[o], p.ab[p.nout + o]);   // eval BatchNorm1d
+        float mine = 0.0f;
+#pragma unroll
+        for (int o = 0; o < kMaxOut; ++o) {
+            if (o < p.nout) {
+                float part = 0.0f;
+#pragma unroll
+                for (int q = 0; q < Q; ++q) part = fmaf(hwt[o][q], v[q], part);
+                const float s = wave_sum(part);
+                if (lane == o) mine = s;
+            }
         }
+        if (lane < p.nout) p.out[(size_t)row * p.nout + lane] = fmaf(mine + hbias, bn_a, bn_b);   // eval BatchNorm1d
     }
 }
 
 int launch_heads(const HeadBatch &hb, hipStream_t st)
 {
-    PTX_REQUIRE(hb.C % 64 == 0 && hb.C <= 64 * kMaxPerLane, "heads: C=%d unsupported", hb.C);
+    PTX_REQUIRE(hb.C == 256, "heads: C=%d unsupported (256 only)", hb.C);
     int rmax = 0;
-    for (int g = 0; g < hb.n; ++g) rmax = hb.p[g].R > rmax ? hb.p[g].R : rmax;
+    for (int g = 0; g < hb.n; ++g) {
+        PTX_REQUIRE(hb.p[g].nout >= 1 && hb.p[g].nout <= 9, "heads: nout=%d", hb.p[g].nout);
+        rmax = hb.p[g].R > rmax ? hb.p[g].R : rmax;
+    }
     if (rmax == 0) return PTX_OK;
-    hipLaunchKernelGGL(k_heads, dim3(cdiv(rmax, 4), hb.n), dim3(256), 0, st, hb);
+    hipLaunchKernelGGL(k_heads, dim3(cdiv(rmax, 4 * kHeadRows), hb.n), dim3(256), 0, st, hb);
     PTX_LAUNCHED("k_heads");
     return PTX_OK;
 }

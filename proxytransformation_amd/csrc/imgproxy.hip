@@ -21,6 +21,9 @@
 
 namespace ptx {
 
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-B load at 4-B alignment
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 // one wave per group of 4 channel rows = 4*hw contiguous floats = hw float4
 __global__ __launch_bounds__(256) void k_img_mean(const float *__restrict__ img, int ngroups,
                                                   int hw, float *__restrict__ fm)
@@ -28,10 +31,10 @@ __global__ __launch_bounds__(256) void k_img_mean(const float *__restrict__ img,
     const int lane = lane_id();
     const int g = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (g >= ngroups) return;
-    const float4 *src = reinterpret_cast<const float4 *>(img + (size_t)g * 4 * hw);
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(img + (size_t)g * 4 * hw);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     for (int j = lane; j < hw; j += 64) {
-        const float4 v = src[j];
+        const f32x4 v = __builtin_nontemporal_load(src + j);      // streamed once per pass: keep L2 for weights / tokens
         const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -58,8 +61,6 @@ int launch_img_mean(const float *img, int nimg, int in_dim, int hw, float *fm, h
     return PTX_OK;
 }
 
-typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-B load at 4-B alignment
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kMaxHeads = 8;
 
 // ---- pass 2: scores + softmax ---------------------------------------------------------------
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(kScoreWaves * 64) void k_img_scores(
     for (int cc = 0; cc < cper; ++cc) {
         const int c = cbeg + cc;
         float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-        if (vec) { const f4u t = *reinterpret_cast<const f4u *>(f + (size_t)c * hw + poff); v0 = t.x; v1 = t.y; v2 = t.z; v3 = t.w; }
+        if (vec) { const f4u t = __builtin_nontemporal_load(reinterpret_cast<const f4u *>(f + (size_t)c * hw + poff)); v0 = t.x; v1 = t.y; v2 = t.z; v3 = t.w; }
 #pragma unroll
         for (int h = 0; h < HEADS; ++h) {
             const float wv = wim[(size_t)h * KT1 + c];           // wave-uniform -> scalar load
@@ -214,6 +215,8 @@ __global__ __launch_bounds__(256) void k_img_gather(const float *__restrict__ im
 #pragma unroll 4
     for (int kb = 0; kb < nkb; ++kb) {
         const int p0 = 32 * kb + 8 * kq;
+        // (default cache policy on purpose: f0 / f1 and the neighbouring kq lanes share 128-B lines;
+        //  non-temporal loads here were measured 1.7x slower)
         const f4u f0 = *reinterpret_cast<const f4u *>(row + p0);
         const f4u f1 = *reinterpret_cast<const f4u *>(row + p0 + 4);
         float4 b0 = *reinterpret_cast<const float4 *>(arow + p0);
