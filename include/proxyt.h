@@ -198,7 +198,10 @@ int ptx_affine_compact(const PtxShape *s, const float *points, const uint32_t *t
                        float *out, int32_t *counts, void *workspace, size_t ws_bytes, void *stream);
 
 /* Whole forward, PRE:424-469, enqueued on `stream` (an internal second stream forks the
- * image branch).  text_mask (B,L) uint8, 1 = valid.  out (B,N,3) capacity, counts (B) int32.
+ * image branch).  Points: either `points` (B,N,3) stacked, or `points_list` = HOST array of B
+ * device pointers to (N,3) clouds (the reference's list input, used in place; B <= 32), the other
+ * NULL.  text_mask (B,L) uint8, 1 = valid.  out (B,N,3) capacity, counts (B) int32 (device or
+ * device-mapped pinned host memory).
  * debug (optional, may be NULL): struct of device pointers that receive intermediates. */
 typedef struct PtxDebug {
     float *centers0, *cluster1, *offsets, *centers, *cluster2;
@@ -209,8 +212,8 @@ typedef struct PtxDebug {
 } PtxDebug;
 
 int ptx_forward(const PtxShape *s, const PtxWeights *w, const void *prep, const float *lin,
-                const float *points, const float *text_feats, const uint8_t *text_mask,
-                const float *img_feat, const int32_t *order_override,
+                const float *points, const float *const *points_list, const float *text_feats,
+                const uint8_t *text_mask, const float *img_feat, const int32_t *order_override,
                 const float *centers_override,
                 float *out, int32_t *counts, void *workspace, size_t ws_bytes,
                 const PtxDebug *debug, void *stream);

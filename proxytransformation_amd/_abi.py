@@ -83,7 +83,7 @@ SIGNATURES = {
     "ptx_proxy_block": (_I, [_SH, _W, _P, _I, _P, _P, _I, _P, _P, _P, _P, _Z, _P]),
     "ptx_affine_scatter": (_I, [_SH, _P, _P, _P, _P, _P, _P, _P]),
     "ptx_affine_compact": (_I, [_SH, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
-    "ptx_forward": (_I, [_SH, _W, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z,
+    "ptx_forward": (_I, [_SH, _W, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z,
                          C.POINTER(PtxDebug), _P]),
 }
 

@@ -153,11 +153,27 @@ static int side_stream(SideStream **out)
     std::lock_guard<std::mutex> lk(g_side_mu);
     SideStream &s = g_side[dev];
     if (s.st == nullptr) {
-        PTX_HIP(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
+        // lowest priority: the image branch is bandwidth-bound and long; the latency-bound clustering
+        // chain on the caller's stream must win work-group dispatch whenever both have work
+        int lo = 0, hi = 0;
+        PTX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        PTX_HIP(hipStreamCreateWithPriority(&s.st, hipStreamNonBlocking, lo));
         PTX_HIP(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming));
         PTX_HIP(hipEventCreateWithFlags(&s.join, hipEventDisableTiming));
     }
     *out = &s;
+    return PTX_OK;
+}
+
+int make_scene_pts(const float *stacked, const float *const *list, int B, int N, ScenePts *out)
+{
+    PTX_REQUIRE(B >= 1 && B <= kMaxScenes, "at most %d scenes per call (got %d): split the batch", kMaxScenes, B);
+    PTX_REQUIRE(stacked || list, "null points");
+    for (int b = 0; b < kMaxScenes; ++b) out->p[b] = nullptr;
+    for (int b = 0; b < B; ++b) {
+        out->p[b] = list ? list[b] : stacked + (size_t)b * N * 3;
+        PTX_REQUIRE(out->p[b] != nullptr, "null point cloud for scene %d", b);
+    }
     return PTX_OK;
 }
 
@@ -403,8 +419,10 @@ int ptx_grid_centers(const float *points, int B, int N, const float *lin, int gs
     hipStream_t st = static_cast<hipStream_t>(stream);
     uint32_t *enc = static_cast<uint32_t *>(workspace);
     PTX_HIP(hipMemsetAsync(enc, 0, (size_t)B * 6 * 4, st));
-    PTX_TRY(launch_minmax(points, B, N, enc, st));
-    return launch_ball_query(nullptr, enc, lin, gs, margin, minmax, centers, points, B, gs * gs * gs, N, 0,
+    ScenePts sp;
+    PTX_TRY(make_scene_pts(points, nullptr, B, N, &sp));
+    PTX_TRY(launch_minmax(sp, B, N, enc, st));
+    return launch_ball_query(nullptr, enc, lin, gs, margin, minmax, centers, sp, B, gs * gs * gs, N, 0,
                              0.0f, nullptr, nullptr, nullptr, st);
 }
 
@@ -413,7 +431,9 @@ int ptx_ball_query(const float *centers, const float *points, int B, int M, int 
 {
     PTX_REQUIRE(centers && points && idx && cluster, "ptx_ball_query: null argument");
     PTX_REQUIRE(B >= 1 && M >= 1 && N >= 1 && K >= 1, "ptx_ball_query: B=%d M=%d N=%d K=%d", B, M, N, K);
-    return launch_ball_query(centers, nullptr, nullptr, 0, 0.0f, nullptr, nullptr, points, B, M, N, K, radius,
+    ScenePts sp;
+    PTX_TRY(make_scene_pts(points, nullptr, B, N, &sp));
+    return launch_ball_query(centers, nullptr, nullptr, 0, 0.0f, nullptr, nullptr, sp, B, M, N, K, radius,
                              idx, cluster, pad_count, static_cast<hipStream_t>(stream));
 }
 
@@ -500,7 +520,9 @@ int ptx_affine_scatter(const PtxShape *s, const float *points, const uint32_t *t
 {
     PTX_REQUIRE(s && points && tag && kcenter && translate && transform && new_points, "ptx_affine_scatter: null argument");
     PTX_TRY(validate_shape(*s));
-    return launch_affine(*s, points, tag, kcenter, translate, transform, new_points, nullptr, nullptr, false,
+    ScenePts sp;
+    PTX_TRY(make_scene_pts(points, nullptr, s->B, s->N, &sp));
+    return launch_affine(*s, sp, tag, kcenter, translate, transform, new_points, nullptr, nullptr, false,
                          static_cast<hipStream_t>(stream));
 }
 
@@ -513,19 +535,25 @@ int ptx_affine_compact(const PtxShape *s, const float *points, const uint32_t *t
     hipStream_t st = static_cast<hipStream_t>(stream);
     int32_t *tc = at<int32_t>(workspace, ws_layout(*s).tile_counts);
     PTX_TRY(launch_tile_count(tag, s->B, s->N, tc, st));
-    return launch_affine(*s, points, tag, kcenter, translate, transform, out, counts, tc, true, st);
+    ScenePts sp;
+    PTX_TRY(make_scene_pts(points, nullptr, s->B, s->N, &sp));
+    return launch_affine(*s, sp, tag, kcenter, translate, transform, out, counts, tc, true, st);
 }
 
 #define PTX_DBG(field, src, bytes)                                                                         do {                                                                                                       if (debug && debug->field)                                                                                 PTX_HIP(hipMemcpyAsync(debug->field, src, bytes, hipMemcpyDeviceToDevice, st));                } while (0)
 
 int ptx_forward(const PtxShape *s, const PtxWeights *w, const void *prep, const float *lin,
-                const float *points, const float *text_feats, const uint8_t *text_mask,
-                const float *img_feat, const int32_t *order_override, const float *centers_override,
+                const float *points, const float *const *points_list, const float *text_feats,
+                const uint8_t *text_mask, const float *img_feat, const int32_t *order_override,
+                const float *centers_override,
                 float *out, int32_t *counts, void *workspace, size_t ws_bytes, const PtxDebug *debug,
                 void *stream)
 {
-    PTX_REQUIRE(w && prep && lin && points && text_feats && img_feat && out && counts, "ptx_forward: null argument");
+    PTX_REQUIRE(w && prep && lin && (points || points_list) && text_feats && img_feat && out && counts,
+                "ptx_forward: null argument");
     PTX_TRY(check_bufs(s, workspace, ws_bytes));
+    ScenePts sp;
+    PTX_TRY(make_scene_pts(points, points_list, s->B, s->N, &sp));
     hipStream_t st = static_cast<hipStream_t>(stream);
     const PtxShape &S = *s;
     const PrepLayout P = prep_layout(S);
@@ -550,15 +578,15 @@ int ptx_forward(const PtxShape *s, const PtxWeights *w, const void *prep, const 
     float *centers = at<float>(ws, L.centers), *cluster2 = at<float>(ws, L.cluster2);
     int32_t *idx2 = at<int32_t>(ws, L.idx2), *pad_count = at<int32_t>(ws, L.pad_count);
     { Timed t_(KID_MEMSET, st); PTX_HIP(hipMemsetAsync(at<char>(ws, L.zero_begin), 0, L.zero_bytes, st)); }
-    PTX_TIMED(KID_MINMAX, st, launch_minmax(points, B, S.N, mm_enc, st));
+    PTX_TIMED(KID_MINMAX, st, launch_minmax(sp, B, S.N, mm_enc, st));
     // ball query #1 on the unclamped grid centres; only the gathered xyz is used (PRE:56, Q3)
-    PTX_TIMED(KID_BQ1, st, launch_ball_query(nullptr, mm_enc, lin, S.grid_size, S.margin, minmax, centers0, points,
+    PTX_TIMED(KID_BQ1, st, launch_ball_query(nullptr, mm_enc, lin, S.grid_size, S.margin, minmax, centers0, sp,
                                              B, M, S.N, K, S.radius, idx2, cluster1, nullptr, st));
     PTX_TIMED(KID_OFFSET, st, launch_offset_net(pf + P.off_ab, w->offset, w->offset_map_w, centers0, cluster1,
                                                 minmax, B * M, M, K, S.margin, centers, offsets, st));
     if (centers_override)
         PTX_HIP(hipMemcpyAsync(centers, centers_override, (size_t)B * M * 3 * 4, hipMemcpyDeviceToDevice, st));
-    PTX_TIMED(KID_BQ2, st, launch_ball_query(centers, nullptr, nullptr, 0, 0.0f, nullptr, nullptr, points, B, M,
+    PTX_TIMED(KID_BQ2, st, launch_ball_query(centers, nullptr, nullptr, 0, 0.0f, nullptr, nullptr, sp, B, M,
                                              S.N, K, S.radius, idx2, cluster2, pad_count, st));   // PRE:65
 
     // ---- dynamic cluster dropout (PRE:433)
@@ -589,7 +617,7 @@ int ptx_forward(const PtxShape *s, const PtxWeights *w, const void *prep, const 
     PTX_TRY(run_blocks(S, br, 2, point_proxy, ws, st, 2));
 
     // ---- submanifold reshape + scatter + drop (PRE:459-467)
-    PTX_TIMED(KID_AFFINE, st, launch_affine(S, points, tag, kcenter, translate, transform, out, counts, tile_counts,
+    PTX_TIMED(KID_AFFINE, st, launch_affine(S, sp, tag, kcenter, translate, transform, out, counts, tile_counts,
                                             true, st));
 
     PTX_DBG(centers0, centers0, (size_t)B * M * 3 * 4);

@@ -16,11 +16,11 @@ namespace ptx {
 // ------------------------------------------------------------------------------ min / max
 // mm_enc[b][0..2] = ~ord(min_d)   (so that atomicMax over a zeroed word yields the minimum)
 // mm_enc[b][3..5] =  ord(max_d)
-__global__ __launch_bounds__(256) void k_minmax(const float *__restrict__ points, int N,
+__global__ __launch_bounds__(256) void k_minmax(ScenePts points, int N,
                                                 uint32_t *__restrict__ mm_enc)
 {
     const int b = blockIdx.y;
-    const float *p = points + (size_t)b * N * 3;
+    const float *__restrict__ p = points.p[b];
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int nth = gridDim.x * blockDim.x;
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void k_minmax(const float *__restrict__ points
     }
 }
 
-int launch_minmax(const float *points, int B, int N, uint32_t *mm_enc, hipStream_t st)
+int launch_minmax(const ScenePts &points, int B, int N, uint32_t *mm_enc, hipStream_t st)
 {
     int per_scene = cdiv(N, 256 * 16);
     if (per_scene < 1) per_scene = 1;
@@ -87,7 +87,7 @@ template <bool GRID>
 __global__ __launch_bounds__(256) void k_ball_query(
     const float *__restrict__ centers, const uint32_t *__restrict__ mm_enc,
     const float *__restrict__ lin, int gs, float margin, float *__restrict__ minmax_out,
-    float *__restrict__ centers_out, const float *__restrict__ points, int BM, int M, int N, int K,
+    float *__restrict__ centers_out, ScenePts points, int BM, int M, int N, int K,
     float radius, int32_t *__restrict__ idx, float *__restrict__ cluster,
     int32_t *__restrict__ pad_count)
 {
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void k_ball_query(
         cx = centers[(size_t)w * 3 + 0]; cy = centers[(size_t)w * 3 + 1]; cz = centers[(size_t)w * 3 + 2];
     }
     const float r2 = __fmul_rn(radius, radius);
-    const float *p = points + (size_t)b * N * 3;
+    const float *__restrict__ p = points.p[b];
     int32_t *oi = idx + (size_t)w * K;
     float *oc = cluster + (size_t)w * K * 3;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void k_ball_query(
 }
 
 int launch_ball_query(const float *centers, const uint32_t *mm_enc, const float *lin, int gs,
-                      float margin, float *minmax_out, float *centers_out, const float *points,
+                      float margin, float *minmax_out, float *centers_out, const ScenePts &points,
                       int B, int M, int N, int K, float radius, int32_t *idx, float *cluster,
                       int32_t *pad_count, hipStream_t st)
 {
@@ -539,7 +539,7 @@ int launch_tile_count(const uint32_t *tag, int B, int N, int32_t *tile_counts, h
 }
 
 struct AffineArgs {
-    const float *points; const uint32_t *tag; const float *kcenter, *translate, *transform;
+    ScenePts points; const uint32_t *tag; const float *kcenter, *translate, *transform;
     float *out; int32_t *counts; const int32_t *tile_counts; int N, Mk, K;
 };
 
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(256) void k_affine(AffineArgs a)
     const int b = blockIdx.y, tile = blockIdx.x, ntiles = gridDim.x;
     const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
     const uint32_t *tg = a.tag + (size_t)b * a.N;
-    const float *pts = a.points + (size_t)b * a.N * 3;
+    const float *__restrict__ pts = a.points.p[b];
     float *out = a.out + (size_t)b * a.N * 3;
     constexpr int R = kTilePts / 256;
     __shared__ int s_cnt[R][4];
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(256) void k_affine(AffineArgs a)
     if (tile == ntiles - 1 && tid == 0) a.counts[b] = run;
 }
 
-int launch_affine(const PtxShape &s, const float *points, const uint32_t *tag, const float *kcenter,
+int launch_affine(const PtxShape &s, const ScenePts &points, const uint32_t *tag, const float *kcenter,
                   const float *translate, const float *transform, float *out, int32_t *counts,
                   const int32_t *tile_counts, bool compact, hipStream_t st)
 {

@@ -159,10 +159,17 @@ struct AttnProb {
 struct AttnBatch { AttnProb p[2]; int n; int B, heads; float scale; };
 int launch_attn32(const AttnBatch &ab, hipStream_t st);
 
+// Per-scene base pointers of the point clouds, passed by value as a kernel argument: the caller's
+// list of (N,3) tensors is used in place (the reference stacks them into a copy, PRE:426-427; the
+// path never writes to its input, so no copy is needed).
+constexpr int kMaxScenes = 32;
+struct ScenePts { const float *p[kMaxScenes]; };
+int make_scene_pts(const float *stacked, const float *const *list, int B, int N, ScenePts *out);
+
 // ---- clustering / apply (cluster.hip) ---------------------------------------------------
-int launch_minmax(const float *points, int B, int N, uint32_t *mm_enc, hipStream_t st);
+int launch_minmax(const ScenePts &points, int B, int N, uint32_t *mm_enc, hipStream_t st);
 int launch_ball_query(const float *centers, const uint32_t *mm_enc, const float *lin, int gs,
-                      float margin, float *minmax_out, float *centers_out, const float *points,
+                      float margin, float *minmax_out, float *centers_out, const ScenePts &points,
                       int B, int M, int N, int K, float radius, int32_t *idx, float *cluster,
                       int32_t *pad_count, hipStream_t st);
 int launch_offset_net(const float *ab, const PtxSlotMlp &mlp, const float *map_w,
@@ -178,7 +185,7 @@ int launch_select(const PtxShape &s, const int32_t *idx, const float *centers, c
                   int32_t *picks, int32_t *keep, float *kcenter, float *kcluster, int32_t *kidx,
                   int32_t *drop_idx, uint32_t *tag, hipStream_t st);
 int launch_tile_count(const uint32_t *tag, int B, int N, int32_t *tile_counts, hipStream_t st);
-int launch_affine(const PtxShape &s, const float *points, const uint32_t *tag, const float *kcenter,
+int launch_affine(const PtxShape &s, const ScenePts &points, const uint32_t *tag, const float *kcenter,
                   const float *translate, const float *transform, float *out, int32_t *counts,
                   const int32_t *tile_counts, bool compact, hipStream_t st);
 

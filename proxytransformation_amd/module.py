@@ -160,6 +160,7 @@ class ProxyTransformationNormReverse(nn.Module):
         self._prep: Optional[torch.Tensor] = None
         self._lin: Optional[torch.Tensor] = None
         self._ws: Dict[tuple, torch.Tensor] = {}
+        self._shapes: Dict[tuple, _abi.PtxShape] = {}
         # test-only hooks: replay a captured argsort / inject clamped centres
         self._order_override: Optional[torch.Tensor] = None
         self._centers_override: Optional[torch.Tensor] = None
@@ -275,72 +276,92 @@ class ProxyTransformationNormReverse(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def _check_inputs(self, points, text_dict, img_feat):
+        """Validate the reference's input contract; returns device-ready tensors.
+
+        The point clouds are used IN PLACE through a table of per-scene pointers (the path never
+        writes to its input; the reference's stacked copy, PRE:426-427, exists only because its
+        scatter is in-place).  Only irregular inputs (non-fp32, non-contiguous, > 32 scenes)
+        are stacked into a fresh tensor."""
         if self.training:
             raise NotImplementedError(
                 "train-mode forward (batch-stat BatchNorm, dropout, autograd) is not built yet; "
                 "call .eval() -- see DESIGN.md 'next'")
         if not isinstance(points, (list, tuple)) or len(points) == 0:
             raise ValueError("points must be a non-empty list of (N,3) tensors")
-        pts = torch.stack([p for p in points], dim=0)        # RuntimeError on unequal N, like torch.cat (PRE:427)
-        if pts.dim() != 3 or pts.shape[-1] != 3:
-            raise RuntimeError(f"points must be (N,3) per scene, got {tuple(pts.shape[1:])}")
-        if not pts.is_cuda:
+        p0 = points[0]
+        if not p0.is_cuda:
             raise RuntimeError("ProxyTransformationNormReverse (HIP) needs GPU tensors: there is no CPU path")
+        B, shp = len(points), p0.shape
+        if len(shp) != 2 or shp[1] != 3:
+            raise RuntimeError(f"points must be (N,3) per scene, got {tuple(shp)}")
+        direct = B <= 32
+        for p in points:
+            if p.shape != shp:                                   # like torch.cat at PRE:427
+                raise RuntimeError(f"all scenes must have the same number of points: {tuple(p.shape)} vs {tuple(shp)}")
+            if p.dtype != torch.float32 or not p.is_contiguous() or p.device != p0.device:
+                direct = False
+        if direct:
+            pts, plist = None, (ctypes.c_void_p * B)(*[p.data_ptr() for p in points])
+        else:
+            pts, plist = torch.stack([p.to(device=p0.device, dtype=torch.float32) for p in points]).contiguous(), None
         text_feats, text_mask = self.get_text_proxy(text_dict)   # positional unpack (PRE:440)
-        B, N, _ = pts.shape
-        if text_feats.shape[0] != B or text_feats.shape[-1] != self.embed_dim:
+        if text_feats.shape[0] != B or text_feats.shape[-1] != self.embed_dim or text_feats.dim() != 3:
             raise RuntimeError(f"text_feats must be ({B},L,{self.embed_dim}), got {tuple(text_feats.shape)}")
-        if tuple(text_mask.shape) != tuple(text_feats.shape[:2]):
+        if text_mask.shape != text_feats.shape[:2]:
             raise RuntimeError("text_token_mask must be (B,L)")
         hw = self.img_spacial_dim
-        if img_feat.dim() != 5 or img_feat.shape[0] != B or img_feat.shape[2] != self.input_dim \
-                or img_feat.shape[3] != hw or img_feat.shape[4] != hw:
-            raise RuntimeError(f"img_feat must be ({B},V,{self.input_dim},{hw},{hw}), got {tuple(img_feat.shape)}")
+        ish = img_feat.shape
+        if len(ish) != 5 or ish[0] != B or ish[2] != self.input_dim or ish[3] != hw or ish[4] != hw:
+            raise RuntimeError(f"img_feat must be ({B},V,{self.input_dim},{hw},{hw}), got {tuple(ish)}")
         assert self.real_cluster_num >= 1                        # PRE:209
-        pts = pts.to(torch.float32).contiguous()
-        text_feats = text_feats.to(torch.float32).contiguous()
+        if text_feats.dtype != torch.float32 or not text_feats.is_contiguous():
+            text_feats = text_feats.to(torch.float32).contiguous()
         if text_mask.dtype == torch.bool and text_mask.is_contiguous():
             mask_u8 = text_mask.view(torch.uint8)                 # zero-copy: bool is one byte, 0 / 1
         else:
             mask_u8 = (text_mask != 0).to(torch.uint8).contiguous()
-        img = img_feat.to(torch.float32).contiguous()
-        return pts, text_feats, mask_u8, img
+        if img_feat.dtype != torch.float32 or not img_feat.is_contiguous():
+            img_feat = img_feat.to(torch.float32).contiguous()
+        return (B, shp[0], p0.device), pts, plist, text_feats, mask_u8, img_feat
 
     def _run(self, points, text_dict, img_feat, debug: bool):
-        pts, text_feats, mask_u8, img = self._check_inputs(points, text_dict, img_feat)
-        dev = pts.device
-        B, N, _ = pts.shape
-        shape = self._shape(B, N, text_feats.shape[1], img.shape[1])
+        (B, N, dev), pts, plist, text_feats, mask_u8, img = self._check_inputs(points, text_dict, img_feat)
+        skey = (B, N, text_feats.shape[1], img.shape[1])
+        shape = self._shapes.get(skey)
+        if shape is None:
+            shape = self._shapes[skey] = self._shape(*skey)
         lib = _abi.lib()
-        with torch.cuda.device(dev):
-            stream = torch.cuda.current_stream(dev).cuda_stream
-            self._ensure_prepared(shape, dev, stream)
-            ws = self._workspace(shape, dev)
-            out = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
-            # per-scene survivor counts land directly in pinned (device-mapped) host memory:
-            # the path's one host sync is a plain stream synchronise, no D2H copy
-            counts = self._counts_host
-            if counts is None or counts.numel() < B:
-                counts = torch.empty((max(B, 64),), dtype=torch.int32).pin_memory()
-                self._counts_host = counts
-            dbg_struct, dbg = None, {}
-            if debug:
-                dbg = self._alloc_debug(shape, dev)
-                dbg_struct = _abi.PtxDebug(**{k: v.data_ptr() for k, v in dbg.items()})
-            oo = self._order_override
-            co = self._centers_override
-            if oo is not None:
-                oo = oo.to(device=dev, dtype=torch.int32).contiguous()
-            if co is not None:
-                co = co.to(device=dev, dtype=torch.float32).contiguous()
-            _abi.check(lib.ptx_forward(
-                ctypes.byref(shape), ctypes.byref(self._wstruct), self._prep.data_ptr(),
-                self._lin.data_ptr(), pts.data_ptr(), text_feats.data_ptr(), mask_u8.data_ptr(),
-                img.data_ptr(), _ptr(oo), _ptr(co), out.data_ptr(), counts.data_ptr(),
-                ws.data_ptr(), ws.numel(), ctypes.byref(dbg_struct) if dbg_struct else None, stream),
-                "ptx_forward")
-            torch.cuda.current_stream(dev).synchronize()   # the one host sync of the path (list lengths)
-            n_keep = counts[:B].tolist()
+        if dev.index is not None and dev.index != torch.cuda.current_device():
+            raise RuntimeError(f"inputs are on {dev} but the current device is cuda:{torch.cuda.current_device()}")
+        tstream = torch.cuda.current_stream(dev)
+        stream = tstream.cuda_stream
+        self._ensure_prepared(shape, dev, stream)
+        ws = self._workspace(shape, dev)
+        out = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
+        # per-scene survivor counts land directly in pinned (device-mapped) host memory:
+        # the path's one host sync is a plain stream synchronise, no D2H copy
+        counts = self._counts_host
+        if counts is None or counts.numel() < B:
+            counts = torch.empty((max(B, 64),), dtype=torch.int32).pin_memory()
+            self._counts_host = counts
+        dbg_struct, dbg = None, {}
+        if debug:
+            dbg = self._alloc_debug(shape, dev)
+            dbg_struct = _abi.PtxDebug(**{k: v.data_ptr() for k, v in dbg.items()})
+        oo = self._order_override
+        co = self._centers_override
+        if oo is not None:
+            oo = oo.to(device=dev, dtype=torch.int32).contiguous()
+        if co is not None:
+            co = co.to(device=dev, dtype=torch.float32).contiguous()
+        _abi.check(lib.ptx_forward(
+            ctypes.byref(shape), ctypes.byref(self._wstruct), self._prep.data_ptr(),
+            self._lin.data_ptr(), _ptr(pts), plist, text_feats.data_ptr(), mask_u8.data_ptr(),
+            img.data_ptr(), _ptr(oo), _ptr(co), out.data_ptr(), counts.data_ptr(),
+            ws.data_ptr(), ws.numel(), ctypes.byref(dbg_struct) if dbg_struct else None, stream),
+            "ptx_forward")
+        tstream.synchronize()                              # the one host sync of the path (list lengths)
+        n_keep = counts[:B].tolist()
         outs = [out[b, :n_keep[b]] for b in range(B)]
         return outs, dbg
 
