@@ -188,6 +188,9 @@ def main():
         if launches.value > 0 and not abytes:
             roof = dict(kernel=args.time_kernel, avg_launch_us=round(total_ms.value / launches.value * 1e3, 2))
         if launches.value > 0 and abytes:
+            # the image branch is launched once per slice of scenes (2 slices per forward): the
+            # algorithmic bytes of a step are spread over the launches actually recorded
+            abytes = abytes * args.steps // launches.value
             avg_s = total_ms.value / launches.value / 1e3
             ach = abytes / avg_s / 1e9
             roof = dict(bound="hbm", kernel=args.time_kernel, achieved=round(ach, 1), peak=HBM_PEAK_GBS,
