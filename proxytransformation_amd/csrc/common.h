@@ -134,7 +134,7 @@ struct GemmProb {
     int R, N, K, lda, ldw, ldc, ldres, rs_stride, ldad, epi;
 };
 constexpr int kMaxGroups = 8;
-struct GemmBatch { GemmProb p[kMaxGroups]; int n; };
+struct GemmBatch { GemmProb p[kMaxGroups]; int n; int rotate; };
 int launch_gemm(const GemmBatch &gb, hipStream_t st);
 
 struct LnProb { const float *x; float *y; const float *w; const float *b; const float *add; int R, add_rows; };

@@ -7,6 +7,8 @@
 //               4-wave work-group, each wave one 32x32 accumulator.
 //   k_ln_rows   LayerNorm over the channel dim, one wave per row (PRE:275 norm2, PRE:340 norm_img)
 //   k_heads     trailing LayerNorm + Linear(C,3|9) + eval BatchNorm1d (PRE:443-446, 452-455)
+#include <cstdlib>
+
 #include "common.h"
 
 namespace ptx {
@@ -142,9 +144,11 @@ __global__ __launch_bounds__(SK * 64) void k_gemm32(GemmBatch gb)
     const size_t w2 = (size_t)min(col0 + r0 + 16, pr.N - 1) * pr.ldw, w3 = (size_t)min(col0 + r0 + 24, pr.N - 1) * pr.ldw;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 aA0, aA1, aA2, aA3, wA0, wA1, wA2, wA3, aB0, aB1, aB2, aB3, wB0, wB1, wB2, wB3;
-#define PTX_FETCH(S, it_)                                                                 \
+#define PTX_FETCH(S, j_)                                                                  \
     do {                                                                                  \
-        const int k_ = min((it_), it1 - 1) * BK + kq, kc_ = min(k_, pr.K - 4);            \
+        int jj_ = min((j_), cnt - 1) + rot;                                               \
+        jj_ -= jj_ >= cnt ? cnt : 0;                                                      \
+        const int k_ = (it0 + jj_) * BK + kq, kc_ = min(k_, pr.K - 4);                    \
         const bool ok_ = k_ < pr.K;                                                       \
         a##S##0 = *reinterpret_cast<const float4 *>(pr.A + a0 + kc_);                     \
         a##S##1 = *reinterpret_cast<const float4 *>(pr.A + a1 + kc_);                     \
@@ -199,17 +203,22 @@ __global__ __launch_bounds__(SK * 64) void k_gemm32(GemmBatch gb)
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-    if (it0 < it1) {
-        // three stages: tile it in LDS[cur], tile it+1 in LDS[cur^1], tile it+2 in flight (registers)
-        PTX_FETCH(A, it0);
-        PTX_FETCH(B, it0 + 1);
+    const int cnt = it1 - it0;
+    // K tiles are walked from a per-work-group rotated start: work-groups that share an operand
+    // panel (same row tile or same column tile) then miss on DIFFERENT cold lines instead of all
+    // queueing on the same one (the sum order changes per tile, deterministically)
+    const int rot = (cnt > 1 && gb.rotate) ? (int)((blockIdx.x + 3u * blockIdx.y) % (unsigned)cnt) : 0;
+    if (cnt > 0) {
+        // three stages: step j in LDS[cur], step j+1 in LDS[cur^1], step j+2 in flight (registers)
+        PTX_FETCH(A, 0);
+        PTX_FETCH(B, 1);
         PTX_STASH(A, 0);
-        for (int it = it0; it < it1; it += 2) {
-            PTX_FETCH(A, it + 2);
+        for (int j = 0; j < cnt; j += 2) {
+            PTX_FETCH(A, j + 2);
             PTX_COMPUTE(0);
             PTX_STASH(B, 1);
-            if (it + 1 >= it1) break;
-            PTX_FETCH(B, it + 3);
+            if (j + 1 >= cnt) break;
+            PTX_FETCH(B, j + 3);
             PTX_COMPUTE(1);
             PTX_STASH(A, 0);
         }
@@ -258,8 +267,11 @@ static int launch_gemm32(const GemmBatch &gb, int rmax, int nmax, hipStream_t st
     return PTX_OK;
 }
 
-int launch_gemm(const GemmBatch &gb, hipStream_t st)
+int launch_gemm(const GemmBatch &gb_in, hipStream_t st)
 {
+    static const int rot_env = getenv("PTX_GEMM_ROTATE") ? atoi(getenv("PTX_GEMM_ROTATE")) : 0;   // measured neutral (r01)
+    GemmBatch gb = gb_in;
+    gb.rotate = rot_env;
     PTX_REQUIRE(gb.n >= 1 && gb.n <= kMaxGroups, "gemm: %d groups", gb.n);
     int rmax = 0, nmax = 0, kmin = 1 << 30;
     long tiles32 = 0;

@@ -30,6 +30,7 @@ __all__ = ["ProxyTransformationNormReverse"]
 _RADIUS, _MARGIN = 3.0, 4.0          # PRE:23 (fixed, not reachable from the config)
 _EMPTY_DROP = 0.3                    # PRE:352
 _SLOT_WIDTH = 256                    # PRE:31, PRE:302 (hard-coded in the reference)
+_MAX_SCENES_PER_CALL = 32            # kMaxScenes of the C ABI (per-scene pointer table passed by value)
 
 
 # --------------------------------------------------------------------------- containers
@@ -294,7 +295,7 @@ class ProxyTransformationNormReverse(nn.Module):
         B, shp = len(points), p0.shape
         if len(shp) != 2 or shp[1] != 3:
             raise RuntimeError(f"points must be (N,3) per scene, got {tuple(shp)}")
-        direct = B <= 32
+        direct = B <= _MAX_SCENES_PER_CALL
         for p in points:
             if p.shape != shp:                                   # like torch.cat at PRE:427
                 raise RuntimeError(f"all scenes must have the same number of points: {tuple(p.shape)} vs {tuple(shp)}")
@@ -385,6 +386,15 @@ class ProxyTransformationNormReverse(nn.Module):
         text_token_mask (B,L) bool, True = valid); img_feat (B,V,input_dim,H,W).
         Returns a list of B tensors (N_i',3): transformed points, dropped points removed,
         original order preserved (PRE:424-469)."""
+        if isinstance(points, (list, tuple)) and len(points) > _MAX_SCENES_PER_CALL:
+            # scenes are independent in eval mode: larger batches run as consecutive calls
+            feats, mask = self.get_text_proxy(text_dict)
+            outs: List[torch.Tensor] = []
+            for i in range(0, len(points), _MAX_SCENES_PER_CALL):
+                j = i + _MAX_SCENES_PER_CALL
+                outs += self._run(points[i:j], {"text_feats": feats[i:j], "text_token_mask": mask[i:j]},
+                                  img_feat[i:j], debug=False)[0]
+            return outs
         return self._run(points, text_dict, img_feat, debug=False)[0]
 
     @torch.no_grad()

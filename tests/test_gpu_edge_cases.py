@@ -1,0 +1,127 @@
+"""Edge cases of the path on the GPU, each checked against the CPU oracle on the same seeded inputs
+(oracle centres injected so that every index tensor must be bit-identical).
+
+Covered: the reference's only shipped configuration shape (gs = 12 -> 691 kept clusters: not a multiple
+of any tile size; 3 + 3 blocks), fewer points than slots (every cluster padded), a single scene / single
+proxy, fully masked text, duplicate points, more than 32 scenes (stacked fallback), non-contiguous and
+fp64 inputs, and point counts that break the 16-byte fast paths."""
+import numpy as np
+import pytest
+import torch
+
+from proxytransformation_amd.synth import PreshapeConfig, make_scene_batch
+from tests.util import assert_close, build_module, oracle_kwargs
+
+pytestmark = pytest.mark.gpu
+
+INT_KEYS = ("idx2", "order", "picks", "keep", "kidx", "drop_idx")
+
+
+def _check(cfg, batch=None, mutate=None, atol=1e-4):
+    from oracle import oracle
+    from tests.gpu_util import t
+    m, sd = build_module(cfg)
+    m = m.cuda()
+    pts, text, mask, img = batch if batch is not None else make_scene_batch(cfg)
+    ref = oracle.forward(sd, **oracle_kwargs(cfg), points=pts, text_feats=text, text_mask=mask, img_feat=img,
+                         num_threads=1)
+    m._centers_override = torch.from_numpy(ref["centers"])
+    points = [t(p) for p in pts]
+    td = {"text_feats": t(text), "text_token_mask": t(mask)}
+    im = t(img)
+    if mutate is not None:
+        points, td, im = mutate(points, td, im)
+    d = m.forward_debug(points, td, im)
+    for k in INT_KEYS:
+        assert np.array_equal(d[k].cpu().numpy().astype(np.int64), ref[k]), k
+    assert np.array_equal(d["pad_count"].cpu().numpy().astype(np.int64), ref["pad_counts"])
+    assert_close(d["translate"].cpu().numpy(), ref["translate"], atol=5e-5, rtol=1e-5, what="translate")
+    assert_close(d["transform"].cpu().numpy(), ref["transform"], atol=5e-5, rtol=1e-5, what="transform")
+    for b in range(len(pts)):
+        got = d["outputs"][b].cpu().numpy()
+        assert got.shape == ref["outputs"][b].shape, (b, got.shape, ref["outputs"][b].shape)
+        assert_close(got, ref["outputs"][b], atol=atol, what=f"scene {b}")
+    return d, ref
+
+
+def test_shipped_config_shape():
+    """CFG:41: grid_size=12 (1728 clusters -> 1210 -> 691 kept, 519 FPS picks), 3+3 blocks, V=50 views,
+    L=20 tokens with padding; N reduced to 30k to keep the CPU oracle quick."""
+    cfg = PreshapeConfig("cfg4s", B=2, N=30000, grid_size=12, dynamic_drop_radio=0.6, L=20, V=50,
+                         text_blocks=3, img_blocks=3, seed_base=4100)
+    assert (cfg.M, cfg.Mt, cfg.M_keep, cfg.Kd) == (1728, 1210, 691, 519)
+    _check(cfg)
+
+
+def test_fewer_points_than_slots():
+    """N = 20 < K = 30: every cluster is padded, padding counts decide the order, most points dropped."""
+    cfg = PreshapeConfig("tiny", B=2, N=20, grid_size=4, dynamic_drop_radio=0.5, L=4, V=1, seed_base=11)
+    d, ref = _check(cfg)
+    assert (ref["idx2"] == -1).any()
+
+
+def test_single_scene_single_proxy():
+    cfg = PreshapeConfig("one", B=1, N=1000, grid_size=4, dynamic_drop_radio=0.5, L=1, V=1, seed_base=12)
+    _check(cfg)
+
+
+def test_all_text_tokens_masked_in_one_scene():
+    """masked_fill(-1e9) on every key: softmax degenerates to uniform over the masked tokens (PRE:247)."""
+    cfg = PreshapeConfig("mask", B=2, N=3000, grid_size=4, dynamic_drop_radio=0.5, L=6, V=2, seed_base=13)
+    pts, text, mask, img = make_scene_batch(cfg)
+    mask[0, :] = False
+    _check(cfg, batch=(pts, text, mask, img))
+
+
+def test_duplicate_points_and_exact_zero_point():
+    """Coincident points land in the same clusters; a point at exactly (0,0,0) is indistinguishable
+    from a padded slot for the slot networks (PRE:94) -- the oracle has the same quirk."""
+    cfg = PreshapeConfig("dup", B=1, N=4000, grid_size=4, dynamic_drop_radio=0.5, L=4, V=1, seed_base=14)
+    pts, text, mask, img = make_scene_batch(cfg)
+    pts[0, 100:200] = pts[0, 0:100]
+    pts[0, 7] = 0.0
+    _check(cfg, batch=(pts, text, mask, img))
+
+
+@pytest.mark.parametrize("N", [1001, 2050, 4099])
+def test_point_counts_off_the_vector_paths(N):
+    cfg = PreshapeConfig("odd", B=2, N=N, grid_size=4, dynamic_drop_radio=0.5, L=5, V=2, seed_base=15)
+    _check(cfg)
+
+
+def test_more_than_32_scenes_are_split_into_calls():
+    """The C ABI takes at most 32 scenes per call (pointer table by value); forward() splits larger
+    batches, which is exact because scenes are independent in eval mode."""
+    from oracle import oracle
+    from tests.gpu_util import t
+    cfg = PreshapeConfig("many", B=35, N=600, grid_size=4, dynamic_drop_radio=0.5, L=4, V=1, seed_base=16)
+    m, sd = build_module(cfg)
+    m = m.cuda()
+    pts, text, mask, img = make_scene_batch(cfg)
+    outs = m([t(p) for p in pts], {"text_feats": t(text), "text_token_mask": t(mask)}, t(img))
+    assert len(outs) == 35
+    sel = [0, 31, 32, 34]
+    ref = oracle.forward(sd, **oracle_kwargs(cfg), points=pts[sel], text_feats=text[sel], text_mask=mask[sel],
+                         img_feat=img[sel], num_threads=1)
+    for j, b in enumerate(sel):
+        got = outs[b].cpu().numpy()
+        # no centre injection here: identical shapes are expected for these boundary-safe seeds only if no
+        # membership flips; compare only when the drop sets agree, always check the count is plausible
+        assert abs(got.shape[0] - ref["outputs"][j].shape[0]) <= 2
+        if got.shape == ref["outputs"][j].shape:
+            assert_close(got, ref["outputs"][j], atol=1e-4, what=f"scene {b}")
+    with pytest.raises(RuntimeError, match="at most 32 scenes"):
+        m.forward_debug([t(p) for p in pts], {"text_feats": t(text), "text_token_mask": t(mask)}, t(img))
+
+
+def test_irregular_inputs_are_normalised():
+    """fp64 / non-contiguous point tensors and an int mask take the slow (copying) host path."""
+    cfg = PreshapeConfig("irr", B=2, N=1500, grid_size=4, dynamic_drop_radio=0.5, L=6, V=2, seed_base=17)
+
+    def mutate(points, td, im):
+        wide = torch.zeros((points[0].shape[0], 6), device=points[0].device)
+        wide[:, :3] = points[0]
+        pts = [wide[:, :3], points[1].double()]                       # non-contiguous view, fp64
+        td2 = {"text_feats": td["text_feats"].double(), "text_token_mask": td["text_token_mask"].to(torch.int64)}
+        return pts, td2, im.transpose(3, 4).contiguous().transpose(3, 4)   # non-contiguous image features
+    _check(cfg, mutate=mutate)
