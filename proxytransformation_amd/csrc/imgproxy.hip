@@ -71,8 +71,8 @@ constexpr int kMaxHeads = 8;
 // load instruction.  The 8 head weights of a row are wave-uniform: they sit in 8 VGPRs per wave
 // (lane = channel) and are broadcast with v_readlane, so the inner loop is 32 FMAs + 8 readlanes
 // per 16-B load and touches memory only for the image.
-// Measured alternatives that were NOT faster (r01, MI355X): LDS-broadcast weights instead of
-// s_load, 2 / 4 / 16 waves per image, unroll 2 / 8, explicit register double-buffering, 16-B
+// Measured alternatives that were NOT faster (r01, MI355X): LDS-broadcast weights, interleaving the
+// waves' rows so an image is read front to back, 2 / 4 / 16 waves per image, unroll 2 / 8, explicit register double-buffering, 16-B
 // aligned rows, and (image, 64- or 128-channel chunk) work-groups with a last-arriver reduction
 // (write-through partials + agent-scope counter): the per-chunk hand-off costs more than the
 // 784-images-over-256-CUs imbalance it removes.
@@ -205,28 +205,33 @@ __global__ __launch_bounds__(256) void k_img_gather(const float *__restrict__ im
     const int chunks = in_dim / kGatherCh;
     const int im = blockIdx.x / chunks, c0 = (blockIdx.x - im * chunks) * kGatherCh;
     const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
-    for (int i = tid; i < heads * hwp; i += 256) {
-        const int h = i / hwp, p = i - h * hwp;
-        a_s[i] = p < hw ? gbuf[((size_t)im * heads + h) * KT2p + in_dim + 1 + p] : 0.0f;
-    }
-    __syncthreads();
     const int ci = lane & 15, kq = lane >> 4;
     const int cb = c0 + wid * 16;
     const float *row = img + ((size_t)im * in_dim + cb + ci) * hw;
     const bool live = ci < heads;
     const float *arow = a_s + (size_t)(live ? ci : 0) * hwp;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     // 32 pixels per step: lane (ci, kq) reads pixels 32*kb + 8*kq .. +7 (two 16-B loads), so the
     // four kq groups of a row consume one full 128-B line back to back; MFMA step (j, t) contracts
     // pixel 32*kb + 8*kq + 4*j + t on both operands.
+    // (default cache policy on purpose: f0 / f1 and the neighbouring kq lanes share 128-B lines;
+    //  non-temporal loads here were measured 1.7x slower)
     const int nkb = hw >> 5;
-#pragma unroll 4
-    for (int kb = 0; kb < nkb; ++kb) {
+    constexpr int PRE = 4;                                   // steps whose image loads are issued before the
+    f4u pf0[PRE], pf1[PRE];                                  // softmax weights are staged (they do not depend on them)
+#pragma unroll
+    for (int kb = 0; kb < PRE; ++kb) {
+        const int p0 = 32 * min(kb, nkb - 1) + 8 * kq;
+        pf0[kb] = *reinterpret_cast<const f4u *>(row + p0);
+        pf1[kb] = *reinterpret_cast<const f4u *>(row + p0 + 4);
+    }
+    for (int i = tid; i < heads * hwp; i += 256) {
+        const int h = i / hwp, p = i - h * hwp;
+        a_s[i] = p < hw ? gbuf[((size_t)im * heads + h) * KT2p + in_dim + 1 + p] : 0.0f;
+    }
+    __syncthreads();
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    auto step = [&](int kb, const f4u &f0, const f4u &f1) {
         const int p0 = 32 * kb + 8 * kq;
-        // (default cache policy on purpose: f0 / f1 and the neighbouring kq lanes share 128-B lines;
-        //  non-temporal loads here were measured 1.7x slower)
-        const f4u f0 = *reinterpret_cast<const f4u *>(row + p0);
-        const f4u f1 = *reinterpret_cast<const f4u *>(row + p0 + 4);
         float4 b0 = *reinterpret_cast<const float4 *>(arow + p0);
         float4 b1 = *reinterpret_cast<const float4 *>(arow + p0 + 4);
         if (!live) { b0 = make_float4(0.f, 0.f, 0.f, 0.f); b1 = b0; }
@@ -238,6 +243,16 @@ __global__ __launch_bounds__(256) void k_img_gather(const float *__restrict__ im
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f1.y, b1.y, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f1.z, b1.z, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f1.w, b1.w, acc, 0, 0, 0);
+    };
+#pragma unroll
+    for (int kb = 0; kb < PRE; ++kb)
+        if (kb < nkb) step(kb, pf0[kb], pf1[kb]);
+#pragma unroll 3
+    for (int kb = PRE; kb < nkb; ++kb) {
+        const int p0 = 32 * kb + 8 * kq;
+        const f4u f0 = *reinterpret_cast<const f4u *>(row + p0);
+        const f4u f1 = *reinterpret_cast<const f4u *>(row + p0 + 4);
+        step(kb, f0, f1);
     }
     for (int pp = 32 * nkb; pp < hw; pp += 4) {             // pixel tail (1 pixel for 15 x 15)
         const int p = pp + kq;
