@@ -1,5 +1,6 @@
 // extern "C" surface of libproxyt_hip.so (include/proxyt.h) and the forward driver.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <utility>
@@ -141,10 +142,7 @@ WsLayout ws_layout(const PtxShape &s)
 }
 
 // ---- second stream for the image branch (the only process-wide state; lazily created) -------
-struct SideStream {
-    hipStream_t st = nullptr, st2 = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr, join2 = nullptr, mean = nullptr;
-};
+struct SideStream { hipStream_t st = nullptr, lo = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
 static std::mutex g_side_mu;
 static SideStream g_side[16];
 
@@ -156,14 +154,12 @@ static int side_stream(SideStream **out)
     std::lock_guard<std::mutex> lk(g_side_mu);
     SideStream &s = g_side[dev];
     if (s.st == nullptr) {
-        // lowest priority: the image branch is bandwidth-bound and long; the latency-bound clustering
-        // chain on the caller's stream must win work-group dispatch whenever both have work
+        // highest priority: the latency-bound clustering chain runs here next to the long,
+        // bandwidth-bound image passes on the caller's stream and must win work-group dispatch
         int lo = 0, hi = 0;
         PTX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        PTX_HIP(hipStreamCreateWithPriority(&s.st, hipStreamNonBlocking, lo));
-        PTX_HIP(hipStreamCreateWithPriority(&s.st2, hipStreamNonBlocking, lo));
-        PTX_HIP(hipEventCreateWithFlags(&s.join2, hipEventDisableTiming));
-        PTX_HIP(hipEventCreateWithFlags(&s.mean, hipEventDisableTiming));
+        PTX_HIP(hipStreamCreateWithPriority(&s.st, hipStreamNonBlocking, hi));
+        PTX_HIP(hipStreamCreateWithPriority(&s.lo, hipStreamNonBlocking, lo));
         PTX_HIP(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming));
         PTX_HIP(hipEventCreateWithFlags(&s.join, hipEventDisableTiming));
     }
@@ -187,25 +183,19 @@ template <typename T>
 static inline T *at(void *base, size_t off) { return reinterpret_cast<T *>(static_cast<char *>(base) + off); }
 
 // ---- image chain ---------------------------------------------------------------------------------
-// Image chain for the images [i0, i0 + nimg) of the call (all buffers are image-major).  `after_mean`
-// (optional) is recorded on `st` right after the first streaming pass so that a second slice can be
-// chained behind it on another stream.
-static int run_img_proxy(const PtxShape &s, const PtxWeights &w, const float *prep, const float *img_all,
-                         float *img_proxy_all, void *ws, hipStream_t st, int i0 = 0, int nimg = -1,
-                         hipEvent_t after_mean = nullptr)
+// Image chain (PRE:335-342).  phase 0: everything; 1: only the first streaming pass (image means);
+// 2: everything after it.
+static int run_img_proxy(const PtxShape &s, const PtxWeights &w, const float *prep, const float *img,
+                         float *img_proxy, void *ws, hipStream_t st, int phase = 0)
 {
     const PrepLayout P = prep_layout(s);
     const WsLayout L = ws_layout(s);
-    const int C = s.C, hd = P.hd;
-    if (nimg < 0) nimg = s.B * s.V;
-    const float *img = img_all + (size_t)i0 * s.in_dim * s.hw;
-    float *img_proxy = img_proxy_all + (size_t)i0 * C;
-    float *fm = at<float>(ws, L.fm) + (size_t)i0 * s.in_dim, *qkv0 = at<float>(ws, L.qkv0) + (size_t)i0 * 3 * C;
-    float *we = at<float>(ws, L.we) + (size_t)i0 * s.heads * P.KT1;
-    float *gbuf = at<float>(ws, L.gbuf) + (size_t)i0 * s.heads * P.KT2p;
-    float *obuf = at<float>(ws, L.obuf) + (size_t)i0 * C, *cbuf = at<float>(ws, L.cbuf) + (size_t)i0 * C;
-    PTX_TIMED(KID_IMG_MEAN, st, launch_img_mean(img, nimg, s.in_dim, s.hw, fm, st));
-    if (after_mean) PTX_HIP(hipEventRecord(after_mean, st));
+    const int C = s.C, hd = P.hd, nimg = s.B * s.V;
+    float *fm = at<float>(ws, L.fm), *qkv0 = at<float>(ws, L.qkv0);
+    float *we = at<float>(ws, L.we), *gbuf = at<float>(ws, L.gbuf);
+    float *obuf = at<float>(ws, L.obuf), *cbuf = at<float>(ws, L.cbuf);
+    if (phase != 2) PTX_TIMED(KID_IMG_MEAN, st, launch_img_mean(img, nimg, s.in_dim, s.hw, fm, st));
+    if (phase == 1) return PTX_OK;
     {   // [q | k0 | v0] of token 0 = W3 mean(f) + b3
         GemmBatch g{}; g.n = 1;
         g.p[0] = GemmProb{fm, prep + P.w3, qkv0, prep + P.b3, nullptr, nullptr, nullptr,
@@ -577,25 +567,26 @@ int ptx_forward(const PtxShape *s, const PtxWeights *w, const void *prep, const 
     void *ws = workspace;
     const int M = S.grid_size * S.grid_size * S.grid_size, B = S.B, K = S.K, Kd = S.Mt - S.Mk;
 
-    // ---- fork: the image branch only depends on img_feat (PRE:449)
+    // ---- two streams.  The image branch (PRE:449) only depends on img_feat and is the critical
+    // path (three streaming passes over 90 MB per scene): it stays on the CALLER's stream together
+    // with everything after the join, so no cross-stream hop sits on the critical path.  The
+    // clustering chain (PRE:430-437) runs on the library's high-priority stream `cs`, finishes long
+    // before the image branch and its join event is already complete when the caller's stream
+    // reaches it.  (Running the image branch as two slices of scenes on two streams, to hide its
+    // small table GEMMs behind the other slice's streaming, was measured slower: 7.85k vs 8.1k
+    // scenes/s at cfg2, B = 4.)
     SideStream *side = nullptr;
     PTX_TRY(side_stream(&side));
+    static const int mode = getenv("PTX_STREAM_MODE") ? atoi(getenv("PTX_STREAM_MODE")) : 0;
+    // mode 0: image branch on the caller's stream, clustering on the high-priority stream
+    // mode 1: image branch on the low-priority stream, clustering on the caller's stream
+    hipStream_t cs = mode == 0 ? side->st : st;
+    hipStream_t is = mode == 0 ? st : side->lo;
+    hipStream_t other = mode == 0 ? cs : is;
     PTX_HIP(hipEventRecord(side->fork, st));
-    PTX_HIP(hipStreamWaitEvent(side->st, side->fork, 0));
+    PTX_HIP(hipStreamWaitEvent(other, side->fork, 0));
     float *img_proxy = at<float>(ws, L.img_proxy);
-    // The image chain can be run as two slices of scenes on two streams (second slice chained behind
-    // the first slice's mean pass, so that one slice streams while the other runs its small table
-    // GEMMs).  Measured on MI355X (cfg2, B = 4): 7.85k vs 8.1k scenes/s -- concurrent streaming
-    // kernels cost more (shared bandwidth, L2 thrash of the gather pass) than the ~60 us of GEMM
-    // latency they hide, so one slice is used.
-    const int bA = B, bB = 0;
-    PTX_TRY(run_img_proxy(S, *w, pf, img_feat, img_proxy, ws, side->st, 0, bA * S.V, bB > 0 ? side->mean : nullptr));
-    PTX_HIP(hipEventRecord(side->join, side->st));
-    if (bB > 0) {
-        PTX_HIP(hipStreamWaitEvent(side->st2, side->mean, 0));
-        PTX_TRY(run_img_proxy(S, *w, pf, img_feat, img_proxy, ws, side->st2, bA * S.V, bB * S.V));
-        PTX_HIP(hipEventRecord(side->join2, side->st2));
-    }
+    PTX_TRY(run_img_proxy(S, *w, pf, img_feat, img_proxy, ws, is, 1));      // first pass starts at once
 
     // ---- clustering (PRE:430)
     uint32_t *mm_enc = at<uint32_t>(ws, L.mm_enc), *tag = at<uint32_t>(ws, L.tag);
@@ -603,44 +594,46 @@ int ptx_forward(const PtxShape *s, const PtxWeights *w, const void *prep, const 
     float *cluster1 = at<float>(ws, L.cluster1), *offsets = at<float>(ws, L.offsets);
     float *centers = at<float>(ws, L.centers), *cluster2 = at<float>(ws, L.cluster2);
     int32_t *idx2 = at<int32_t>(ws, L.idx2), *pad_count = at<int32_t>(ws, L.pad_count);
-    { Timed t_(KID_MEMSET, st); PTX_HIP(hipMemsetAsync(at<char>(ws, L.zero_begin), 0, L.zero_bytes, st)); }
-    PTX_TIMED(KID_MINMAX, st, launch_minmax(sp, B, S.N, mm_enc, st));
+    { Timed t_(KID_MEMSET, cs); PTX_HIP(hipMemsetAsync(at<char>(ws, L.zero_begin), 0, L.zero_bytes, cs)); }
+    PTX_TIMED(KID_MINMAX, cs, launch_minmax(sp, B, S.N, mm_enc, cs));
     // ball query #1 on the unclamped grid centres; only the gathered xyz is used (PRE:56, Q3)
-    PTX_TIMED(KID_BQ1, st, launch_ball_query(nullptr, mm_enc, lin, S.grid_size, S.margin, minmax, centers0, sp,
-                                             B, M, S.N, K, S.radius, idx2, cluster1, nullptr, st));
-    PTX_TIMED(KID_OFFSET, st, launch_offset_net(pf + P.off_ab, w->offset, w->offset_map_w, centers0, cluster1,
-                                                minmax, B * M, M, K, S.margin, centers, offsets, st));
+    PTX_TIMED(KID_BQ1, cs, launch_ball_query(nullptr, mm_enc, lin, S.grid_size, S.margin, minmax, centers0, sp,
+                                             B, M, S.N, K, S.radius, idx2, cluster1, nullptr, cs));
+    PTX_TIMED(KID_OFFSET, cs, launch_offset_net(pf + P.off_ab, w->offset, w->offset_map_w, centers0, cluster1,
+                                                minmax, B * M, M, K, S.margin, centers, offsets, cs));
     if (centers_override)
-        PTX_HIP(hipMemcpyAsync(centers, centers_override, (size_t)B * M * 3 * 4, hipMemcpyDeviceToDevice, st));
-    PTX_TIMED(KID_BQ2, st, launch_ball_query(centers, nullptr, nullptr, 0, 0.0f, nullptr, nullptr, sp, B, M,
-                                             S.N, K, S.radius, idx2, cluster2, pad_count, st));   // PRE:65
+        PTX_HIP(hipMemcpyAsync(centers, centers_override, (size_t)B * M * 3 * 4, hipMemcpyDeviceToDevice, cs));
+    PTX_TIMED(KID_BQ2, cs, launch_ball_query(centers, nullptr, nullptr, 0, 0.0f, nullptr, nullptr, sp, B, M,
+                                             S.N, K, S.radius, idx2, cluster2, pad_count, cs));   // PRE:65
 
     // ---- dynamic cluster dropout (PRE:433)
     int32_t *order = at<int32_t>(ws, L.order), *picks = at<int32_t>(ws, L.picks), *keep = at<int32_t>(ws, L.keep);
     float *kcenter = at<float>(ws, L.kcenter), *kcluster = at<float>(ws, L.kcluster);
     int32_t *kidx = at<int32_t>(ws, L.kidx), *drop_idx = at<int32_t>(ws, L.drop_idx);
-    PTX_TIMED(KID_SELECT, st, launch_select(S, idx2, centers, cluster2, pad_count, order_override, order, picks,
-                                            keep, kcenter, kcluster, kidx, drop_idx, tag, st));
+    PTX_TIMED(KID_SELECT, cs, launch_select(S, idx2, centers, cluster2, pad_count, order_override, order, picks,
+                                            keep, kcenter, kcluster, kidx, drop_idx, tag, cs));
     int32_t *tile_counts = at<int32_t>(ws, L.tile_counts);
-    PTX_TIMED(KID_TILECOUNT, st, launch_tile_count(tag, B, S.N, tile_counts, st));
+    PTX_TIMED(KID_TILECOUNT, cs, launch_tile_count(tag, B, S.N, tile_counts, cs));
 
     // ---- point proxies (PRE:437) + norm1 / slot bias of both blocks
     float *point_proxy = at<float>(ws, L.point_proxy);
     float *xin_t = at<float>(ws, L.x_in[0]), *xin_i = at<float>(ws, L.x_in[1]);
-    PTX_TIMED(KID_POINTNET, st, launch_pointnet(pf + P.enc_ab, w->encoder, kcenter, kcluster, B * S.Mk, S.Mk, K,
+    PTX_TIMED(KID_POINTNET, cs, launch_pointnet(pf + P.enc_ab, w->encoder, kcenter, kcluster, B * S.Mk, S.Mk, K,
                                                 point_proxy, &w->text, &w->img, pf + P.posb_t, pf + P.posb_i, xin_t,
-                                                xin_i, S.ln_eps, st));
+                                                xin_i, S.ln_eps, cs));
 
     // ---- both proxy blocks + heads in shared launches (PRE:440-455); the input projections that
-    // do not need the image proxies run before the join
+    // do not need the image proxies still run on the clustering stream
     float *translate = at<float>(ws, L.head[0]), *transform = at<float>(ws, L.head[1]);
     float *guide_t = (debug && debug->text_guide) ? at<float>(ws, L.guide[0]) : nullptr;
     float *guide_i = (debug && debug->img_guide) ? at<float>(ws, L.guide[1]) : nullptr;
     Branch br[2] = {make_branch(S, *w, pf, 0, xin_t, text_feats, S.L, text_mask, translate, guide_t),
                     make_branch(S, *w, pf, 1, xin_i, img_proxy, S.V, nullptr, transform, guide_i)};
-    PTX_TRY(run_blocks(S, br, 2, point_proxy, ws, st, 1));
+    PTX_TRY(run_blocks(S, br, 2, point_proxy, ws, cs, 1));
+    if (mode == 0) PTX_HIP(hipEventRecord(side->join, cs));
+    PTX_TRY(run_img_proxy(S, *w, pf, img_feat, img_proxy, ws, is, 2));      // rest of the image chain
+    if (mode != 0) PTX_HIP(hipEventRecord(side->join, is));
     PTX_HIP(hipStreamWaitEvent(st, side->join, 0));
-    if (bB > 0) PTX_HIP(hipStreamWaitEvent(st, side->join2, 0));
     PTX_TRY(run_blocks(S, br, 2, point_proxy, ws, st, 2));
 
     // ---- submanifold reshape + scatter + drop (PRE:459-467)
