@@ -7,7 +7,9 @@
 
 A *step* is one eval forward of ``ProxyTransformationNormReverse`` over this rank's batch of
 synthetic scenes (BASELINE.json configs[1] shape: 100k points, 8^3 grid -> 256 kept clusters,
-64 text + 196 image proxies, d = 256; 4 scenes per GPU = the per-GPU shard of configs[2]).
+64 text + 196 image proxies, d = 256, image features stored as bf16 as that config names; 4 scenes
+per GPU = the per-GPU shard of configs[2]).  All arithmetic is fp32; the rate with fp32-stored
+features is measured in the same run and reported as `value_f32_features`.
 Inputs are resident in HBM before the timed region; the step ends when the list of output
 tensors exists (this includes the path's single host sync for the per-scene lengths).
 Scenes are sharded by scene id with no data-path collective (weak scaling).
@@ -48,6 +50,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--scenes-per-gpu", type=int, default=None)
+    ap.add_argument("--img-dtype", default="bf16", choices=["f32", "bf16", "f16"],
+                    help="storage type of the image features (BASELINE config 2 names bf16; arithmetic is fp32 "
+                         "either way); the fp32-feature rate is reported next to it")
     ap.add_argument("--time-kernel", default="k_img_scores", help="launch site timed for the roofline object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scenes", type=int, default=None, help="scenes in the CPU baseline sample")
@@ -69,9 +74,9 @@ def kernel_id(lib, name):
     return names.index(name), names
 
 
-def algorithmic_bytes(cfg, B, name):
+def algorithmic_bytes(cfg, B, name, img_itemsize=4):
     """Algorithmic HBM bytes one launch of `name` must move (kernel table)."""
-    img = B * cfg.V * cfg.input_dim * cfg.img_spacial_dim ** 2 * 4
+    img = B * cfg.V * cfg.input_dim * cfg.img_spacial_dim ** 2 * img_itemsize
     table = {
         "k_img_mean": img, "k_img_scores": img, "k_img_gather": img,
         "k_minmax": B * cfg.N * 12,
@@ -138,7 +143,9 @@ def main():
     points = [torch.from_numpy(p).to(device) for p in pts]
     text_dict = {"text_feats": torch.from_numpy(text).to(device),
                  "text_token_mask": torch.from_numpy(mask).to(device)}
-    img_feat = torch.from_numpy(img).to(device)
+    tdt = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[args.img_dtype]
+    img_f32 = torch.from_numpy(img).to(device)
+    img_feat = img_f32 if tdt is torch.float32 else img_f32.to(tdt)
     lib = _abi.lib()
     kid, names = kernel_id(lib, args.time_kernel)
 
@@ -162,6 +169,18 @@ def main():
         lib.ptx_timing_read(ctypes.byref(launches), ctypes.byref(total_ms))
         lib.ptx_timing_select(-1)
 
+        # the same workload with fp32-stored image features (the reference's non-AMP layout)
+        elapsed_f32 = None
+        if tdt is not torch.float32:
+            for _ in range(max(2, args.warmup // 2)):
+                mod(points, text_dict, img_f32)
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                mod(points, text_dict, img_f32)
+            barrier()
+            elapsed_f32 = time.perf_counter() - t1
+
         breakdown = None
         if args.breakdown and rank == 0:
             breakdown = {}
@@ -176,14 +195,16 @@ def main():
             lib.ptx_timing_select(-1)
             print("per-kernel us/launch:", json.dumps(breakdown), file=sys.stderr)
 
-    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    t = torch.tensor([elapsed, elapsed_f32 or 0.0], device=device, dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed = float(t[0].item())
+    if elapsed_f32 is not None:
+        elapsed_f32 = float(t[1].item())
 
     if rank == 0:
         total_scenes = world * B * args.steps
-        abytes = algorithmic_bytes(cfg, B, args.time_kernel)
+        abytes = algorithmic_bytes(cfg, B, args.time_kernel, img_feat.element_size())
         roof = None
         if launches.value > 0 and not abytes:
             roof = dict(kernel=args.time_kernel, avg_launch_us=round(total_ms.value / launches.value * 1e3, 2))
@@ -204,8 +225,12 @@ def main():
                     config=dict(workload=f"{cfg.name}: N={cfg.N} pts, gs={cfg.grid_size}->M'={cfg.M_keep} kept clusters, "
                                          f"L={cfg.L} text + V={cfg.V} image proxies, d={cfg.embed_dim}, eval forward",
                                 scenes_per_gpu=B, global_scenes_per_step=world * B, sharding="by scene, no collective",
-                                img_feat_dtype="f32", surviving_points_per_step=n_out),
+                                img_feat_dtype=args.img_dtype, arithmetic="fp32 (exact-fp32 MFMA / VALU)",
+                                surviving_points_per_step=n_out),
                     roofline=roof)
+        if elapsed_f32 is not None:
+            line["value_f32_features"] = round(total_scenes / elapsed_f32, 2)
+            line["ms_per_step_f32_features"] = round(1e3 * elapsed_f32 / args.steps, 4)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(cfg, sd, args.cpu_scenes or min(B, 2))

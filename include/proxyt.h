@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PTX_ABI_VERSION 1
+#define PTX_ABI_VERSION 2
 
 #define PTX_OK          0
 #define PTX_EINVAL     -1   /* bad shape / null pointer / unsupported size */
@@ -51,6 +51,8 @@ typedef struct PtxShape {
     int32_t hidden;     /* int(C*mlp_radio) (1024)                               */
     int32_t in_dim;     /* image feature channels (512)                          */
     int32_t hw;         /* img_spacial_dim^2 (225)                               */
+    int32_t img_dtype;  /* storage type of img_feat: 0 = fp32, 1 = bf16, 2 = fp16 (AMP backbones);
+                           arithmetic is fp32 in every case                      */
     float   radius;     /* 3.0 (PRE:23)                                          */
     float   margin;     /* 4.0 (PRE:23)                                          */
     float   bn_eps;     /* 1e-5                                                  */
@@ -171,8 +173,8 @@ int ptx_pointnet(const PtxShape *s, const PtxWeights *w, const void *prep, const
                  const float *kcluster, float *point_proxy, void *stream);
 
 /* get_img_proxy, PRE:335-342 (1x1 conv + AttentionPool2d token 0 + LayerNorm)
- * img_feat (B,V,in_dim,hw) -> img_proxy (B,V,C). */
-int ptx_img_proxy(const PtxShape *s, const PtxWeights *w, const void *prep, const float *img_feat,
+ * img_feat (B,V,in_dim,hw) of s->img_dtype -> img_proxy (B,V,C). */
+int ptx_img_proxy(const PtxShape *s, const PtxWeights *w, const void *prep, const void *img_feat,
                   float *img_proxy, void *workspace, size_t ws_bytes, void *stream);
 
 /* ProxyBlock (eval) + trailing LayerNorm + Linear head + BatchNorm1d(eval):
@@ -213,7 +215,7 @@ typedef struct PtxDebug {
 
 int ptx_forward(const PtxShape *s, const PtxWeights *w, const void *prep, const float *lin,
                 const float *points, const float *const *points_list, const float *text_feats,
-                const uint8_t *text_mask, const float *img_feat, const int32_t *order_override,
+                const uint8_t *text_mask, const void *img_feat, const int32_t *order_override,
                 const float *centers_override,
                 float *out, int32_t *counts, void *workspace, size_t ws_bytes,
                 const PtxDebug *debug, void *stream);

@@ -13,7 +13,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libproxyt_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_float_p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 
@@ -21,7 +21,7 @@ c_float_p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr()
 class PtxShape(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("B", "N", "grid_size", "K", "Mt", "Mk", "L", "V", "C", "heads", "hidden",
-                 "in_dim", "hw")] + \
+                 "in_dim", "hw", "img_dtype")] + \
                [(n, C.c_float) for n in ("radius", "margin", "bn_eps", "ln_eps")]
 
 

@@ -82,6 +82,7 @@ int validate_shape(const PtxShape &s)
     PTX_REQUIRE(s.in_dim >= 64 && s.in_dim % 64 == 0, "shape: in_dim=%d must be a multiple of 64", s.in_dim);
     PTX_REQUIRE(s.hw >= 1 && s.L >= 1 && s.V >= 1, "shape: hw=%d L=%d V=%d", s.hw, s.L, s.V);
     PTX_REQUIRE((long)s.Mk * s.K < (1l << 31) - 1, "shape: Mk*K overflows the ownership tag");
+    PTX_REQUIRE(s.img_dtype >= 0 && s.img_dtype <= 2, "shape: img_dtype=%d (0 fp32, 1 bf16, 2 fp16)", s.img_dtype);
     return PTX_OK;
 }
 
@@ -185,7 +186,7 @@ static inline T *at(void *base, size_t off) { return reinterpret_cast<T *>(stati
 // ---- image chain ---------------------------------------------------------------------------------
 // Image chain (PRE:335-342).  phase 0: everything; 1: only the first streaming pass (image means);
 // 2: everything after it.
-static int run_img_proxy(const PtxShape &s, const PtxWeights &w, const float *prep, const float *img,
+static int run_img_proxy(const PtxShape &s, const PtxWeights &w, const float *prep, const void *img_any,
                          float *img_proxy, void *ws, hipStream_t st, int phase = 0)
 {
     const PrepLayout P = prep_layout(s);
@@ -194,7 +195,12 @@ static int run_img_proxy(const PtxShape &s, const PtxWeights &w, const float *pr
     float *fm = at<float>(ws, L.fm), *qkv0 = at<float>(ws, L.qkv0);
     float *we = at<float>(ws, L.we), *gbuf = at<float>(ws, L.gbuf);
     float *obuf = at<float>(ws, L.obuf), *cbuf = at<float>(ws, L.cbuf);
-    if (phase != 2) PTX_TIMED(KID_IMG_MEAN, st, launch_img_mean(img, nimg, s.in_dim, s.hw, fm, st));
+    const float *img = static_cast<const float *>(img_any);
+    const int dt = s.img_dtype;
+    if (phase != 2) {
+        if (dt == 0) PTX_TIMED(KID_IMG_MEAN, st, launch_img_mean(img, nimg, s.in_dim, s.hw, fm, st));
+        else PTX_TIMED(KID_IMG_MEAN, st, launch_img_mean16(img_any, dt, nimg, s.in_dim, s.hw, fm, st));
+    }
     if (phase == 1) return PTX_OK;
     {   // [q | k0 | v0] of token 0 = W3 mean(f) + b3
         GemmBatch g{}; g.n = 1;
@@ -210,9 +216,15 @@ static int run_img_proxy(const PtxShape &s, const PtxWeights &w, const float *pr
                               s.heads * P.KT1, 0, 0, 0, EPI_NONE};
         PTX_TIMED(KID_IMG_WE, st, launch_gemm(g, st));
     }
-    PTX_TIMED(KID_IMG_SCORES, st, launch_img_scores(img, we, qkv0, nimg, s.in_dim, s.hw, s.heads, C, P.KT1,
-                                                    P.KT2p, attn_scale(hd), gbuf, st));
-    PTX_TIMED(KID_IMG_GATHER, st, launch_img_gather(img, nimg, s.in_dim, s.hw, s.heads, P.KT2p, gbuf, st));
+    if (dt == 0) {
+        PTX_TIMED(KID_IMG_SCORES, st, launch_img_scores(img, we, qkv0, nimg, s.in_dim, s.hw, s.heads, C, P.KT1,
+                                                        P.KT2p, attn_scale(hd), gbuf, st));
+        PTX_TIMED(KID_IMG_GATHER, st, launch_img_gather(img, nimg, s.in_dim, s.hw, s.heads, P.KT2p, gbuf, st));
+    } else {
+        PTX_TIMED(KID_IMG_SCORES, st, launch_img_scores16(img_any, dt, we, qkv0, nimg, s.in_dim, s.hw, s.heads, C,
+                                                          P.KT1, P.KT2p, attn_scale(hd), gbuf, st));
+        PTX_TIMED(KID_IMG_GATHER, st, launch_img_gather16(img_any, dt, nimg, s.in_dim, s.hw, s.heads, P.KT2p, gbuf, st));
+    }
     {   // per head: o_h = [g_h | a_h] T2_h^T + a_h(0) v0_h + bv_h
         GemmBatch g{}; g.n = s.heads;
         for (int h = 0; h < s.heads; ++h)
@@ -489,7 +501,7 @@ int ptx_pointnet(const PtxShape *s, const PtxWeights *w, const void *prep, const
                            nullptr, s->ln_eps, static_cast<hipStream_t>(stream));
 }
 
-int ptx_img_proxy(const PtxShape *s, const PtxWeights *w, const void *prep, const float *img_feat,
+int ptx_img_proxy(const PtxShape *s, const PtxWeights *w, const void *prep, const void *img_feat,
                   float *img_proxy, void *workspace, size_t ws_bytes, void *stream)
 {
     PTX_REQUIRE(w && prep && img_feat && img_proxy, "ptx_img_proxy: null argument");
@@ -549,7 +561,7 @@ int ptx_affine_compact(const PtxShape *s, const float *points, const uint32_t *t
 
 int ptx_forward(const PtxShape *s, const PtxWeights *w, const void *prep, const float *lin,
                 const float *points, const float *const *points_list, const float *text_feats,
-                const uint8_t *text_mask, const float *img_feat, const int32_t *order_override,
+                const uint8_t *text_mask, const void *img_feat, const int32_t *order_override,
                 const float *centers_override,
                 float *out, int32_t *counts, void *workspace, size_t ws_bytes, const PtxDebug *debug,
                 void *stream)

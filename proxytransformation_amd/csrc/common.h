@@ -197,6 +197,12 @@ int launch_img_scores(const float *img, const float *we, const float *qkv0, int 
 int launch_img_gather(const float *img, int nimg, int in_dim, int hw, int heads, int KT2p,
                       float *gbuf, hipStream_t st);
 
+int launch_img_mean16(const void *img, int dt, int nimg, int in_dim, int hw, float *fm, hipStream_t st);
+int launch_img_scores16(const void *img, int dt, const float *we, const float *qkv0, int nimg, int in_dim,
+                        int hw, int heads, int C, int KT1, int KT2p, float scale, float *gbuf, hipStream_t st);
+int launch_img_gather16(const void *img, int dt, int nimg, int in_dim, int hw, int heads, int KT2p, float *gbuf,
+                        hipStream_t st);
+
 // ---- prep (prep.hip) ----------------------------------------------------------------------------
 int run_prepare(const PtxShape &s, const PtxWeights &w, float *prep, hipStream_t st);
 

@@ -71,7 +71,9 @@ constexpr int kMaxHeads = 8;
 // load instruction.  The 8 head weights of a row are wave-uniform: they sit in 8 VGPRs per wave
 // (lane = channel) and are broadcast with v_readlane, so the inner loop is 32 FMAs + 8 readlanes
 // per 16-B load and touches memory only for the image.
-// Measured alternatives that were NOT faster (r01, MI355X): LDS-broadcast weights, interleaving the
+// What the time is (r01, MI355X, cfg2 B=4, fp32 features): 66 us of streaming (5.5 TB/s) + ~10 us of
+// tree / softmax epilogue that cannot overlap because all 784 work-groups are resident and in step.
+// Measured alternatives that were NOT faster: LDS-broadcast weights, interleaving the
 // waves' rows so an image is read front to back, 2 / 4 / 16 waves per image, unroll 2 / 8, explicit register double-buffering, 16-B
 // aligned rows, and (image, 64- or 128-channel chunk) work-groups with a last-arriver reduction
 // (write-through partials + agent-scope counter): the per-chunk hand-off costs more than the
@@ -108,26 +110,46 @@ __global__ __launch_bounds__(kScoreWaves * 64) void k_img_scores(
     float wreg[HEADS];
 #pragma unroll
     for (int h = 0; h < HEADS; ++h) wreg[h] = lane < cper ? wim[(size_t)h * KT1 + cbeg + lane] : 0.0f;
-#pragma unroll 4
-    for (int cc = 0; cc < cper; ++cc) {
-        const int c = cbeg + cc;
-        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-        if (vec) { const f4u t = __builtin_nontemporal_load(reinterpret_cast<const f4u *>(f + (size_t)c * hw + poff)); v0 = t.x; v1 = t.y; v2 = t.z; v3 = t.w; }
+    // token 0: s_h(0) = scale * q_h . k0_h -- wave h computes head h up front (one load round trip that
+    // overlaps the first image loads; as a 32-step scalar loop after the stream it was a chain of
+    // dependent round trips that cost ~15 us per launch)
+    if (wid < heads) {
+        const int hd = C / heads;
+        const float *q = qkv0 + (size_t)im * 3 * C + wid * hd;
+        const float qk = lane < hd ? q[lane] * q[C + lane] : 0.0f;
+        const float s0 = wave_sum(qk);
+        if (lane == 0) S[wid * (hw + 1)] = s0 * scale;
+    }
+    // Branch-free inner loop: lanes beyond the row re-read lane 0's pixels (their accumulators are
+    // never stored), so the body is one basic block and UNR row loads are in flight per wave.  (With
+    // an `if (lane < nv4)` around the load hipcc neither unrolled nor hoisted it: one exposed
+    // ~1 us round trip per row and wave -- the kernel ran at 88 us regardless of the bytes moved.)
+    constexpr int UNR = 8;
+    const float *fl = f + (vec ? poff : 0);
+    for (int cc = 0; cc < cper; cc += UNR) {               // cper is a multiple of 8 (validated by the host)
+        f4u t[UNR];
 #pragma unroll
-        for (int h = 0; h < HEADS; ++h) {
-            const float wv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wreg[h]), cc));
-            acc[h][0] = fmaf(wv, v0, acc[h][0]); acc[h][1] = fmaf(wv, v1, acc[h][1]);
-            acc[h][2] = fmaf(wv, v2, acc[h][2]); acc[h][3] = fmaf(wv, v3, acc[h][3]);
+        for (int u = 0; u < UNR; ++u)
+            t[u] = __builtin_nontemporal_load(reinterpret_cast<const f4u *>(fl + (size_t)(cbeg + cc + u) * hw));
+        __builtin_amdgcn_sched_barrier(0);                  // keep all UNR loads ahead of the first FMA
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+#pragma unroll
+            for (int h = 0; h < HEADS; ++h) {
+                const float wv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wreg[h]), cc + u));
+                acc[h][0] = fmaf(wv, t[u].x, acc[h][0]); acc[h][1] = fmaf(wv, t[u].y, acc[h][1]);
+                acc[h][2] = fmaf(wv, t[u].z, acc[h][2]); acc[h][3] = fmaf(wv, t[u].w, acc[h][3]);
+            }
         }
     }
-    if (tid < heads) {                              // token 0: s_h(0) = scale * q_h . k0_h
-        const int hd = C / heads;
-        const float *q = qkv0 + (size_t)im * 3 * C + tid * hd;
-        const float *k0 = q + C;
-        float s = 0.0f;
-        for (int d = 0; d < hd; ++d) s = fmaf(q[d], k0[d], s);
-        S[tid * (hw + 1)] = s * scale;
-    }
+    // positional score terms e_h(p) of this lane's pixels: requested before the tree so that the
+    // round trip hides behind it (used by wave 0 only)
+    float ev[HEADS][4];
+#pragma unroll
+    for (int h = 0; h < HEADS; ++h)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            ev[h][c] = (wid == 0 && vec && c >= cfirst) ? wim[(size_t)h * KT1 + in_dim + 1 + poff + c] : 0.0f;
     // fixed-order tree over the NW channel slices: upper half parks, lower half adds
     // (red is indexed by lane, not by pixel: the edge lane overlaps its neighbour's pixels)
 #pragma unroll
@@ -152,10 +174,9 @@ __global__ __launch_bounds__(kScoreWaves * 64) void k_img_scores(
 #pragma unroll
         for (int h = 0; h < HEADS; ++h) {
             float *d = S + h * (hw + 1) + 1 + poff;
-            const float *e = wim + (size_t)h * KT1 + in_dim + 1 + poff;
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-                if (c >= cfirst) d[c] = acc[h][c] + e[c];
+                if (c >= cfirst) d[c] = acc[h][c] + ev[h][c];
         }
     }
     __syncthreads();
@@ -177,7 +198,7 @@ int launch_img_scores(const float *img, const float *we, const float *qkv0, int 
                       int hw, int heads, int C, int KT1, int KT2p, float scale, float *gbuf,
                       hipStream_t st)
 {
-    PTX_REQUIRE(heads == kMaxHeads && in_dim % kScoreWaves == 0 && in_dim / kScoreWaves <= 64,
+    PTX_REQUIRE(heads == kMaxHeads && in_dim % (8 * kScoreWaves) == 0 && in_dim / kScoreWaves <= 64,
                 "img scores: heads=%d in_dim=%d unsupported", heads, in_dim);
     PTX_REQUIRE(hw >= 4 && (hw >> 2) + ((hw & 3) ? 1 : 0) <= 64, "img scores: hw=%d (supported: 4..256 pixels)", hw);
     const size_t lds = sizeof(float) * ((size_t)(kScoreWaves / 2) * heads * 256 + (size_t)heads * (hw + 1));

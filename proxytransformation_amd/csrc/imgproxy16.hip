@@ -1,0 +1,334 @@
+// The three image-streaming kernels of imgproxy.hip for image features STORED as bf16 or fp16
+// (an AMP backbone hands over half-precision feature maps; BASELINE config 2 names bf16).  Only the
+// storage changes: every element is widened to fp32 on load and all arithmetic, accumulation and
+// outputs are fp32 exactly as in the fp32 kernels, so the result equals the fp32 path run on the
+// same (rounded) inputs.  The dominant HBM stream of the path halves (in_dim*hw*2 B per image).
+//
+// Layout facts used below: a row (one channel of one image) is hw*2 bytes, i.e. only 2-byte aligned
+// (hw = 225 is odd); gfx950 global_load_dwordx4 accepts that.  A 16-B load holds 8 pixels, so a
+// 15x15 row needs only 29 lanes: every instruction serves TWO rows (lanes 0-31 row r, lanes 32-63
+// row r+1).
+#include <hip/hip_fp16.h>
+
+#include "common.h"
+
+namespace ptx {
+
+__device__ __forceinline__ float half_bits_to_float(unsigned short u)
+{
+    _Float16 h;
+    __builtin_memcpy(&h, &u, 2);
+    return (float)h;
+}
+
+typedef unsigned int u4u2 __attribute__((ext_vector_type(4), aligned(2)));    // 16-B load at 2-B alignment
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kMaxHeads = 8;
+
+// widen the 8 half-precision values packed in 4 dwords (element 2i = low half of dword i)
+template <int DT>   // 1 = bf16, 2 = fp16
+__device__ __forceinline__ void widen8(const u32x4 &d, float (&v)[8])
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (DT == 1) {
+            v[2 * i] = __uint_as_float(d[i] << 16);
+            v[2 * i + 1] = __uint_as_float(d[i] & 0xffff0000u);
+        } else {
+            v[2 * i] = half_bits_to_float((unsigned short)(d[i] & 0xffffu));
+            v[2 * i + 1] = half_bits_to_float((unsigned short)(d[i] >> 16));
+        }
+    }
+}
+template <int DT>
+__device__ __forceinline__ float widen1(unsigned short u)
+{
+    return DT == 1 ? __uint_as_float((unsigned int)u << 16) : half_bits_to_float(u);
+}
+
+// per-lane view of a row: lane j (within its half-wave) owns pixels 8j..8j+7; the hw % 8 tail pixels
+// are covered by one more lane that re-reads the LAST 8 pixels and keeps only the last `tail` ones
+struct RowLanes {
+    int half, j, poff, cfirst; bool act;
+    __device__ RowLanes(int lane, int hw) {
+        half = lane >> 5; j = lane & 31;
+        const int nv8 = hw >> 3, tail = hw & 7;
+        const bool edge = tail != 0 && j == nv8;
+        act = j < nv8 || edge;
+        poff = edge ? hw - 8 : 8 * j;
+        cfirst = edge ? 8 - tail : 0;
+    }
+};
+
+// ---- pass 1: per-channel means.  One wave per 8 rows (4 load instructions of 2 rows each).
+template <int DT>
+__global__ __launch_bounds__(256) void k_img_mean16(const unsigned short *__restrict__ img, int ngroups,
+                                                    int hw, float *__restrict__ fm)
+{
+    const int lane = lane_id();
+    const int g = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (g >= ngroups) return;
+    const RowLanes rl(lane, hw);
+    const unsigned short *base = img + (size_t)g * 8 * hw;
+    float s[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        s[u] = 0.0f;
+        if (rl.act) {
+            const u32x4 d = __builtin_nontemporal_load(reinterpret_cast<const u4u2 *>(base + (size_t)(2 * u + rl.half) * hw + rl.poff));
+            float v[8];
+            widen8<DT>(d, v);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) s[u] += c >= rl.cfirst ? v[c] : 0.0f;
+        }
+    }
+    const float inv = 1.0f / (float)hw;
+    float out = 0.0f;                                       // lane r (r < 8) ends up with the mean of row r
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        float v = s[u];
+        v += PTX_ROR_F(v, 8); v += PTX_ROR_F(v, 4); v += PTX_ROR_F(v, 2); v += PTX_ROR_F(v, 1);   // 16-lane rows
+        const float lo = PTX_LANE_F(v, 0) + PTX_LANE_F(v, 16), hi = PTX_LANE_F(v, 32) + PTX_LANE_F(v, 48);
+        if (lane == 2 * u) out = lo * inv;
+        if (lane == 2 * u + 1) out = hi * inv;
+    }
+    if (lane < 8) fm[(size_t)g * 8 + lane] = out;
+}
+
+// ---- pass 2: scores + softmax.  Exactly the structure of k_img_scores (imgproxy.hip): one work-group
+// of 8 waves per image, wave w owns channels [w*in_dim/8, (w+1)*in_dim/8), lane j owns pixels
+// 4j..4j+3 of every row (one 8-B load per lane and row here), head weights in 8 VGPRs broadcast by
+// v_readlane, 32 accumulators per lane.  (Two rows per 16-B-load instruction -- 64 accumulators per
+// lane plus a per-half weight select -- was measured 1.7x slower: 128+ VGPRs, one work-group per CU.)
+constexpr int kScoreWaves = 8;
+typedef unsigned int u2u2 __attribute__((ext_vector_type(2), aligned(2)));    // 8-B load at 2-B alignment
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+template <int HEADS, int DT>
+__global__ __launch_bounds__(kScoreWaves * 64) void k_img_scores16(
+    const unsigned short *__restrict__ img, const float *__restrict__ we, const float *__restrict__ qkv0,
+    int in_dim, int hw, int C, int KT1, int KT2p, float scale, float *__restrict__ gbuf)
+{
+    constexpr int heads = HEADS, NW = kScoreWaves;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *red = sm;                               // [NW/2][heads][64 lanes x 4]
+    float *S = sm + (NW / 2) * heads * 256;        // [heads][hw + 1]
+    const int im = gridDim.x - 1 - blockIdx.x, tid = threadIdx.x, lane = lane_id();
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float *wim = we + (size_t)im * heads * KT1;
+    const unsigned short *f = img + (size_t)im * in_dim * hw;
+    const int nv4 = hw >> 2, tail = hw & 3;
+    const bool edge = tail != 0 && lane == nv4;
+    const bool vec = lane < nv4 || edge;
+    const int poff = edge ? hw - 4 : 4 * lane;
+    const int cfirst = edge ? 4 - tail : 0;
+    float acc[HEADS][4];
+#pragma unroll
+    for (int h = 0; h < HEADS; ++h) { acc[h][0] = acc[h][1] = acc[h][2] = acc[h][3] = 0.0f; }
+    const int cper = in_dim / NW, cbeg = wid * cper;        // cper <= 64 (validated by the host)
+    float wreg[HEADS];
+#pragma unroll
+    for (int h = 0; h < HEADS; ++h) wreg[h] = lane < cper ? wim[(size_t)h * KT1 + cbeg + lane] : 0.0f;
+    // token 0: s_h(0) = scale * q_h . k0_h -- wave h computes head h up front (one load round trip that
+    // overlaps the first image loads; as a 32-step scalar loop after the stream it was a chain of
+    // dependent round trips that cost ~15 us per launch)
+    if (wid < heads) {
+        const int hd = C / heads;
+        const float *q = qkv0 + (size_t)im * 3 * C + wid * hd;
+        const float qk = lane < hd ? q[lane] * q[C + lane] : 0.0f;
+        const float s0 = wave_sum(qk);
+        if (lane == 0) S[wid * (hw + 1)] = s0 * scale;
+    }
+    // branch-free inner loop (see k_img_scores): lanes beyond the row re-read lane 0's pixels
+    constexpr int UNR = 8;
+    const unsigned short *fl = f + (vec ? poff : 0);
+    for (int cc = 0; cc < cper; cc += UNR) {               // cper is a multiple of 8 (validated by the host)
+        u32x2 d[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+            d[u] = __builtin_nontemporal_load(reinterpret_cast<const u2u2 *>(fl + (size_t)(cbeg + cc + u) * hw));
+        __builtin_amdgcn_sched_barrier(0);                  // keep all UNR loads ahead of the first FMA
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            float v0, v1, v2, v3;
+            if (DT == 1) {
+                v0 = __uint_as_float(d[u][0] << 16); v1 = __uint_as_float(d[u][0] & 0xffff0000u);
+                v2 = __uint_as_float(d[u][1] << 16); v3 = __uint_as_float(d[u][1] & 0xffff0000u);
+            } else {
+                v0 = half_bits_to_float((unsigned short)(d[u][0] & 0xffffu)); v1 = half_bits_to_float((unsigned short)(d[u][0] >> 16));
+                v2 = half_bits_to_float((unsigned short)(d[u][1] & 0xffffu)); v3 = half_bits_to_float((unsigned short)(d[u][1] >> 16));
+            }
+#pragma unroll
+            for (int h = 0; h < HEADS; ++h) {
+                const float wv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wreg[h]), cc + u));
+                acc[h][0] = fmaf(wv, v0, acc[h][0]); acc[h][1] = fmaf(wv, v1, acc[h][1]);
+                acc[h][2] = fmaf(wv, v2, acc[h][2]); acc[h][3] = fmaf(wv, v3, acc[h][3]);
+            }
+        }
+    }
+    // positional score terms e_h(p) of this lane's pixels: requested before the tree so that the
+    // round trip hides behind it (used by wave 0 only)
+    float ev[HEADS][4];
+#pragma unroll
+    for (int h = 0; h < HEADS; ++h)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            ev[h][c] = (wid == 0 && vec && c >= cfirst) ? wim[(size_t)h * KT1 + in_dim + 1 + poff + c] : 0.0f;
+    // fixed-order tree over the NW channel slices
+#pragma unroll
+    for (int half = NW / 2; half >= 1; half >>= 1) {
+        if (wid >= half && wid < 2 * half) {
+#pragma unroll
+            for (int h = 0; h < HEADS; ++h)
+                *reinterpret_cast<float4 *>(red + ((size_t)(wid - half) * heads + h) * 256 + 4 * lane) =
+                    make_float4(acc[h][0], acc[h][1], acc[h][2], acc[h][3]);
+        }
+        __syncthreads();
+        if (wid < half) {
+#pragma unroll
+            for (int h = 0; h < HEADS; ++h) {
+                const float4 t = *reinterpret_cast<const float4 *>(red + ((size_t)wid * heads + h) * 256 + 4 * lane);
+                acc[h][0] += t.x; acc[h][1] += t.y; acc[h][2] += t.z; acc[h][3] += t.w;
+            }
+        }
+        __syncthreads();
+    }
+    if (wid == 0 && vec) {
+#pragma unroll
+        for (int h = 0; h < HEADS; ++h) {
+            float *d = S + h * (hw + 1) + 1 + poff;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c >= cfirst) d[c] = acc[h][c] + ev[h][c];
+        }
+    }
+    __syncthreads();
+    for (int h = wid; h < heads; h += NW) {         // softmax over hw + 1 tokens, one wave per head
+        const float *sh = S + h * (hw + 1);
+        float mx = -INFINITY;
+        for (int i = lane; i <= hw; i += 64) mx = fmaxf(mx, sh[i]);
+        mx = wave_max(mx);
+        float sum = 0.0f;
+        for (int i = lane; i <= hw; i += 64) sum += expf(sh[i] - mx);
+        sum = wave_sum(sum);
+        const float inv = 1.0f / sum;
+        float *dst = gbuf + ((size_t)im * heads + h) * KT2p + in_dim;
+        for (int i = lane; i < KT2p - in_dim; i += 64) dst[i] = i <= hw ? expf(sh[i] - mx) * inv : 0.0f;
+    }
+}
+
+// ---- pass 3: g_h = sum_p a_h(p) f_p, v_mfma_f32_16x16x4_f32 with the A operand widened from one
+// 16-B load per lane and step (8 pixels): lane (ci, kq) covers pixels 32 kb + 8 kq .. +7.
+constexpr int kGatherCh = 64;
+
+template <int DT>
+__global__ __launch_bounds__(256) void k_img_gather16(const unsigned short *__restrict__ img, int in_dim,
+                                                      int hw, int heads, int KT2p, float *__restrict__ gbuf)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int hwp = (hw + 3) & ~3;
+    float *a_s = sm;                                        // [heads][hwp], zero padded
+    const int chunks = in_dim / kGatherCh;
+    const int im = blockIdx.x / chunks, c0 = (blockIdx.x - im * chunks) * kGatherCh;
+    const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
+    const int ci = lane & 15, kq = lane >> 4;
+    const int cb = c0 + wid * 16;
+    const unsigned short *row = img + ((size_t)im * in_dim + cb + ci) * hw;
+    const bool live = ci < heads;
+    const float *arow = a_s + (size_t)(live ? ci : 0) * hwp;
+    const int nkb = hw >> 5;
+    constexpr int PRE = 4;
+    u32x4 pf[PRE];
+#pragma unroll
+    for (int kb = 0; kb < PRE; ++kb)
+        pf[kb] = *reinterpret_cast<const u4u2 *>(row + 32 * min(kb, nkb - 1) + 8 * kq);
+    for (int i = tid; i < heads * hwp; i += 256) {
+        const int h = i / hwp, p = i - h * hwp;
+        a_s[i] = p < hw ? gbuf[((size_t)im * heads + h) * KT2p + in_dim + 1 + p] : 0.0f;
+    }
+    __syncthreads();
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    auto step = [&](int kb, const u32x4 &d) {
+        const int p0 = 32 * kb + 8 * kq;
+        float fv[8];
+        widen8<DT>(d, fv);
+        float4 b0 = *reinterpret_cast<const float4 *>(arow + p0);
+        float4 b1 = *reinterpret_cast<const float4 *>(arow + p0 + 4);
+        if (!live) { b0 = make_float4(0.f, 0.f, 0.f, 0.f); b1 = b0; }
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fv[0], b0.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fv[1], b0.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fv[2], b0.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fv[3], b0.w, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fv[4], b1.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fv[5], b1.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fv[6], b1.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fv[7], b1.w, acc, 0, 0, 0);
+    };
+#pragma unroll
+    for (int kb = 0; kb < PRE; ++kb)
+        if (kb < nkb) step(kb, pf[kb]);
+#pragma unroll 3
+    for (int kb = PRE; kb < nkb; ++kb) {
+        const u32x4 d = *reinterpret_cast<const u4u2 *>(row + 32 * kb + 8 * kq);
+        step(kb, d);
+    }
+    for (int pp = 32 * nkb; pp < hw; pp += 4) {             // pixel tail (1 pixel for 15 x 15)
+        const int p = pp + kq;
+        const float fa = p < hw ? widen1<DT>(row[p]) : 0.0f;
+        const float ba = (p < hw && live) ? arow[p] : 0.0f;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, ba, acc, 0, 0, 0);
+    }
+    if (live) {
+        float *dst = gbuf + ((size_t)im * heads + ci) * KT2p + cb + 4 * kq;
+        *reinterpret_cast<float4 *>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+}
+
+// ---- launchers ---------------------------------------------------------------------------------------
+int launch_img_mean16(const void *img, int dt, int nimg, int in_dim, int hw, float *fm, hipStream_t st)
+{
+    PTX_REQUIRE(in_dim % 8 == 0, "img mean: in_dim=%d must be a multiple of 8", in_dim);
+    PTX_REQUIRE(hw >= 8 && (hw >> 3) + ((hw & 7) ? 1 : 0) <= 32, "half-precision image features: hw=%d (supported: 8..255)", hw);
+    const int ngroups = nimg * (in_dim / 8);
+    const unsigned short *p = static_cast<const unsigned short *>(img);
+    if (dt == 1) hipLaunchKernelGGL(k_img_mean16<1>, dim3(cdiv(ngroups, 4)), dim3(256), 0, st, p, ngroups, hw, fm);
+    else         hipLaunchKernelGGL(k_img_mean16<2>, dim3(cdiv(ngroups, 4)), dim3(256), 0, st, p, ngroups, hw, fm);
+    PTX_LAUNCHED("k_img_mean16");
+    return PTX_OK;
+}
+
+int launch_img_scores16(const void *img, int dt, const float *we, const float *qkv0, int nimg, int in_dim,
+                        int hw, int heads, int C, int KT1, int KT2p, float scale, float *gbuf, hipStream_t st)
+{
+    PTX_REQUIRE(heads == kMaxHeads && in_dim % (8 * kScoreWaves) == 0 && in_dim / kScoreWaves <= 64,
+                "img scores: heads=%d in_dim=%d unsupported", heads, in_dim);
+    PTX_REQUIRE(hw >= 4 && (hw >> 2) + ((hw & 3) ? 1 : 0) <= 64, "img scores: hw=%d (supported: 4..256 pixels)", hw);
+    const size_t lds = sizeof(float) * ((size_t)(kScoreWaves / 2) * heads * 256 + (size_t)heads * (hw + 1));
+    PTX_REQUIRE(lds <= 64 * 1024, "img scores: %zu B of LDS", lds);
+    const unsigned short *p = static_cast<const unsigned short *>(img);
+    if (dt == 1)
+        hipLaunchKernelGGL((k_img_scores16<kMaxHeads, 1>), dim3(nimg), dim3(kScoreWaves * 64), lds, st, p, we, qkv0,
+                           in_dim, hw, C, KT1, KT2p, scale, gbuf);
+    else
+        hipLaunchKernelGGL((k_img_scores16<kMaxHeads, 2>), dim3(nimg), dim3(kScoreWaves * 64), lds, st, p, we, qkv0,
+                           in_dim, hw, C, KT1, KT2p, scale, gbuf);
+    PTX_LAUNCHED("k_img_scores16");
+    return PTX_OK;
+}
+
+int launch_img_gather16(const void *img, int dt, int nimg, int in_dim, int hw, int heads, int KT2p, float *gbuf,
+                        hipStream_t st)
+{
+    PTX_REQUIRE(in_dim % kGatherCh == 0 && heads <= kMaxHeads, "img gather: in_dim=%d heads=%d", in_dim, heads);
+    const int hwp = (hw + 3) & ~3;
+    const size_t lds = sizeof(float) * (size_t)heads * hwp;
+    const unsigned short *p = static_cast<const unsigned short *>(img);
+    const dim3 grid(nimg * (in_dim / kGatherCh));
+    if (dt == 1) hipLaunchKernelGGL(k_img_gather16<1>, grid, dim3(256), lds, st, p, in_dim, hw, heads, KT2p, gbuf);
+    else         hipLaunchKernelGGL(k_img_gather16<2>, grid, dim3(256), lds, st, p, in_dim, hw, heads, KT2p, gbuf);
+    PTX_LAUNCHED("k_img_gather16");
+    return PTX_OK;
+}
+
+}  // namespace ptx

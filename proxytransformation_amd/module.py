@@ -30,6 +30,7 @@ __all__ = ["ProxyTransformationNormReverse"]
 _RADIUS, _MARGIN = 3.0, 4.0          # PRE:23 (fixed, not reachable from the config)
 _EMPTY_DROP = 0.3                    # PRE:352
 _SLOT_WIDTH = 256                    # PRE:31, PRE:302 (hard-coded in the reference)
+_IMG_DTYPES = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}   # PtxShape.img_dtype
 _MAX_SCENES_PER_CALL = 32            # kMaxScenes of the C ABI (per-scene pointer table passed by value)
 
 
@@ -171,12 +172,12 @@ class ProxyTransformationNormReverse(nn.Module):
         return text_dict.values()
 
     # ------------------------------------------------------------------ shape / weights plumbing
-    def _shape(self, B: int, N: int, L: int, V: int) -> _abi.PtxShape:
+    def _shape(self, B: int, N: int, L: int, V: int, img_dtype: int = 0) -> _abi.PtxShape:
         M = self.num_cluster
         return _abi.PtxShape(B=B, N=N, grid_size=self.grid_size, K=self.num_sub,
                              Mt=M - int(M * _EMPTY_DROP), Mk=self.real_cluster_num, L=L, V=V,
                              C=self.embed_dim, heads=self.num_heads, hidden=self.mlp_hidden,
-                             in_dim=self.input_dim, hw=self.img_spacial_dim ** 2,
+                             in_dim=self.input_dim, hw=self.img_spacial_dim ** 2, img_dtype=img_dtype,
                              radius=_RADIUS, margin=_MARGIN, bn_eps=self.text_trans_norm.eps,
                              ln_eps=self.norm_img.eps)
 
@@ -265,7 +266,7 @@ class ProxyTransformationNormReverse(nn.Module):
         self._wstruct, self._prep, self._lin, self._wkey = w, prep, lin, key
 
     def _workspace(self, shape: _abi.PtxShape, device: torch.device) -> torch.Tensor:
-        key = (shape.B, shape.N, shape.L, shape.V, str(device))
+        key = (shape.B, shape.N, shape.L, shape.V, str(device))           # layout does not depend on img_dtype
         ws = self._ws.get(key)
         if ws is None:
             nbytes = _abi.lib().ptx_workspace_bytes(ctypes.byref(shape))
@@ -321,13 +322,17 @@ class ProxyTransformationNormReverse(nn.Module):
             mask_u8 = text_mask.view(torch.uint8)                 # zero-copy: bool is one byte, 0 / 1
         else:
             mask_u8 = (text_mask != 0).to(torch.uint8).contiguous()
-        if img_feat.dtype != torch.float32 or not img_feat.is_contiguous():
-            img_feat = img_feat.to(torch.float32).contiguous()
+        # image features are consumed in their storage type (fp32, or bf16 / fp16 from an AMP backbone);
+        # arithmetic is fp32 either way
+        if img_feat.dtype not in _IMG_DTYPES:
+            img_feat = img_feat.to(torch.float32)
+        if not img_feat.is_contiguous():
+            img_feat = img_feat.contiguous()
         return (B, shp[0], p0.device), pts, plist, text_feats, mask_u8, img_feat
 
     def _run(self, points, text_dict, img_feat, debug: bool):
         (B, N, dev), pts, plist, text_feats, mask_u8, img = self._check_inputs(points, text_dict, img_feat)
-        skey = (B, N, text_feats.shape[1], img.shape[1])
+        skey = (B, N, text_feats.shape[1], img.shape[1], _IMG_DTYPES[img.dtype])
         shape = self._shapes.get(skey)
         if shape is None:
             shape = self._shapes[skey] = self._shape(*skey)

@@ -125,3 +125,32 @@ def test_irregular_inputs_are_normalised():
         td2 = {"text_feats": td["text_feats"].double(), "text_token_mask": td["text_token_mask"].to(torch.int64)}
         return pts, td2, im.transpose(3, 4).contiguous().transpose(3, 4)   # non-contiguous image features
     _check(cfg, mutate=mutate)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", ["small", "cfg4like"])
+def test_half_precision_image_features(dtype, shape):
+    """Image features STORED as bf16 / fp16 (AMP backbone, BASELINE config 2): the HIP path widens on
+    load and computes in fp32, so it must match the fp32 oracle run on the same rounded features."""
+    from oracle import oracle
+    from tests.gpu_util import t
+    if shape == "small":
+        cfg = PreshapeConfig("h16", B=2, N=3000, grid_size=4, dynamic_drop_radio=0.5, L=6, V=5, seed_base=18)
+    else:
+        cfg = PreshapeConfig("h16b", B=1, N=20000, grid_size=8, dynamic_drop_radio=0.5, L=20, V=50, seed_base=19)
+    m, sd = build_module(cfg)
+    m = m.cuda()
+    pts, text, mask, img = make_scene_batch(cfg)
+    img_h = torch.from_numpy(img).to(dtype)
+    ref = oracle.forward(sd, **oracle_kwargs(cfg), points=pts, text_feats=text, text_mask=mask,
+                         img_feat=img_h.float().numpy(), num_threads=1)
+    m._centers_override = torch.from_numpy(ref["centers"])
+    d = m.forward_debug([t(p) for p in pts], {"text_feats": t(text), "text_token_mask": t(mask)}, img_h.cuda())
+    for k in INT_KEYS:
+        assert np.array_equal(d[k].cpu().numpy().astype(np.int64), ref[k]), k
+    assert_close(d["img_proxy"].cpu().numpy(), ref["img_proxy"], atol=5e-5, rtol=1e-5, what="img_proxy")
+    assert_close(d["transform"].cpu().numpy(), ref["transform"], atol=5e-5, rtol=1e-5, what="transform")
+    for b in range(cfg.B):
+        got = d["outputs"][b].cpu().numpy()
+        assert got.shape == ref["outputs"][b].shape
+        assert_close(got, ref["outputs"][b], atol=1e-4, what=f"scene {b}")
