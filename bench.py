@@ -10,14 +10,19 @@ synthetic scenes (BASELINE.json configs[1] shape: 100k points, 8^3 grid -> 256 k
 64 text + 196 image proxies, d = 256, image features stored as bf16 as that config names; 4 scenes
 per GPU = the per-GPU shard of configs[2]).  All arithmetic is fp32; the rate with fp32-stored
 features is measured in the same run and reported as `value_f32_features`.
-Inputs are resident in HBM before the timed region; the step ends when the list of output
-tensors exists (this includes the path's single host sync for the per-scene lengths).
+Inputs are resident in HBM before the timed region; a step returns when the list of output
+tensors exists (the host waits for the per-scene lengths, which the clustering chain publishes
+early; the tensors' contents are stream-ordered like any torch result) and the timed region is
+closed by a full device synchronise, so every step's GPU work is inside it.
 Scenes are sharded by scene id with no data-path collective (weak scaling).
 
 Rank 0 prints ONE JSON line.  Extra objects:
   roofline      dominant kernel (k_img_scores, one streaming read of img_feat): algorithmic
                 bytes per launch / average launch duration, timed with HIP events recorded by
-                the library on the kernel's own stream during the timed steps
+                the library on the kernel's own stream during the timed steps; `traffic` = HBM
+                bytes per launch from the committed rocprofv3 PMC pass (profiles/pmc_traffic.json,
+                FETCH_SIZE corrected as MI355X_MICROARCH.md prescribes, + WRITE_SIZE), null if the
+                file has no entry for this kernel / shape
   cpu_baseline  the CPU oracle (torch CPU fp32 + C ball query / FPS, "port") on this box's
                 host cores, same workload, bounded sample (rank 0, N = 1 only)
 """
@@ -84,6 +89,20 @@ def algorithmic_bytes(cfg, B, name, img_itemsize=4):
         "k_tile_count": B * cfg.N * 4,
     }
     return table.get(name)
+
+
+def pmc_traffic(kernel, dt, cfg, B):
+    """HBM bytes per launch of `kernel` from the committed PMC digest (tools/profile_round.sh)."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if d.get("config") != cfg.name or d.get("scenes_per_gpu") != B:
+            return None
+        for name, v in d[dt].items():
+            if kernel in name:
+                return int(v["fetch_bytes"] + v["write_bytes"])
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
 
 
 def cpu_baseline(cfg, sd, n_scenes):
@@ -215,7 +234,8 @@ def main():
             avg_s = total_ms.value / launches.value / 1e3
             ach = abytes / avg_s / 1e9
             roof = dict(bound="hbm", kernel=args.time_kernel, achieved=round(ach, 1), peak=HBM_PEAK_GBS,
-                        unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
+                        unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
+                        traffic=pmc_traffic(args.time_kernel, args.img_dtype, cfg, B),
                         avg_launch_us=round(avg_s * 1e6, 2), launches=launches.value,
                         algorithmic_bytes_per_launch=abytes)
         line = dict(metric="scenes/sec (100k pts, 256 clusters, 64 proxies)", value=round(total_scenes / elapsed, 2),

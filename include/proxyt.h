@@ -29,12 +29,13 @@
 extern "C" {
 #endif
 
-#define PTX_ABI_VERSION 2
+#define PTX_ABI_VERSION 3
 
 #define PTX_OK          0
 #define PTX_EINVAL     -1   /* bad shape / null pointer / unsupported size */
 #define PTX_ELAUNCH    -2   /* HIP launch or runtime error */
 #define PTX_ENOSPACE   -3   /* workspace / prep buffer too small */
+#define PTX_ETIMEOUT   -4   /* ptx_wait_counts: counts not published in time */
 
 /* Static shape of one forward (PRE:282-330 constructor values + input sizes). */
 typedef struct PtxShape {
@@ -203,7 +204,11 @@ int ptx_affine_compact(const PtxShape *s, const float *points, const uint32_t *t
  * image branch).  Points: either `points` (B,N,3) stacked, or `points_list` = HOST array of B
  * device pointers to (N,3) clouds (the reference's list input, used in place; B <= 32), the other
  * NULL.  text_mask (B,L) uint8, 1 = valid.  out (B,N,3) capacity, counts (B) int32 (device or
- * device-mapped pinned host memory).
+ * device-mapped pinned host memory).  counts is published with a system-scope store as soon as
+ * the drop tags are final (well before the forward has drained): a caller that only needs the
+ * output lengths on the host (PRE:467 returns a list of (N_i',3) views) presets counts[b] = -1
+ * in pinned memory, calls ptx_forward and then ptx_wait_counts instead of synchronising the
+ * stream; `out` itself is ordered on `stream` like any other asynchronous result.
  * debug (optional, may be NULL): struct of device pointers that receive intermediates. */
 typedef struct PtxDebug {
     float *centers0, *cluster1, *offsets, *centers, *cluster2;
@@ -219,6 +224,11 @@ int ptx_forward(const PtxShape *s, const PtxWeights *w, const void *prep, const 
                 const float *centers_override,
                 float *out, int32_t *counts, void *workspace, size_t ws_bytes,
                 const PtxDebug *debug, void *stream);
+
+/* Host-side spin until counts_host[0..B) (pinned host memory, preset to -1 by the caller) are all
+ * >= 0, or timeout_us elapses.  Returns 0 when the counts are there, PTX_ETIMEOUT otherwise
+ * (the caller then falls back to a stream synchronise, which also surfaces device faults). */
+int ptx_wait_counts(const int32_t *counts_host, int B, int64_t timeout_us);
 
 #ifdef __cplusplus
 }

@@ -13,7 +13,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libproxyt_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_float_p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 
@@ -83,6 +83,7 @@ SIGNATURES = {
     "ptx_proxy_block": (_I, [_SH, _W, _P, _I, _P, _P, _I, _P, _P, _P, _P, _Z, _P]),
     "ptx_affine_scatter": (_I, [_SH, _P, _P, _P, _P, _P, _P, _P]),
     "ptx_affine_compact": (_I, [_SH, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "ptx_wait_counts": (_I, [_P, _I, C.c_int64]),
     "ptx_forward": (_I, [_SH, _W, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z,
                          C.POINTER(PtxDebug), _P]),
 }

@@ -1,4 +1,6 @@
 // extern "C" surface of libproxyt_hip.so (include/proxyt.h) and the forward driver.
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -405,6 +407,26 @@ int ptx_timing_read(int *launches, float *total_ms)
 }
 const char *ptx_last_error(void) { return g_err; }
 
+int ptx_wait_counts(const int32_t *counts_host, int B, int64_t timeout_us)
+{
+    PTX_REQUIRE(counts_host && B > 0, "ptx_wait_counts: null argument");
+    const volatile int32_t *c = counts_host;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spin = 0;; ++spin) {
+        int b = 0;
+        while (b < B && c[b] >= 0) ++b;
+        if (b == B) {
+            std::atomic_thread_fence(std::memory_order_acquire);
+            return PTX_OK;
+        }
+        __builtin_ia32_pause();
+        if ((spin & 1023u) == 1023u &&
+            std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >
+                timeout_us)
+            return PTX_ETIMEOUT;
+    }
+}
+
 size_t ptx_prep_bytes(const PtxShape *s)
 {
     if (s == nullptr || validate_shape(*s) != PTX_OK) return 0;
@@ -551,7 +573,7 @@ int ptx_affine_compact(const PtxShape *s, const float *points, const uint32_t *t
     PTX_TRY(check_bufs(s, workspace, ws_bytes));
     hipStream_t st = static_cast<hipStream_t>(stream);
     int32_t *tc = at<int32_t>(workspace, ws_layout(*s).tile_counts);
-    PTX_TRY(launch_tile_count(tag, s->B, s->N, tc, st));
+    PTX_TRY(launch_tile_count(tag, s->B, s->N, tc, counts, st));
     ScenePts sp;
     PTX_TRY(make_scene_pts(points, nullptr, s->B, s->N, &sp));
     return launch_affine(*s, sp, tag, kcenter, translate, transform, out, counts, tc, true, st);
@@ -625,7 +647,7 @@ int ptx_forward(const PtxShape *s, const PtxWeights *w, const void *prep, const 
     PTX_TIMED(KID_SELECT, cs, launch_select(S, idx2, centers, cluster2, pad_count, order_override, order, picks,
                                             keep, kcenter, kcluster, kidx, drop_idx, tag, cs));
     int32_t *tile_counts = at<int32_t>(ws, L.tile_counts);
-    PTX_TIMED(KID_TILECOUNT, cs, launch_tile_count(tag, B, S.N, tile_counts, cs));
+    PTX_TIMED(KID_TILECOUNT, cs, launch_tile_count(tag, B, S.N, tile_counts, counts, cs));   // publishes counts early
 
     // ---- point proxies (PRE:437) + norm1 / slot bias of both blocks
     float *point_proxy = at<float>(ws, L.point_proxy);

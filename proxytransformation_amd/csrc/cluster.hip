@@ -531,10 +531,29 @@ __global__ __launch_bounds__(256) void k_tile_count(const uint32_t *__restrict__
     if (threadIdx.x == 0) tile_counts[b * gridDim.x + tile] = red[0] + red[1] + red[2] + red[3];
 }
 
-int launch_tile_count(const uint32_t *tag, int B, int N, int32_t *tile_counts, hipStream_t st)
+// Surviving points per scene, published as soon as the drop tags are final so that the host can
+// size its output views (PRE:467 masked_select lengths) long before the forward has drained. The
+// store is system scope: `counts` is normally pinned host memory that the caller polls.
+__global__ __launch_bounds__(64) void k_scene_counts(const int32_t *tile_counts, int ntiles, int32_t *counts)
 {
-    hipLaunchKernelGGL(k_tile_count, dim3(cdiv(N, kTilePts), B), dim3(256), 0, st, tag, N, tile_counts);
+    const int b = blockIdx.x;
+    int c = 0;
+    for (int t = threadIdx.x; t < ntiles; t += 64) c += tile_counts[b * ntiles + t];
+    c = wave_sum(c);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(counts + b, c, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+int launch_tile_count(const uint32_t *tag, int B, int N, int32_t *tile_counts, int32_t *counts, hipStream_t st)
+{
+    const int ntiles = cdiv(N, kTilePts);
+    hipLaunchKernelGGL(k_tile_count, dim3(ntiles, B), dim3(256), 0, st, tag, N, tile_counts);
     PTX_LAUNCHED("k_tile_count");
+    if (counts) {
+        hipLaunchKernelGGL(k_scene_counts, dim3(B), dim3(64), 0, st, tile_counts, ntiles, counts);
+        PTX_LAUNCHED("k_scene_counts");
+    }
     return PTX_OK;
 }
 
@@ -615,7 +634,6 @@ __global__ __launch_bounds__(256) void k_affine(AffineArgs a)
         }
         run += s_cnt[r][0] + s_cnt[r][1] + s_cnt[r][2] + s_cnt[r][3];
     }
-    if (tile == ntiles - 1 && tid == 0) a.counts[b] = run;
 }
 
 int launch_affine(const PtxShape &s, const ScenePts &points, const uint32_t *tag, const float *kcenter,

@@ -184,7 +184,7 @@ int launch_select(const PtxShape &s, const int32_t *idx, const float *centers, c
                   const int32_t *pad_count, const int32_t *order_override, int32_t *order,
                   int32_t *picks, int32_t *keep, float *kcenter, float *kcluster, int32_t *kidx,
                   int32_t *drop_idx, uint32_t *tag, hipStream_t st);
-int launch_tile_count(const uint32_t *tag, int B, int N, int32_t *tile_counts, hipStream_t st);
+int launch_tile_count(const uint32_t *tag, int B, int N, int32_t *tile_counts, int32_t *counts, hipStream_t st);
 int launch_affine(const PtxShape &s, const ScenePts &points, const uint32_t *tag, const float *kcenter,
                   const float *translate, const float *transform, float *out, int32_t *counts,
                   const int32_t *tile_counts, bool compact, hipStream_t st);

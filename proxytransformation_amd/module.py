@@ -17,6 +17,7 @@ extension is missing, or the inputs are not on a GPU, ``forward`` raises.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -31,6 +32,7 @@ _RADIUS, _MARGIN = 3.0, 4.0          # PRE:23 (fixed, not reachable from the con
 _EMPTY_DROP = 0.3                    # PRE:352
 _SLOT_WIDTH = 256                    # PRE:31, PRE:302 (hard-coded in the reference)
 _IMG_DTYPES = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}   # PtxShape.img_dtype
+_COUNTS_TIMEOUT_US = 20_000_000         # then fall back to a stream synchronise
 _MAX_SCENES_PER_CALL = 32            # kMaxScenes of the C ABI (per-scene pointer table passed by value)
 
 
@@ -157,6 +159,11 @@ class ProxyTransformationNormReverse(nn.Module):
         # host-side caches (not part of the state_dict)
         self._tensors = None
         self._counts_host: Optional[torch.Tensor] = None
+        self._counts_np = None
+        self._last_stream = None
+        #: True = block until the whole forward has drained (the pre-ABI-3 behaviour); default is
+        #: to return once the output lengths are known, like any asynchronous torch op
+        self.sync_outputs = os.environ.get("PTX_SYNC_OUTPUTS", "0") == "1"
         self._wkey = None
         self._wstruct: Optional[_abi.PtxWeights] = None
         self._prep: Optional[torch.Tensor] = None
@@ -344,12 +351,20 @@ class ProxyTransformationNormReverse(nn.Module):
         self._ensure_prepared(shape, dev, stream)
         ws = self._workspace(shape, dev)
         out = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
-        # per-scene survivor counts land directly in pinned (device-mapped) host memory:
-        # the path's one host sync is a plain stream synchronise, no D2H copy
+        # per-scene survivor counts land directly in pinned (device-mapped) host memory, published
+        # by the clustering chain as soon as the drop tags are final: the host only waits for
+        # those B integers (the list lengths of PRE:467), not for the forward to drain
         counts = self._counts_host
         if counts is None or counts.numel() < B:
             counts = torch.empty((max(B, 64),), dtype=torch.int32).pin_memory()
-            self._counts_host = counts
+            self._counts_host, self._counts_np = counts, counts.numpy()
+        self._counts_np[:B] = -1
+        # the workspace is reused call to call: a call on a different stream must not overtake
+        # the previous one, which may still be running
+        last = self._last_stream
+        if last is not None and last.cuda_stream != stream:
+            last.synchronize()
+        self._last_stream = tstream
         dbg_struct, dbg = None, {}
         if debug:
             dbg = self._alloc_debug(shape, dev)
@@ -366,8 +381,11 @@ class ProxyTransformationNormReverse(nn.Module):
             img.data_ptr(), _ptr(oo), _ptr(co), out.data_ptr(), counts.data_ptr(),
             ws.data_ptr(), ws.numel(), ctypes.byref(dbg_struct) if dbg_struct else None, stream),
             "ptx_forward")
-        tstream.synchronize()                              # the one host sync of the path (list lengths)
-        n_keep = counts[:B].tolist()
+        if debug or self.sync_outputs or lib.ptx_wait_counts(counts.data_ptr(), B, _COUNTS_TIMEOUT_US) != 0:
+            tstream.synchronize()                          # full drain; also surfaces device faults
+        n_keep = self._counts_np[:B].tolist()
+        if min(n_keep) < 0:
+            raise RuntimeError("ptx_forward finished without publishing the survivor counts")
         outs = [out[b, :n_keep[b]] for b in range(B)]
         return outs, dbg
 

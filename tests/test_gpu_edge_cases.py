@@ -154,3 +154,35 @@ def test_half_precision_image_features(dtype, shape):
         got = d["outputs"][b].cpu().numpy()
         assert got.shape == ref["outputs"][b].shape
         assert_close(got, ref["outputs"][b], atol=1e-4, what=f"scene {b}")
+
+
+def test_back_to_back_calls_do_not_wait_for_the_gpu():
+    """forward() returns once the output lengths are on the host (counts published early by the
+    clustering chain), so consecutive calls overlap the previous call's tail on the GPU and share one
+    workspace: results must be the same as with a full drain after every call, on one stream and
+    across a stream switch."""
+    from tests.gpu_util import t
+    cfg = PreshapeConfig("b2b", B=3, N=6000, grid_size=5, dynamic_drop_radio=0.5, L=12, V=5, seed_base=7100)
+    m, _ = build_module(cfg)
+    m = m.cuda()
+    batches = []
+    for i in range(4):
+        pts, text, mask, img = make_scene_batch(cfg, scene_ids=range(10 * i, 10 * i + cfg.B))
+        batches.append(([t(p) for p in pts], {"text_feats": t(text), "text_token_mask": t(mask)}, t(img)))
+    m.sync_outputs = True
+    want = [[o.clone() for o in m(*b)] for b in batches]
+    m.sync_outputs = False
+    got = [m(*b) for b in batches for _ in range(1)]                # no sync in between
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        got_side = m(*batches[0])
+    got_back = m(*batches[1])
+    torch.cuda.synchronize()
+    for w, g in zip(want, got):
+        assert [x.shape for x in w] == [x.shape for x in g]
+        for a, b in zip(w, g):
+            assert torch.equal(a, b)
+    for a, b in zip(want[0], got_side):
+        assert torch.equal(a, b)
+    for a, b in zip(want[1], got_back):
+        assert torch.equal(a, b)

@@ -1,0 +1,65 @@
+"""Digest the rocprofv3 output of tools/profile_round.sh into the small files profiles/ keeps.
+
+  <tag>_kernel_stats_<dtype>.csv : per-kernel calls / total / average / share (from --kernel-trace --stats)
+  <tag>_pmc_traffic.json         : per-kernel HBM bytes per launch from FETCH_SIZE / WRITE_SIZE
+
+Corrections (MI355X_MICROARCH.md, "HBM"): rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB-like units
+of 1024 B, and on gfx950 FETCH_SIZE tallies the 128-B requests of a wide coalesced read at 64 B, so
+fetch bytes = FETCH_SIZE * 1024 * 2.  WRITE_SIZE is uncalibrated and is reported as measured * 1024.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def short(name: str) -> str:
+    name = name.replace("(anonymous namespace)::", "")
+    cut = name.find("(")
+    return name[:cut] if cut > 0 else name
+
+
+def stats(odir, tag, dt):
+    files = glob.glob(os.path.join(odir, f"stats_{dt}", "**", "*kernel_stats.csv"), recursive=True)
+    if not files:
+        return
+    rows = list(csv.DictReader(open(files[0])))
+    out = os.path.join(odir, f"{tag}_kernel_stats_{dt}.csv")
+    with open(out, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "percent"])
+        for r in rows:
+            w.writerow([short(r["Name"]), r["Calls"], f'{float(r["TotalDurationNs"]) / 1e3:.1f}',
+                        f'{float(r["AverageNs"]) / 1e3:.2f}', f'{float(r["MinNs"]) / 1e3:.2f}',
+                        f'{float(r["MaxNs"]) / 1e3:.2f}', r["Percentage"]])
+
+
+def pmc(odir, counter, dt):
+    files = glob.glob(os.path.join(odir, f"pmc_{counter}_{dt}", "**", "*counter_collection.csv"), recursive=True)
+    acc = defaultdict(lambda: [0, 0.0])
+    for fn in files:
+        for r in csv.DictReader(open(fn)):
+            if r["Counter_Name"] != counter:
+                continue
+            a = acc[short(r["Kernel_Name"])]
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+    return {k: v[1] / v[0] for k, v in acc.items()}
+
+
+def main():
+    odir, tag = sys.argv[1], sys.argv[2]
+    traffic = {"config": "cfg2", "scenes_per_gpu": 4, "units": "bytes per launch", "correction": "FETCH_SIZE*1024*2 (gfx950 half-count), WRITE_SIZE*1024"}
+    for dt in ("bf16", "f32"):
+        stats(odir, tag, dt)
+        fetch, write = pmc(odir, "FETCH_SIZE", dt), pmc(odir, "WRITE_SIZE", dt)
+        traffic[dt] = {k: {"fetch_bytes": fetch[k] * 2048.0, "write_bytes": write.get(k, 0.0) * 1024.0,
+                           "raw_FETCH_SIZE": fetch[k], "raw_WRITE_SIZE": write.get(k)}
+                       for k in sorted(fetch) if k.startswith("k_") or "k_" in k}
+    json.dump(traffic, open(os.path.join(odir, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
