@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void k_select(SelectArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int T = blockDim.x, tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
     const int b = blockIdx.x;
-    const int M = a.M, K = a.K, Mt = a.Mt, Mk = a.Mk, Kd = a.Kd;
+    const int M = a.M, Mt = a.Mt, Mk = a.Mk, Kd = a.Kd;
     // LDS carve
     int *s_order = reinterpret_cast<int *>(smem);                 // Mt
     float *sx = reinterpret_cast<float *>(s_order + Mt);          // Mt each
@@ -443,8 +443,9 @@ __global__ __launch_bounds__(256) void k_select(SelectArgs a)
     }
     __syncthreads();
 
-    // ---- 4/5. gathers, drop list, tags
-    uint32_t *tag = a.tag ? a.tag + (size_t)b * a.N : nullptr;
+    // ---- 4. kept centres; the slot gathers, drop list and tags are spread over the chip by
+    // k_select_slots (they are dependent-load chains: one work-group per scene made them the
+    // longest part of this kernel once the image branch loads the memory system)
     for (int j = tid; j < Mk; j += T) {
         const int t = s_keep[j];
         a.keep[(size_t)b * Mk + j] = t;
@@ -452,25 +453,42 @@ __global__ __launch_bounds__(256) void k_select(SelectArgs a)
         a.kcenter[((size_t)b * Mk + j) * 3 + 1] = sy[t];
         a.kcenter[((size_t)b * Mk + j) * 3 + 2] = sz[t];
     }
-    for (int e = tid; e < Mk * K; e += T) {
+}
+
+// One thread per slot of the kept clusters (gather xyz + idx, ownership tag) and of the dropped
+// clusters (drop list, drop bit).  Ownership = last writer in flat (m,k) order = atomicMax of
+// 1 + flat slot; the drop bit is OR-ed in concurrently, so an owner that finds the
+// bit already set repeats its max above the bit: every interleaving ends at
+// bit31 | max(owner slots).
+__global__ __launch_bounds__(256) void k_select_slots(SelectArgs a)
+{
+    const int b = blockIdx.y;
+    const int M = a.M, K = a.K, Mt = a.Mt, Mk = a.Mk, Kd = a.Kd;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int kn = Kd < Mt ? Kd : Mt;
+    uint32_t *tag = a.tag ? a.tag + (size_t)b * a.N : nullptr;
+    const int32_t *order = a.order + (size_t)b * Mt;
+    if (e < Mk * K) {
         const int j = e / K, k = e - j * K;
-        const int src = s_order[s_keep[j]];
+        const int src = order[a.keep[(size_t)b * Mk + j]];
         const int id = a.idx[((size_t)b * M + src) * K + k];
-        a.kidx[(size_t)b * Mk * K + e] = id;
         const float *cp = a.cluster + (((size_t)b * M + src) * K + k) * 3;
+        const float x = cp[0], y = cp[1], z = cp[2];
+        a.kidx[(size_t)b * Mk * K + e] = id;
         float *op = a.kcluster + ((size_t)b * Mk * K + e) * 3;
-        op[0] = cp[0]; op[1] = cp[1]; op[2] = cp[2];
-        if (tag && id >= 0) atomicMax(&tag[id], (uint32_t)(e + 1));              // last (m,k) writer wins
-    }
-    // every owner atomic of this scene has completed (vmcnt(0) + barrier) before a drop bit is
-    // OR-ed in, so a dropped point keeps its owner in the low 31 bits
-    __syncthreads();
-    for (int e = tid; e < Kd * K; e += T) {
-        const int kk = e / K, k = e - kk * K;
-        const int pk = kk < kn ? s_picks[kk] : -1;
+        op[0] = x; op[1] = y; op[2] = z;
+        if (tag && id >= 0) {
+            const uint32_t v = (uint32_t)(e + 1);
+            const uint32_t old = atomicMax(&tag[id], v);
+            if (old & 0x80000000u) atomicMax(&tag[id], 0x80000000u | v);
+        }
+    } else if (e < (Mk + Kd) * K) {
+        const int ed = e - Mk * K;
+        const int kk = ed / K, k = ed - kk * K;
+        const int pk = kk < kn ? a.picks[(size_t)b * Kd + kk] : -1;
         int id = -1;
-        if (pk >= 0) id = a.idx[((size_t)b * M + s_order[pk]) * K + k];
-        a.drop_idx[(size_t)b * Kd * K + e] = id;
+        if (pk >= 0) id = a.idx[((size_t)b * M + order[pk]) * K + k];
+        a.drop_idx[(size_t)b * Kd * K + ed] = id;
         if (tag && id >= 0) atomicOr(&tag[id], 0x80000000u);
     }
 }
@@ -507,6 +525,8 @@ int launch_select(const PtxShape &s, const int32_t *idx, const float *centers, c
     else { set_error("select: Mt=%d too large (max %d)", s.Mt, 64 * 64); return PTX_EINVAL; }
 #undef PTX_SEL
     PTX_LAUNCHED("k_select");
+    hipLaunchKernelGGL(k_select_slots, dim3(cdiv(s.Mt * s.K, 256), s.B), dim3(256), 0, st, a);
+    PTX_LAUNCHED("k_select_slots");
     return PTX_OK;
 }
 

@@ -9,6 +9,7 @@
 // 15x15 row needs only 29 lanes: every instruction serves TWO rows (lanes 0-31 row r, lanes 32-63
 // row r+1).
 #include <hip/hip_fp16.h>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -285,6 +286,141 @@ __global__ __launch_bounds__(256) void k_img_gather16(const unsigned short *__re
     }
 }
 
+// ---- pass 3 for bf16 features on the bf16 matrix pipe, still exact to fp32: the probabilities are split
+// a = a1 + a2 + a3 into three bf16 parts (8 significant bits each, the split is exact), every product
+// a_i * f of two bf16 values is exact in fp32, and v_mfma_f32_16x16x32_bf16 accumulates in fp32 -- so
+// the result is an fp32 dot product in a different summation order, at 1/16 of the f32-MFMA cost and
+// with no widening VALU work: the 16-B load of 8 pixels IS the A fragment.
+//
+// The cheap MFMA is spent on a fragment map the memory pipe likes.  Measured with loads only
+// (scratch/pattern_bench.hip, 180 MB of 450-B rows): a wave instruction streams at full rate (24.5 us) only
+// if ADJACENT LANES read ADJACENT 16-B chunks in groups of four (one 64-B request per quad); the natural
+// MFMA map (lane & 15 = channel row, so neighbouring lanes are 450 B apart) runs at half that (45.5 us),
+// whatever the length of the per-row runs.  So one MFMA here covers FOUR channel rows x 128 pixels:
+//   A row  m = (channel m >> 2, pixel set m & 3)      B column n = (head n >> 2, pixel set n & 3)
+//   pixel of (set, K-lane kq, element i) = 128 * step + 32 * kq + 8 * set + i
+// lane (m, kq) loads 16 B at that pixel: a quad reads 64 contiguous bytes, 16 lanes read 256.  Only the
+// output blocks whose row and column sets agree mean anything (1/4 of the MFMA, which is cheap enough);
+// they sit in acc[lane & 3] and are summed over the sets with two quad permutes.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int kGbPad = 264;             // LDS row stride in elements (256 pixels + 8)
+
+template <int NG>                       // 16-channel groups per wave; a work-group covers 64 * NG channels
+__global__ __launch_bounds__(256) void k_img_gather_bf(const unsigned short *__restrict__ img, int in_dim, int hw,
+                                                       int KT2p, float *__restrict__ gbuf)
+{
+    constexpr int heads = kMaxHeads;
+    // [part][head][pixel], zero beyond hw; then [part][head][8] for the window that straddles the row end
+    __shared__ __attribute__((aligned(16))) unsigned short parts[3 * heads * kGbPad + 3 * heads * 8];
+    unsigned short *etail = parts + 3 * heads * kGbPad;
+    const int chunk = 64 * NG, chunks = in_dim / chunk;
+    const int im = blockIdx.x / chunks, c0 = (blockIdx.x - im * chunks) * chunk;
+    const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
+    const int m = lane & 15, kq = lane >> 4, cr = m >> 2, ps = m & 3;
+    const int nsteps = hw > 128 ? 2 : 1;
+    // this lane's pixel window per step: inside the row, straddling its end, or beyond it
+    int aoff[2], boff[2];                                       // element offsets: into the row / into `parts`
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        const int px = 128 * st + 32 * kq + 8 * ps;
+        const bool full = px + 8 <= hw, edge = !full && px < hw;
+        aoff[st] = full ? px : (edge ? hw - 8 : 0);             // beyond: any valid address, B is zero there
+        boff[st] = edge ? -1 : px;
+    }
+    const int estart = hw & ~7;                                 // first pixel of the straddling window
+    // group g of this wave = channels c0 + (4 g + wid) * 16 .. +15; tile t, row cr = channel 4 cr + t of them
+    const unsigned short *wrow = img + ((size_t)im * in_dim + c0 + wid * 16 + 4 * cr) * hw;
+    const size_t gstride = (size_t)64 * hw;
+    u32x4 pf[2][4][2];
+    auto fetch = [&](int buf, const unsigned short *r) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+                pf[buf][t][st] = *reinterpret_cast<const u4u2 *>(r + (size_t)t * hw + aoff[st < nsteps ? st : 0]);
+    };
+    fetch(0, wrow);
+    {   // thread = pixel; all eight head loads are issued before any is used (as a loop the compiler
+        // waited for each one -- and for the feature loads above -- in turn: ~9 us per launch)
+        const int p = tid;
+        float av[heads];
+#pragma unroll
+        for (int h = 0; h < heads; ++h)
+            av[h] = p < hw ? gbuf[((size_t)im * heads + h) * KT2p + in_dim + 1 + p] : 0.0f;
+#pragma unroll
+        for (int h = 0; h < heads; ++h) {
+            const float a = av[h];
+            const unsigned int u1 = __float_as_uint(a) & 0xffff0000u;
+            const float r1 = a - __uint_as_float(u1);
+            const unsigned int u2 = __float_as_uint(r1) & 0xffff0000u;
+            const float r2 = r1 - __uint_as_float(u2);
+            const unsigned short q1 = (unsigned short)(u1 >> 16), q2 = (unsigned short)(u2 >> 16),
+                                 q3 = (unsigned short)(__float_as_uint(r2) >> 16);
+            parts[(0 * heads + h) * kGbPad + p] = q1;
+            parts[(1 * heads + h) * kGbPad + p] = q2;
+            parts[(2 * heads + h) * kGbPad + p] = q3;
+            // the straddling window is loaded from pixel hw - 8: its B fragment holds the probabilities of
+            // the pixels from `estart` on at the matching elements and zero before (other lanes' pixels)
+            const int e = p - (hw - 8);
+            if (e >= 0 && e < 8) {
+                const bool own = p >= estart;
+                etail[(0 * heads + h) * 8 + e] = own ? q1 : (unsigned short)0;
+                etail[(1 * heads + h) * 8 + e] = own ? q2 : (unsigned short)0;
+                etail[(2 * heads + h) * 8 + e] = own ? q3 : (unsigned short)0;
+            }
+        }
+    }
+    __syncthreads();
+    const int hh = m >> 2;                                      // head within the group for B columns
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int cur = g & 1;
+        if (g + 1 < NG) fetch(cur ^ 1, wrow + (size_t)(g + 1) * gstride);
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t][0] = acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            if (st < nsteps) {
+#pragma unroll
+                for (int hg = 0; hg < 2; ++hg) {
+                    bf16x8 bfr[3];
+#pragma unroll
+                    for (int pt = 0; pt < 3; ++pt) {
+                        const int row = pt * heads + 4 * hg + hh;
+                        const unsigned short *bp = boff[st] >= 0 ? parts + (size_t)row * kGbPad + boff[st]
+                                                                 : etail + row * 8;
+                        bfr[pt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(bp));
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const bf16x8 fa = __builtin_bit_cast(bf16x8, pf[cur][t][st]);
+#pragma unroll
+                        for (int pt = 0; pt < 3; ++pt)
+                            acc[t][hg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, bfr[pt], acc[t][hg], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // D[row 4 kq + i][col m]: row = (channel kq, set i), col = (head hh, set ps): keep i == ps, sum the quad
+#pragma unroll
+        for (int hg = 0; hg < 2; ++hg) {
+            float v[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float x = ps == 0 ? acc[t][hg][0] : ps == 1 ? acc[t][hg][1] : ps == 2 ? acc[t][hg][2] : acc[t][hg][3];
+                x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+                x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+                v[t] = x;
+            }
+            if (ps == 0) {       // lane (kq, hh): channels 4 kq + 0..3 of the group, head 4 hg + hh
+                float *dst = gbuf + ((size_t)im * heads + 4 * hg + hh) * KT2p + c0 + (4 * g + wid) * 16 + 4 * kq;
+                *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+}
+
 // ---- launchers ---------------------------------------------------------------------------------------
 int launch_img_mean16(const void *img, int dt, int nimg, int in_dim, int hw, float *fm, hipStream_t st)
 {
@@ -325,7 +461,13 @@ int launch_img_gather16(const void *img, int dt, int nimg, int in_dim, int hw, i
     const size_t lds = sizeof(float) * (size_t)heads * hwp;
     const unsigned short *p = static_cast<const unsigned short *>(img);
     const dim3 grid(nimg * (in_dim / kGatherCh));
-    if (dt == 1) hipLaunchKernelGGL(k_img_gather16<1>, grid, dim3(256), lds, st, p, in_dim, hw, heads, KT2p, gbuf);
+    static const int use_mfma16 = getenv("PTX_GATHER_F32MFMA") ? 0 : 1;
+    static const int ng = getenv("PTX_GATHER_NG") ? atoi(getenv("PTX_GATHER_NG")) : 4;
+    if (dt == 1 && use_mfma16 && heads == kMaxHeads && hw >= 8 && hw <= 256 && in_dim % 512 == 0) {
+#define PTX_GN(N_) case N_: hipLaunchKernelGGL(k_img_gather_bf<N_>, dim3(nimg * (in_dim / (64 * N_))), dim3(256), 0, st, p, in_dim, hw, KT2p, gbuf); break;
+        switch (ng) { PTX_GN(1) PTX_GN(2) PTX_GN(8) default: PTX_GN(4) }
+#undef PTX_GN
+    } else if (dt == 1) hipLaunchKernelGGL(k_img_gather16<1>, grid, dim3(256), lds, st, p, in_dim, hw, heads, KT2p, gbuf);
     else         hipLaunchKernelGGL(k_img_gather16<2>, grid, dim3(256), lds, st, p, in_dim, hw, heads, KT2p, gbuf);
     PTX_LAUNCHED("k_img_gather16");
     return PTX_OK;

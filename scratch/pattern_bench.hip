@@ -1,0 +1,127 @@
+// Microbenchmark: how fast can a wave-per-16-rows kernel stream (nimg*512) rows of 225 bf16 under
+// different lane->address maps?  hipcc --offload-arch=gfx950 -O3 pattern_bench.hip -o pattern_bench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef unsigned int u4u2 __attribute__((ext_vector_type(4), aligned(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1);} } while (0)
+
+__device__ __forceinline__ unsigned fold(const u32x4 &d) { return d[0] ^ d[1] ^ d[2] ^ d[3]; }
+
+// V: 0 = 16 rows x 64 B per instruction (8 instr per 16 rows)      [gather map]
+//    1 = 4 rows x 256 B per instruction (2 instr per 4 rows, 4 tiles)
+//    2 = 2 rows per instruction, 29 lanes x 16 B each (8 instr per 16 rows)  [mean map]
+//    3 = like 0 but non-temporal
+//    4 = 1 row per instruction, 57 lanes x 8 B   [scores map], 16 instr
+template <int V>
+__global__ __launch_bounds__(256) void k(const unsigned short *img, int hw, int ngroups, unsigned *out)
+{
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= ngroups) return;
+    const unsigned short *base = img + (size_t)g * 16 * hw;
+    unsigned acc = 0;
+    if (V == 0 || V == 3) {
+        const int ci = lane & 15, kq = lane >> 4;
+        const unsigned short *row = base + (size_t)ci * hw + 8 * kq;
+        u32x4 d[7];
+#pragma unroll
+        for (int kb = 0; kb < 7; ++kb)
+            d[kb] = V == 3 ? __builtin_nontemporal_load(reinterpret_cast<const u4u2 *>(row + 32 * kb))
+                           : *reinterpret_cast<const u4u2 *>(row + 32 * kb);
+#pragma unroll
+        for (int kb = 0; kb < 7; ++kb) acc ^= fold(d[kb]);
+        acc ^= (lane < 16) ? base[(size_t)lane * hw + 224] : 0;
+    } else if (V == 1) {
+        const int m = lane & 15, kq = lane >> 4, cr = m & 3, ps = m >> 2;
+        const int px0 = 32 * ps + 8 * kq, px1 = 128 + px0;
+        u32x4 d[8];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const unsigned short *row = base + (size_t)(4 * t + cr) * hw;
+            d[2 * t] = *reinterpret_cast<const u4u2 *>(row + px0);
+            d[2 * t + 1] = *reinterpret_cast<const u4u2 *>(row + (px1 + 8 <= hw ? px1 : 0));
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc ^= fold(d[t]);
+    } else if (V == 5 || V == 6 || V == 7) {
+        // A row m = (channel m >> SB, pixel set m & (2^SB - 1)): adjacent lanes read adjacent 16-B chunks
+        constexpr int SB = V == 5 ? 2 : (V == 6 ? 3 : 1);          // sets per channel: 4 / 8 / 2
+        constexpr int NS = 1 << SB, NC = 16 >> SB;                  // channels per instruction: 4 / 2 / 8
+        constexpr int SPAN = 32 * NS;                               // pixels per step: 128 / 256 / 64
+        constexpr int STEPS = (225 + SPAN - 1) / SPAN;              // 2 / 1 / 4
+        const int m = lane & 15, kq = lane >> 4, cr = m >> SB, ps = m & (NS - 1);
+        const int px = 8 * ps + 8 * NS * kq;
+        u32x4 d[(16 / NC) * STEPS];
+#pragma unroll
+        for (int t = 0; t < 16 / NC; ++t) {
+            const unsigned short *row = base + (size_t)(NC * t + cr) * hw;
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) {
+                const int p = px + SPAN * s;
+                d[t * STEPS + s] = *reinterpret_cast<const u4u2 *>(row + (p + 8 <= hw ? p : 0));
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < (16 / NC) * STEPS; ++t) acc ^= fold(d[t]);
+    } else if (V == 2) {
+        const int half = lane >> 5, j = lane & 31;
+        const bool act = j < 28 || j == 28;
+        const int poff = j == 28 ? hw - 8 : 8 * j;
+        u32x4 d[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            d[u] = act ? *reinterpret_cast<const u4u2 *>(base + (size_t)(2 * u + half) * hw + poff) : u32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc ^= fold(d[u]);
+    } else if (V == 4) {
+        typedef unsigned int u2u2 __attribute__((ext_vector_type(2), aligned(2)));
+        const int poff = lane < 56 ? 4 * lane : (lane == 56 ? hw - 4 : 0);
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        u32x2 d[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) d[u] = *reinterpret_cast<const u2u2 *>(base + (size_t)u * hw + poff);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc ^= d[u][0] ^ d[u][1];
+    }
+    if (acc == 0x12345678u) out[g] = acc;      // practically never: keeps the loads alive
+}
+
+template <int V>
+float run(const unsigned short *img, int hw, int ngroups, unsigned *out, int iters)
+{
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k<V>, dim3((ngroups + 3) / 4), dim3(256), 0, 0, img, hw, ngroups, out);
+    CK(hipEventRecord(a));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(k<V>, dim3((ngroups + 3) / 4), dim3(256), 0, 0, img, hw, ngroups, out);
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    return ms / iters * 1e3f;
+}
+
+int main()
+{
+    const int nimg = 784, in_dim = 512, hw = 225;
+    const size_t n = (size_t)nimg * in_dim * hw;
+    unsigned short *img; unsigned *out;
+    CK(hipMalloc(&img, n * 2 + 256)); CK(hipMalloc(&out, (size_t)nimg * in_dim * 4));
+    std::vector<unsigned short> h(n);
+    for (size_t i = 0; i < n; ++i) h[i] = (unsigned short)(0x3f80 + (i * 2654435761u >> 25));
+    CK(hipMemcpy(img, h.data(), n * 2, hipMemcpyHostToDevice));
+    const int ngroups = nimg * in_dim / 16;
+    const double mb = n * 2 / 1e6;
+    float t;
+    t = run<0>(img, hw, ngroups, out, 20); printf("V0 16 rows x 64 B      : %7.1f us  %6.0f GB/s\n", t, mb / t * 1e3);
+    t = run<3>(img, hw, ngroups, out, 20); printf("V3 16 rows x 64 B (nt) : %7.1f us  %6.0f GB/s\n", t, mb / t * 1e3);
+    t = run<1>(img, hw, ngroups, out, 20); printf("V1 4 rows x 256 B      : %7.1f us  %6.0f GB/s\n", t, mb / t * 1e3);
+    t = run<2>(img, hw, ngroups, out, 20); printf("V2 2 rows / instr      : %7.1f us  %6.0f GB/s\n", t, mb / t * 1e3);
+    t = run<4>(img, hw, ngroups, out, 20); printf("V4 1 row / instr (8 B) : %7.1f us  %6.0f GB/s\n", t, mb / t * 1e3);
+    t = run<5>(img, hw, ngroups, out, 20); printf("V5 4 rows x 256 B, quads contiguous : %7.1f us  %6.0f GB/s\n", t, mb / t * 1e3);
+    t = run<6>(img, hw, ngroups, out, 20); printf("V6 2 rows x 512 B, octets contiguous: %7.1f us  %6.0f GB/s\n", t, mb / t * 1e3);
+    t = run<7>(img, hw, ngroups, out, 20); printf("V7 8 rows x 128 B, pairs contiguous : %7.1f us  %6.0f GB/s\n", t, mb / t * 1e3);
+    return 0;
+}
