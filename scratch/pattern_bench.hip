@@ -89,6 +89,82 @@ __global__ __launch_bounds__(256) void k(const unsigned short *img, int hw, int 
     if (acc == 0x12345678u) out[g] = acc;      // practically never: keeps the loads alive
 }
 
+// ---- scores-like structure: unit = (image, half of the channels), 4 waves = (pixel tile, channel quarter),
+// each wave streams NKB blocks of 32 channels (8 loads of 4 rows x 256 B each).
+//   MODE 0: one block prefetched ahead   1: + prologue (8 dependent loads -> LDS -> barrier)
+//   MODE 2: all blocks' loads issued up front   3: like 0 but two blocks ahead
+template <int MODE, int NKB>
+__global__ __launch_bounds__(256) void ks(const unsigned short *img, const float *we, int hw, int in_dim, int nunits_per_img, unsigned *out)
+{
+    __shared__ float lds[2048];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int im = blockIdx.x / nunits_per_img, part = blockIdx.x % nunits_per_img;
+    const int T = wid & 1, q = wid >> 1;
+    const int n = lane & 15, kq = lane >> 4;
+    const int px = 128 * T + 8 * n;
+    const int cbeg = part * (in_dim / nunits_per_img) + q * (NKB * 32);
+    const unsigned short *f = img + (size_t)im * in_dim * hw + px;
+    unsigned acc = 0;
+    u32x4 L[MODE == 2 ? NKB : (MODE == 3 ? 3 : 2)][8];
+    auto fetch = [&](int b, int kb) {
+        const unsigned short *r = f + (size_t)(cbeg + 32 * kb + 8 * kq) * hw;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) L[b][i] = __builtin_nontemporal_load(reinterpret_cast<const u4u2 *>(r + (size_t)i * hw));
+    };
+    auto use = [&](int b) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc ^= fold(L[b][i]);
+    };
+    if (MODE == 2) {
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) fetch(kb, kb);
+    } else {
+        fetch(0, 0);
+        if (MODE == 3 && NKB > 1) fetch(1, 1);
+    }
+    if (MODE == 1) {
+        float w[8];
+#pragma unroll
+        for (int h = 0; h < 8; ++h) w[h] = we[((size_t)im * 8 + h) * 738 + part * 256 + threadIdx.x];
+#pragma unroll
+        for (int h = 0; h < 8; ++h) lds[h * 256 + threadIdx.x] = w[h] * 1.5f;
+        __syncthreads();
+        acc ^= __float_as_uint(lds[(lane * 37 + wid) & 2047]);
+    }
+    if (MODE == 2) {
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) use(kb);
+    } else if (MODE == 3) {
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            if (kb + 2 < NKB) fetch((kb + 2) % 3, kb + 2);
+            use(kb % 3);
+        }
+    } else {
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            if (kb + 1 < NKB) fetch((kb + 1) & 1, kb + 1);
+            use(kb & 1);
+        }
+    }
+    if (acc == 0x12345678u) out[blockIdx.x] = acc;
+}
+
+template <int MODE, int NKB>
+float runs(const unsigned short *img, const float *we, int hw, int in_dim, int nimg, unsigned *out, int iters)
+{
+    const int per = in_dim / (NKB * 64);                     // units per image
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((ks<MODE, NKB>), dim3(nimg * per), dim3(256), 0, 0, img, we, hw, in_dim, per, out);
+    CK(hipEventRecord(a));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((ks<MODE, NKB>), dim3(nimg * per), dim3(256), 0, 0, img, we, hw, in_dim, per, out);
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    return ms / iters * 1e3f;
+}
+
 template <int V>
 float run(const unsigned short *img, int hw, int ngroups, unsigned *out, int iters)
 {
@@ -123,5 +199,16 @@ int main()
     t = run<5>(img, hw, ngroups, out, 20); printf("V5 4 rows x 256 B, quads contiguous : %7.1f us  %6.0f GB/s\n", t, mb / t * 1e3);
     t = run<6>(img, hw, ngroups, out, 20); printf("V6 2 rows x 512 B, octets contiguous: %7.1f us  %6.0f GB/s\n", t, mb / t * 1e3);
     t = run<7>(img, hw, ngroups, out, 20); printf("V7 8 rows x 128 B, pairs contiguous : %7.1f us  %6.0f GB/s\n", t, mb / t * 1e3);
+    float *we; CK(hipMalloc(&we, (size_t)nimg * 8 * 738 * 4)); CK(hipMemset(we, 0, (size_t)nimg * 8 * 738 * 4));
+    printf("scores-like structure (units x 4 waves, NKB blocks of 32 channels per wave)\n");
+    t = runs<0, 4>(img, we, hw, in_dim, nimg, out, 20); printf("S0 half-image units, 1 block ahead      : %7.1f us\n", t);
+    t = runs<1, 4>(img, we, hw, in_dim, nimg, out, 20); printf("S1  + prologue (8 loads, LDS, barrier)  : %7.1f us\n", t);
+    t = runs<2, 4>(img, we, hw, in_dim, nimg, out, 20); printf("S2 half-image units, all loads up front : %7.1f us\n", t);
+    t = runs<3, 4>(img, we, hw, in_dim, nimg, out, 20); printf("S3 half-image units, 2 blocks ahead     : %7.1f us\n", t);
+    t = runs<0, 2>(img, we, hw, in_dim, nimg, out, 20); printf("S4 quarter-image units, 1 block ahead   : %7.1f us\n", t);
+    t = runs<1, 2>(img, we, hw, in_dim, nimg, out, 20); printf("S5  + prologue                          : %7.1f us\n", t);
+    t = runs<2, 1>(img, we, hw, in_dim, nimg, out, 20); printf("S6 eighth-image units (1 block / wave)  : %7.1f us\n", t);
+    t = runs<0, 8>(img, we, hw, in_dim, nimg, out, 20); printf("S7 whole-image units, 1 block ahead     : %7.1f us\n", t);
+    t = runs<3, 8>(img, we, hw, in_dim, nimg, out, 20); printf("S8 whole-image units, 2 blocks ahead    : %7.1f us\n", t);
     return 0;
 }
