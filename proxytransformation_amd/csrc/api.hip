@@ -133,6 +133,7 @@ WsLayout ws_layout(const PtxShape &s)
     for (int i = 0; i < 2; ++i) L.x_in[i] = take(R * C * 4);
     L.fm = take(nimg * s.in_dim * 4); L.qkv0 = take(nimg * 3 * C * 4);
     L.we = take(nimg * s.heads * (size_t)P.KT1 * 4); L.sraw = take(nimg * 2 * s.heads * (size_t)kSrawLd * 4); L.aparts = take(img16_aparts_bytes((int)nimg));
+    L.pool = take(img_pool_bytes((int)nimg, s.in_dim));
     L.gbuf = take(nimg * s.heads * (size_t)P.KT2p * 4);
     L.obuf = take(nimg * C * 4); L.cbuf = take(nimg * C * 4); L.img_proxy = take(nimg * C * 4);
     for (int i = 0; i < 2; ++i) {
@@ -223,6 +224,10 @@ static int run_img_proxy(const PtxShape &s, const PtxWeights &w, const float *pr
         PTX_TIMED(KID_IMG_SCORES, st, launch_img_scores(img, we, qkv0, nimg, s.in_dim, s.hw, s.heads, C, P.KT1,
                                                         P.KT2p, attn_scale(hd), gbuf, st));
         PTX_TIMED(KID_IMG_GATHER, st, launch_img_gather(img, nimg, s.in_dim, s.hw, s.heads, P.KT2p, gbuf, st));
+    } else if (img_pool_supported(dt, s.in_dim, s.hw, s.heads)) {
+        PTX_TIMED(KID_IMG_SCORES, st, launch_img_pool(img_any, we, nimg, s.in_dim, s.hw, P.KT1, at<float>(ws, L.pool), st));
+        PTX_TIMED(KID_IMG_GATHER, st, launch_img_pool_merge(at<float>(ws, L.pool), qkv0, nimg, s.in_dim, s.hw, C, P.KT2p,
+                                                            attn_scale(hd), gbuf, st));
     } else {
         PTX_TIMED(KID_IMG_SCORES, st, launch_img_scores16(img_any, dt, we, qkv0, nimg, s.in_dim, s.hw, s.heads, C,
                                                           P.KT1, P.KT2p, attn_scale(hd), sraw, gbuf, st));

@@ -1,0 +1,371 @@
+// Attention pooling of bf16-stored image features in ONE pass over the features after the mean
+// (AttentionPool2d query 0, PRE:158-176; algebra in imgproxy.hip).  Replaces the pair
+// k_img_scores_bf -> k_img_softmax_bf -> k_img_gather_bf (two passes + a softmax launch) of imgproxy16.hip.
+//
+// A work unit is (image, tile of 128 pixels): 512 channel rows x 256 B = 128 KB, which is held in the
+// REGISTERS of one 8-wave work-group (16 loads of 16 B per lane) from the moment it is loaded until it has
+// been used twice:
+//   1. scores   s_h(p) = sum_c w_h(c) f(c,p)  on the bf16 matrix pipe, K = channels: the lane's 8 x 8 block
+//      of (channel, pixel) values is transposed in registers (v_perm_b32) into B fragments (see
+//      k_img_scores_bf); the per-image head weights are split exactly into three bf16 parts (A operand);
+//      the eight waves' channel slices are summed through LDS in a fixed order by the wave that owns the head
+//   2. tile-local softmax numerators  e = exp(s - m_tile), l_tile = sum e  (wave = head), split exactly into
+//      three bf16 parts
+//   3. weighted sums  G_h(c) = sum_p e_h(p) f(c,p), K = pixels: the SAME registers, moved to the lane map
+//      that the MFMA needs with ds_bpermute (a fixed lane permutation that swaps the roles of "pixel
+//      window" and "channel sub-block"), 4 channel rows x 128 pixels per MFMA (see k_img_gather_bf)
+// The unit writes (m_tile, l_tile, e, G) and k_img_pool_merge combines the two tiles of an image with the
+// mean token into the [g_h | a_h] rows that the o-projection GEMM reads: the usual split softmax,
+//   m = max(m_0, m_1, s(0)),  l = l_0 e^(m_0-m) + l_1 e^(m_1-m) + e^(s(0)-m),  g = (G_0 e^(m_0-m) + G_1 e^(m_1-m)) / l.
+// Every product is of two bf16 values (exact in fp32) accumulated in fp32: the result is the fp32 value in a
+// different summation order.
+#include <cstdlib>
+
+#include "common.h"
+
+namespace ptx {
+
+typedef unsigned int u4u2 __attribute__((ext_vector_type(4), aligned(2)));    // 16-B load at 2-B alignment
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kPoolHeads = 8;
+constexpr int kPoolWPad = 544;          // LDS row stride (elements) of the split weights: rows 16 words apart mod 64
+constexpr int kPoolPPad = 136;          // LDS row stride (elements) of the split numerators (128 pixels + 8)
+
+// the exact three-way bf16 split x = x1 + x2 + x3 (8 significant bits each)
+__device__ __forceinline__ void split3(float x, unsigned short &q1, unsigned short &q2, unsigned short &q3)
+{
+    const unsigned int u1 = __float_as_uint(x) & 0xffff0000u;
+    const float r1 = x - __uint_as_float(u1);
+    const unsigned int u2 = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(u2);
+    q1 = (unsigned short)(u1 >> 16); q2 = (unsigned short)(u2 >> 16); q3 = (unsigned short)(__float_as_uint(r2) >> 16);
+}
+
+// 128-bit logical right shift by k elements of 16 bits (k = 0..7)
+__device__ __forceinline__ u32x4 shr_elems(const u32x4 &v, int k)
+{
+    const int ws = k >> 1;
+    unsigned int w[8] = {v[0], v[1], v[2], v[3], 0u, 0u, 0u, 0u};
+    u32x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        unsigned int lo = 0u, hi = 0u;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (ws == s) { lo = w[q + s]; hi = w[q + s + 1]; }
+        }
+        o[q] = (k & 1) ? ((lo >> 16) | (hi << 16)) : lo;
+    }
+    return o;
+}
+
+struct PoolArgs {
+    const unsigned short *img; const float *we;
+    int nimg, in_dim, hw, KT1;
+    float *Gs;          // [nimg][2][heads][in_dim]  sum_p e_h(p) f(c,p) of the tile
+    float *Ps;          // [nimg][2][heads][128]     e_h(p) = exp(s_h(p) - m_tile)
+    float *ML;          // [nimg][2][heads][2]       m_tile, l_tile
+};
+
+template <int X>
+__global__ __launch_bounds__(512) void k_img_pool_bf(PoolArgs a)
+{
+    constexpr int heads = kPoolHeads;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *partial = reinterpret_cast<float *>(smem);                               // [8 waves][heads][128]; later G [heads][in_dim]
+    unsigned short *wpart = reinterpret_cast<unsigned short *>(partial + 8 * heads * 128);   // [24][kPoolWPad]
+    unsigned short *parts = wpart + 24 * kPoolWPad;                                  // [24][kPoolPPad]
+    const int in_dim = a.in_dim, hw = a.hw;
+    // The two tiles of an image run back to back on the SAME XCD (work-groups go round-robin over the 8 XCDs
+    // by id): every row has a cache line at the tile boundary, and the run-on lanes of tile 1 read the head of
+    // the next row, which both must come out of one L2 -- with the tiles on different XCDs the same loads took
+    // 50 us instead of 33 (scratch/pattern_bench.hip P0/P2).  Images in reverse order: the mean pass left
+    // the last ones in cache.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int T = slot & 1, imr = (slot >> 1) * 8 + xcd;
+    if (imr >= a.nimg) return;
+    const int im = a.nimg - 1 - imr;
+    const int slab = im * 2 + T;
+    const int tid = threadIdx.x, lane = lane_id();
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, kq = lane >> 4;
+    const float *wim = a.we + (size_t)im * heads * a.KT1;
+    const unsigned short *f = a.img + (size_t)im * in_dim * hw;
+    // This lane's window of 8 pixels.  A window that sticks out of the row simply runs on into the next row
+    // (rows are contiguous; those lines are wanted anyway) and the surplus columns are ignored -- except in
+    // the very last row of the tensor, where the load is moved back inside and the data shifted into place.
+    const int px = 128 * T + 8 * n;
+    const bool full = px + 8 <= hw;
+    const int cw = 64 * wid;                                    // this wave's 64 channels = two blocks of 32
+    // Two work-groups fit on a CU.  Dispatched together they stay in lockstep -- both loading, then both
+    // computing -- and nothing overlaps (measured: 71 us, the sum of the phases).  The work-groups that fill
+    // the second slots of the first round (ids 256..511: 8 XCDs x 32 CUs get one each before any gets two)
+    // start half a period late; after that the slots free up alternately by themselves.
+    if (X & 8) {
+        if (blockIdx.x >= 256 && blockIdx.x < 512) {
+            __builtin_amdgcn_s_sleep(127);
+            if (X & 16) __builtin_amdgcn_s_sleep(127);
+        }
+    }
+    u32x4 L[2][8];
+    const bool tensor_end = im == a.nimg - 1 && cw + 64 == in_dim;    // wave-uniform
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const unsigned short *r = f + (size_t)(cw + 32 * kb + 8 * kq) * hw + px;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (kb == 1 && i == 7 && tensor_end) {
+                const bool lastrow = kq == 3 && !full;
+                const int back = lastrow ? px + 8 - hw : 0;     // elements moved back (>= 8: wholly beyond the row)
+                const int bk = back > 8 ? px - (hw - 8) : back;
+                u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u4u2 *>(r + (size_t)i * hw - bk));
+                L[kb][i] = lastrow ? (back >= 8 ? u32x4{0u, 0u, 0u, 0u} : shr_elems(v, back)) : v;
+            } else {
+                L[kb][i] = __builtin_nontemporal_load(reinterpret_cast<const u4u2 *>(r + (size_t)i * hw));
+            }
+        }
+    }
+    // positional score terms of head `wid` for this tile's pixels (lane, lane + 64)
+    float ev[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int p = 128 * T + lane + 64 * u;
+        ev[u] = p < hw ? wim[(size_t)wid * a.KT1 + in_dim + 1 + p] : 0.0f;
+    }
+    // head weights of this image -> three bf16 parts in LDS (thread = channel, all loads first)
+    for (int c = tid; c < in_dim; c += 512) {
+        float wv[heads];
+#pragma unroll
+        for (int h = 0; h < heads; ++h) wv[h] = wim[(size_t)h * a.KT1 + c];
+#pragma unroll
+        for (int h = 0; h < heads; ++h) {
+            unsigned short q1, q2, q3;
+            split3(wv[h], q1, q2, q3);
+            wpart[(size_t)h * kPoolWPad + c] = q1;
+            wpart[(size_t)(8 + h) * kPoolWPad + c] = q2;
+            wpart[(size_t)(16 + h) * kPoolWPad + c] = q3;
+        }
+    }
+    __syncthreads();
+
+    // ---- 1. scores of this wave's 64 channels: D rows 0-7 = heads, column n of MFMA j = pixel 8n + j
+    {
+        f32x4 acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const bool lo = n < heads;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            bf16x8 af[3];
+#pragma unroll
+            for (int pt = 0; pt < 3; ++pt) {
+                u32x4 t = *reinterpret_cast<const u32x4 *>(wpart + (size_t)(pt * 8 + (n & 7)) * kPoolWPad + cw + 32 * kb + 8 * kq);
+                if (!lo) t = u32x4{0u, 0u, 0u, 0u};
+                af[pt] = __builtin_bit_cast(bf16x8, t);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned int sel = (j & 1) ? 0x07060302u : 0x05040100u;
+                u32x4 b;
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) b[qd] = __builtin_amdgcn_perm(L[kb][2 * qd + 1][j >> 1], L[kb][2 * qd][j >> 1], sel);
+                const bf16x8 bf = __builtin_bit_cast(bf16x8, b);
+                if (X & 1) { acc[j][0] += __uint_as_float(b[0] ^ b[3]); continue; }
+#pragma unroll
+                for (int pt = 0; pt < 3; ++pt) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[pt], bf, acc[j], 0, 0, 0);
+            }
+        }
+        if (kq < 2) {                                           // rows 4 kq + r = heads
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float *d = partial + ((size_t)wid * heads + 4 * kq + r) * 128 + 8 * n;
+                *reinterpret_cast<float4 *>(d) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+                *reinterpret_cast<float4 *>(d + 4) = make_float4(acc[4][r], acc[5][r], acc[6][r], acc[7][r]);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- 2. wave = head: sum the eight channel slices (fixed order), tile-local softmax numerators
+    {
+        const int h = wid;
+        float e[2], mloc = -INFINITY, sv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int p = lane + 64 * u;
+            float s = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) s += partial[((size_t)w * heads + h) * 128 + p];
+            sv[u] = 128 * T + p < hw ? s + ev[u] : -INFINITY;
+            mloc = fmaxf(mloc, sv[u]);
+        }
+        const float m = wave_max(mloc);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) e[u] = 128 * T + lane + 64 * u < hw ? expf(sv[u] - m) : 0.0f;
+        const float l = wave_sum(e[0] + e[1]);
+        if (lane == 0) {
+            a.ML[((size_t)slab * heads + h) * 2] = m;
+            a.ML[((size_t)slab * heads + h) * 2 + 1] = l;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int p = lane + 64 * u;
+            a.Ps[((size_t)slab * heads + h) * 128 + p] = e[u];
+            unsigned short q1, q2, q3;
+            split3(e[u], q1, q2, q3);
+            parts[(size_t)h * kPoolPPad + p] = q1;
+            parts[(size_t)(8 + h) * kPoolPPad + p] = q2;
+            parts[(size_t)(16 + h) * kPoolPPad + p] = q3;
+        }
+    }
+    __syncthreads();
+
+    // ---- 3. weighted sums over the tile's pixels from the registers.  Load map: lane (n, kq) register i =
+    // row 8 kq + i, window n.  MFMA map: A row m = (channel sub-block cr = m >> 2, window set ps = m & 3),
+    // K-lane kq' = windows ps + 4 kq'; B column = (head hh = m >> 2 of the group, window set ps).  Lane
+    // (m, kq') therefore takes register i of lane (n = ps + 4 kq', kq = cr): one ds_bpermute per dword.
+    {
+        const int ps = n & 3, hh = n >> 2;                      // also cr = n >> 2 for the A side
+        const int src = ((ps + 4 * kq) + 16 * (n >> 2)) * 4;    // byte index of the source lane
+        bf16x8 bfr[2][3];
+#pragma unroll
+        for (int hg = 0; hg < 2; ++hg)
+#pragma unroll
+            for (int pt = 0; pt < 3; ++pt)
+                bfr[hg][pt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(
+                    parts + (size_t)(pt * 8 + 4 * hg + hh) * kPoolPPad + 8 * (ps + 4 * kq)));
+        float *G = partial;                                     // [heads][in_dim]; the slices are dead (barrier above)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if ((X & 2) && i > 0) continue;
+                u32x4 av;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) av[d] = (X & 64) ? L[kb][i][d] : (unsigned int)__builtin_amdgcn_ds_bpermute(src, (int)L[kb][i][d]);
+                const bf16x8 af = __builtin_bit_cast(bf16x8, av);
+#pragma unroll
+                for (int hg = 0; hg < 2; ++hg) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int pt = 0; pt < 3; ++pt) {
+                        if (X & 32) { acc[pt] += __uint_as_float(av[pt] ^ av[3]); continue; }
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[hg][pt], acc, 0, 0, 0);
+                    }
+                    // D[row 4 kq + r][col n]: row = (channel sub-block kq, set r), col = (head hh, set ps): keep r == ps
+                    float x = ps == 0 ? acc[0] : ps == 1 ? acc[1] : ps == 2 ? acc[2] : acc[3];
+                    x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+                    x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+                    // channel of this row: cw + 32 kb + 8 kq + i; one lane of the quad stores it
+                    if (ps == 0) G[(size_t)(4 * hg + hh) * in_dim + cw + 32 * kb + 8 * kq + i] = x;
+                }
+            }
+    }
+    __syncthreads();
+    {
+        const float *G = partial;
+        float *dst = a.Gs + (size_t)slab * heads * in_dim;
+        for (int i = tid * 4; i < ((X & 4) ? 2048 : heads * in_dim); i += 512 * 4)
+            *reinterpret_cast<float4 *>(dst + i) = *reinterpret_cast<const float4 *>(G + i);
+    }
+}
+
+// ---- merge of the two tiles of an image with the mean token (PRE:168-176 softmax over hw + 1 tokens)
+struct MergeArgs {
+    const float *Gs, *Ps, *ML, *qkv0;
+    int in_dim, hw, C, KT2p; float scale;
+    float *gbuf;
+};
+
+__global__ __launch_bounds__(256) void k_img_pool_merge(MergeArgs a)
+{
+    constexpr int heads = kPoolHeads;
+    __shared__ float c0s[heads], c1s[heads], cts[heads];        // e^(m_0-m)/l, e^(m_1-m)/l, a_h(0)
+    const int im = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
+    const int in_dim = a.in_dim, hw = a.hw;
+    const bool two = hw > 128;
+    {   // wave w: heads w and w + 4
+        const int hd = a.C / heads;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int h = wid + 4 * k;
+            const float *qv = a.qkv0 + (size_t)im * 3 * a.C + h * hd;
+            const float qk = lane < hd ? qv[lane] * qv[a.C + lane] : 0.0f;
+            const float s0 = wave_sum(qk) * a.scale;            // mean token: scale * q_h . k0_h
+            if (lane == 0) {
+                const float *ml = a.ML + ((size_t)(im * 2) * heads + h) * 2;
+                const float m0 = ml[0], l0 = ml[1];
+                const float m1 = two ? ml[heads * 2] : -INFINITY, l1 = two ? ml[heads * 2 + 1] : 0.0f;
+                const float m = fmaxf(fmaxf(m0, m1), s0);
+                const float e0 = expf(m0 - m), e1 = two ? expf(m1 - m) : 0.0f, et = expf(s0 - m);
+                const float inv = 1.0f / ((l0 * e0 + l1 * e1) + et);
+                c0s[h] = e0 * inv; c1s[h] = e1 * inv; cts[h] = et * inv;
+            }
+        }
+    }
+    __syncthreads();
+    const float *G0 = a.Gs + (size_t)(im * 2) * heads * in_dim, *G1 = G0 + (size_t)heads * in_dim;
+    const float *P0 = a.Ps + (size_t)(im * 2) * heads * 128, *P1 = P0 + (size_t)heads * 128;
+#pragma unroll
+    for (int h = 0; h < heads; ++h) {
+        const float c0 = c0s[h], c1 = c1s[h];
+        float *row = a.gbuf + ((size_t)im * heads + h) * a.KT2p;
+        for (int c = tid; c < in_dim; c += 256) {
+            const float g1 = two ? G1[(size_t)h * in_dim + c] : 0.0f;
+            row[c] = G0[(size_t)h * in_dim + c] * c0 + g1 * c1;
+        }
+        const int t = tid;                                      // token: 0 = mean token, t >= 1 = pixel t - 1
+        if (t < a.KT2p - in_dim) {
+            float v = 0.0f;
+            if (t == 0) v = cts[h];
+            else if (t - 1 < hw) {
+                const int p = t - 1;
+                v = p < 128 ? P0[h * 128 + p] * c0 : P1[h * 128 + (p - 128)] * c1;
+            }
+            row[in_dim + t] = v;
+        }
+    }
+}
+
+bool img_pool_supported(int dt, int in_dim, int hw, int heads)
+{
+    static const int off = getenv("PTX_IMG_POOL_OFF") ? 1 : 0;
+    return !off && dt == 1 && heads == kPoolHeads && in_dim == 512 && hw > 128 && hw <= 255;
+}
+
+size_t img_pool_bytes(int nimg, int in_dim)
+{
+    return (size_t)nimg * 2 * kPoolHeads * ((size_t)in_dim + 128 + 2) * sizeof(float);
+}
+
+// `scratch` = img_pool_bytes(nimg, in_dim) bytes (Gs | Ps | ML)
+int launch_img_pool(const void *img, const float *we, int nimg, int in_dim, int hw, int KT1, float *scratch,
+                    hipStream_t st)
+{
+    float *Gs = scratch, *Ps = Gs + (size_t)nimg * 2 * kPoolHeads * in_dim, *ML = Ps + (size_t)nimg * 2 * kPoolHeads * 128;
+    PoolArgs pa{static_cast<const unsigned short *>(img), we, nimg, in_dim, hw, KT1, Gs, Ps, ML};
+    const size_t lds = sizeof(float) * 8 * kPoolHeads * 128 + sizeof(unsigned short) * 24 * (kPoolWPad + kPoolPPad);
+    PTX_REQUIRE(lds <= 64 * 1024, "img pool: %zu B of LDS", lds);
+    static const int px_ = getenv("PTX_POOL_X") ? atoi(getenv("PTX_POOL_X")) : 0;
+#define PTX_PX(X_) case X_: hipLaunchKernelGGL(k_img_pool_bf<X_>, dim3(cdiv(nimg, 8) * 16), dim3(512), lds, st, pa); break;
+    switch (px_) { PTX_PX(32) PTX_PX(64) PTX_PX(96) PTX_PX(33) default: PTX_PX(0) }
+#undef PTX_PX
+    PTX_LAUNCHED("k_img_pool_bf");
+    return PTX_OK;
+}
+
+int launch_img_pool_merge(const float *scratch, const float *qkv0, int nimg, int in_dim, int hw, int C, int KT2p,
+                          float scale, float *gbuf, hipStream_t st)
+{
+    PTX_REQUIRE(KT2p - in_dim <= 256, "img pool: %d tokens", KT2p - in_dim);
+    const float *Gs = scratch, *Ps = Gs + (size_t)nimg * 2 * kPoolHeads * in_dim, *ML = Ps + (size_t)nimg * 2 * kPoolHeads * 128;
+    MergeArgs ma{Gs, Ps, ML, qkv0, in_dim, hw, C, KT2p, scale, gbuf};
+    hipLaunchKernelGGL(k_img_pool_merge, dim3(nimg), dim3(256), 0, st, ma);
+    PTX_LAUNCHED("k_img_pool_merge");
+    return PTX_OK;
+}
+
+}  // namespace ptx

@@ -8,6 +8,6 @@ f=glob.glob("$R/gpurun_out/ks_$TAG/**/k_kernel_stats.csv",recursive=True)[0]
 print("== $TAG $@")
 for r in csv.DictReader(open(f)):
     n=r["Name"]
-    if "img" in n and "16" in n or "_bf" in n:
+    if "img" in n and ("16" in n or "_bf" in n or "pool" in n):
         print(f'   {n[:60]:60s} calls {r["Calls"]:>4s} avg {float(r["AverageNs"])/1e3:7.2f} us')
 PY

@@ -150,6 +150,61 @@ __global__ __launch_bounds__(256) void ks(const unsigned short *img, const float
     if (acc == 0x12345678u) out[blockIdx.x] = acc;
 }
 
+// ---- fused-pool structure: unit = (image, tile of 128 px), 8 waves x 64 channels, all 16 loads of a lane
+// issued up front, prologue (8 loads -> LDS -> barrier), consume, 16 KB written per unit
+template <int MODE>
+__global__ __launch_bounds__(512) void kp(const unsigned short *img, const float *we, int hw, int in_dim, float *out)
+{
+    __shared__ float lds[8 * 512 + 4096];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int im = blockIdx.x >> 1, T = blockIdx.x & 1;
+    if (MODE >= 2) { const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3; T = slot & 1; im = (slot >> 1) * 8 + xcd; }
+    const int n = lane & 15, kq = lane >> 4;
+    const int px = 128 * T + 8 * n;
+    const unsigned short *f = img + (size_t)im * in_dim * hw + px;
+    u32x4 L[2][8];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const unsigned short *r = f + (size_t)(64 * wid + 32 * kb + 8 * kq) * hw;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) L[kb][i] = __builtin_nontemporal_load(reinterpret_cast<const u4u2 *>(r + (size_t)i * hw));
+    }
+    float w[8];
+#pragma unroll
+    for (int h = 0; h < 8; ++h) w[h] = we[((size_t)im * 8 + h) * 738 + threadIdx.x];
+#pragma unroll
+    for (int h = 0; h < 8; ++h) lds[h * 512 + threadIdx.x] = w[h] * 1.5f;
+    __syncthreads();
+    unsigned acc = __float_as_uint(lds[(lane * 37 + wid) & 4095]);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc ^= fold(L[kb][i]);
+    if (MODE == 1 || MODE == 3) {
+        lds[4096 + threadIdx.x] = __uint_as_float(acc);
+        __syncthreads();
+        acc ^= __float_as_uint(lds[4096 + ((threadIdx.x * 7) & 511)]);
+        __syncthreads();
+        float *dst = out + (size_t)blockIdx.x * 4096;
+        for (int i = threadIdx.x * 4; i < 4096; i += 2048)
+            *reinterpret_cast<float4 *>(dst + i) = make_float4(__uint_as_float(acc), 0.f, 1.f, 2.f);
+    } else if (acc == 0x12345678u) out[blockIdx.x] = 1.0f;
+}
+
+template <int MODE>
+float runp(const unsigned short *img, const float *we, int hw, int in_dim, int nimg, float *out, int iters)
+{
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kp<MODE>, dim3(nimg * 2), dim3(512), 0, 0, img, we, hw, in_dim, out);
+    CK(hipEventRecord(a));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kp<MODE>, dim3(nimg * 2), dim3(512), 0, 0, img, we, hw, in_dim, out);
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    return ms / iters * 1e3f;
+}
+
 template <int MODE, int NKB>
 float runs(const unsigned short *img, const float *we, int hw, int in_dim, int nimg, unsigned *out, int iters)
 {
@@ -210,5 +265,10 @@ int main()
     t = runs<2, 1>(img, we, hw, in_dim, nimg, out, 20); printf("S6 eighth-image units (1 block / wave)  : %7.1f us\n", t);
     t = runs<0, 8>(img, we, hw, in_dim, nimg, out, 20); printf("S7 whole-image units, 1 block ahead     : %7.1f us\n", t);
     t = runs<3, 8>(img, we, hw, in_dim, nimg, out, 20); printf("S8 whole-image units, 2 blocks ahead    : %7.1f us\n", t);
+    float *outp; CK(hipMalloc(&outp, (size_t)nimg * 2 * 4096 * 4));
+    t = runp<0>(img, we, hw, in_dim, nimg, outp, 20); printf("P0 fused-pool structure, loads only      : %7.1f us\n", t);
+    t = runp<1>(img, we, hw, in_dim, nimg, outp, 20); printf("P1  + 2 barriers + 16 KB out per unit    : %7.1f us\n", t);
+    t = runp<2>(img, we, hw, in_dim, nimg, outp, 20); printf("P2 = P0 with both tiles on one XCD       : %7.1f us\n", t);
+    t = runp<3>(img, we, hw, in_dim, nimg, outp, 20); printf("P3 = P1 with both tiles on one XCD       : %7.1f us\n", t);
     return 0;
 }
