@@ -17,7 +17,8 @@ closed by a full device synchronise, so every step's GPU work is inside it.
 Scenes are sharded by scene id with no data-path collective (weak scaling).
 
 Rank 0 prints ONE JSON line.  Extra objects:
-  roofline      dominant kernel (k_img_scores, one streaming read of img_feat): algorithmic
+  roofline      dominant kernel (the one pass over img_feat after the means: k_img_pool_bf for bf16-stored
+                features, k_img_scores for fp32): algorithmic
                 bytes per launch / average launch duration, timed with HIP events recorded by
                 the library on the kernel's own stream during the timed steps; `traffic` = HBM
                 bytes per launch from the committed rocprofv3 PMC pass (profiles/pmc_traffic.json,
@@ -58,7 +59,9 @@ def parse():
     ap.add_argument("--img-dtype", default="bf16", choices=["f32", "bf16", "f16"],
                     help="storage type of the image features (BASELINE config 2 names bf16; arithmetic is fp32 "
                          "either way); the fp32-feature rate is reported next to it")
-    ap.add_argument("--time-kernel", default="k_img_scores", help="launch site timed for the roofline object")
+    ap.add_argument("--time-kernel", default="img_pass2",
+                    help="launch site timed for the roofline object (img_pass2 = the dominant stream over img_feat "
+                         "after the mean pass: k_img_pool_bf for bf16 features, k_img_scores for fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scenes", type=int, default=None, help="scenes in the CPU baseline sample")
     ap.add_argument("--breakdown", action="store_true", help="print per-kernel event timings to stderr")
@@ -79,16 +82,31 @@ def kernel_id(lib, name):
     return names.index(name), names
 
 
-def algorithmic_bytes(cfg, B, name, img_itemsize=4):
+def algorithmic_bytes(cfg, B, name, img_itemsize=4, dt="f32"):
     """Algorithmic HBM bytes one launch of `name` must move (kernel table)."""
     img = B * cfg.V * cfg.input_dim * cfg.img_spacial_dim ** 2 * img_itemsize
     table = {
-        "k_img_mean": img, "k_img_scores": img, "k_img_gather": img,
+        "k_img_mean": img, "img_pass2": img,
+        # bf16: k_img_pool_merge reads the two tiles' (G, e, m, l) and writes the [g | a] rows
+        "img_pass3": (B * cfg.V * 8 * (2 * (cfg.input_dim + 130) + cfg.input_dim + cfg.img_spacial_dim ** 2 + 1) * 4
+                      if dt == "bf16" else img),
         "k_minmax": B * cfg.N * 12,
         "k_affine<compact>": B * cfg.N * (12 + 4 + 12),
         "k_tile_count": B * cfg.N * 4,
     }
     return table.get(name)
+
+
+# the kernel behind a launch site depends on the storage type of the image features
+SITE_KERNEL = {
+    "img_pass2": {"bf16": "k_img_pool_bf", "f32": "k_img_scores", "f16": "k_img_scores16"},
+    "img_pass3": {"bf16": "k_img_pool_merge", "f32": "k_img_gather", "f16": "k_img_gather16"},
+    "k_img_mean": {"bf16": "k_img_mean16", "f32": "k_img_mean", "f16": "k_img_mean16"},
+}
+
+
+def site_kernel(site, dt):
+    return SITE_KERNEL.get(site, {}).get(dt, site)
 
 
 def pmc_traffic(kernel, dt, cfg, B):
@@ -223,19 +241,19 @@ def main():
 
     if rank == 0:
         total_scenes = world * B * args.steps
-        abytes = algorithmic_bytes(cfg, B, args.time_kernel, img_feat.element_size())
+        abytes = algorithmic_bytes(cfg, B, args.time_kernel, img_feat.element_size(), args.img_dtype)
         roof = None
         if launches.value > 0 and not abytes:
-            roof = dict(kernel=args.time_kernel, avg_launch_us=round(total_ms.value / launches.value * 1e3, 2))
+            roof = dict(kernel=site_kernel(args.time_kernel, args.img_dtype), avg_launch_us=round(total_ms.value / launches.value * 1e3, 2))
         if launches.value > 0 and abytes:
             # the image branch is launched once per slice of scenes (2 slices per forward): the
             # algorithmic bytes of a step are spread over the launches actually recorded
             abytes = abytes * args.steps // launches.value
             avg_s = total_ms.value / launches.value / 1e3
             ach = abytes / avg_s / 1e9
-            roof = dict(bound="hbm", kernel=args.time_kernel, achieved=round(ach, 1), peak=HBM_PEAK_GBS,
+            roof = dict(bound="hbm", kernel=site_kernel(args.time_kernel, args.img_dtype), achieved=round(ach, 1), peak=HBM_PEAK_GBS,
                         unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
-                        traffic=pmc_traffic(args.time_kernel, args.img_dtype, cfg, B),
+                        traffic=pmc_traffic(site_kernel(args.time_kernel, args.img_dtype), args.img_dtype, cfg, B),
                         avg_launch_us=round(avg_s * 1e6, 2), launches=launches.value,
                         algorithmic_bytes_per_launch=abytes)
         line = dict(metric="scenes/sec (100k pts, 256 clusters, 64 proxies)", value=round(total_scenes / elapsed, 2),

@@ -25,10 +25,12 @@ void set_error(const char *fmt, ...)
 // ---- optional per-kernel timing (bench.py's roofline leg) -----------------------------------------
 // One launch site of the forward can be bracketed by HIP events recorded on the stream the kernel
 // is launched on; ptx_timing_read() returns launches and summed milliseconds.  Off by default.
+// img_pass2 / img_pass3 are the launch sites after the mean pass: k_img_pool_bf / k_img_pool_merge for bf16
+// features, k_img_scores / k_img_gather for fp32, k_img_scores16 / k_img_gather16 for fp16.
 static const char *const kKernelNames[] = {
     "memset", "k_minmax", "k_ball_query<grid>", "k_slot_net<offset>", "k_ball_query", "k_select",
     "k_tile_count", "k_slot_net<pointnet>", "k_img_mean", "k_gemm_nt[qkv0]",
-    "k_gemm_nt[we]", "k_img_scores", "k_img_gather", "k_gemm_nt[o]", "k_gemm_nt[c_proj]",
+    "k_gemm_nt[we]", "img_pass2", "img_pass3", "k_gemm_nt[o]", "k_gemm_nt[c_proj]",
     "k_ln_rows[norm_img]", "k_gemm_nt[qkv+proxy_proj]", "k_attn32[proxy_as_query]",
     "k_attn32[proxy_as_key]", "k_gemm_nt[proj]", "k_ln_rows[norm2]", "k_gemm_nt[fc1]", "k_gemm_nt[fc2]",
     "k_heads", "k_affine<compact>"};

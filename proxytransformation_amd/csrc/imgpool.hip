@@ -287,6 +287,25 @@ __global__ __launch_bounds__(256) void k_img_pool_merge(MergeArgs a)
     const int im = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
     const int in_dim = a.in_dim, hw = a.hw;
     const bool two = hw > 128;
+    const float *G0 = a.Gs + (size_t)(im * 2) * heads * in_dim, *G1 = G0 + (size_t)heads * in_dim;
+    const float *P0 = a.Ps + (size_t)(im * 2) * heads * 128, *P1 = P0 + (size_t)heads * 128;
+    // everything that does not depend on the scale factors is requested first (in_dim = 512: thread = one
+    // float4 of one of two heads per round, four rounds; thread = token for the probabilities)
+    const int nv = in_dim / 4, per = 256 / nv;                  // float4 per head row, heads per round
+    const int hsel = tid / nv, c4 = tid - hsel * nv;
+    float4 g0[4], g1[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int h = r * per + hsel;
+        const bool on = per > 0 && h < heads;
+        g0[r] = on ? reinterpret_cast<const float4 *>(G0 + (size_t)h * in_dim)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        g1[r] = (on && two) ? reinterpret_cast<const float4 *>(G1 + (size_t)h * in_dim)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int t = tid, p = tid - 1;                             // token: 0 = mean token, t >= 1 = pixel t - 1
+    float pv[heads];
+#pragma unroll
+    for (int h = 0; h < heads; ++h)
+        pv[h] = (p >= 0 && p < hw) ? (p < 128 ? P0[h * 128 + p] : P1[h * 128 + (p - 128)]) : 0.0f;
     {   // wave w: heads w and w + 4
         const int hd = a.C / heads;
 #pragma unroll
@@ -307,25 +326,21 @@ __global__ __launch_bounds__(256) void k_img_pool_merge(MergeArgs a)
         }
     }
     __syncthreads();
-    const float *G0 = a.Gs + (size_t)(im * 2) * heads * in_dim, *G1 = G0 + (size_t)heads * in_dim;
-    const float *P0 = a.Ps + (size_t)(im * 2) * heads * 128, *P1 = P0 + (size_t)heads * 128;
 #pragma unroll
-    for (int h = 0; h < heads; ++h) {
-        const float c0 = c0s[h], c1 = c1s[h];
-        float *row = a.gbuf + ((size_t)im * heads + h) * a.KT2p;
-        for (int c = tid; c < in_dim; c += 256) {
-            const float g1 = two ? G1[(size_t)h * in_dim + c] : 0.0f;
-            row[c] = G0[(size_t)h * in_dim + c] * c0 + g1 * c1;
+    for (int r = 0; r < 4; ++r) {
+        const int h = r * per + hsel;
+        if (per > 0 && h < heads) {
+            const float c0 = c0s[h], c1 = c1s[h];
+            float *row = a.gbuf + ((size_t)im * heads + h) * a.KT2p;
+            reinterpret_cast<float4 *>(row)[c4] = make_float4(g0[r].x * c0 + g1[r].x * c1, g0[r].y * c0 + g1[r].y * c1,
+                                                              g0[r].z * c0 + g1[r].z * c1, g0[r].w * c0 + g1[r].w * c1);
         }
-        const int t = tid;                                      // token: 0 = mean token, t >= 1 = pixel t - 1
-        if (t < a.KT2p - in_dim) {
-            float v = 0.0f;
-            if (t == 0) v = cts[h];
-            else if (t - 1 < hw) {
-                const int p = t - 1;
-                v = p < 128 ? P0[h * 128 + p] * c0 : P1[h * 128 + (p - 128)] * c1;
-            }
-            row[in_dim + t] = v;
+    }
+    if (t < a.KT2p - in_dim) {
+#pragma unroll
+        for (int h = 0; h < heads; ++h) {
+            const float v = t == 0 ? cts[h] : pv[h] * (p < 128 ? c0s[h] : c1s[h]);
+            a.gbuf[((size_t)im * heads + h) * a.KT2p + in_dim + t] = v;
         }
     }
 }
