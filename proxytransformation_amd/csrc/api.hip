@@ -134,7 +134,7 @@ WsLayout ws_layout(const PtxShape &s)
     L.point_proxy = take(R * C * 4);
     for (int i = 0; i < 2; ++i) L.x_in[i] = take(R * C * 4);
     L.fm = take(nimg * s.in_dim * 4); L.qkv0 = take(nimg * 3 * C * 4);
-    L.we = take(nimg * s.heads * (size_t)P.KT1 * 4); L.sraw = take(nimg * 2 * s.heads * (size_t)kSrawLd * 4); L.aparts = take(img16_aparts_bytes((int)nimg));
+    L.we = take(nimg * s.heads * (size_t)P.KT1 * 4);
     L.pool = take(img_pool_bytes((int)nimg, s.in_dim));
     L.gbuf = take(nimg * s.heads * (size_t)P.KT2p * 4);
     L.obuf = take(nimg * C * 4); L.cbuf = take(nimg * C * 4); L.img_proxy = take(nimg * C * 4);
@@ -199,7 +199,7 @@ static int run_img_proxy(const PtxShape &s, const PtxWeights &w, const float *pr
     const WsLayout L = ws_layout(s);
     const int C = s.C, hd = P.hd, nimg = s.B * s.V;
     float *fm = at<float>(ws, L.fm), *qkv0 = at<float>(ws, L.qkv0);
-    float *we = at<float>(ws, L.we), *gbuf = at<float>(ws, L.gbuf), *sraw = at<float>(ws, L.sraw);
+    float *we = at<float>(ws, L.we), *gbuf = at<float>(ws, L.gbuf);
     float *obuf = at<float>(ws, L.obuf), *cbuf = at<float>(ws, L.cbuf);
     const float *img = static_cast<const float *>(img_any);
     const int dt = s.img_dtype;
@@ -232,9 +232,8 @@ static int run_img_proxy(const PtxShape &s, const PtxWeights &w, const float *pr
                                                             attn_scale(hd), gbuf, st));
     } else {
         PTX_TIMED(KID_IMG_SCORES, st, launch_img_scores16(img_any, dt, we, qkv0, nimg, s.in_dim, s.hw, s.heads, C,
-                                                          P.KT1, P.KT2p, attn_scale(hd), sraw, gbuf, st));
-        PTX_TIMED(KID_IMG_GATHER, st, launch_img_gather16(img_any, dt, nimg, s.in_dim, s.hw, s.heads, P.KT2p, sraw,
-                                                          at<unsigned short>(ws, L.aparts), gbuf, st));
+                                                          P.KT1, P.KT2p, attn_scale(hd), gbuf, st));
+        PTX_TIMED(KID_IMG_GATHER, st, launch_img_gather16(img_any, dt, nimg, s.in_dim, s.hw, s.heads, P.KT2p, gbuf, st));
     }
     {   // per head: o_h = [g_h | a_h] T2_h^T + a_h(0) v0_h + bv_h
         GemmBatch g{}; g.n = s.heads;

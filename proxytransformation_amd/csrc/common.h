@@ -115,7 +115,7 @@ struct WsLayout {
     size_t minmax, centers0, cluster1, offsets, centers, idx2, cluster2, pad_count;
     size_t order, picks, keep, kcenter, kcluster, kidx, drop_idx, tile_counts;
     size_t point_proxy, x_in[2];    // x_in: LN1(x)+slot bias per branch (B*Mk,C)
-    size_t fm, qkv0, we, sraw, aparts, pool, gbuf, obuf, cbuf, img_proxy;
+    size_t fm, qkv0, we, pool, gbuf, obuf, cbuf, img_proxy;
     size_t qkv[2], pt[2], pv[2], ao[2], x1[2], xn2[2], hbuf[2], x2[2], guide[2], head[2];
     size_t total;
 };
@@ -198,11 +198,10 @@ int launch_img_gather(const float *img, int nimg, int in_dim, int hw, int heads,
                       float *gbuf, hipStream_t st);
 
 int launch_img_mean16(const void *img, int dt, int nimg, int in_dim, int hw, float *fm, hipStream_t st);
-constexpr int kSrawLd = 256;            // raw scores per (image, head) in `sraw`: token 0, then the pixels
 int launch_img_scores16(const void *img, int dt, const float *we, const float *qkv0, int nimg, int in_dim,
-                        int hw, int heads, int C, int KT1, int KT2p, float scale, float *sraw, float *gbuf,
+                        int hw, int heads, int C, int KT1, int KT2p, float scale, float *gbuf, hipStream_t st);
+int launch_img_gather16(const void *img, int dt, int nimg, int in_dim, int hw, int heads, int KT2p, float *gbuf,
                         hipStream_t st);
-size_t img16_aparts_bytes(int nimg);
 // imgpool.hip: single-pass attention pooling of bf16 features (scores + softmax numerators + weighted sums)
 bool img_pool_supported(int dt, int in_dim, int hw, int heads);
 size_t img_pool_bytes(int nimg, int in_dim);
@@ -210,8 +209,6 @@ int launch_img_pool(const void *img, const float *we, int nimg, int in_dim, int 
                     hipStream_t st);
 int launch_img_pool_merge(const float *scratch, const float *qkv0, int nimg, int in_dim, int hw, int C, int KT2p,
                           float scale, float *gbuf, hipStream_t st);
-int launch_img_gather16(const void *img, int dt, int nimg, int in_dim, int hw, int heads, int KT2p,
-                        const float *sraw, unsigned short *aparts, float *gbuf, hipStream_t st);
 
 // ---- prep (prep.hip) ----------------------------------------------------------------------------
 int run_prepare(const PtxShape &s, const PtxWeights &w, float *prep, hipStream_t st);

@@ -19,6 +19,23 @@
 //   m = max(m_0, m_1, s(0)),  l = l_0 e^(m_0-m) + l_1 e^(m_1-m) + e^(s(0)-m),  g = (G_0 e^(m_0-m) + G_1 e^(m_1-m)) / l.
 // Every product is of two bf16 values (exact in fp32) accumulated in fp32: the result is the fp32 value in a
 // different summation order.
+//
+// Measurements behind the design (cfg2, B = 4: 784 images, 180.6 MB of bf16 features; us per launch):
+//   * three-pass predecessors: VALU scores 57-62 + f32-MFMA weighted sums 72-76.  Moving the weighted sums to the
+//     bf16 pipe alone changed nothing (75): the matrix time was never the limit, the load map was --
+//   * a wave instruction streams at full rate only if ADJACENT LANES READ ADJACENT 16-B CHUNKS in groups of four
+//     (scratch/pattern_bench.hip, loads only: whole rows 24.6; 4 rows x 256 B with quads contiguous 24.5; the
+//     natural MFMA map, lane & 15 = row, 45.5; 4 rows x 256 B with lane & 3 = row 52).  Hence one MFMA of stage 3
+//     covers FOUR channel rows x 128 pixels (A row = (channel m >> 2, pixel set m & 3), B column = (head, pixel
+//     set)); only the blocks with equal sets mean anything -- 1/4 of a cheap MFMA
+//   * separate matrix-pipe kernels: scores over (image, half the channels) units 54 + softmax launch 9 + weighted
+//     sums 46 = 109; removing any ONE of {weight prologue, MFMA work, reduction + output} from the scores kernel
+//     left it at 50-54: what remained was the serial chain inside each round of work-groups
+//   * this kernel with the two tiles of an image on different XCDs: 71; on one XCD: 58-60 (the tiles share a
+//     cache line per row and the run-on lanes of tile 1 read the head of the next row; loads only: 50 vs 33)
+//   * phases of a unit (s_memtime, 2.35 GHz): waiting for the 16 loads 53 %, scores 8 %, softmax 7 %, weighted sums
+//     27 %, barriers 3 %; a unit lives 12.3 us, two are resident per CU (120 VGPRs x 8 waves), 1568 units on 512
+//     slots = 3.06 rounds, i.e. four: ~20 % of the launch is the last, nearly empty round
 #include <cstdlib>
 
 #include "common.h"
@@ -70,7 +87,6 @@ struct PoolArgs {
     float *ML;          // [nimg][2][heads][2]       m_tile, l_tile
 };
 
-template <int X>
 __global__ __launch_bounds__(512) void k_img_pool_bf(PoolArgs a)
 {
     constexpr int heads = kPoolHeads;
@@ -100,16 +116,6 @@ __global__ __launch_bounds__(512) void k_img_pool_bf(PoolArgs a)
     const int px = 128 * T + 8 * n;
     const bool full = px + 8 <= hw;
     const int cw = 64 * wid;                                    // this wave's 64 channels = two blocks of 32
-    // Two work-groups fit on a CU.  Dispatched together they stay in lockstep -- both loading, then both
-    // computing -- and nothing overlaps (measured: 71 us, the sum of the phases).  The work-groups that fill
-    // the second slots of the first round (ids 256..511: 8 XCDs x 32 CUs get one each before any gets two)
-    // start half a period late; after that the slots free up alternately by themselves.
-    if (X & 8) {
-        if (blockIdx.x >= 256 && blockIdx.x < 512) {
-            __builtin_amdgcn_s_sleep(127);
-            if (X & 16) __builtin_amdgcn_s_sleep(127);
-        }
-    }
     u32x4 L[2][8];
     const bool tensor_end = im == a.nimg - 1 && cw + 64 == in_dim;    // wave-uniform
 #pragma unroll
@@ -173,7 +179,6 @@ __global__ __launch_bounds__(512) void k_img_pool_bf(PoolArgs a)
 #pragma unroll
                 for (int qd = 0; qd < 4; ++qd) b[qd] = __builtin_amdgcn_perm(L[kb][2 * qd + 1][j >> 1], L[kb][2 * qd][j >> 1], sel);
                 const bf16x8 bf = __builtin_bit_cast(bf16x8, b);
-                if (X & 1) { acc[j][0] += __uint_as_float(b[0] ^ b[3]); continue; }
 #pragma unroll
                 for (int pt = 0; pt < 3; ++pt) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[pt], bf, acc[j], 0, 0, 0);
             }
@@ -242,19 +247,15 @@ __global__ __launch_bounds__(512) void k_img_pool_bf(PoolArgs a)
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                if ((X & 2) && i > 0) continue;
                 u32x4 av;
 #pragma unroll
-                for (int d = 0; d < 4; ++d) av[d] = (X & 64) ? L[kb][i][d] : (unsigned int)__builtin_amdgcn_ds_bpermute(src, (int)L[kb][i][d]);
+                for (int d = 0; d < 4; ++d) av[d] = (unsigned int)__builtin_amdgcn_ds_bpermute(src, (int)L[kb][i][d]);
                 const bf16x8 af = __builtin_bit_cast(bf16x8, av);
 #pragma unroll
                 for (int hg = 0; hg < 2; ++hg) {
                     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int pt = 0; pt < 3; ++pt) {
-                        if (X & 32) { acc[pt] += __uint_as_float(av[pt] ^ av[3]); continue; }
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[hg][pt], acc, 0, 0, 0);
-                    }
+                    for (int pt = 0; pt < 3; ++pt) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[hg][pt], acc, 0, 0, 0);
                     // D[row 4 kq + r][col n]: row = (channel sub-block kq, set r), col = (head hh, set ps): keep r == ps
                     float x = ps == 0 ? acc[0] : ps == 1 ? acc[1] : ps == 2 ? acc[2] : acc[3];
                     x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(512) void k_img_pool_bf(PoolArgs a)
     {
         const float *G = partial;
         float *dst = a.Gs + (size_t)slab * heads * in_dim;
-        for (int i = tid * 4; i < ((X & 4) ? 2048 : heads * in_dim); i += 512 * 4)
+        for (int i = tid * 4; i < heads * in_dim; i += 512 * 4)
             *reinterpret_cast<float4 *>(dst + i) = *reinterpret_cast<const float4 *>(G + i);
     }
 }
@@ -364,10 +365,7 @@ int launch_img_pool(const void *img, const float *we, int nimg, int in_dim, int 
     PoolArgs pa{static_cast<const unsigned short *>(img), we, nimg, in_dim, hw, KT1, Gs, Ps, ML};
     const size_t lds = sizeof(float) * 8 * kPoolHeads * 128 + sizeof(unsigned short) * 24 * (kPoolWPad + kPoolPPad);
     PTX_REQUIRE(lds <= 64 * 1024, "img pool: %zu B of LDS", lds);
-    static const int px_ = getenv("PTX_POOL_X") ? atoi(getenv("PTX_POOL_X")) : 0;
-#define PTX_PX(X_) case X_: hipLaunchKernelGGL(k_img_pool_bf<X_>, dim3(cdiv(nimg, 8) * 16), dim3(512), lds, st, pa); break;
-    switch (px_) { PTX_PX(32) PTX_PX(64) PTX_PX(96) PTX_PX(33) default: PTX_PX(0) }
-#undef PTX_PX
+    hipLaunchKernelGGL(k_img_pool_bf, dim3(cdiv(nimg, 8) * 16), dim3(512), lds, st, pa);
     PTX_LAUNCHED("k_img_pool_bf");
     return PTX_OK;
 }

@@ -245,9 +245,20 @@ __global__ __launch_bounds__(256) void k_img_gather(const float *__restrict__ im
         pf0[kb] = *reinterpret_cast<const f4u *>(row + p0);
         pf1[kb] = *reinterpret_cast<const f4u *>(row + p0 + 4);
     }
-    for (int i = tid; i < heads * hwp; i += 256) {
-        const int h = i / hwp, p = i - h * hwp;
-        a_s[i] = p < hw ? gbuf[((size_t)im * heads + h) * KT2p + in_dim + 1 + p] : 0.0f;
+    {   // all loads of the probabilities first, then the LDS stores (as one loop the compiler waited for each
+        // load -- and for the feature loads above -- in turn)
+        constexpr int NR = 8;                                   // heads * hwp <= 8 * 256 (validated by the host)
+        float av[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int i = tid + 256 * r, h = i / hwp, p = i - h * hwp;
+            av[r] = (i < heads * hwp && p < hw) ? gbuf[((size_t)im * heads + h) * KT2p + in_dim + 1 + p] : 0.0f;
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int i = tid + 256 * r;
+            if (i < heads * hwp) a_s[i] = av[r];
+        }
     }
     __syncthreads();
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -292,6 +303,7 @@ int launch_img_gather(const float *img, int nimg, int in_dim, int hw, int heads,
                       float *gbuf, hipStream_t st)
 {
     PTX_REQUIRE(in_dim % kGatherCh == 0 && heads <= kMaxHeads, "img gather: in_dim=%d heads=%d", in_dim, heads);
+    PTX_REQUIRE(hw <= 256, "img gather: hw=%d (max 256 pixels)", hw);
     const int hwp = (hw + 3) & ~3;
     const size_t lds = sizeof(float) * (size_t)heads * hwp;
     PTX_REQUIRE(lds <= 64 * 1024, "img gather: %zu B of LDS", lds);

@@ -1,5 +1,7 @@
 // The three image-streaming kernels of imgproxy.hip for image features STORED as bf16 or fp16
-// (an AMP backbone hands over half-precision feature maps; BASELINE config 2 names bf16).  Only the
+// (an AMP backbone hands over half-precision feature maps).  bf16 features of the path's own shape
+// (in_dim = 512, 128 < hw <= 255) take the two-pass matrix-pipe route of imgpool.hip after the mean pass of
+// this file; these three-pass kernels serve fp16 storage and any other shape.  Only the
 // storage changes: every element is widened to fp32 on load and all arithmetic, accumulation and
 // outputs are fp32 exactly as in the fp32 kernels, so the result equals the fp32 path run on the
 // same (rounded) inputs.  The dominant HBM stream of the path halves (in_dim*hw*2 B per image).
@@ -244,9 +246,20 @@ __global__ __launch_bounds__(256) void k_img_gather16(const unsigned short *__re
 #pragma unroll
     for (int kb = 0; kb < PRE; ++kb)
         pf[kb] = *reinterpret_cast<const u4u2 *>(row + 32 * min(kb, nkb - 1) + 8 * kq);
-    for (int i = tid; i < heads * hwp; i += 256) {
-        const int h = i / hwp, p = i - h * hwp;
-        a_s[i] = p < hw ? gbuf[((size_t)im * heads + h) * KT2p + in_dim + 1 + p] : 0.0f;
+    {   // all loads of the probabilities first, then the LDS stores (as one loop the compiler waited for each
+        // load -- and for the feature loads above -- in turn)
+        constexpr int NR = 8;                                   // heads * hwp <= 8 * 256 (validated by the host)
+        float av[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int i = tid + 256 * r, h = i / hwp, p = i - h * hwp;
+            av[r] = (i < heads * hwp && p < hw) ? gbuf[((size_t)im * heads + h) * KT2p + in_dim + 1 + p] : 0.0f;
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int i = tid + 256 * r;
+            if (i < heads * hwp) a_s[i] = av[r];
+        }
     }
     __syncthreads();
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -286,355 +299,6 @@ __global__ __launch_bounds__(256) void k_img_gather16(const unsigned short *__re
     }
 }
 
-// ---- between pass 2 and pass 3 (bf16 path): softmax of the raw scores and everything the gather
-// work-groups would otherwise each redo in their prologue.  One work-group per image, thread = token
-// (0 = the mean token, t >= 1 = pixel t - 1).  Writes a_h to the [g_h | a_h] rows of gbuf (the o-projection
-// GEMM reads them) and the LDS image of k_img_gather_bf: the exact three-way bf16 split of a_h(p).
-// (With the softmax in the gather prologue, a chain of 16 loads and two block reductions in front of
-// every work-group's first MFMA, the gather took 63-70 us instead of 50.)
-constexpr int kGbPad = 264;             // row stride in elements (256 pixels + 8)
-constexpr int kApartsLd = 3 * kMaxHeads * kGbPad + 3 * kMaxHeads * 8;   // + the straddling-window fragments
-
-__global__ __launch_bounds__(512) void k_img_softmax_bf(const float *__restrict__ sraw, int in_dim, int hw, int KT2p,
-                                                        float *__restrict__ gbuf, unsigned short *__restrict__ aparts)
-{
-    // one wave per head, lane l owns tokens l, l + 64, l + 128, l + 192: wave reductions only, no barrier
-    // (as thread = token with two block reductions the launch took 11-13 us)
-    constexpr int heads = kMaxHeads;
-    const int im = blockIdx.x, lane = lane_id(), h = threadIdx.x >> 6;
-    unsigned short *parts = aparts + (size_t)im * kApartsLd;
-    unsigned short *etail = parts + 3 * heads * kGbPad;
-    const int estart = hw & ~7;                                 // first pixel of the window that straddles the row end
-    const float *s0 = sraw + ((size_t)im * 2 * heads + h) * kSrawLd, *s1 = s0 + (size_t)heads * kSrawLd;
-    float sv[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int t = lane + 64 * u;
-        sv[u] = t <= hw ? s0[t] + s1[t] : -INFINITY;           // the two channel halves of pass 2
-    }
-    const float mx = wave_max(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])));
-    float ex[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) ex[u] = lane + 64 * u <= hw ? expf(sv[u] - mx) : 0.0f;
-    const float inv = 1.0f / wave_sum((ex[0] + ex[1]) + (ex[2] + ex[3]));
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int t = lane + 64 * u, p = t - 1;
-        const float a = ex[u] * inv;
-        if (t < KT2p - in_dim) gbuf[((size_t)im * heads + h) * KT2p + in_dim + t] = a;   // [g_h | a_h] row of the o GEMM
-        const unsigned int u1 = __float_as_uint(a) & 0xffff0000u;
-        const float r1 = a - __uint_as_float(u1);
-        const unsigned int u2 = __float_as_uint(r1) & 0xffff0000u;
-        const float r2 = r1 - __uint_as_float(u2);
-        unsigned short q1 = (unsigned short)(u1 >> 16), q2 = (unsigned short)(u2 >> 16),
-                       q3 = (unsigned short)(__float_as_uint(r2) >> 16);
-        const int pp = p < 0 ? 255 : p;                         // token 0 clears the last padding pixel instead
-        if (p < 0) q1 = q2 = q3 = 0;
-        parts[(0 * heads + h) * kGbPad + pp] = q1;
-        parts[(1 * heads + h) * kGbPad + pp] = q2;
-        parts[(2 * heads + h) * kGbPad + pp] = q3;
-        // the window that straddles the row end is loaded from pixel hw - 8 in the last image (see
-        // k_img_gather_bf): its B fragment holds the probabilities from `estart` on, zero before
-        const int e = p - (hw - 8);
-        if (p >= 0 && e >= 0 && e < 8) {
-            const bool own = p >= estart;
-            etail[(0 * heads + h) * 8 + e] = own ? q1 : (unsigned short)0;
-            etail[(1 * heads + h) * 8 + e] = own ? q2 : (unsigned short)0;
-            etail[(2 * heads + h) * 8 + e] = own ? q3 : (unsigned short)0;
-        }
-    }
-    // padding columns 256..263 of each row are never read (windows end at pixel 255)
-}
-
-// ---- pass 3 for bf16 features on the bf16 matrix pipe, still exact to fp32: the probabilities are split
-// a = a1 + a2 + a3 into three bf16 parts (8 significant bits each, the split is exact), every product
-// a_i * f of two bf16 values is exact in fp32, and v_mfma_f32_16x16x32_bf16 accumulates in fp32 -- so
-// the result is an fp32 dot product in a different summation order, at 1/16 of the f32-MFMA cost and
-// with no widening VALU work: the 16-B load of 8 pixels IS the A fragment.
-//
-// The cheap MFMA is spent on a fragment map the memory pipe likes.  Measured with loads only
-// (scratch/pattern_bench.hip, 180 MB of 450-B rows): a wave instruction streams at full rate (24.5 us) only
-// if ADJACENT LANES read ADJACENT 16-B chunks in groups of four (one 64-B request per quad); the natural
-// MFMA map (lane & 15 = channel row, so neighbouring lanes are 450 B apart) runs at half that (45.5 us),
-// whatever the length of the per-row runs.  So one MFMA here covers FOUR channel rows x 128 pixels:
-//   A row  m = (channel m >> 2, pixel set m & 3)      B column n = (head n >> 2, pixel set n & 3)
-//   pixel of (set, K-lane kq, element i) = 128 * step + 32 * kq + 8 * set + i
-// lane (m, kq) loads 16 B at that pixel: a quad reads 64 contiguous bytes, 16 lanes read 256.  Only the
-// output blocks whose row and column sets agree mean anything (1/4 of the MFMA, which is cheap enough);
-// they sit in acc[lane & 3] and are summed over the sets with two quad permutes.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-template <int NG>                       // 16-channel groups per wave; a work-group covers 64 * NG channels
-__global__ __launch_bounds__(256) void k_img_gather_bf(const unsigned short *__restrict__ img, int nimg, int in_dim,
-                                                       int hw, int KT2p,
-                                                       const unsigned short *__restrict__ aparts,
-                                                       float *__restrict__ gbuf)
-{
-    constexpr int heads = kMaxHeads;
-    // [part][head][pixel], zero beyond hw; then [part][head][8] for the window that straddles the row end
-    __shared__ __attribute__((aligned(16))) unsigned short parts[3 * heads * kGbPad + 3 * heads * 8];
-    unsigned short *etail = parts + 3 * heads * kGbPad;
-    const int chunk = 64 * NG, chunks = in_dim / chunk;
-    const int im = blockIdx.x / chunks, c0 = (blockIdx.x - im * chunks) * chunk;
-    const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
-    const int m = lane & 15, kq = lane >> 4, cr = m >> 2, ps = m & 3;
-    const int nsteps = hw > 128 ? 2 : 1;
-    const bool nat = im != nimg - 1;
-    // this lane's pixel window per step: inside the row, straddling its end, or beyond it
-    int aoff[2], boff[2];                                       // element offsets: into the row / into `parts`
-#pragma unroll
-    for (int st = 0; st < 2; ++st) {
-        const int px = 128 * st + 32 * kq + 8 * ps;
-        const bool full = px + 8 <= hw, edge = !full && px < hw;
-        // a window that sticks out of the row runs on into the next row (contiguous; finite values times
-        // the zero padding of `parts`); only the last image of the tensor re-reads its last window instead
-        aoff[st] = (full || nat) ? px : hw - 8;
-        boff[st] = (edge && !nat) ? -1 : px;
-    }
-    // group g of this wave = channels c0 + (4 g + wid) * 16 .. +15; tile t, row cr = channel 4 cr + t of them
-    const unsigned short *wrow = img + ((size_t)im * in_dim + c0 + wid * 16 + 4 * cr) * hw;
-    const size_t gstride = (size_t)64 * hw;
-    u32x4 pf[2][4][2];
-    auto fetch = [&](int buf, const unsigned short *r) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int st = 0; st < 2; ++st)
-                pf[buf][t][st] = *reinterpret_cast<const u4u2 *>(r + (size_t)t * hw + aoff[st < nsteps ? st : 0]);
-    };
-    fetch(0, wrow);
-    {   // the prepared probabilities of this image (k_img_softmax_bf) -> LDS: one round trip
-        const u32x4 *src = reinterpret_cast<const u32x4 *>(aparts + (size_t)im * kApartsLd);
-        u32x4 *dst = reinterpret_cast<u32x4 *>(parts);
-        constexpr int NV = kApartsLd / 8;                       // 16-B vectors
-        u32x4 v[(NV + 255) / 256];
-#pragma unroll
-        for (int i = 0; i < (NV + 255) / 256; ++i) if (tid + 256 * i < NV) v[i] = src[tid + 256 * i];
-#pragma unroll
-        for (int i = 0; i < (NV + 255) / 256; ++i) if (tid + 256 * i < NV) dst[tid + 256 * i] = v[i];
-    }
-    __syncthreads();
-    const int hh = m >> 2;                                      // head within the group for B columns
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const int cur = g & 1;
-        if (g + 1 < NG) fetch(cur ^ 1, wrow + (size_t)(g + 1) * gstride);
-        f32x4 acc[4][2];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t][0] = acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            if (st < nsteps) {
-#pragma unroll
-                for (int hg = 0; hg < 2; ++hg) {
-                    bf16x8 bfr[3];
-#pragma unroll
-                    for (int pt = 0; pt < 3; ++pt) {
-                        const int row = pt * heads + 4 * hg + hh;
-                        const unsigned short *bp = boff[st] >= 0 ? parts + (size_t)row * kGbPad + boff[st]
-                                                                 : etail + row * 8;
-                        bfr[pt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(bp));
-                    }
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const bf16x8 fa = __builtin_bit_cast(bf16x8, pf[cur][t][st]);
-#pragma unroll
-                        for (int pt = 0; pt < 3; ++pt)
-                            acc[t][hg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, bfr[pt], acc[t][hg], 0, 0, 0);
-                    }
-                }
-            }
-        }
-        // D[row 4 kq + i][col m]: row = (channel kq, set i), col = (head hh, set ps): keep i == ps, sum the quad
-#pragma unroll
-        for (int hg = 0; hg < 2; ++hg) {
-            float v[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                float x = ps == 0 ? acc[t][hg][0] : ps == 1 ? acc[t][hg][1] : ps == 2 ? acc[t][hg][2] : acc[t][hg][3];
-                x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
-                x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
-                v[t] = x;
-            }
-            if (ps == 0) {       // lane (kq, hh): channels 4 kq + 0..3 of the group, head 4 hg + hh
-                float *dst = gbuf + ((size_t)im * heads + 4 * hg + hh) * KT2p + c0 + (4 * g + wid) * 16 + 4 * kq;
-                *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-            }
-        }
-    }
-}
-
-// ---- pass 2 for bf16 features on the bf16 matrix pipe (exact to fp32 like k_img_gather_bf: here the
-// per-image head weights w_h are the operand that is split into three bf16 parts).  The VALU kernel
-// above spends 8 FMAs + 1 widening op per element; this one spends half a v_perm per element:
-//   s_h(p) = sum_c w_h(c) f(c,p)   as   D[16 x 16] += A[16 x 32 channels] * B[32 channels x 16 pixels]
-//   A row m  = w1 of head m (m < 8) | w2 of head m-8; a second MFMA adds w3 (rows 8-15 zero)
-//   B col n  = one pixel; K-lane kq holds channels 8 kq .. 8 kq + 7 of the 32-channel block
-// Lane (n, kq) loads, for i = 0..7, the 16 B = pixels 8n .. 8n+7 of channel row (block + 8 kq + i): four
-// rows x 256 contiguous bytes per instruction, quads contiguous (see k_img_gather_bf).  The 8 x 8 block
-// of (channel, pixel) values a lane then holds is transposed in registers with v_perm_b32 into eight
-// B fragments (one per pixel j; column n of MFMA j is pixel 8n + j), each with its own accumulator.
-//
-// Work unit = (image, half of the channels), 4 waves = (pixel tile of 128) x (channel quarter of the half);
-// the two quarters are summed through LDS and the unit writes RAW partial scores to `sraw`
-// ([image][half][head][token]; half 0 adds the positional terms and token 0).  The gather kernel adds
-// the halves and normalises in its prologue, so no unit waits for a partner.  Measured on the way:
-//   * whole images as units (784 on 256 CUs: 3.06 per CU, 4 on some, two resident at a time): 62 us, the
-//     same as the VALU kernel -- the launch was two rounds of work-group lifetimes long
-//   * removing any ONE of {weight prologue, perm + MFMA work, reduction + output} from this kernel leaves it
-//     at 50-54 us, removing all three gives 39 (a load-only copy of its structure runs at 33 in isolation,
-//     scratch/pattern_bench.hip): what is left is the serial chain inside each of the 2 x 3 rounds of
-//     work-groups, not any one resource
-//   * (image, pixel tile) units: 53 us, but 1.8x the L1->L2 requests of a whole-row stream (PMC
-//     TCP_TCC_READ_REQ 2.9 M vs 1.6 M): every row has a cache line at the tile boundary that both units
-//     fetch, and lanes beyond the row, clamped to offset 0, touched one more line per row
-constexpr int kSbPad = 520;             // LDS row stride (elements) of the split weights: 16 rows x 16 B hit all banks
-typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-
-__global__ __launch_bounds__(256) void k_img_scores_bf(
-    const unsigned short *__restrict__ img, const float *__restrict__ we, const float *__restrict__ qkv0,
-    int nimg, int in_dim, int hw, int C, int KT1, float scale, float *__restrict__ sraw)
-{
-    constexpr int heads = kMaxHeads;
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float *red = sm;                                            // [2 tiles][heads][128]
-    unsigned short *wpart = reinterpret_cast<unsigned short *>(red + 2 * heads * 128);   // [24][kSbPad]
-    // images in reverse order (the mean pass left the last ones in cache)
-    const int half = blockIdx.x & 1, im = nimg - 1 - (blockIdx.x >> 1);
-    const int tid = threadIdx.x, lane = lane_id();
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int T = wid & 1, q = wid >> 1;                        // pixel tile, channel quarter of this half
-    const int n = lane & 15, kq = lane >> 4;
-    const float *wim = we + (size_t)im * heads * KT1;
-    const unsigned short *f = img + (size_t)im * in_dim * hw;
-    // this lane's window of 8 pixels: inside the row, straddling its end (loaded from hw - 8) or beyond
-    // Windows that stick out of the row simply run on into the next row (rows are contiguous; those lines
-    // are the ones the next load instruction needs anyway) and the surplus columns are discarded.  Only in
-    // the last image of the tensor, where that would read past the buffer, they re-read the last window.
-    const bool nat = im != nimg - 1;
-    const int px = 128 * T + 8 * n;
-    const bool full = px + 8 <= hw, edge = !full && px < hw;
-    const int aoff = (full || nat) ? px : hw - 8;
-    const int own_from = (full || nat) ? px : (edge ? (hw & ~7) : 1 << 30);
-    const int ch = in_dim / 2, cq = ch / 2, cbeg = half * ch + q * cq, nkb = cq / 32;
-    u32x4 L[2][8];
-    auto fetch = [&](u32x4 (&Lb)[8], int kb) {
-        const unsigned short *r = f + (size_t)(cbeg + 32 * kb + 8 * kq) * hw + aoff;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) Lb[i] = __builtin_nontemporal_load(reinterpret_cast<const u4u2 *>(r + (size_t)i * hw));
-    };
-    fetch(L[0], 0);
-    // head weights of this half -> three bf16 parts in LDS (thread = channel, all loads first)
-    for (int c = tid; c < ch; c += 256) {
-        float wv[heads];
-#pragma unroll
-        for (int h = 0; h < heads; ++h) wv[h] = wim[(size_t)h * KT1 + half * ch + c];
-#pragma unroll
-        for (int h = 0; h < heads; ++h) {
-            const unsigned int u1 = __float_as_uint(wv[h]) & 0xffff0000u;
-            const float r1 = wv[h] - __uint_as_float(u1);
-            const unsigned int u2 = __float_as_uint(r1) & 0xffff0000u;
-            const float r2 = r1 - __uint_as_float(u2);
-            wpart[(size_t)h * kSbPad + c] = (unsigned short)(u1 >> 16);
-            wpart[(size_t)(8 + h) * kSbPad + c] = (unsigned short)(u2 >> 16);
-            wpart[(size_t)(16 + h) * kSbPad + c] = (unsigned short)(__float_as_uint(r2) >> 16);
-        }
-    }
-    // token 0: s_h(0) = scale * q_h . k0_h with half 0 (wave w computes heads w and w + 4), 0 with half 1
-    {
-        const int hd = C / heads;
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const int h = wid + 4 * hh;
-            const float *qv = qkv0 + (size_t)im * 3 * C + h * hd;
-            const float qk = (half == 0 && lane < hd) ? qv[lane] * qv[C + lane] : 0.0f;
-            const float s0 = wave_sum(qk);
-            if (lane == 0) sraw[(((size_t)im * 2 + half) * heads + h) * kSrawLd] = s0 * scale;
-        }
-    }
-    __syncthreads();
-    f32x4 acc[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const unsigned short *a1p = wpart + (size_t)n * kSbPad + q * cq + 8 * kq;               // rows 0-15: w1 | w2
-    const unsigned short *a2p = wpart + (size_t)(16 + (n & 7)) * kSbPad + q * cq + 8 * kq;   // rows 16-23: w3
-    const bool lo = n < 8;
-    auto block = [&](const u32x4 (&Lb)[8], int kb) {
-        const bf16x8 a1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(a1p + 32 * kb));
-        u32x4 a2u = *reinterpret_cast<const u32x4 *>(a2p + 32 * kb);
-        if (!lo) a2u = u32x4{0u, 0u, 0u, 0u};
-        const bf16x8 a2 = __builtin_bit_cast(bf16x8, a2u);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const unsigned int sel = (j & 1) ? 0x07060302u : 0x05040100u;
-            u32x4 b;
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) b[qd] = __builtin_amdgcn_perm(Lb[2 * qd + 1][j >> 1], Lb[2 * qd][j >> 1], sel);
-            const bf16x8 bf = __builtin_bit_cast(bf16x8, b);
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bf, acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, bf, acc[j], 0, 0, 0);
-        }
-    };
-    for (int kb = 0; kb < nkb; kb += 2) {                       // nkb is even (validated by the host)
-        fetch(L[1], kb + 1);
-        block(L[0], kb);
-        if (kb + 2 < nkb) fetch(L[0], kb + 2);
-        block(L[1], kb + 1);
-    }
-    // rows 8-15 (lanes 32-63) hold the w2 contribution of heads 0-7: fold onto rows 0-7
-    float sv[4][8];                                             // [head 4 kq + i][pixel aoff + j], lanes kq < 2
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) sv[i][j] = acc[j][i] + __shfl_xor(acc[j][i], 32, 64);
-    // positional terms of this lane's pixels (half 0 adds them), requested before the reduction
-    float ev[4][8];
-    const bool fin = q == 0 && kq < 2;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = e0;
-        if (fin && half == 0 && px < hw) {
-            const float *ep = wim + (size_t)(4 * kq + i) * KT1 + in_dim + 1 + aoff;
-            e0 = *reinterpret_cast<const f32x4u *>(ep);
-            e1 = *reinterpret_cast<const f32x4u *>(ep + 4);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { ev[i][j] = e0[j]; ev[i][4 + j] = e1[j]; }
-    }
-    // fixed-order sum of the two channel quarters of this half, staged through LDS so that the unit
-    // writes its scores as whole rows (scattered 4-B stores straight from the MFMA layout were as
-    // many memory requests as the whole feature stream)
-    if (q == 1 && kq < 2) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float *d = red + ((size_t)T * heads + 4 * kq + i) * 128 + 8 * n;
-            *reinterpret_cast<float4 *>(d) = make_float4(sv[i][0], sv[i][1], sv[i][2], sv[i][3]);
-            *reinterpret_cast<float4 *>(d + 4) = make_float4(sv[i][4], sv[i][5], sv[i][6], sv[i][7]);
-        }
-    }
-    __syncthreads();
-    float *S = reinterpret_cast<float *>(wpart);                // [heads][256] by pixel; the weights are dead
-    if (fin) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float *r = red + ((size_t)T * heads + 4 * kq + i) * 128 + 8 * n;
-            const float4 t0 = *reinterpret_cast<const float4 *>(r), t1 = *reinterpret_cast<const float4 *>(r + 4);
-            const float add[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int p = aoff + j;
-                if (p >= own_from && p < hw) S[(4 * kq + i) * 256 + p] = (sv[i][j] + add[j]) + ev[i][j];
-            }
-        }
-    }
-    __syncthreads();
-    if (tid < hw) {
-#pragma unroll
-        for (int h = 0; h < heads; ++h)
-            sraw[(((size_t)im * 2 + half) * heads + h) * kSrawLd + 1 + tid] = S[h * 256 + tid];
-    }
-}
-
 // ---- launchers ---------------------------------------------------------------------------------------
 int launch_img_mean16(const void *img, int dt, int nimg, int in_dim, int hw, float *fm, hipStream_t st)
 {
@@ -648,26 +312,10 @@ int launch_img_mean16(const void *img, int dt, int nimg, int in_dim, int hw, flo
     return PTX_OK;
 }
 
-// bf16 features with the shapes of the path take the matrix-pipe pair (raw scores in `sraw`, softmax in
-// the gather prologue); anything else (fp16 storage, unusual in_dim / hw) the VALU / f32-MFMA pair
-static bool bf_pair(int dt, int in_dim, int hw, int heads)
-{
-    static const int off = getenv("PTX_IMG16_VALU") ? 1 : 0;
-    return !off && dt == 1 && heads == kMaxHeads && in_dim % 512 == 0 && in_dim / 2 <= kSbPad - 8 && hw > 128 && hw <= 255;
-}
-
 int launch_img_scores16(const void *img, int dt, const float *we, const float *qkv0, int nimg, int in_dim,
-                        int hw, int heads, int C, int KT1, int KT2p, float scale, float *sraw, float *gbuf,
-                        hipStream_t st)
+                        int hw, int heads, int C, int KT1, int KT2p, float scale, float *gbuf, hipStream_t st)
 {
     const unsigned short *p = static_cast<const unsigned short *>(img);
-    if (bf_pair(dt, in_dim, hw, heads)) {
-        const size_t lds = sizeof(float) * 2 * heads * 128 + sizeof(unsigned short) * 24 * kSbPad;
-        hipLaunchKernelGGL(k_img_scores_bf, dim3(nimg * 2), dim3(256), lds, st, p, we, qkv0, nimg, in_dim, hw, C, KT1,
-                           scale, sraw);
-        PTX_LAUNCHED("k_img_scores_bf");
-        return PTX_OK;
-    }
     PTX_REQUIRE(heads == kMaxHeads && in_dim % (8 * kScoreWaves) == 0 && in_dim / kScoreWaves <= 64,
                 "img scores: heads=%d in_dim=%d unsupported", heads, in_dim);
     PTX_REQUIRE(hw >= 4 && (hw >> 2) + ((hw & 3) ? 1 : 0) <= 64, "img scores: hw=%d (supported: 4..256 pixels)", hw);
@@ -683,23 +331,12 @@ int launch_img_scores16(const void *img, int dt, const float *we, const float *q
     return PTX_OK;
 }
 
-size_t img16_aparts_bytes(int nimg) { return (size_t)nimg * kApartsLd * sizeof(unsigned short); }
-
-int launch_img_gather16(const void *img, int dt, int nimg, int in_dim, int hw, int heads, int KT2p,
-                        const float *sraw, unsigned short *aparts, float *gbuf, hipStream_t st)
+int launch_img_gather16(const void *img, int dt, int nimg, int in_dim, int hw, int heads, int KT2p, float *gbuf,
+                        hipStream_t st)
 {
     PTX_REQUIRE(in_dim % kGatherCh == 0 && heads <= kMaxHeads, "img gather: in_dim=%d heads=%d", in_dim, heads);
+    PTX_REQUIRE(hw <= 256, "img gather: hw=%d (max 256 pixels)", hw);
     const unsigned short *p = static_cast<const unsigned short *>(img);
-    if (bf_pair(dt, in_dim, hw, heads)) {
-        hipLaunchKernelGGL(k_img_softmax_bf, dim3(nimg), dim3(512), 0, st, sraw, in_dim, hw, KT2p, gbuf, aparts);
-        PTX_LAUNCHED("k_img_softmax_bf");
-        static const int ng = getenv("PTX_GATHER_NG") ? atoi(getenv("PTX_GATHER_NG")) : 4;
-#define PTX_GN(N_) case N_: hipLaunchKernelGGL(k_img_gather_bf<N_>, dim3(nimg * (in_dim / (64 * N_))), dim3(256), 0, st, p, nimg, in_dim, hw, KT2p, aparts, gbuf); break;
-        switch (ng) { PTX_GN(1) PTX_GN(2) PTX_GN(8) default: PTX_GN(4) }
-#undef PTX_GN
-        PTX_LAUNCHED("k_img_gather_bf");
-        return PTX_OK;
-    }
     const int hwp = (hw + 3) & ~3;
     const size_t lds = sizeof(float) * (size_t)heads * hwp;
     const dim3 grid(nimg * (in_dim / kGatherCh));
