@@ -186,3 +186,26 @@ def test_back_to_back_calls_do_not_wait_for_the_gpu():
         assert torch.equal(a, b)
     for a, b in zip(want[1], got_back):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("side,V", [(13, 9), (12, 3), (11, 4), (16, 2)])
+def test_bf16_features_at_other_feature_map_sizes(side, V):
+    """bf16 features take the single-pass pooling kernel when 128 < H*W <= 255 (two pixel tiles per image,
+    the second one ragged: 169 = 128 + 41, 144 = 128 + 16; odd and even row lengths, image counts that are
+    not a multiple of the XCD count) and the three-pass kernels otherwise (121 and 256 pixels)."""
+    from oracle import oracle
+    from tests.gpu_util import t
+    cfg = PreshapeConfig(f"s{side}", B=2, N=3000, grid_size=4, dynamic_drop_radio=0.5, L=5, V=V, seed_base=40 + side,
+                         img_spacial_dim=side)
+    m, sd = build_module(cfg)
+    m = m.cuda()
+    pts, text, mask, img = make_scene_batch(cfg)
+    img_h = torch.from_numpy(img).to(torch.bfloat16)
+    ref = oracle.forward(sd, **oracle_kwargs(cfg), points=pts, text_feats=text, text_mask=mask,
+                         img_feat=img_h.float().numpy(), num_threads=1)
+    m._centers_override = torch.from_numpy(ref["centers"])
+    d = m.forward_debug([t(p) for p in pts], {"text_feats": t(text), "text_token_mask": t(mask)}, img_h.cuda())
+    assert_close(d["img_proxy"].cpu().numpy(), ref["img_proxy"], atol=5e-5, rtol=1e-5, what="img_proxy")
+    assert_close(d["transform"].cpu().numpy(), ref["transform"], atol=5e-5, rtol=1e-5, what="transform")
+    for b in range(cfg.B):
+        assert_close(d["outputs"][b].cpu().numpy(), ref["outputs"][b], atol=1e-4, what=f"scene {b}")
