@@ -36,6 +36,12 @@
 //   * phases of a unit (s_memtime, 2.35 GHz): waiting for the 16 loads 53 %, scores 8 %, softmax 7 %, weighted sums
 //     27 %, barriers 3 %; a unit lives 12.3 us, two are resident per CU (120 VGPRs x 8 waves), 1568 units on 512
 //     slots = 3.06 rounds, i.e. four: ~20 % of the launch is the last, nearly empty round
+//   * whole images as units (both tiles in sequence in one work-group, running sums rescaled, no partials and no
+//     merge launch; 128 VGPRs once the tile code was straight-line -- as a loop the allocator kept two copies of
+//     the 64 tile registers): 90 us vs 59 + 13 -- 784 units on 512 slots are two rounds of 32-us lifetimes
+//   * persistent, double-buffered variants (64-pixel tiles, or 16 waves x 32 channels) in isolation: the loads
+//     alone take 57 / 43 us instead of 33 (128-B runs per row; one work-group per CU), and time spent between
+//     issuing a prefetch and using it is simply added on top (scratch/pattern_bench.hip Q*/R*) -- not pursued
 #include <cstdlib>
 
 #include "common.h"

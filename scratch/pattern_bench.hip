@@ -191,6 +191,147 @@ __global__ __launch_bounds__(512) void kp(const unsigned short *img, const float
     } else if (acc == 0x12345678u) out[blockIdx.x] = 1.0f;
 }
 
+// ---- persistent double-buffered structure: 512 work-groups x 8 waves, each owns a contiguous range of
+// (image, 64-pixel tile) units; per tile a lane issues 8 loads (8 rows x 128 B per instruction); the next
+// tile's loads are in flight while the current one is consumed.  MODE 1 adds 3 barriers and ~DELAY of
+// dependent ALU work per tile (stand-in for the matrix / softmax phases).
+template <int MODE, int DELAY>
+__global__ __launch_bounds__(512) void kq(const unsigned short *img, int hw, int in_dim, int ntiles_total, float *out)
+{
+    __shared__ float lds[1024];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int n = lane & 15, kq_ = lane >> 4, win = n & 7, g = n >> 3;
+    const int W = gridDim.x;
+    const int t0 = (int)((long long)blockIdx.x * ntiles_total / W), t1 = (int)((long long)(blockIdx.x + 1) * ntiles_total / W);
+    u32x4 L[2][8];
+    auto fetch = [&](u32x4 (&Lb)[8], int t) {
+        const int im = t >> 2, tt = t & 3;
+        const unsigned short *r = img + ((size_t)im * in_dim + 64 * wid + 32 * g + 8 * kq_) * hw + 64 * tt + 8 * win;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) Lb[i] = __builtin_nontemporal_load(reinterpret_cast<const u4u2 *>(r + (size_t)i * hw));
+    };
+    unsigned acc = 0;
+    auto use = [&](const u32x4 (&Lb)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc ^= fold(Lb[i]);
+        if (MODE == 1) {
+            __syncthreads();
+            float x = __uint_as_float(acc & 0x3fffffffu);
+            for (int k = 0; k < DELAY; ++k) x = x * 1.0001f + 0.5f;      // dependent chain: ~4 cycles each
+            lds[threadIdx.x] = x;
+            __syncthreads();
+            acc ^= __float_as_uint(lds[(threadIdx.x * 7) & 511]);
+            __syncthreads();
+        }
+    };
+    int t = t0;
+    if (t < t1) fetch(L[0], t);
+    while (t < t1) {
+        if (t + 1 < t1) fetch(L[1], t + 1);
+        use(L[0]);
+        if (++t >= t1) break;
+        if (t + 1 < t1) fetch(L[0], t + 1);
+        use(L[1]);
+        ++t;
+    }
+    if (acc == 0x12345678u) out[blockIdx.x] = 1.0f;
+}
+
+// ---- same, 128-pixel tiles: 256 work-groups x 16 waves (1024 threads), wave = 32 channels, a lane issues 8
+// loads per tile (4 rows x 256 B per instruction), tiles of an image consecutive in one work-group
+template <int MODE, int DELAY>
+__global__ __launch_bounds__(1024) void kr(const unsigned short *img, int hw, int in_dim, int ntiles_total, float *out)
+{
+    __shared__ float lds[1024];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int n = lane & 15, kq_ = lane >> 4;
+    const int W = gridDim.x;
+    const int t0 = (int)((long long)blockIdx.x * ntiles_total / W), t1 = (int)((long long)(blockIdx.x + 1) * ntiles_total / W);
+    u32x4 L[2][8];
+    auto fetch = [&](u32x4 (&Lb)[8], int t) {
+        const int im = t >> 1, tt = t & 1;
+        const unsigned short *r = img + ((size_t)im * in_dim + 32 * wid + 8 * kq_) * hw + 128 * tt + 8 * n;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) Lb[i] = __builtin_nontemporal_load(reinterpret_cast<const u4u2 *>(r + (size_t)i * hw));
+    };
+    unsigned acc = 0;
+    auto use = [&](const u32x4 (&Lb)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc ^= fold(Lb[i]);
+        if (MODE == 1) {
+            __syncthreads();
+            float x = __uint_as_float(acc & 0x3fffffffu);
+            for (int k = 0; k < DELAY; ++k) x = x * 1.0001f + 0.5f;
+            lds[threadIdx.x] = x;
+            __syncthreads();
+            acc ^= __float_as_uint(lds[(threadIdx.x * 7) & 1023]);
+            __syncthreads();
+        }
+        if (MODE == 4) {        // no barrier at all: only a sleep between issuing the prefetch and using it
+            for (int k = 0; k < DELAY / 8; ++k) __builtin_amdgcn_s_sleep(2);
+        }
+        if (MODE == 3) {        // like 2, but the "work" is s_sleep: no VALU pressure while the prefetch is in flight
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            for (int k = 0; k < DELAY / 8; ++k) __builtin_amdgcn_s_sleep(2);      // 2 x 64 cycles
+            lds[threadIdx.x] = __uint_as_float(acc);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            acc ^= __float_as_uint(lds[(threadIdx.x * 7) & 1023]);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        if (MODE == 2) {        // barrier that orders LDS only: global loads stay in flight across it
+#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+            LDS_BARRIER();
+            float x = __uint_as_float(acc & 0x3fffffffu);
+            for (int k = 0; k < DELAY; ++k) x = x * 1.0001f + 0.5f;
+            lds[threadIdx.x] = x;
+            LDS_BARRIER();
+            acc ^= __float_as_uint(lds[(threadIdx.x * 7) & 1023]);
+            LDS_BARRIER();
+        }
+    };
+    // the prefetch is UNCONDITIONAL (the last one re-reads the last tile): behind a branch the compiler cannot
+    // count the loads in flight and waits for all of them (s_waitcnt vmcnt(0)) before using the current tile
+    int t = t0;
+    if (t < t1) fetch(L[0], t);
+    while (t < t1) {
+        fetch(L[1], min(t + 1, t1 - 1));
+        use(L[0]);
+        if (++t >= t1) break;
+        fetch(L[0], min(t + 1, t1 - 1));
+        use(L[1]);
+        ++t;
+    }
+    if (acc == 0x12345678u) out[blockIdx.x] = 1.0f;
+}
+
+template <int MODE, int DELAY>
+float runr(const unsigned short *img, int hw, int in_dim, int nimg, float *out, int iters, int nwg)
+{
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((kr<MODE, DELAY>), dim3(nwg), dim3(1024), 0, 0, img, hw, in_dim, nimg * 2, out);
+    CK(hipEventRecord(a));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((kr<MODE, DELAY>), dim3(nwg), dim3(1024), 0, 0, img, hw, in_dim, nimg * 2, out);
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    return ms / iters * 1e3f;
+}
+
+template <int MODE, int DELAY>
+float runq(const unsigned short *img, int hw, int in_dim, int nimg, float *out, int iters, int nwg)
+{
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((kq<MODE, DELAY>), dim3(nwg), dim3(512), 0, 0, img, hw, in_dim, nimg * 4, out);
+    CK(hipEventRecord(a));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((kq<MODE, DELAY>), dim3(nwg), dim3(512), 0, 0, img, hw, in_dim, nimg * 4, out);
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    return ms / iters * 1e3f;
+}
+
 template <int MODE>
 float runp(const unsigned short *img, const float *we, int hw, int in_dim, int nimg, float *out, int iters)
 {
@@ -270,5 +411,21 @@ int main()
     t = runp<1>(img, we, hw, in_dim, nimg, outp, 20); printf("P1  + 2 barriers + 16 KB out per unit    : %7.1f us\n", t);
     t = runp<2>(img, we, hw, in_dim, nimg, outp, 20); printf("P2 = P0 with both tiles on one XCD       : %7.1f us\n", t);
     t = runp<3>(img, we, hw, in_dim, nimg, outp, 20); printf("P3 = P1 with both tiles on one XCD       : %7.1f us\n", t);
+    t = runq<0, 0>(img, hw, in_dim, nimg, outp, 20, 512);    printf("Q0 persistent 512 WGs, 64-px tiles, loads only        : %7.1f us\n", t);
+    t = runq<1, 500>(img, hw, in_dim, nimg, outp, 20, 512);  printf("Q1  + 3 barriers + ~0.9 us of dependent work per tile  : %7.1f us\n", t);
+    t = runq<1, 1000>(img, hw, in_dim, nimg, outp, 20, 512); printf("Q2  + 3 barriers + ~1.7 us of dependent work per tile  : %7.1f us\n", t);
+    t = runq<1, 2000>(img, hw, in_dim, nimg, outp, 20, 512); printf("Q3  + 3 barriers + ~3.4 us of dependent work per tile  : %7.1f us\n", t);
+    t = runq<0, 0>(img, hw, in_dim, nimg, outp, 20, 256);    printf("Q4 persistent 256 WGs, loads only                      : %7.1f us\n", t);
+    t = runq<1, 1000>(img, hw, in_dim, nimg, outp, 20, 256); printf("Q5 256 WGs + barriers + ~1.7 us per tile                : %7.1f us\n", t);
+    t = runr<0, 0>(img, hw, in_dim, nimg, outp, 20, 256);    printf("R0 persistent 256 WGs x 16 waves, 128-px tiles, loads   : %7.1f us\n", t);
+    t = runr<1, 500>(img, hw, in_dim, nimg, outp, 20, 256);  printf("R1  + 3 barriers + ~0.9 us per tile                     : %7.1f us\n", t);
+    t = runr<1, 1000>(img, hw, in_dim, nimg, outp, 20, 256); printf("R2  + 3 barriers + ~1.7 us per tile                     : %7.1f us\n", t);
+    t = runr<1, 2000>(img, hw, in_dim, nimg, outp, 20, 256); printf("R3  + 3 barriers + ~3.4 us per tile                     : %7.1f us\n", t);
+    t = runr<2, 500>(img, hw, in_dim, nimg, outp, 20, 256);  printf("R4 = R1 with LDS-only barriers (loads stay in flight)    : %7.1f us\n", t);
+    t = runr<2, 1000>(img, hw, in_dim, nimg, outp, 20, 256); printf("R5 = R2 with LDS-only barriers                          : %7.1f us\n", t);
+    t = runr<2, 2000>(img, hw, in_dim, nimg, outp, 20, 256); printf("R6 = R3 with LDS-only barriers                          : %7.1f us\n", t);
+    t = runr<3, 500>(img, hw, in_dim, nimg, outp, 20, 256);  printf("R7 LDS-only barriers + s_sleep ~3.3 us per tile           : %7.1f us\n", t);
+    t = runr<3, 1000>(img, hw, in_dim, nimg, outp, 20, 256); printf("R8 LDS-only barriers + s_sleep ~6.7 us per tile           : %7.1f us\n", t);
+    t = runr<4, 500>(img, hw, in_dim, nimg, outp, 20, 256);  printf("R9 no barriers, s_sleep ~3.3 us per tile                  : %7.1f us\n", t);
     return 0;
 }
