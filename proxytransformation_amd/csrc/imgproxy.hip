@@ -215,6 +215,9 @@ int launch_img_scores(const float *img, const float *we, const float *qkv0, int 
 // pixel 16*kb + 4*kq straight from global (no LDS staging of the image), MFMA step t contracts
 // pixel 16*kb + 4*kq + t; the B operand a_h(p) (h = l & 15, zero for h >= heads) comes from a
 // 7 KB LDS copy of the softmax output.  fp32 in / fp32 accumulate: exact products.
+// (The quad-contiguous map of imgpool.hip -- 4 channel rows x 64 pixels per MFMA, 2.25x the f32 matrix work for
+// loads that stream at full rate -- was measured at 93 us against 92 for this kernel: with the f32 MFMA at
+// 1/16 of the bf16 rate the pass turns matrix-bound.)
 constexpr int kGatherCh = 64;      // channels per work-group (4 waves x 16)
 
 __global__ __launch_bounds__(256) void k_img_gather(const float *__restrict__ img, int in_dim, int hw,
