@@ -321,7 +321,7 @@ struct SelectArgs {
     int M, K, Mt, Mk, Kd, N;
 };
 
-template <int P>   // points per lane of the FPS wave (64 * P >= Mt)
+template <int P>   // points per thread of the FPS (256 * P >= Mt)
 __global__ __launch_bounds__(256) void k_select(SelectArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -336,6 +336,8 @@ __global__ __launch_bounds__(256) void k_select(SelectArgs a)
     int *s_keep = s_flag + Mt;                                    // Mk
     int *s_picks = s_keep + Mk;                                   // Kd
     int *s_hist = s_picks + (Kd > 0 ? Kd : 1);                    // 64
+    float *s_candv = reinterpret_cast<float *>(s_hist + 64);      // [2][4] FPS candidates of the four waves
+    int *s_candi = reinterpret_cast<int *>(s_candv + 8);          // [2][4]
 
     const int32_t *pc = a.pad_count + (size_t)b * M;
     // ---- 1. ordering
@@ -384,24 +386,27 @@ __global__ __launch_bounds__(256) void k_select(SelectArgs a)
     }
     __syncthreads();
 
-    // ---- 2. farthest point sampling: sequential in k, so it runs in ONE wave with no barrier.
-    // Lane l keeps points l*P .. l*P+P-1 (blocked: lane order == index order) and their running
-    // minimum distances in registers; per pick: P distance updates, a DPP row-rotate max, one
-    // ballot.  First-max tie-break (PRE:613): in-lane strict '>', across lanes lowest set ballot bit.
+    // ---- 2. farthest point sampling: sequential in k.  The four waves (one per SIMD) each keep a quarter of
+    // the points and their running minimum distances in registers: thread g holds points g*P .. g*P+P-1 (blocked:
+    // thread order == index order).  Per pick: P distance updates, a DPP row-rotate max and one ballot per wave,
+    // the four wave candidates exchanged through LDS with one barrier, and every wave takes the same decision.
+    // First-max tie-break (PRE:613): in-lane strict '>', across lanes the lowest set ballot bit, across waves the
+    // lowest wave.  (One wave with all points, no barrier: 0.37 us per pick at Mt = 359 but 1.04 us at the
+    // shipped configuration's Mt = 1210 -- VALU-bound on one SIMD, 540 us for its 519 picks.)
     const int kn = Kd < Mt ? Kd : Mt;                                            // PRE:595
-    if (wid == 0) {
-        // the whole scene waits on this one latency-bound wave while bandwidth-bound kernels of the
-        // image branch share the CU: give it issue priority
+    {
+        // the whole scene waits on this latency-bound loop while bandwidth-bound kernels of the image branch
+        // share the CU: give it issue priority
         __builtin_amdgcn_s_setprio(3);
         float px[P], py[P], pz[P], mind[P];
 #pragma unroll
         for (int i = 0; i < P; ++i) {
-            const int t = lane * P + i;
+            const int t = tid * P + i;
             if (t < Mt) { px[i] = sx[t]; py[i] = sy[t]; pz[i] = sz[t]; mind[i] = INFINITY; }
             else        { px[i] = py[i] = pz[i] = 0.0f; mind[i] = -1.0f; }      // never the maximum
         }
         int last = 0;
-        if (lane == 0 && Kd > 0) s_picks[0] = 0;
+        if (tid == 0 && Kd > 0) s_picks[0] = 0;
         for (int k = 1; k < kn; ++k) {
             const float lx = sx[last], ly = sy[last], lz = sz[last];
             float bv = -1.0f; int bi = 0;
@@ -415,8 +420,18 @@ __global__ __launch_bounds__(256) void k_select(SelectArgs a)
             const float gmax = wave_max_dpp(bv);
             const unsigned long long who = __ballot(bv == gmax);
             const int leader = __ffsll((long long)who) - 1;
-            last = leader * P + __builtin_amdgcn_readlane(bi, leader);
-            if (lane == 0) s_picks[k] = last;
+            const int cand = (wid * 64 + leader) * P + __builtin_amdgcn_readlane(bi, leader);
+            const int par = (k & 1) * 4;                         // double-buffered: one barrier per pick
+            if (lane == 0) { s_candv[par + wid] = gmax; s_candi[par + wid] = cand; }
+            __syncthreads();
+            float best = s_candv[par];
+            last = s_candi[par];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const float v = s_candv[par + w];
+                if (v > best) { best = v; last = s_candi[par + w]; }
+            }
+            if (tid == 0) s_picks[k] = last;
         }
         __builtin_amdgcn_s_setprio(0);
     }
@@ -496,7 +511,7 @@ __global__ __launch_bounds__(256) void k_select_slots(SelectArgs a)
 static size_t select_lds_bytes(const PtxShape &s)
 {
     const int Kd = s.Mt - s.Mk;
-    return sizeof(int) * ((size_t)s.Mt * 5 + s.Mk + (Kd > 0 ? Kd : 1) + 64 + 16);
+    return sizeof(int) * ((size_t)s.Mt * 5 + s.Mk + (Kd > 0 ? Kd : 1) + 64 + 16 + 16);
 }
 
 int launch_select(const PtxShape &s, const int32_t *idx, const float *centers, const float *cluster,
@@ -509,7 +524,7 @@ int launch_select(const PtxShape &s, const int32_t *idx, const float *centers, c
                  s.Mk, s.Mt - s.Mk, s.N};
     const size_t lds = select_lds_bytes(s);
     PTX_REQUIRE(lds <= 160 * 1024, "select: Mt=%d needs %zu B of LDS (> 160 KiB)", s.Mt, lds);
-    const int per = cdiv(s.Mt, 64);
+    const int per = cdiv(s.Mt, 256);
     const dim3 grid(s.B), block(256);
 #define PTX_SEL(P_)                                                                          \
     do {                                                                                     \
@@ -518,11 +533,16 @@ int launch_select(const PtxShape &s, const int32_t *idx, const float *centers, c
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(k_select<P_>, grid, block, lds, st, a);                           \
     } while (0)
-    if (per <= 8) PTX_SEL(8);
+    if (per <= 1) PTX_SEL(1);
+    else if (per <= 2) PTX_SEL(2);
+    else if (per <= 3) PTX_SEL(3);
+    else if (per <= 4) PTX_SEL(4);
+    else if (per <= 5) PTX_SEL(5);
+    else if (per <= 6) PTX_SEL(6);
+    else if (per <= 8) PTX_SEL(8);
+    else if (per <= 12) PTX_SEL(12);
     else if (per <= 16) PTX_SEL(16);
-    else if (per <= 32) PTX_SEL(32);
-    else if (per <= 64) PTX_SEL(64);
-    else { set_error("select: Mt=%d too large (max %d)", s.Mt, 64 * 64); return PTX_EINVAL; }
+    else { set_error("select: Mt=%d too large (max %d)", s.Mt, 256 * 16); return PTX_EINVAL; }
 #undef PTX_SEL
     PTX_LAUNCHED("k_select");
     hipLaunchKernelGGL(k_select_slots, dim3(cdiv(s.Mt * s.K, 256), s.B), dim3(256), 0, st, a);
