@@ -209,3 +209,36 @@ def test_bf16_features_at_other_feature_map_sizes(side, V):
     assert_close(d["transform"].cpu().numpy(), ref["transform"], atol=5e-5, rtol=1e-5, what="transform")
     for b in range(cfg.B):
         assert_close(d["outputs"][b].cpu().numpy(), ref["outputs"][b], atol=1e-4, what=f"scene {b}")
+
+
+@pytest.mark.parametrize("gs", [3, 7, 9, 10, 11, 13, 14, 15, 16])
+def test_cluster_selection_at_every_grid_size_class(gs):
+    """ptx_select_clusters against the C oracle on synthetic ball-query results: every points-per-thread
+    variant of the four-wave farthest point sampling (Mt from 19 to 2868: 1, 2, 3, 4, 5 (gs = 12, covered by
+    the shipped-shape test), 6.., 8, 12 per thread), padding counts full of ties, coincident centres (ties in
+    the FPS maximum), bit-identical order / picks / keep / kept idx / drop idx."""
+    from oracle import oracle
+    from tests.gpu_util import Stages, t
+    cfg = PreshapeConfig(f"sel{gs}", B=2, N=4000, grid_size=gs, dynamic_drop_radio=0.55, L=2, V=1, seed_base=900 + gs)
+    m, _ = build_module(cfg)
+    m = m.cuda()
+    st = Stages(m, cfg.B, cfg.N, cfg.L, cfg.V)
+    M, K, Mt, Mk = cfg.M, cfg.num_sub, cfg.Mt, cfg.M_keep
+    rng = np.random.default_rng(gs)
+    idx = rng.integers(0, cfg.N, size=(cfg.B, M, K)).astype(np.int64)
+    fill = rng.integers(0, K + 1, size=(cfg.B, M))                  # slots used per cluster: many equal counts
+    idx[np.arange(K)[None, None, :] >= fill[:, :, None]] = -1
+    centers = (rng.random((cfg.B, M, 3)) * np.array([12, 12, 9])).astype(np.float32)
+    centers[:, 5::17] = centers[:, 4::17][:, :centers[:, 5::17].shape[1]]       # coincident centres
+    cluster = rng.random((cfg.B, M, K, 3)).astype(np.float32)
+    ref = oracle.select_clusters(idx, centers, Mt, Mk)
+    o = st.select(t(idx, torch.int32), t(centers), t(cluster), t(ref["pad_counts"], torch.int32))
+    for k in ("order", "picks", "keep"):
+        assert np.array_equal(o[k].cpu().numpy().astype(np.int64), ref[k]), k
+    order, keep, picks = ref["order"], ref["keep"], ref["picks"]
+    for b in range(cfg.B):
+        src = order[b][keep[b]]
+        assert np.array_equal(o["kidx"][b].cpu().numpy().astype(np.int64), idx[b][src])
+        assert np.array_equal(o["kcenter"][b].cpu().numpy(), centers[b][src])
+        want_drop = np.where(picks[b][:, None] >= 0, idx[b][order[b][np.maximum(picks[b], 0)]], -1).reshape(-1)
+        assert np.array_equal(o["drop_idx"][b].cpu().numpy().astype(np.int64), want_drop)
