@@ -610,11 +610,10 @@ int ptx_forward(const PtxShape *s, const PtxWeights *w, const void *prep, const 
     const int M = S.grid_size * S.grid_size * S.grid_size, B = S.B, K = S.K, Kd = S.Mt - S.Mk;
 
     // ---- two streams.  The image branch (PRE:449) only depends on img_feat and is the critical
-    // path (three streaming passes over 90 MB per scene): it stays on the CALLER's stream together
+    // path (two or three streaming passes over 45 / 90 MB per scene): it stays on the CALLER's stream together
     // with everything after the join, so no cross-stream hop sits on the critical path.  The
-    // clustering chain (PRE:430-437) runs on the library's high-priority stream `cs`, finishes long
-    // before the image branch and its join event is already complete when the caller's stream
-    // reaches it.  (Running the image branch as two slices of scenes on two streams, to hide its
+    // clustering chain (PRE:430-437) runs on the library's high-priority stream `cs` and finishes at about
+    // the same time as the image branch (cfg2 shape, bf16 features: both ~185 us).  (Running the image branch as two slices of scenes on two streams, to hide its
     // small table GEMMs behind the other slice's streaming, was measured slower: 7.85k vs 8.1k
     // scenes/s at cfg2, B = 4.)
     SideStream *side = nullptr;
