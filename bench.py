@@ -17,7 +17,7 @@ closed by a full device synchronise, so every step's GPU work is inside it.
 Scenes are sharded by scene id with no data-path collective (weak scaling).
 
 Rank 0 prints ONE JSON line.  Extra objects:
-  roofline      dominant kernel (the one pass over img_feat after the means: k_img_pool_bf for bf16-stored
+  roofline      dominant kernel (the one pass over img_feat after the means: k_img_pool for bf16-stored
                 features, k_img_scores for fp32): algorithmic
                 bytes per launch / average launch duration, timed with HIP events recorded by
                 the library on the kernel's own stream during the timed steps; `traffic` = HBM
@@ -61,7 +61,7 @@ def parse():
                          "either way); the fp32-feature rate is reported next to it")
     ap.add_argument("--time-kernel", default="img_pass2",
                     help="launch site timed for the roofline object (img_pass2 = the dominant stream over img_feat "
-                         "after the mean pass: k_img_pool_bf for bf16 features, k_img_scores for fp32)")
+                         "after the mean pass: k_img_pool for bf16 features, k_img_scores for fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scenes", type=int, default=None, help="scenes in the CPU baseline sample")
     ap.add_argument("--breakdown", action="store_true", help="print per-kernel event timings to stderr")
@@ -89,7 +89,7 @@ def algorithmic_bytes(cfg, B, name, img_itemsize=4, dt="f32"):
         "k_img_mean": img, "img_pass2": img,
         # bf16: k_img_pool_merge reads the two tiles' (G, e, m, l) and writes the [g | a] rows
         "img_pass3": (B * cfg.V * 8 * (2 * (cfg.input_dim + 130) + cfg.input_dim + cfg.img_spacial_dim ** 2 + 1) * 4
-                      if dt == "bf16" else img),
+                      if dt in ("bf16", "f16") else img),
         "k_minmax": B * cfg.N * 12,
         "k_affine<compact>": B * cfg.N * (12 + 4 + 12),
         "k_tile_count": B * cfg.N * 4,
@@ -99,8 +99,8 @@ def algorithmic_bytes(cfg, B, name, img_itemsize=4, dt="f32"):
 
 # the kernel behind a launch site depends on the storage type of the image features
 SITE_KERNEL = {
-    "img_pass2": {"bf16": "k_img_pool_bf", "f32": "k_img_scores", "f16": "k_img_scores16"},
-    "img_pass3": {"bf16": "k_img_pool_merge", "f32": "k_img_gather", "f16": "k_img_gather16"},
+    "img_pass2": {"bf16": "k_img_pool", "f32": "k_img_scores", "f16": "k_img_pool"},
+    "img_pass3": {"bf16": "k_img_pool_merge", "f32": "k_img_gather", "f16": "k_img_pool_merge"},
     "k_img_mean": {"bf16": "k_img_mean16", "f32": "k_img_mean", "f16": "k_img_mean16"},
 }
 

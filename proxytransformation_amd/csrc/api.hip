@@ -25,7 +25,7 @@ void set_error(const char *fmt, ...)
 // ---- optional per-kernel timing (bench.py's roofline leg) -----------------------------------------
 // One launch site of the forward can be bracketed by HIP events recorded on the stream the kernel
 // is launched on; ptx_timing_read() returns launches and summed milliseconds.  Off by default.
-// img_pass2 / img_pass3 are the launch sites after the mean pass: k_img_pool_bf / k_img_pool_merge for bf16
+// img_pass2 / img_pass3 are the launch sites after the mean pass: k_img_pool / k_img_pool_merge for bf16
 // features, k_img_scores / k_img_gather for fp32, k_img_scores16 / k_img_gather16 for fp16.
 static const char *const kKernelNames[] = {
     "memset", "k_minmax", "k_ball_query<grid>", "k_slot_net<offset>", "k_ball_query", "k_select",
@@ -227,7 +227,7 @@ static int run_img_proxy(const PtxShape &s, const PtxWeights &w, const float *pr
                                                         P.KT2p, attn_scale(hd), gbuf, st));
         PTX_TIMED(KID_IMG_GATHER, st, launch_img_gather(img, nimg, s.in_dim, s.hw, s.heads, P.KT2p, gbuf, st));
     } else if (img_pool_supported(dt, s.in_dim, s.hw, s.heads)) {
-        PTX_TIMED(KID_IMG_SCORES, st, launch_img_pool(img_any, we, nimg, s.in_dim, s.hw, P.KT1, at<float>(ws, L.pool), st));
+        PTX_TIMED(KID_IMG_SCORES, st, launch_img_pool(img_any, dt, we, nimg, s.in_dim, s.hw, P.KT1, at<float>(ws, L.pool), st));
         PTX_TIMED(KID_IMG_GATHER, st, launch_img_pool_merge(at<float>(ws, L.pool), qkv0, nimg, s.in_dim, s.hw, C, P.KT2p,
                                                             attn_scale(hd), gbuf, st));
     } else {

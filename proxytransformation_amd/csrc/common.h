@@ -202,10 +202,10 @@ int launch_img_scores16(const void *img, int dt, const float *we, const float *q
                         int hw, int heads, int C, int KT1, int KT2p, float scale, float *gbuf, hipStream_t st);
 int launch_img_gather16(const void *img, int dt, int nimg, int in_dim, int hw, int heads, int KT2p, float *gbuf,
                         hipStream_t st);
-// imgpool.hip: single-pass attention pooling of bf16 features (scores + softmax numerators + weighted sums)
+// imgpool.hip: single-pass attention pooling of bf16 / fp16 features (scores + softmax numerators + weighted sums)
 bool img_pool_supported(int dt, int in_dim, int hw, int heads);
 size_t img_pool_bytes(int nimg, int in_dim);
-int launch_img_pool(const void *img, const float *we, int nimg, int in_dim, int hw, int KT1, float *scratch,
+int launch_img_pool(const void *img, int dt, const float *we, int nimg, int in_dim, int hw, int KT1, float *scratch,
                     hipStream_t st);
 int launch_img_pool_merge(const float *scratch, const float *qkv0, int nimg, int in_dim, int hw, int C, int KT2p,
                           float scale, float *gbuf, hipStream_t st);

@@ -57,15 +57,48 @@ constexpr int kPoolHeads = 8;
 constexpr int kPoolWPad = 544;          // LDS row stride (elements) of the split weights: rows 16 words apart mod 64
 constexpr int kPoolPPad = 136;          // LDS row stride (elements) of the split numerators (128 pixels + 8)
 
-// the exact three-way bf16 split x = x1 + x2 + x3 (8 significant bits each)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// The exact three-way split x = x1 + x2 + x3 of an fp32 operand into the storage type of the features
+// (DT 1 = bf16: truncation, 3 x 8 significant bits; DT 2 = fp16: round to nearest, 3 x 11 bits).  fp16 has
+// fp32's precision to spare but not its range: fp16 operands are first scaled by a power of two (exact) so
+// that the largest one sits at 2^13..2^14 -- the third part of anything that matters then stays above the
+// fp16 subnormal resolution -- and the MFMA result is scaled back.
+template <int DT>
 __device__ __forceinline__ void split3(float x, unsigned short &q1, unsigned short &q2, unsigned short &q3)
 {
-    const unsigned int u1 = __float_as_uint(x) & 0xffff0000u;
-    const float r1 = x - __uint_as_float(u1);
-    const unsigned int u2 = __float_as_uint(r1) & 0xffff0000u;
-    const float r2 = r1 - __uint_as_float(u2);
-    q1 = (unsigned short)(u1 >> 16); q2 = (unsigned short)(u2 >> 16); q3 = (unsigned short)(__float_as_uint(r2) >> 16);
+    if (DT == 1) {
+        const unsigned int u1 = __float_as_uint(x) & 0xffff0000u;
+        const float r1 = x - __uint_as_float(u1);
+        const unsigned int u2 = __float_as_uint(r1) & 0xffff0000u;
+        const float r2 = r1 - __uint_as_float(u2);
+        q1 = (unsigned short)(u1 >> 16); q2 = (unsigned short)(u2 >> 16); q3 = (unsigned short)(__float_as_uint(r2) >> 16);
+    } else {
+        const _Float16 h1 = (_Float16)x;
+        const float r1 = x - (float)h1;
+        const _Float16 h2 = (_Float16)r1;
+        const float r2 = r1 - (float)h2;
+        const _Float16 h3 = (_Float16)r2;
+        q1 = __builtin_bit_cast(unsigned short, h1); q2 = __builtin_bit_cast(unsigned short, h2);
+        q3 = __builtin_bit_cast(unsigned short, h3);
+    }
 }
+
+template <int DT>
+__device__ __forceinline__ f32x4 mfma16(const u32x4 &a, const u32x4 &b, const f32x4 &c)
+{
+    if (DT == 1) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// exponent k of the power-of-two scale 2^k that puts |x| <= amax at 2^13 .. 2^14 (0 for amax = 0 / non-finite)
+__device__ __forceinline__ int pow2_scale_exp(float amax)
+{
+    const int e = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 127;           // floor(log2 amax) for normal numbers
+    return (amax > 0.0f && e > -100 && e < 100) ? 13 - e : 0;
+}
+__device__ __forceinline__ float pow2f(int k) { return __uint_as_float((unsigned int)(127 + k) << 23); }
+constexpr float kPoolEScale = 16384.0f;       // fp16: softmax numerators (<= 1) are split at 2^14
 
 // 128-bit logical right shift by k elements of 16 bits (k = 0..7)
 __device__ __forceinline__ u32x4 shr_elems(const u32x4 &v, int k)
@@ -93,7 +126,8 @@ struct PoolArgs {
     float *ML;          // [nimg][2][heads][2]       m_tile, l_tile
 };
 
-__global__ __launch_bounds__(512) void k_img_pool_bf(PoolArgs a)
+template <int DT>   // storage type of the features: 1 = bf16, 2 = fp16
+__global__ __launch_bounds__(512) void k_img_pool(PoolArgs a)
 {
     constexpr int heads = kPoolHeads;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -147,15 +181,24 @@ __global__ __launch_bounds__(512) void k_img_pool_bf(PoolArgs a)
         const int p = 128 * T + lane + 64 * u;
         ev[u] = p < hw ? wim[(size_t)wid * a.KT1 + in_dim + 1 + p] : 0.0f;
     }
-    // head weights of this image -> three bf16 parts in LDS (thread = channel, all loads first)
+    // head weights of this image -> three 16-bit parts in LDS.  Thread = channel, so wave w splits exactly the 64
+    // channels it contracts in stage 1 (in_dim = 512 = one channel per thread) and, for fp16, scales them by a
+    // power of two of its own: no other wave needs to know it (all loads first).
+    // (the inverse scales live in the padding of the weight rows in LDS, 4 B per (head, wave): eight more live
+    // registers through stage 1 would cost the second work-group per CU)
     for (int c = tid; c < in_dim; c += 512) {
         float wv[heads];
 #pragma unroll
         for (int h = 0; h < heads; ++h) wv[h] = wim[(size_t)h * a.KT1 + c];
 #pragma unroll
         for (int h = 0; h < heads; ++h) {
+            if (DT == 2) {
+                const int k = pow2_scale_exp(wave_max(fabsf(wv[h])));
+                wv[h] *= pow2f(k);
+                if (lane == 0) *reinterpret_cast<float *>(wpart + (size_t)h * kPoolWPad + in_dim + 2 * wid) = pow2f(-k);
+            }
             unsigned short q1, q2, q3;
-            split3(wv[h], q1, q2, q3);
+            split3<DT>(wv[h], q1, q2, q3);
             wpart[(size_t)h * kPoolWPad + c] = q1;
             wpart[(size_t)(8 + h) * kPoolWPad + c] = q2;
             wpart[(size_t)(16 + h) * kPoolWPad + c] = q3;
@@ -171,12 +214,12 @@ __global__ __launch_bounds__(512) void k_img_pool_bf(PoolArgs a)
         const bool lo = n < heads;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            bf16x8 af[3];
+            u32x4 af[3];
 #pragma unroll
             for (int pt = 0; pt < 3; ++pt) {
                 u32x4 t = *reinterpret_cast<const u32x4 *>(wpart + (size_t)(pt * 8 + (n & 7)) * kPoolWPad + cw + 32 * kb + 8 * kq);
                 if (!lo) t = u32x4{0u, 0u, 0u, 0u};
-                af[pt] = __builtin_bit_cast(bf16x8, t);
+                af[pt] = t;
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -184,17 +227,18 @@ __global__ __launch_bounds__(512) void k_img_pool_bf(PoolArgs a)
                 u32x4 b;
 #pragma unroll
                 for (int qd = 0; qd < 4; ++qd) b[qd] = __builtin_amdgcn_perm(L[kb][2 * qd + 1][j >> 1], L[kb][2 * qd][j >> 1], sel);
-                const bf16x8 bf = __builtin_bit_cast(bf16x8, b);
 #pragma unroll
-                for (int pt = 0; pt < 3; ++pt) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[pt], bf, acc[j], 0, 0, 0);
+                for (int pt = 0; pt < 3; ++pt) acc[j] = mfma16<DT>(af[pt], b, acc[j]);
             }
         }
         if (kq < 2) {                                           // rows 4 kq + r = heads
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
+                float us = 1.0f;                                // undo this wave's weight scale
+                if (DT == 2) us = *reinterpret_cast<const float *>(wpart + (size_t)(4 * kq + r) * kPoolWPad + in_dim + 2 * wid);
                 float *d = partial + ((size_t)wid * heads + 4 * kq + r) * 128 + 8 * n;
-                *reinterpret_cast<float4 *>(d) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
-                *reinterpret_cast<float4 *>(d + 4) = make_float4(acc[4][r], acc[5][r], acc[6][r], acc[7][r]);
+                *reinterpret_cast<float4 *>(d) = make_float4(acc[0][r] * us, acc[1][r] * us, acc[2][r] * us, acc[3][r] * us);
+                *reinterpret_cast<float4 *>(d + 4) = make_float4(acc[4][r] * us, acc[5][r] * us, acc[6][r] * us, acc[7][r] * us);
             }
         }
     }
@@ -226,7 +270,7 @@ __global__ __launch_bounds__(512) void k_img_pool_bf(PoolArgs a)
             const int p = lane + 64 * u;
             a.Ps[((size_t)slab * heads + h) * 128 + p] = e[u];
             unsigned short q1, q2, q3;
-            split3(e[u], q1, q2, q3);
+            split3<DT>(DT == 2 ? e[u] * kPoolEScale : e[u], q1, q2, q3);
             parts[(size_t)h * kPoolPPad + p] = q1;
             parts[(size_t)(8 + h) * kPoolPPad + p] = q2;
             parts[(size_t)(16 + h) * kPoolPPad + p] = q3;
@@ -241,13 +285,12 @@ __global__ __launch_bounds__(512) void k_img_pool_bf(PoolArgs a)
     {
         const int ps = n & 3, hh = n >> 2;                      // also cr = n >> 2 for the A side
         const int src = ((ps + 4 * kq) + 16 * (n >> 2)) * 4;    // byte index of the source lane
-        bf16x8 bfr[2][3];
+        u32x4 bfr[2][3];
 #pragma unroll
         for (int hg = 0; hg < 2; ++hg)
 #pragma unroll
             for (int pt = 0; pt < 3; ++pt)
-                bfr[hg][pt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(
-                    parts + (size_t)(pt * 8 + 4 * hg + hh) * kPoolPPad + 8 * (ps + 4 * kq)));
+                bfr[hg][pt] = *reinterpret_cast<const u32x4 *>(parts + (size_t)(pt * 8 + 4 * hg + hh) * kPoolPPad + 8 * (ps + 4 * kq));
         float *G = partial;                                     // [heads][in_dim]; the slices are dead (barrier above)
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -256,18 +299,17 @@ __global__ __launch_bounds__(512) void k_img_pool_bf(PoolArgs a)
                 u32x4 av;
 #pragma unroll
                 for (int d = 0; d < 4; ++d) av[d] = (unsigned int)__builtin_amdgcn_ds_bpermute(src, (int)L[kb][i][d]);
-                const bf16x8 af = __builtin_bit_cast(bf16x8, av);
 #pragma unroll
                 for (int hg = 0; hg < 2; ++hg) {
                     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int pt = 0; pt < 3; ++pt) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[hg][pt], acc, 0, 0, 0);
+                    for (int pt = 0; pt < 3; ++pt) acc = mfma16<DT>(av, bfr[hg][pt], acc);
                     // D[row 4 kq + r][col n]: row = (channel sub-block kq, set r), col = (head hh, set ps): keep r == ps
                     float x = ps == 0 ? acc[0] : ps == 1 ? acc[1] : ps == 2 ? acc[2] : acc[3];
                     x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
                     x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
                     // channel of this row: cw + 32 kb + 8 kq + i; one lane of the quad stores it
-                    if (ps == 0) G[(size_t)(4 * hg + hh) * in_dim + cw + 32 * kb + 8 * kq + i] = x;
+                    if (ps == 0) G[(size_t)(4 * hg + hh) * in_dim + cw + 32 * kb + 8 * kq + i] = DT == 2 ? x * (1.0f / kPoolEScale) : x;
                 }
             }
     }
@@ -355,7 +397,7 @@ __global__ __launch_bounds__(256) void k_img_pool_merge(MergeArgs a)
 bool img_pool_supported(int dt, int in_dim, int hw, int heads)
 {
     static const int off = getenv("PTX_IMG_POOL_OFF") ? 1 : 0;
-    return !off && dt == 1 && heads == kPoolHeads && in_dim == 512 && hw > 128 && hw <= 255;
+    return !off && (dt == 1 || dt == 2) && heads == kPoolHeads && in_dim == 512 && hw > 128 && hw <= 255;
 }
 
 size_t img_pool_bytes(int nimg, int in_dim)
@@ -364,15 +406,16 @@ size_t img_pool_bytes(int nimg, int in_dim)
 }
 
 // `scratch` = img_pool_bytes(nimg, in_dim) bytes (Gs | Ps | ML)
-int launch_img_pool(const void *img, const float *we, int nimg, int in_dim, int hw, int KT1, float *scratch,
+int launch_img_pool(const void *img, int dt, const float *we, int nimg, int in_dim, int hw, int KT1, float *scratch,
                     hipStream_t st)
 {
     float *Gs = scratch, *Ps = Gs + (size_t)nimg * 2 * kPoolHeads * in_dim, *ML = Ps + (size_t)nimg * 2 * kPoolHeads * 128;
     PoolArgs pa{static_cast<const unsigned short *>(img), we, nimg, in_dim, hw, KT1, Gs, Ps, ML};
     const size_t lds = sizeof(float) * 8 * kPoolHeads * 128 + sizeof(unsigned short) * 24 * (kPoolWPad + kPoolPPad);
     PTX_REQUIRE(lds <= 64 * 1024, "img pool: %zu B of LDS", lds);
-    hipLaunchKernelGGL(k_img_pool_bf, dim3(cdiv(nimg, 8) * 16), dim3(512), lds, st, pa);
-    PTX_LAUNCHED("k_img_pool_bf");
+    if (dt == 1) hipLaunchKernelGGL(k_img_pool<1>, dim3(cdiv(nimg, 8) * 16), dim3(512), lds, st, pa);
+    else         hipLaunchKernelGGL(k_img_pool<2>, dim3(cdiv(nimg, 8) * 16), dim3(512), lds, st, pa);
+    PTX_LAUNCHED("k_img_pool");
     return PTX_OK;
 }
 

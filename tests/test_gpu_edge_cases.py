@@ -128,19 +128,23 @@ def test_irregular_inputs_are_normalised():
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("shape", ["small", "cfg4like"])
+@pytest.mark.parametrize("shape", ["small", "cfg4like", "peaky"])
 def test_half_precision_image_features(dtype, shape):
-    """Image features STORED as bf16 / fp16 (AMP backbone, BASELINE config 2): the HIP path widens on
-    load and computes in fp32, so it must match the fp32 oracle run on the same rounded features."""
+    """Image features STORED as bf16 / fp16 (AMP backbone, BASELINE config 2): the HIP path computes on the
+    16-bit matrix pipe through exact three-way operand splits with fp32 accumulation, so it must match the fp32
+    oracle run on the same rounded features.  "peaky": features 12x larger -- near one-hot softmaxes, score
+    magnitudes that exercise the power-of-two operand scaling of the fp16 route."""
     from oracle import oracle
     from tests.gpu_util import t
-    if shape == "small":
-        cfg = PreshapeConfig("h16", B=2, N=3000, grid_size=4, dynamic_drop_radio=0.5, L=6, V=5, seed_base=18)
-    else:
+    if shape == "cfg4like":
         cfg = PreshapeConfig("h16b", B=1, N=20000, grid_size=8, dynamic_drop_radio=0.5, L=20, V=50, seed_base=19)
+    else:
+        cfg = PreshapeConfig("h16", B=2, N=3000, grid_size=4, dynamic_drop_radio=0.5, L=6, V=5, seed_base=18)
     m, sd = build_module(cfg)
     m = m.cuda()
     pts, text, mask, img = make_scene_batch(cfg)
+    if shape == "peaky":
+        img = img * 12.0
     img_h = torch.from_numpy(img).to(dtype)
     ref = oracle.forward(sd, **oracle_kwargs(cfg), points=pts, text_feats=text, text_mask=mask,
                          img_feat=img_h.float().numpy(), num_threads=1)
