@@ -87,9 +87,7 @@ def algorithmic_bytes(cfg, B, name, img_itemsize=4, dt="f32"):
     img = B * cfg.V * cfg.input_dim * cfg.img_spacial_dim ** 2 * img_itemsize
     table = {
         "k_img_mean": img, "img_pass2": img,
-        # bf16: k_img_pool_merge reads the two tiles' (G, e, m, l) and writes the [g | a] rows
-        "img_pass3": (B * cfg.V * 8 * (2 * (cfg.input_dim + 130) + cfg.input_dim + cfg.img_spacial_dim ** 2 + 1) * 4
-                      if dt in ("bf16", "f16") else img),
+        "img_pass3": None if dt in ("bf16", "f16") else img,
         "k_minmax": B * cfg.N * 12,
         "k_affine<compact>": B * cfg.N * (12 + 4 + 12),
         "k_tile_count": B * cfg.N * 4,
@@ -100,7 +98,7 @@ def algorithmic_bytes(cfg, B, name, img_itemsize=4, dt="f32"):
 # the kernel behind a launch site depends on the storage type of the image features
 SITE_KERNEL = {
     "img_pass2": {"bf16": "k_img_pool", "f32": "k_img_scores", "f16": "k_img_pool"},
-    "img_pass3": {"bf16": "k_img_pool_merge", "f32": "k_img_gather", "f16": "k_img_pool_merge"},
+    "img_pass3": {"bf16": None, "f32": "k_img_gather", "f16": None},      # 16-bit features: no third launch
     "k_img_mean": {"bf16": "k_img_mean16", "f32": "k_img_mean", "f16": "k_img_mean16"},
 }
 

@@ -25,8 +25,8 @@ void set_error(const char *fmt, ...)
 // ---- optional per-kernel timing (bench.py's roofline leg) -----------------------------------------
 // One launch site of the forward can be bracketed by HIP events recorded on the stream the kernel
 // is launched on; ptx_timing_read() returns launches and summed milliseconds.  Off by default.
-// img_pass2 / img_pass3 are the launch sites after the mean pass: k_img_pool / k_img_pool_merge for bf16
-// features, k_img_scores / k_img_gather for fp32, k_img_scores16 / k_img_gather16 for fp16.
+// img_pass2 / img_pass3 are the launch sites after the mean pass: k_img_pool (no third launch) for bf16 / fp16
+// features of the path's shape, k_img_scores / k_img_gather for fp32, k_img_scores16 / k_img_gather16 otherwise.
 static const char *const kKernelNames[] = {
     "memset", "k_minmax", "k_ball_query<grid>", "k_slot_net<offset>", "k_ball_query", "k_select",
     "k_tile_count", "k_slot_net<pointnet>", "k_img_mean", "k_gemm_nt[qkv0]",
@@ -135,7 +135,7 @@ WsLayout ws_layout(const PtxShape &s)
     for (int i = 0; i < 2; ++i) L.x_in[i] = take(R * C * 4);
     L.fm = take(nimg * s.in_dim * 4); L.qkv0 = take(nimg * 3 * C * 4);
     L.we = take(nimg * s.heads * (size_t)P.KT1 * 4);
-    L.pool = take(img_pool_bytes((int)nimg, s.in_dim));
+    L.pool = take(img_pool_bytes((int)nimg, s.in_dim, P.KT2p - s.in_dim));
     L.gbuf = take(nimg * s.heads * (size_t)P.KT2p * 4);
     L.obuf = take(nimg * C * 4); L.cbuf = take(nimg * C * 4); L.img_proxy = take(nimg * C * 4);
     for (int i = 0; i < 2; ++i) {
@@ -222,14 +222,14 @@ static int run_img_proxy(const PtxShape &s, const PtxWeights &w, const float *pr
                               s.heads * P.KT1, 0, 0, 0, EPI_NONE};
         PTX_TIMED(KID_IMG_WE, st, launch_gemm(g, st));
     }
+    const bool pooled = img_pool_supported(dt, s.in_dim, s.hw, s.heads);
     if (dt == 0) {
         PTX_TIMED(KID_IMG_SCORES, st, launch_img_scores(img, we, qkv0, nimg, s.in_dim, s.hw, s.heads, C, P.KT1,
                                                         P.KT2p, attn_scale(hd), gbuf, st));
         PTX_TIMED(KID_IMG_GATHER, st, launch_img_gather(img, nimg, s.in_dim, s.hw, s.heads, P.KT2p, gbuf, st));
-    } else if (img_pool_supported(dt, s.in_dim, s.hw, s.heads)) {
-        PTX_TIMED(KID_IMG_SCORES, st, launch_img_pool(img_any, dt, we, nimg, s.in_dim, s.hw, P.KT1, at<float>(ws, L.pool), st));
-        PTX_TIMED(KID_IMG_GATHER, st, launch_img_pool_merge(at<float>(ws, L.pool), qkv0, nimg, s.in_dim, s.hw, C, P.KT2p,
-                                                            attn_scale(hd), gbuf, st));
+    } else if (pooled) {
+        PTX_TIMED(KID_IMG_SCORES, st, launch_img_pool(img_any, dt, we, qkv0, nimg, s.in_dim, s.hw, C, P.KT1,
+                                                      P.KT2p - s.in_dim, attn_scale(hd), at<float>(ws, L.pool), st));
     } else {
         PTX_TIMED(KID_IMG_SCORES, st, launch_img_scores16(img_any, dt, we, qkv0, nimg, s.in_dim, s.hw, s.heads, C,
                                                           P.KT1, P.KT2p, attn_scale(hd), gbuf, st));
@@ -237,11 +237,22 @@ static int run_img_proxy(const PtxShape &s, const PtxWeights &w, const float *pr
     }
     {   // per head: o_h = [g_h | a_h] T2_h^T + a_h(0) v0_h + bv_h
         GemmBatch g{}; g.n = s.heads;
-        for (int h = 0; h < s.heads; ++h)
+        float *Gs = nullptr, *E = nullptr, *ML = nullptr;
+        const int EW = P.KT2p - s.in_dim;
+        if (pooled) img_pool_layout(at<float>(ws, L.pool), nimg, s.in_dim, EW, &Gs, &E, &ML);
+        for (int h = 0; h < s.heads; ++h) {
             g.p[h] = GemmProb{gbuf + (size_t)h * P.KT2p, prep + P.t2 + (size_t)h * hd * P.KT2p, obuf + h * hd,
                               w.v_b + h * hd, nullptr, gbuf + (size_t)h * P.KT2p + s.in_dim,
                               qkv0 + 2 * C + h * hd, nimg, hd, P.KT2p, s.heads * P.KT2p, P.KT2p, C,
                               0, s.heads * P.KT2p, 3 * C, EPI_NONE};
+            if (pooled) {       // [g_h | a_h] is merged from the pooling tiles while it is loaded
+                g.p[h].A = nullptr; g.p[h].rs = nullptr;
+                g.p[h].pg = Gs + (size_t)h * s.in_dim; g.p[h].ldg = 2 * s.heads * s.in_dim; g.p[h].gslab = s.heads * s.in_dim;
+                g.p[h].pe = E + (size_t)h * EW; g.p[h].lde = s.heads * EW;
+                g.p[h].pml = ML + (size_t)h * 5; g.p[h].ldml = s.heads * 5;
+                g.p[h].kg = s.in_dim;
+            }
+        }
         PTX_TIMED(KID_IMG_O, st, launch_gemm(g, st));
     }
     {   // c_proj

@@ -132,6 +132,11 @@ struct GemmProb {
     const float *rs;        // per-row scalar, element r*rs_stride, or null
     const float *ad;        // addend (R,N) ld = ldad, multiplied by rs
     int R, N, K, lda, ldw, ldc, ldres, rs_stride, ldad, epi;
+    // A operand produced on the fly from the per-tile results of k_img_pool (imgpool.hip) instead of read from
+    // `A` (null then): row r, column k = [ G0[r][k] c0 + G1[r][k] c1  (k < kg) | E[r][k - kg] scale(k - kg) ]
+    // with the split-softmax factors of row r computed from ML[r] = (m0, l0, m1, l1, s(0)); the row scalar
+    // `rs` is then a_h(0) = ct (gemm.hip, k_gemm32<SK, 1>)
+    const float *pg, *pe, *pml; int ldg, gslab, lde, ldml, kg;
 };
 constexpr int kMaxGroups = 8;
 struct GemmBatch { GemmProb p[kMaxGroups]; int n; int rotate; };
@@ -204,11 +209,10 @@ int launch_img_gather16(const void *img, int dt, int nimg, int in_dim, int hw, i
                         hipStream_t st);
 // imgpool.hip: single-pass attention pooling of bf16 / fp16 features (scores + softmax numerators + weighted sums)
 bool img_pool_supported(int dt, int in_dim, int hw, int heads);
-size_t img_pool_bytes(int nimg, int in_dim);
-int launch_img_pool(const void *img, int dt, const float *we, int nimg, int in_dim, int hw, int KT1, float *scratch,
-                    hipStream_t st);
-int launch_img_pool_merge(const float *scratch, const float *qkv0, int nimg, int in_dim, int hw, int C, int KT2p,
-                          float scale, float *gbuf, hipStream_t st);
+size_t img_pool_bytes(int nimg, int in_dim, int EW);
+void img_pool_layout(float *scratch, int nimg, int in_dim, int EW, float **Gs, float **E, float **ML);
+int launch_img_pool(const void *img, int dt, const float *we, const float *qkv0, int nimg, int in_dim, int hw, int C,
+                    int KT1, int EW, float scale, float *scratch, hipStream_t st);
 
 // ---- prep (prep.hip) ----------------------------------------------------------------------------
 int run_prepare(const PtxShape &s, const PtxWeights &w, float *prep, hipStream_t st);

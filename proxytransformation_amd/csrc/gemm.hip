@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void k_gemm64(GemmBatch gb)
 // basic block and hipcc interleaves the next tile's global loads with the MFMAs.
 // blockIdx.x = row tile: work-groups that share an A row-panel land on the same XCD (b % 8)
 // whenever the row-tile count is a multiple of 8.
-template <int SK>
+template <int SK, int AMODE>   // AMODE 1: A merged on the fly from the k_img_pool tiles (see GemmProb)
 __global__ __launch_bounds__(SK * 64) void k_gemm32(GemmBatch gb)
 {
     const GemmProb pr = gb.p[blockIdx.z];
@@ -144,25 +144,80 @@ __global__ __launch_bounds__(SK * 64) void k_gemm32(GemmBatch gb)
     const size_t w2 = (size_t)min(col0 + r0 + 16, pr.N - 1) * pr.ldw, w3 = (size_t)min(col0 + r0 + 24, pr.N - 1) * pr.ldw;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 aA0, aA1, aA2, aA3, wA0, wA1, wA2, wA3, aB0, aB1, aB2, aB3, wB0, wB1, wB2, wB3;
+    float4 gA0 = z4, gA1 = z4, gA2 = z4, gA3 = z4, gB0 = z4, gB1 = z4, gB2 = z4, gB3 = z4;      // AMODE 1: second tile's sums
+    int kA = 0, kB = 0;
+    (void)kA; (void)kB;
+    // AMODE 1: rows of the pooled partials and the split-softmax factors of this lane's four staging rows
+    size_t g0 = 0, g1 = 0, g2 = 0, g3 = 0, e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+    float fc0[4] = {0.f, 0.f, 0.f, 0.f}, fc1[4] = {0.f, 0.f, 0.f, 0.f}, fct[4] = {0.f, 0.f, 0.f, 0.f};
+    float *cts = lds + (size_t)SK * (4 * 32 * LDT);         // [32] a_h(0) of the tile's rows (AMODE 1)
+    if (AMODE == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = min(row0 + r0 + 8 * i, pr.R - 1);
+            const float *ml = pr.pml + (size_t)row * pr.ldml;
+            const float m0 = ml[0], l0 = ml[1], m1 = ml[2], l1 = ml[3], s0 = ml[4];
+            const float m = fmaxf(fmaxf(m0, m1), s0);
+            const float x0 = expf(m0 - m), x1 = expf(m1 - m), xt = expf(s0 - m);
+            const float inv = 1.0f / ((l0 * x0 + l1 * x1) + xt);
+            fc0[i] = x0 * inv; fc1[i] = x1 * inv; fct[i] = xt * inv;
+            if (wv == 0 && (lane & 7) == 0) cts[r0 + 8 * i] = fct[i];
+        }
+        g0 = (size_t)min(row0 + r0, pr.R - 1) * pr.ldg; g1 = (size_t)min(row0 + r0 + 8, pr.R - 1) * pr.ldg;
+        g2 = (size_t)min(row0 + r0 + 16, pr.R - 1) * pr.ldg; g3 = (size_t)min(row0 + r0 + 24, pr.R - 1) * pr.ldg;
+        e0 = (size_t)min(row0 + r0, pr.R - 1) * pr.lde; e1 = (size_t)min(row0 + r0 + 8, pr.R - 1) * pr.lde;
+        e2 = (size_t)min(row0 + r0 + 16, pr.R - 1) * pr.lde; e3 = (size_t)min(row0 + r0 + 24, pr.R - 1) * pr.lde;
+    }
 #define PTX_FETCH(S, j_)                                                                  \
     do {                                                                                  \
         int jj_ = min((j_), cnt - 1) + rot;                                               \
         jj_ -= jj_ >= cnt ? cnt : 0;                                                      \
         const int k_ = (it0 + jj_) * BK + kq, kc_ = min(k_, pr.K - 4);                    \
         const bool ok_ = k_ < pr.K;                                                       \
-        a##S##0 = *reinterpret_cast<const float4 *>(pr.A + a0 + kc_);                     \
-        a##S##1 = *reinterpret_cast<const float4 *>(pr.A + a1 + kc_);                     \
-        a##S##2 = *reinterpret_cast<const float4 *>(pr.A + a2 + kc_);                     \
-        a##S##3 = *reinterpret_cast<const float4 *>(pr.A + a3 + kc_);                     \
+        if (AMODE == 0) {                                                                 \
+            a##S##0 = *reinterpret_cast<const float4 *>(pr.A + a0 + kc_);                 \
+            a##S##1 = *reinterpret_cast<const float4 *>(pr.A + a1 + kc_);                 \
+            a##S##2 = *reinterpret_cast<const float4 *>(pr.A + a2 + kc_);                 \
+            a##S##3 = *reinterpret_cast<const float4 *>(pr.A + a3 + kc_);                 \
+        } else if (kc_ < pr.kg) {     /* wave-uniform: kg is a multiple of BK */          \
+            a##S##0 = *reinterpret_cast<const float4 *>(pr.pg + g0 + kc_);                \
+            a##S##1 = *reinterpret_cast<const float4 *>(pr.pg + g1 + kc_);                \
+            a##S##2 = *reinterpret_cast<const float4 *>(pr.pg + g2 + kc_);                \
+            a##S##3 = *reinterpret_cast<const float4 *>(pr.pg + g3 + kc_);                \
+            g##S##0 = *reinterpret_cast<const float4 *>(pr.pg + g0 + pr.gslab + kc_);     \
+            g##S##1 = *reinterpret_cast<const float4 *>(pr.pg + g1 + pr.gslab + kc_);     \
+            g##S##2 = *reinterpret_cast<const float4 *>(pr.pg + g2 + pr.gslab + kc_);     \
+            g##S##3 = *reinterpret_cast<const float4 *>(pr.pg + g3 + pr.gslab + kc_);     \
+        } else {                                                                          \
+            a##S##0 = *reinterpret_cast<const float4 *>(pr.pe + e0 + (kc_ - pr.kg));      \
+            a##S##1 = *reinterpret_cast<const float4 *>(pr.pe + e1 + (kc_ - pr.kg));      \
+            a##S##2 = *reinterpret_cast<const float4 *>(pr.pe + e2 + (kc_ - pr.kg));      \
+            a##S##3 = *reinterpret_cast<const float4 *>(pr.pe + e3 + (kc_ - pr.kg));      \
+        }                                                                                 \
+        k##S = kc_;                                                                       \
         w##S##0 = *reinterpret_cast<const float4 *>(pr.W + w0 + kc_);                     \
         w##S##1 = *reinterpret_cast<const float4 *>(pr.W + w1 + kc_);                     \
         w##S##2 = *reinterpret_cast<const float4 *>(pr.W + w2 + kc_);                     \
         w##S##3 = *reinterpret_cast<const float4 *>(pr.W + w3 + kc_);                     \
         if (!ok_) { w##S##0 = z4; w##S##1 = z4; w##S##2 = z4; w##S##3 = z4; }             \
     } while (0)
+#define PTX_MERGE(S, i_)                                                                  \
+    do {                                                                                  \
+        if (k##S < pr.kg) {                                                               \
+            a##S##i_ = make_float4(a##S##i_.x * fc0[i_] + g##S##i_.x * fc1[i_], a##S##i_.y * fc0[i_] + g##S##i_.y * fc1[i_], \
+                                   a##S##i_.z * fc0[i_] + g##S##i_.z * fc1[i_], a##S##i_.w * fc0[i_] + g##S##i_.w * fc1[i_]); \
+        } else {                                                                          \
+            const int t_ = k##S - pr.kg;      /* token: 0 = mean token, 1..128 tile 0, 129.. tile 1 */ \
+            a##S##i_.x *= t_ == 0 ? fct[i_] : (t_ <= 128 ? fc0[i_] : fc1[i_]);           \
+            a##S##i_.y *= t_ + 1 <= 128 ? fc0[i_] : fc1[i_];                              \
+            a##S##i_.z *= t_ + 2 <= 128 ? fc0[i_] : fc1[i_];                              \
+            a##S##i_.w *= t_ + 3 <= 128 ? fc0[i_] : fc1[i_];                              \
+        }                                                                                 \
+    } while (0)
 #define PTX_STASH(S, buf_)                                                                \
     do {                                                                                  \
         float *A_s = base + (buf_) * (2 * 32 * LDT) + r0 * LDT + kq, *W_s = A_s + 32 * LDT; \
+        if (AMODE == 1) { PTX_MERGE(S, 0); PTX_MERGE(S, 1); PTX_MERGE(S, 2); PTX_MERGE(S, 3); } \
         *reinterpret_cast<float4 *>(A_s) = a##S##0;                                       \
         *reinterpret_cast<float4 *>(A_s + 8 * LDT) = a##S##1;                             \
         *reinterpret_cast<float4 *>(A_s + 16 * LDT) = a##S##2;                            \
@@ -249,21 +304,22 @@ __global__ __launch_bounds__(SK * 64) void k_gemm32(GemmBatch gb)
         if (row < pr.R) {
             float v = acc[r] + bias;
             if (pr.epi == EPI_GELU) v = gelu_erf(v);
-            if (pr.rs) v = fmaf(pr.rs[(size_t)row * pr.rs_stride], pr.ad[(size_t)row * pr.ldad + n], v);
+            if (AMODE == 1) v = fmaf(cts[row - row0], pr.ad[(size_t)row * pr.ldad + n], v);
+            else if (pr.rs) v = fmaf(pr.rs[(size_t)row * pr.rs_stride], pr.ad[(size_t)row * pr.ldad + n], v);
             if (pr.res) v += resv[r];
             pr.C[(size_t)row * pr.ldc + n] = v;
         }
     }
 }
 
-template <int SK>
+template <int SK, int AMODE>
 static int launch_gemm32(const GemmBatch &gb, int rmax, int nmax, hipStream_t st)
 {
-    const size_t lds = sizeof(float) * SK * 4 * 32 * LDT;
+    const size_t lds = sizeof(float) * (SK * 4 * 32 * LDT + (AMODE ? 32 : 0));
     if (lds > 64 * 1024)
-        PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm32<SK>),
+        PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm32<SK, AMODE>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_gemm32<SK>, dim3(cdiv(rmax, 32), cdiv(nmax, 32), gb.n), dim3(SK * 64), lds, st, gb);
+    hipLaunchKernelGGL((k_gemm32<SK, AMODE>), dim3(cdiv(rmax, 32), cdiv(nmax, 32), gb.n), dim3(SK * 64), lds, st, gb);
     return PTX_OK;
 }
 
@@ -277,11 +333,16 @@ int launch_gemm(const GemmBatch &gb_in, hipStream_t st)
     long tiles32 = 0;
     for (int g = 0; g < gb.n; ++g) {
         const GemmProb &p = gb.p[g];
-        PTX_REQUIRE(p.A && p.W && p.C, "gemm: null operand in group %d", g);
+        PTX_REQUIRE((p.A || p.pg) && p.W && p.C, "gemm: null operand in group %d", g);
+        PTX_REQUIRE((p.pg != nullptr) == (gb.p[0].pg != nullptr), "gemm: mixed A modes in one batch");
+        PTX_REQUIRE(p.pg == nullptr || (p.pe && p.pml && p.ad && p.kg % BK == 0 && p.kg <= p.K && p.ldg % 4 == 0 &&
+                                        p.gslab % 4 == 0 && p.lde % 4 == 0),
+                    "gemm: bad pooled-A description in group %d", g);
         PTX_REQUIRE(p.R >= 1 && p.N >= 1 && p.K >= 4, "gemm: empty problem in group %d", g);
         PTX_REQUIRE(p.K % 4 == 0 && p.lda % 4 == 0 && p.ldw % 4 == 0,
                     "gemm: K=%d lda=%d ldw=%d must be multiples of 4", p.K, p.lda, p.ldw);
-        PTX_REQUIRE(((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.W)) & 15) == 0,
+        PTX_REQUIRE(((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.W) | reinterpret_cast<uintptr_t>(p.pg) |
+                      reinterpret_cast<uintptr_t>(p.pe)) & 15) == 0,
                     "gemm: operands of group %d are not 16-byte aligned", g);
         PTX_REQUIRE(p.rs == nullptr || p.ad != nullptr, "gemm: row scale without addend");
         rmax = p.R > rmax ? p.R : rmax;
@@ -289,7 +350,10 @@ int launch_gemm(const GemmBatch &gb_in, hipStream_t st)
         kmin = p.K < kmin ? p.K : kmin;
         tiles32 += (long)cdiv(p.R, 32) * cdiv(p.N, 32);
     }
-    if (tiles32 >= 1536) {
+    if (gb.p[0].pg != nullptr) {
+        // A merged on the fly from the pooling tiles: always the latency-regime kernel, K split four ways
+        PTX_TRY((launch_gemm32<4, 1>(gb, rmax, nmax, st)));
+    } else if (tiles32 >= 1536) {
         // enough tiles to fill the chip: 64x64 tiles re-use each staged operand twice as often
         hipLaunchKernelGGL(k_gemm64, dim3(cdiv(rmax, 64), cdiv(nmax, 64), gb.n), dim3(256), 0, st, gb);
     } else {
@@ -297,9 +361,9 @@ int launch_gemm(const GemmBatch &gb_in, hipStream_t st)
         const int nk = cdiv(kmin, BK);
         int sk = 1;
         while (sk < 4 && tiles32 * sk < 4096 && nk >= 4 * sk) sk *= 2;
-        if (sk == 1) PTX_TRY(launch_gemm32<1>(gb, rmax, nmax, st));
-        else if (sk == 2) PTX_TRY(launch_gemm32<2>(gb, rmax, nmax, st));
-        else PTX_TRY(launch_gemm32<4>(gb, rmax, nmax, st));
+        if (sk == 1) PTX_TRY((launch_gemm32<1, 0>(gb, rmax, nmax, st)));
+        else if (sk == 2) PTX_TRY((launch_gemm32<2, 0>(gb, rmax, nmax, st)));
+        else PTX_TRY((launch_gemm32<4, 0>(gb, rmax, nmax, st)));
     }
     PTX_LAUNCHED("k_gemm");
     return PTX_OK;

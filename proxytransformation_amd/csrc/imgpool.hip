@@ -14,8 +14,9 @@
 //   3. weighted sums  G_h(c) = sum_p e_h(p) f(c,p), K = pixels: the SAME registers, moved to the lane map
 //      that the MFMA needs with ds_bpermute (a fixed lane permutation that swaps the roles of "pixel
 //      window" and "channel sub-block"), 4 channel rows x 128 pixels per MFMA (see k_img_gather_bf)
-// The unit writes (m_tile, l_tile, e, G) and k_img_pool_merge combines the two tiles of an image with the
-// mean token into the [g_h | a_h] rows that the o-projection GEMM reads: the usual split softmax,
+// The unit writes (m_tile, l_tile, e, G); the o-projection GEMM merges the two tiles of an image with the mean
+// token while it loads its A operand (gemm.hip, k_gemm32<4, 1>; as a separate launch the merge cost 13 us): the
+// usual split softmax,
 //   m = max(m_0, m_1, s(0)),  l = l_0 e^(m_0-m) + l_1 e^(m_1-m) + e^(s(0)-m),  g = (G_0 e^(m_0-m) + G_1 e^(m_1-m)) / l.
 // Every product is of two bf16 values (exact in fp32) accumulated in fp32: the result is the fp32 value in a
 // different summation order.
@@ -119,12 +120,15 @@ __device__ __forceinline__ u32x4 shr_elems(const u32x4 &v, int k)
 }
 
 struct PoolArgs {
-    const unsigned short *img; const float *we;
-    int nimg, in_dim, hw, KT1;
+    const unsigned short *img; const float *we, *qkv0;
+    int nimg, in_dim, hw, C, KT1, EW; float scale;
     float *Gs;          // [nimg][2][heads][in_dim]  sum_p e_h(p) f(c,p) of the tile
-    float *Ps;          // [nimg][2][heads][128]     e_h(p) = exp(s_h(p) - m_tile)
-    float *ML;          // [nimg][2][heads][2]       m_tile, l_tile
+    float *E;           // [nimg][heads][EW]         token 0: 1, token 1 + p: e_h(p) = exp(s_h(p) - m_tile), 0 beyond hw
+    float *ML;          // [nimg][heads][5]          m_0, l_0, m_1, l_1, s_h(0) = scale * q_h . k0_h (mean token)
 };
+// These three are the A operand of the o-projection GEMM, which merges the two tiles and the mean token on the
+// fly (split softmax, gemm.hip k_gemm32<4, 1>): m = max(m_0, m_1, s(0)), l = l_0 e^(m_0-m) + l_1 e^(m_1-m) + e^(s(0)-m),
+// g = (G_0 e^(m_0-m) + G_1 e^(m_1-m)) / l, a(p) = e(p) e^(m_T-m) / l, a(0) = e^(s(0)-m) / l.
 
 template <int DT>   // storage type of the features: 1 = bf16, 2 = fp16
 __global__ __launch_bounds__(512) void k_img_pool(PoolArgs a)
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(512) void k_img_pool(PoolArgs a)
     const int T = slot & 1, imr = (slot >> 1) * 8 + xcd;
     if (imr >= a.nimg) return;
     const int im = a.nimg - 1 - imr;
-    const int slab = im * 2 + T;
+    const int slab = im * 2 + T;                                // Gs slab of this unit
     const int tid = threadIdx.x, lane = lane_id();
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kq = lane >> 4;
@@ -180,6 +184,15 @@ __global__ __launch_bounds__(512) void k_img_pool(PoolArgs a)
     for (int u = 0; u < 2; ++u) {
         const int p = 128 * T + lane + 64 * u;
         ev[u] = p < hw ? wim[(size_t)wid * a.KT1 + in_dim + 1 + p] : 0.0f;
+    }
+    // score of the mean token, s_h(0) = scale * q_h . k0_h (wave = head; published by the tile-0 unit)
+    // (only the loads here: reducing right away would wait for them -- and, in order, for all the feature loads
+    // above -- before the weight loads below are even issued)
+    float sq = 0.0f, sk = 0.0f;
+    if (T == 0) {
+        const int hd = a.C / heads;
+        const float *qv = a.qkv0 + (size_t)im * 3 * a.C + wid * hd;
+        if (lane < hd) { sq = qv[lane]; sk = qv[a.C + lane]; }
     }
     // head weights of this image -> three 16-bit parts in LDS.  Thread = channel, so wave w splits exactly the 64
     // channels it contracts in stage 1 (in_dim = 512 = one channel per thread) and, for fp16, scales them by a
@@ -261,14 +274,19 @@ __global__ __launch_bounds__(512) void k_img_pool(PoolArgs a)
 #pragma unroll
         for (int u = 0; u < 2; ++u) e[u] = 128 * T + lane + 64 * u < hw ? expf(sv[u] - m) : 0.0f;
         const float l = wave_sum(e[0] + e[1]);
+        float *erow = a.E + ((size_t)im * heads + h) * a.EW;
+        const float s0 = T == 0 ? wave_sum(sq * sk) * a.scale : 0.0f;
         if (lane == 0) {
-            a.ML[((size_t)slab * heads + h) * 2] = m;
-            a.ML[((size_t)slab * heads + h) * 2 + 1] = l;
+            float *ml = a.ML + ((size_t)im * heads + h) * 5;
+            ml[2 * T] = m;
+            ml[2 * T + 1] = l;
+            if (T == 0) { ml[4] = s0; erow[0] = 1.0f; }
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int p = lane + 64 * u;
-            a.Ps[((size_t)slab * heads + h) * 128 + p] = e[u];
+            const int t = 1 + 128 * T + p;                      // token of this pixel; the last tile also clears the padding
+            if (t <= hw || (T == (hw > 128 ? 1 : 0) && t < a.EW)) erow[t] = t <= hw ? e[u] : 0.0f;
             unsigned short q1, q2, q3;
             split3<DT>(DT == 2 ? e[u] * kPoolEScale : e[u], q1, q2, q3);
             parts[(size_t)h * kPoolPPad + p] = q1;
@@ -322,111 +340,37 @@ __global__ __launch_bounds__(512) void k_img_pool(PoolArgs a)
     }
 }
 
-// ---- merge of the two tiles of an image with the mean token (PRE:168-176 softmax over hw + 1 tokens)
-struct MergeArgs {
-    const float *Gs, *Ps, *ML, *qkv0;
-    int in_dim, hw, C, KT2p; float scale;
-    float *gbuf;
-};
-
-__global__ __launch_bounds__(256) void k_img_pool_merge(MergeArgs a)
-{
-    constexpr int heads = kPoolHeads;
-    __shared__ float c0s[heads], c1s[heads], cts[heads];        // e^(m_0-m)/l, e^(m_1-m)/l, a_h(0)
-    const int im = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
-    const int in_dim = a.in_dim, hw = a.hw;
-    const bool two = hw > 128;
-    const float *G0 = a.Gs + (size_t)(im * 2) * heads * in_dim, *G1 = G0 + (size_t)heads * in_dim;
-    const float *P0 = a.Ps + (size_t)(im * 2) * heads * 128, *P1 = P0 + (size_t)heads * 128;
-    // everything that does not depend on the scale factors is requested first (in_dim = 512: thread = one
-    // float4 of one of two heads per round, four rounds; thread = token for the probabilities)
-    const int nv = in_dim / 4, per = 256 / nv;                  // float4 per head row, heads per round
-    const int hsel = tid / nv, c4 = tid - hsel * nv;
-    float4 g0[4], g1[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int h = r * per + hsel;
-        const bool on = per > 0 && h < heads;
-        g0[r] = on ? reinterpret_cast<const float4 *>(G0 + (size_t)h * in_dim)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
-        g1[r] = (on && two) ? reinterpret_cast<const float4 *>(G1 + (size_t)h * in_dim)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    const int t = tid, p = tid - 1;                             // token: 0 = mean token, t >= 1 = pixel t - 1
-    float pv[heads];
-#pragma unroll
-    for (int h = 0; h < heads; ++h)
-        pv[h] = (p >= 0 && p < hw) ? (p < 128 ? P0[h * 128 + p] : P1[h * 128 + (p - 128)]) : 0.0f;
-    {   // wave w: heads w and w + 4
-        const int hd = a.C / heads;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int h = wid + 4 * k;
-            const float *qv = a.qkv0 + (size_t)im * 3 * a.C + h * hd;
-            const float qk = lane < hd ? qv[lane] * qv[a.C + lane] : 0.0f;
-            const float s0 = wave_sum(qk) * a.scale;            // mean token: scale * q_h . k0_h
-            if (lane == 0) {
-                const float *ml = a.ML + ((size_t)(im * 2) * heads + h) * 2;
-                const float m0 = ml[0], l0 = ml[1];
-                const float m1 = two ? ml[heads * 2] : -INFINITY, l1 = two ? ml[heads * 2 + 1] : 0.0f;
-                const float m = fmaxf(fmaxf(m0, m1), s0);
-                const float e0 = expf(m0 - m), e1 = two ? expf(m1 - m) : 0.0f, et = expf(s0 - m);
-                const float inv = 1.0f / ((l0 * e0 + l1 * e1) + et);
-                c0s[h] = e0 * inv; c1s[h] = e1 * inv; cts[h] = et * inv;
-            }
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int h = r * per + hsel;
-        if (per > 0 && h < heads) {
-            const float c0 = c0s[h], c1 = c1s[h];
-            float *row = a.gbuf + ((size_t)im * heads + h) * a.KT2p;
-            reinterpret_cast<float4 *>(row)[c4] = make_float4(g0[r].x * c0 + g1[r].x * c1, g0[r].y * c0 + g1[r].y * c1,
-                                                              g0[r].z * c0 + g1[r].z * c1, g0[r].w * c0 + g1[r].w * c1);
-        }
-    }
-    if (t < a.KT2p - in_dim) {
-#pragma unroll
-        for (int h = 0; h < heads; ++h) {
-            const float v = t == 0 ? cts[h] : pv[h] * (p < 128 ? c0s[h] : c1s[h]);
-            a.gbuf[((size_t)im * heads + h) * a.KT2p + in_dim + t] = v;
-        }
-    }
-}
-
 bool img_pool_supported(int dt, int in_dim, int hw, int heads)
 {
     static const int off = getenv("PTX_IMG_POOL_OFF") ? 1 : 0;
     return !off && (dt == 1 || dt == 2) && heads == kPoolHeads && in_dim == 512 && hw > 128 && hw <= 255;
 }
 
-size_t img_pool_bytes(int nimg, int in_dim)
+size_t img_pool_bytes(int nimg, int in_dim, int EW)
 {
-    return (size_t)nimg * 2 * kPoolHeads * ((size_t)in_dim + 128 + 2) * sizeof(float);
+    return (size_t)nimg * kPoolHeads * (2 * (size_t)in_dim + EW + 8) * sizeof(float);
 }
 
-// `scratch` = img_pool_bytes(nimg, in_dim) bytes (Gs | Ps | ML)
-int launch_img_pool(const void *img, int dt, const float *we, int nimg, int in_dim, int hw, int KT1, float *scratch,
-                    hipStream_t st)
+void img_pool_layout(float *scratch, int nimg, int in_dim, int EW, float **Gs, float **E, float **ML)
 {
-    float *Gs = scratch, *Ps = Gs + (size_t)nimg * 2 * kPoolHeads * in_dim, *ML = Ps + (size_t)nimg * 2 * kPoolHeads * 128;
-    PoolArgs pa{static_cast<const unsigned short *>(img), we, nimg, in_dim, hw, KT1, Gs, Ps, ML};
+    *Gs = scratch;
+    *E = *Gs + (size_t)nimg * 2 * kPoolHeads * in_dim;
+    *ML = *E + (size_t)nimg * kPoolHeads * EW;
+}
+
+// `scratch` = img_pool_bytes() bytes (Gs | E | ML, img_pool_layout)
+int launch_img_pool(const void *img, int dt, const float *we, const float *qkv0, int nimg, int in_dim, int hw, int C,
+                    int KT1, int EW, float scale, float *scratch, hipStream_t st)
+{
+    PTX_REQUIRE(EW % 4 == 0 && EW >= hw + 1 && hw > 128 && hw <= 255, "img pool: hw=%d EW=%d", hw, EW);
+    float *Gs, *E, *ML;
+    img_pool_layout(scratch, nimg, in_dim, EW, &Gs, &E, &ML);
+    PoolArgs pa{static_cast<const unsigned short *>(img), we, qkv0, nimg, in_dim, hw, C, KT1, EW, scale, Gs, E, ML};
     const size_t lds = sizeof(float) * 8 * kPoolHeads * 128 + sizeof(unsigned short) * 24 * (kPoolWPad + kPoolPPad);
     PTX_REQUIRE(lds <= 64 * 1024, "img pool: %zu B of LDS", lds);
     if (dt == 1) hipLaunchKernelGGL(k_img_pool<1>, dim3(cdiv(nimg, 8) * 16), dim3(512), lds, st, pa);
     else         hipLaunchKernelGGL(k_img_pool<2>, dim3(cdiv(nimg, 8) * 16), dim3(512), lds, st, pa);
     PTX_LAUNCHED("k_img_pool");
-    return PTX_OK;
-}
-
-int launch_img_pool_merge(const float *scratch, const float *qkv0, int nimg, int in_dim, int hw, int C, int KT2p,
-                          float scale, float *gbuf, hipStream_t st)
-{
-    PTX_REQUIRE(KT2p - in_dim <= 256, "img pool: %d tokens", KT2p - in_dim);
-    const float *Gs = scratch, *Ps = Gs + (size_t)nimg * 2 * kPoolHeads * in_dim, *ML = Ps + (size_t)nimg * 2 * kPoolHeads * 128;
-    MergeArgs ma{Gs, Ps, ML, qkv0, in_dim, hw, C, KT2p, scale, gbuf};
-    hipLaunchKernelGGL(k_img_pool_merge, dim3(nimg), dim3(256), 0, st, ma);
-    PTX_LAUNCHED("k_img_pool_merge");
     return PTX_OK;
 }
 
