@@ -624,9 +624,9 @@ int ptx_forward(const PtxShape *s, const PtxWeights *w, const void *prep, const 
     // path (two or three streaming passes over 45 / 90 MB per scene): it stays on the CALLER's stream together
     // with everything after the join, so no cross-stream hop sits on the critical path.  The
     // clustering chain (PRE:430-437) runs on the library's high-priority stream `cs` and finishes at about
-    // the same time as the image branch (cfg2 shape, bf16 features: both ~185 us).  (Running the image branch as two slices of scenes on two streams, to hide its
-    // small table GEMMs behind the other slice's streaming, was measured slower: 7.85k vs 8.1k
-    // scenes/s at cfg2, B = 4.)
+    // the same time as the image branch (cfg2 shape, bf16 features: both ~185 us).  (Running the image
+    // branch as two slices of scenes on two streams, to hide its small table GEMMs behind the other
+    // slice's streaming, was measured slower: 7.85k vs 8.1k scenes/s at cfg2, B = 4, at the time.)
     SideStream *side = nullptr;
     PTX_TRY(side_stream(&side));
     static const int mode = getenv("PTX_STREAM_MODE") ? atoi(getenv("PTX_STREAM_MODE")) : 0;

@@ -1,19 +1,19 @@
-// Attention pooling of bf16-stored image features in ONE pass over the features after the mean
-// (AttentionPool2d query 0, PRE:158-176; algebra in imgproxy.hip).  Replaces the pair
-// k_img_scores_bf -> k_img_softmax_bf -> k_img_gather_bf (two passes + a softmax launch) of imgproxy16.hip.
+// Attention pooling of bf16- / fp16-stored image features in ONE pass over the features after the mean
+// (AttentionPool2d query 0, PRE:158-176; algebra in imgproxy.hip).  It replaced three launches -- scores on the
+// matrix pipe, a softmax launch, weighted sums on the matrix pipe -- whose measurements are kept below.
 //
 // A work unit is (image, tile of 128 pixels): 512 channel rows x 256 B = 128 KB, which is held in the
 // REGISTERS of one 8-wave work-group (16 loads of 16 B per lane) from the moment it is loaded until it has
 // been used twice:
 //   1. scores   s_h(p) = sum_c w_h(c) f(c,p)  on the bf16 matrix pipe, K = channels: the lane's 8 x 8 block
-//      of (channel, pixel) values is transposed in registers (v_perm_b32) into B fragments (see
-//      k_img_scores_bf); the per-image head weights are split exactly into three bf16 parts (A operand);
+//      of (channel, pixel) values is transposed in registers (v_perm_b32) into B fragments, one per pixel
+//      column; the per-image head weights are split exactly into three 16-bit parts (A operand);
 //      the eight waves' channel slices are summed through LDS in a fixed order by the wave that owns the head
 //   2. tile-local softmax numerators  e = exp(s - m_tile), l_tile = sum e  (wave = head), split exactly into
 //      three bf16 parts
 //   3. weighted sums  G_h(c) = sum_p e_h(p) f(c,p), K = pixels: the SAME registers, moved to the lane map
 //      that the MFMA needs with ds_bpermute (a fixed lane permutation that swaps the roles of "pixel
-//      window" and "channel sub-block"), 4 channel rows x 128 pixels per MFMA (see k_img_gather_bf)
+//      window" and "channel sub-block"), 4 channel rows x 128 pixels per MFMA
 // The unit writes (m_tile, l_tile, e, G); the o-projection GEMM merges the two tiles of an image with the mean
 // token while it loads its A operand (gemm.hip, k_gemm32<4, 1>; as a separate launch the merge cost 13 us): the
 // usual split softmax,
