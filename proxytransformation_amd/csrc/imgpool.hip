@@ -160,6 +160,11 @@ __global__ __launch_bounds__(512) void k_img_pool(PoolArgs a)
     const int px = 128 * T + 8 * n;
     const bool full = px + 8 <= hw;
     const int cw = 64 * wid;                                    // this wave's 64 channels = two blocks of 32
+    // the head weights of this image are requested BEFORE the tile: loads return in order, so they are there (and
+    // split into LDS) while the 16 tile loads are still in flight instead of after the last of them
+    float wv[heads];
+#pragma unroll
+    for (int h = 0; h < heads; ++h) wv[h] = wim[(size_t)h * a.KT1 + tid];
     u32x4 L[2][8];
     const bool tensor_end = im == a.nimg - 1 && cw + 64 == in_dim;    // wave-uniform
 #pragma unroll
@@ -199,10 +204,8 @@ __global__ __launch_bounds__(512) void k_img_pool(PoolArgs a)
     // power of two of its own: no other wave needs to know it (all loads first).
     // (the inverse scales live in the padding of the weight rows in LDS, 4 B per (head, wave): eight more live
     // registers through stage 1 would cost the second work-group per CU)
-    for (int c = tid; c < in_dim; c += 512) {
-        float wv[heads];
-#pragma unroll
-        for (int h = 0; h < heads; ++h) wv[h] = wim[(size_t)h * a.KT1 + c];
+    {
+        const int c = tid;                                      // in_dim == 512 == threads (img_pool_supported)
 #pragma unroll
         for (int h = 0; h < heads; ++h) {
             if (DT == 2) {
