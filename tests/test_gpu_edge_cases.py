@@ -246,3 +246,38 @@ def test_cluster_selection_at_every_grid_size_class(gs):
         assert np.array_equal(o["kcenter"][b].cpu().numpy(), centers[b][src])
         want_drop = np.where(picks[b][:, None] >= 0, idx[b][order[b][np.maximum(picks[b], 0)]], -1).reshape(-1)
         assert np.array_equal(o["drop_idx"][b].cpu().numpy().astype(np.int64), want_drop)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_small_configurations(seed):
+    """Randomised sweep over the constructor / input space (scene count, point count, grid size, drop ratio,
+    proxies, feature-map size, feature storage type): full forward against the oracle, indices bit-identical
+    (oracle centres injected), coordinates within 1e-4."""
+    from oracle import oracle
+    from tests.gpu_util import t
+    rng = np.random.default_rng(4242 + seed)
+    gs = int(rng.integers(3, 8))
+    cfg = PreshapeConfig(f"rnd{seed}", B=int(rng.integers(1, 5)), N=int(rng.integers(600, 9000)), grid_size=gs,
+                         dynamic_drop_radio=float(rng.choice([0.3, 0.5, 0.6, 0.8])), L=int(rng.integers(1, 24)),
+                         V=int(rng.integers(1, 12)), seed_base=6000 + 50 * seed,
+                         img_spacial_dim=int(rng.choice([12, 13, 14, 15, 15, 15])))
+    dtype = [torch.float32, torch.bfloat16, torch.float16][seed % 3]
+    m, sd = build_module(cfg)
+    m = m.cuda()
+    pts, text, mask, img = make_scene_batch(cfg)
+    img_t = torch.from_numpy(img).to(dtype)
+    ref = oracle.forward(sd, **oracle_kwargs(cfg), points=pts, text_feats=text, text_mask=mask,
+                         img_feat=img_t.float().numpy(), num_threads=1)
+    m._centers_override = torch.from_numpy(ref["centers"])
+    d = m.forward_debug([t(p) for p in pts], {"text_feats": t(text), "text_token_mask": t(mask)}, img_t.cuda())
+    for k in INT_KEYS:
+        assert np.array_equal(d[k].cpu().numpy().astype(np.int64), ref[k]), (k, cfg)
+    assert_close(d["img_proxy"].cpu().numpy(), ref["img_proxy"], atol=5e-5, rtol=1e-5, what="img_proxy")
+    for b in range(cfg.B):
+        got = d["outputs"][b].cpu().numpy()
+        assert got.shape == ref["outputs"][b].shape, cfg
+        assert_close(got, ref["outputs"][b], atol=1e-4, what=f"scene {b} of {cfg}")
+    # and the plain forward (no debug copies, early-published counts) returns the same tensors
+    outs = m([t(p) for p in pts], {"text_feats": t(text), "text_token_mask": t(mask)}, img_t.cuda())
+    for b in range(cfg.B):
+        assert torch.equal(outs[b], d["outputs"][b])
