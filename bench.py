@@ -261,7 +261,7 @@ def main():
                     config=dict(workload=f"{cfg.name}: N={cfg.N} pts, gs={cfg.grid_size}->M'={cfg.M_keep} kept clusters, "
                                          f"L={cfg.L} text + V={cfg.V} image proxies, d={cfg.embed_dim}, eval forward",
                                 scenes_per_gpu=B, global_scenes_per_step=world * B, sharding="by scene, no collective",
-                                img_feat_dtype=args.img_dtype, arithmetic="fp32 (exact-fp32 MFMA / VALU)",
+                                img_feat_dtype=args.img_dtype, arithmetic="fp32 (exact-fp32 MFMA / VALU; 16-bit matrix pipe only through exact 3-way operand splits, fp32 accumulate)",
                                 surviving_points_per_step=n_out),
                     roofline=roof)
         if elapsed_f32 is not None:
