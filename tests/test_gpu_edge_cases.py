@@ -192,9 +192,10 @@ def test_back_to_back_calls_do_not_wait_for_the_gpu():
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("side,V", [(13, 9), (12, 3), (11, 4), (16, 2)])
-def test_bf16_features_at_other_feature_map_sizes(side, V):
-    """bf16 features take the single-pass pooling kernel when 128 < H*W <= 255 (two pixel tiles per image,
+def test_half_precision_features_at_other_feature_map_sizes(side, V, dtype):
+    """16-bit features take the single-pass pooling kernel when 128 < H*W <= 255 (two pixel tiles per image,
     the second one ragged: 169 = 128 + 41, 144 = 128 + 16; odd and even row lengths, image counts that are
     not a multiple of the XCD count) and the three-pass kernels otherwise (121 and 256 pixels)."""
     from oracle import oracle
@@ -204,7 +205,7 @@ def test_bf16_features_at_other_feature_map_sizes(side, V):
     m, sd = build_module(cfg)
     m = m.cuda()
     pts, text, mask, img = make_scene_batch(cfg)
-    img_h = torch.from_numpy(img).to(torch.bfloat16)
+    img_h = torch.from_numpy(img).to(dtype)
     ref = oracle.forward(sd, **oracle_kwargs(cfg), points=pts, text_feats=text, text_mask=mask,
                          img_feat=img_h.float().numpy(), num_threads=1)
     m._centers_override = torch.from_numpy(ref["centers"])
