@@ -40,6 +40,10 @@
 //   * whole images as units (both tiles in sequence in one work-group, running sums rescaled, no partials and no
 //     merge launch; 128 VGPRs once the tile code was straight-line -- as a loop the allocator kept two copies of
 //     the 64 tile registers): 90 us vs 59 + 13 -- 784 units on 512 slots are two rounds of 32-us lifetimes
+//   * 32 "double" units (both tiles of an image in one work-group, started first) so that 1536 units fill three
+//     rounds exactly: as a second copy of the tile code or a loop around the body the kernel needs 150-190 VGPRs
+//     (one work-group per CU: 76-110 us for everybody); as a separate kernel on a second stream the 32 work-groups
+//     start late (event hand-over) and become the tail themselves: 77 us
 //   * persistent, double-buffered variants (64-pixel tiles, or 16 waves x 32 channels) in isolation: the loads
 //     alone take 57 / 43 us instead of 33 (128-B runs per row; one work-group per CU), and time spent between
 //     issuing a prefetch and using it is simply added on top (scratch/pattern_bench.hip Q*/R*) -- not pursued
