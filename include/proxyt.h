@@ -10,7 +10,8 @@
  * Conventions
  *   - every pointer is a CALLER-OWNED DEVICE pointer (HIP memory of the current
  *     device) unless marked [host]; the library never allocates or frees device
- *     memory and keeps no global mutable state besides a thread-local error string;
+ *     memory; its only mutable state is a thread-local error string, the caller-owned PtxContext
+ *     objects (side streams / events) and the optional per-kernel timing selection;
  *   - all tensors are dense, row-major, fp32 unless a type is given; index tensors
  *     are int32 on this side of the ABI (the reference's int64 -1-padded layout is
  *     kept: -1 = padding);
@@ -29,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PTX_ABI_VERSION 3
+#define PTX_ABI_VERSION 4
 
 #define PTX_OK          0
 #define PTX_EINVAL     -1   /* bad shape / null pointer / unsupported size */
@@ -104,6 +105,16 @@ typedef struct PtxWeights {
 
 int         ptx_abi_version(void);
 const char *ptx_last_error(void);
+
+/* Library-owned streams and events of ONE caller (one nn.Module instance): the clustering chain and the
+ * image chain of a forward run concurrently on private side streams that fork from / join into the
+ * caller's stream.  Contexts are independent: two modules driven from two host threads on the same
+ * device never share an event.  Create on the device the forwards will run on; destroy drains the side
+ * streams first.  ptx_forward(ctx = NULL) uses a process-wide per-device default context and serialises
+ * its enqueue section with a mutex. */
+typedef struct PtxContext PtxContext;
+int ptx_context_create(PtxContext **ctx);
+int ptx_context_destroy(PtxContext *ctx);
 
 /* Per-kernel timing of ptx_forward for roofline measurement (bench.py): select ONE launch
  * site by id (0 .. ptx_kernel_count()-1, -1 = off); every later ptx_forward brackets that
@@ -200,8 +211,8 @@ int ptx_affine_compact(const PtxShape *s, const float *points, const uint32_t *t
                        const float *kcenter, const float *translate, const float *transform,
                        float *out, int32_t *counts, void *workspace, size_t ws_bytes, void *stream);
 
-/* Whole forward, PRE:424-469, enqueued on `stream` (an internal second stream forks the
- * image branch).  Points: either `points` (B,N,3) stacked, or `points_list` = HOST array of B
+/* Whole forward, PRE:424-469, enqueued on `stream` (the side streams of `ctx` fork the
+ * clustering chain).  Points: either `points` (B,N,3) stacked, or `points_list` = HOST array of B
  * device pointers to (N,3) clouds (the reference's list input, used in place; B <= 32), the other
  * NULL.  text_mask (B,L) uint8, 1 = valid.  out (B,N,3) capacity, counts (B) int32 (device or
  * device-mapped pinned host memory).  counts is published with a system-scope store as soon as
@@ -218,7 +229,7 @@ typedef struct PtxDebug {
     uint32_t *tag;
 } PtxDebug;
 
-int ptx_forward(const PtxShape *s, const PtxWeights *w, const void *prep, const float *lin,
+int ptx_forward(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, const void *prep, const float *lin,
                 const float *points, const float *const *points_list, const float *text_feats,
                 const uint8_t *text_mask, const void *img_feat, const int32_t *order_override,
                 const float *centers_override,

@@ -2,7 +2,8 @@
 
 This file is the checker, never the product: only ``tests/``,
 ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
-it.  ``proxytransformation_amd`` must not (tests/test_layout.py enforces that).
+it.  ``proxytransformation_amd`` must not
+(tests/test_host_cpu.py::test_product_never_touches_the_oracle enforces that).
 
 It restates ``ProxyTransformationNormReverse.forward``
 (PRE = embodiedscan/models/necks/preshape_norm_reverse_drop.py:424-469 of the

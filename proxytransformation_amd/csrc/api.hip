@@ -148,29 +148,61 @@ WsLayout ws_layout(const PtxShape &s)
     return L;
 }
 
-// ---- second stream for the image branch (the only process-wide state; lazily created) -------
-struct SideStream { hipStream_t st = nullptr, lo = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
-static std::mutex g_side_mu;
-static SideStream g_side[16];
+// ---- library-owned streams / events of one caller context ------------------------------------------
+// Every module instance owns one PtxContext (ptx_context_create): its side streams and fork / join events are
+// private, so two instances driven from two host threads on one device never wait on each other's events.
+// A NULL context in ptx_forward selects a process-wide per-device default whose enqueue section is serialised
+// by a mutex (the ABI-3 behaviour made safe).
+}  // namespace ptx
+struct PtxContext {
+    int dev = -1;
+    hipStream_t st = nullptr, lo = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr, aux = nullptr;
+    std::mutex mu;                       // held for the whole enqueue section of a forward
+};
+namespace ptx {
 
-static int side_stream(SideStream **out)
+static int context_init(PtxContext *c)
+{
+    PTX_HIP(hipGetDevice(&c->dev));
+    // highest priority: the latency-bound clustering chain runs here next to the long,
+    // bandwidth-bound image passes on the caller's stream and must win work-group dispatch
+    int lo = 0, hi = 0;
+    PTX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    PTX_HIP(hipStreamCreateWithPriority(&c->st, hipStreamNonBlocking, hi));
+    PTX_HIP(hipStreamCreateWithPriority(&c->lo, hipStreamNonBlocking, lo));
+    PTX_HIP(hipEventCreateWithFlags(&c->fork, hipEventDisableTiming));
+    PTX_HIP(hipEventCreateWithFlags(&c->join, hipEventDisableTiming));
+    PTX_HIP(hipEventCreateWithFlags(&c->aux, hipEventDisableTiming));
+    return PTX_OK;
+}
+
+static void context_release(PtxContext *c)
+{
+    if (c->fork) (void)hipEventDestroy(c->fork);
+    if (c->join) (void)hipEventDestroy(c->join);
+    if (c->aux) (void)hipEventDestroy(c->aux);
+    if (c->st) (void)hipStreamDestroy(c->st);
+    if (c->lo) (void)hipStreamDestroy(c->lo);
+    c->fork = c->join = c->aux = nullptr; c->st = c->lo = nullptr;
+}
+
+static std::mutex g_default_mu;
+static PtxContext *g_default_ctx[16] = {};
+
+static int default_context(PtxContext **out)
 {
     int dev = 0;
     PTX_HIP(hipGetDevice(&dev));
     PTX_REQUIRE(dev >= 0 && dev < 16, "device %d out of range", dev);
-    std::lock_guard<std::mutex> lk(g_side_mu);
-    SideStream &s = g_side[dev];
-    if (s.st == nullptr) {
-        // highest priority: the latency-bound clustering chain runs here next to the long,
-        // bandwidth-bound image passes on the caller's stream and must win work-group dispatch
-        int lo = 0, hi = 0;
-        PTX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        PTX_HIP(hipStreamCreateWithPriority(&s.st, hipStreamNonBlocking, hi));
-        PTX_HIP(hipStreamCreateWithPriority(&s.lo, hipStreamNonBlocking, lo));
-        PTX_HIP(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming));
-        PTX_HIP(hipEventCreateWithFlags(&s.join, hipEventDisableTiming));
+    std::lock_guard<std::mutex> lk(g_default_mu);
+    if (g_default_ctx[dev] == nullptr) {
+        PtxContext *c = new PtxContext();
+        const int rc = context_init(c);
+        if (rc != PTX_OK) { context_release(c); delete c; return rc; }
+        g_default_ctx[dev] = c;
     }
-    *out = &s;
+    *out = g_default_ctx[dev];
     return PTX_OK;
 }
 
@@ -426,6 +458,28 @@ int ptx_timing_read(int *launches, float *total_ms)
 }
 const char *ptx_last_error(void) { return g_err; }
 
+int ptx_context_create(PtxContext **ctx)
+{
+    PTX_REQUIRE(ctx != nullptr, "ptx_context_create: null argument");
+    PtxContext *c = new PtxContext();
+    const int rc = context_init(c);
+    if (rc != PTX_OK) { context_release(c); delete c; *ctx = nullptr; return rc; }
+    *ctx = c;
+    return PTX_OK;
+}
+
+int ptx_context_destroy(PtxContext *ctx)
+{
+    if (ctx == nullptr) return PTX_OK;
+    // the caller guarantees that no forward of this context is still being enqueued; work already
+    // enqueued on the side streams is drained before they are destroyed
+    if (ctx->st) (void)hipStreamSynchronize(ctx->st);
+    if (ctx->lo) (void)hipStreamSynchronize(ctx->lo);
+    context_release(ctx);
+    delete ctx;
+    return PTX_OK;
+}
+
 int ptx_wait_counts(const int32_t *counts_host, int B, int64_t timeout_us)
 {
     PTX_REQUIRE(counts_host && B > 0, "ptx_wait_counts: null argument");
@@ -600,7 +654,7 @@ int ptx_affine_compact(const PtxShape *s, const float *points, const uint32_t *t
 
 #define PTX_DBG(field, src, bytes)                                                                         do {                                                                                                       if (debug && debug->field)                                                                                 PTX_HIP(hipMemcpyAsync(debug->field, src, bytes, hipMemcpyDeviceToDevice, st));                } while (0)
 
-int ptx_forward(const PtxShape *s, const PtxWeights *w, const void *prep, const float *lin,
+int ptx_forward(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, const void *prep, const float *lin,
                 const float *points, const float *const *points_list, const float *text_feats,
                 const uint8_t *text_mask, const void *img_feat, const int32_t *order_override,
                 const float *centers_override,
@@ -627,8 +681,14 @@ int ptx_forward(const PtxShape *s, const PtxWeights *w, const void *prep, const 
     // the same time as the image branch (cfg2 shape, bf16 features: both ~185 us).  (Running the image
     // branch as two slices of scenes on two streams, to hide its small table GEMMs behind the other
     // slice's streaming, was measured slower: 7.85k vs 8.1k scenes/s at cfg2, B = 4, at the time.)
-    SideStream *side = nullptr;
-    PTX_TRY(side_stream(&side));
+    PtxContext *side = ctx;
+    if (side == nullptr) PTX_TRY(default_context(&side));
+    {
+        int dev = 0;
+        PTX_HIP(hipGetDevice(&dev));
+        PTX_REQUIRE(dev == side->dev, "ptx_forward: context belongs to device %d, current device is %d", side->dev, dev);
+    }
+    std::lock_guard<std::mutex> enqueue_lock(side->mu);
     static const int mode = getenv("PTX_STREAM_MODE") ? atoi(getenv("PTX_STREAM_MODE")) : 0;
     // mode 0: image branch on the caller's stream, clustering on the high-priority stream
     // mode 1: image branch on the low-priority stream, clustering on the caller's stream

@@ -158,6 +158,10 @@ class ProxyTransformationNormReverse(nn.Module):
 
         # host-side caches (not part of the state_dict)
         self._tensors = None
+        self._slots = None
+        self._ctx: Optional[ctypes.c_void_p] = None
+        self._ctx_dev = None
+        self.register_load_state_dict_post_hook(lambda mod, _keys: mod.invalidate_weights())
         self._counts_host: Optional[torch.Tensor] = None
         self._counts_np = None
         self._last_stream = None
@@ -190,23 +194,39 @@ class ProxyTransformationNormReverse(nn.Module):
 
     def _apply(self, fn, *args, **kwargs):
         # .to() / .cuda() / .float() re-allocate parameter storage: drop every cached pointer
-        self._tensors = None
-        self._wkey = None
+        self.invalidate_weights()
         return super()._apply(fn, *args, **kwargs)
 
+    def train(self, mode: bool = True):
+        # mode switches are where frameworks swap weights behind autograd's back (mmengine's EMAHook copies
+        # through ``.data`` right before ``model.eval()``): re-derive the parameter tables afterwards
+        self.invalidate_weights()
+        return super().train(mode)
+
+    def invalidate_weights(self) -> None:
+        """Force the parameter-derived tables (folded BatchNorm, per-slot bias tables, folded attention-pool
+        matrices) to be rebuilt on the next forward.  Needed only after writes that autograd cannot see
+        (``p.data.copy_()``, ``p.data.normal_()``): every other change -- optimiser steps, ``load_state_dict``
+        (also with ``assign=True``), re-assigned ``nn.Parameter`` objects, ``.to()``, ``train()`` / ``eval()`` --
+        is detected automatically."""
+        self._tensors = None
+        self._slots = None
+        self._wkey = None
+
     def _weights_key(self):
-        """Cheap per-call change detector: in-place updates (optimizer steps, load_state_dict)
-        bump ``_version``; re-allocations go through ``_apply`` above, and a re-assigned
-        ``.data`` / ``assign=True`` load changes ``data_ptr`` (checked on a slow cadence)."""
-        if self._tensors is None:
-            self._tensors = list(self.state_dict(keep_vars=True).values())
-            self._ptrs = tuple(t.data_ptr() for t in self._tensors)
-            self._calls = 0
-        self._calls += 1
-        if (self._calls & 63) == 0 and tuple(t.data_ptr() for t in self._tensors) != self._ptrs:
-            self._tensors = None
-            return self._weights_key()
-        return tuple([t._version for t in self._tensors])
+        """Per-call change detector over the LIVE parameter / buffer objects: the owning ``_parameters`` /
+        ``_buffers`` dicts are read on every call, so re-assigned tensors (``load_state_dict(assign=True)``,
+        ``mod.x.weight = nn.Parameter(...)``) are seen; in-place updates bump ``_version``; storage swaps
+        change ``data_ptr``.  ~20 us of host time per call."""
+        if self._slots is None:
+            slots = []
+            for mod in self.modules():
+                slots += [(mod._parameters, k) for k, v in mod._parameters.items() if v is not None]
+                slots += [(mod._buffers, k) for k, v in mod._buffers.items() if v is not None]
+            self._slots = slots
+        cur = [d[k] for d, k in self._slots]
+        self._tensors = cur                       # keeps the ids below from being recycled
+        return tuple([id(t) for t in cur]), tuple([t._version for t in cur]), tuple([t.data_ptr() for t in cur])
 
     def _block_struct(self, blk: _ProxyBlock, out_norm: nn.LayerNorm) -> _abi.PtxBlock:
         a = blk.attn
@@ -272,6 +292,27 @@ class ProxyTransformationNormReverse(nn.Module):
                                    prep.data_ptr(), nbytes, stream), "ptx_prepare")
         self._wstruct, self._prep, self._lin, self._wkey = w, prep, lin, key
 
+    def _context(self, device: torch.device):
+        """This instance's library-side streams / events (PtxContext), created on first use per device."""
+        if self._ctx is not None and self._ctx_dev == device:
+            return self._ctx
+        self._release_context()
+        ctx = ctypes.c_void_p()
+        _abi.check(_abi.lib().ptx_context_create(ctypes.byref(ctx)), "ptx_context_create")
+        self._ctx, self._ctx_dev = ctx, device
+        return ctx
+
+    def _release_context(self):
+        ctx, self._ctx = getattr(self, "_ctx", None), None
+        if ctx is not None:
+            try:
+                _abi.lib().ptx_context_destroy(ctx)
+            except Exception:      # interpreter shutdown
+                pass
+
+    def __del__(self):
+        self._release_context()
+
     def _workspace(self, shape: _abi.PtxShape, device: torch.device) -> torch.Tensor:
         key = (shape.B, shape.N, shape.L, shape.V, str(device))           # layout does not depend on img_dtype
         ws = self._ws.get(key)
@@ -314,6 +355,10 @@ class ProxyTransformationNormReverse(nn.Module):
         else:
             pts, plist = torch.stack([p.to(device=p0.device, dtype=torch.float32) for p in points]).contiguous(), None
         text_feats, text_mask = self.get_text_proxy(text_dict)   # positional unpack (PRE:440)
+        for name, tns in (("text_feats", text_feats), ("text_token_mask", text_mask), ("img_feat", img_feat)):
+            if not isinstance(tns, torch.Tensor) or tns.device != p0.device:
+                raise RuntimeError(f"{name} must be a tensor on {p0.device} (the device of points), got "
+                                   f"{getattr(tns, 'device', type(tns))}")
         if text_feats.shape[0] != B or text_feats.shape[-1] != self.embed_dim or text_feats.dim() != 3:
             raise RuntimeError(f"text_feats must be ({B},L,{self.embed_dim}), got {tuple(text_feats.shape)}")
         if text_mask.shape != text_feats.shape[:2]:
@@ -337,7 +382,7 @@ class ProxyTransformationNormReverse(nn.Module):
             img_feat = img_feat.contiguous()
         return (B, shp[0], p0.device), pts, plist, text_feats, mask_u8, img_feat
 
-    def _run(self, points, text_dict, img_feat, debug: bool):
+    def _run(self, points, text_dict, img_feat, debug: bool, transforms: bool = False):
         (B, N, dev), pts, plist, text_feats, mask_u8, img = self._check_inputs(points, text_dict, img_feat)
         skey = (B, N, text_feats.shape[1], img.shape[1], _IMG_DTYPES[img.dtype])
         shape = self._shapes.get(skey)
@@ -368,6 +413,10 @@ class ProxyTransformationNormReverse(nn.Module):
         dbg_struct, dbg = None, {}
         if debug:
             dbg = self._alloc_debug(shape, dev)
+        elif transforms:
+            # the per-cluster transforms only: three small stream-ordered copies, no drain
+            dbg = self._alloc_debug(shape, dev, only=("kcenter", "translate", "transform"))
+        if dbg:
             dbg_struct = _abi.PtxDebug(**{k: v.data_ptr() for k, v in dbg.items()})
         oo = self._order_override
         co = self._centers_override
@@ -376,7 +425,7 @@ class ProxyTransformationNormReverse(nn.Module):
         if co is not None:
             co = co.to(device=dev, dtype=torch.float32).contiguous()
         _abi.check(lib.ptx_forward(
-            ctypes.byref(shape), ctypes.byref(self._wstruct), self._prep.data_ptr(),
+            self._context(dev), ctypes.byref(shape), ctypes.byref(self._wstruct), self._prep.data_ptr(),
             self._lin.data_ptr(), _ptr(pts), plist, text_feats.data_ptr(), mask_u8.data_ptr(),
             img.data_ptr(), _ptr(oo), _ptr(co), out.data_ptr(), counts.data_ptr(),
             ws.data_ptr(), ws.numel(), ctypes.byref(dbg_struct) if dbg_struct else None, stream),
@@ -389,7 +438,7 @@ class ProxyTransformationNormReverse(nn.Module):
         outs = [out[b, :n_keep[b]] for b in range(B)]
         return outs, dbg
 
-    def _alloc_debug(self, s: _abi.PtxShape, dev) -> Dict[str, torch.Tensor]:
+    def _alloc_debug(self, s: _abi.PtxShape, dev, only=None) -> Dict[str, torch.Tensor]:
         M, K, Kd = self.num_cluster, s.K, s.Mt - s.Mk
         f32, i32 = torch.float32, torch.int32
         spec = dict(
@@ -402,23 +451,38 @@ class ProxyTransformationNormReverse(nn.Module):
             text_guide=((s.B, s.Mk, s.C), f32), img_guide=((s.B, s.Mk, s.C), f32),
             translate=((s.B, s.Mk, 3), f32), transform=((s.B, s.Mk, 9), f32),
             tag=((s.B, s.N), torch.int32))
-        return {k: torch.empty(shp, dtype=dt, device=dev) for k, (shp, dt) in spec.items()}
+        return {k: torch.empty(shp, dtype=dt, device=dev) for k, (shp, dt) in spec.items()
+                if only is None or k in only}
 
-    def forward(self, points: List[torch.Tensor], text_dict: dict, img_feat: torch.Tensor):
+    def forward(self, points: List[torch.Tensor], text_dict: dict, img_feat: torch.Tensor,
+                return_transforms: bool = False):
         """points: list of B (N,3) fp32 GPU tensors; text_dict.values() -> (text_feats (B,L,C),
         text_token_mask (B,L) bool, True = valid); img_feat (B,V,input_dim,H,W).
         Returns a list of B tensors (N_i',3): transformed points, dropped points removed,
-        original order preserved (PRE:424-469)."""
+        original order preserved (PRE:424-469).
+
+        ``return_transforms=True`` (not in the reference) additionally returns the per-cluster affine
+        parameters ``dict(kcenter (B,M',3), translate (B,M',3), transform (B,M',9))`` -- what
+        ``shard.gather_cluster_transforms`` exchanges between ranks -- as stream-ordered tensors."""
+        chunks = [(0, len(points))]
         if isinstance(points, (list, tuple)) and len(points) > _MAX_SCENES_PER_CALL:
             # scenes are independent in eval mode: larger batches run as consecutive calls
-            feats, mask = self.get_text_proxy(text_dict)
-            outs: List[torch.Tensor] = []
-            for i in range(0, len(points), _MAX_SCENES_PER_CALL):
-                j = i + _MAX_SCENES_PER_CALL
-                outs += self._run(points[i:j], {"text_feats": feats[i:j], "text_token_mask": mask[i:j]},
-                                  img_feat[i:j], debug=False)[0]
-            return outs
-        return self._run(points, text_dict, img_feat, debug=False)[0]
+            chunks = [(i, min(i + _MAX_SCENES_PER_CALL, len(points)))
+                      for i in range(0, len(points), _MAX_SCENES_PER_CALL)]
+        if len(chunks) == 1:
+            outs, extra = self._run(points, text_dict, img_feat, debug=False, transforms=return_transforms)
+            return (outs, extra) if return_transforms else outs
+        feats, mask = self.get_text_proxy(text_dict)
+        outs: List[torch.Tensor] = []
+        extras = []
+        for i, j in chunks:
+            o, e = self._run(points[i:j], {"text_feats": feats[i:j], "text_token_mask": mask[i:j]},
+                             img_feat[i:j], debug=False, transforms=return_transforms)
+            outs += o
+            extras.append(e)
+        if return_transforms:
+            return outs, {k: torch.cat([e[k] for e in extras]) for k in extras[0]}
+        return outs
 
     @torch.no_grad()
     def forward_debug(self, points, text_dict, img_feat):

@@ -81,7 +81,9 @@ def test_registry_and_constructor_surface():
                 drop_path_rate=0.2, num_sub=30, drop_radio=0.2, input_dim=512, img_spacial_dim=15)
     for k, v in want.items():
         assert sig.parameters[k].default == v, k
-    assert list(inspect.signature(m.forward).parameters) == ["points", "text_dict", "img_feat"]
+    fwd = inspect.signature(m.forward).parameters
+    assert list(fwd)[:3] == ["points", "text_dict", "img_feat"]           # the reference's call (DET:385)
+    assert all(p.default is not inspect.Parameter.empty for p in list(fwd.values())[3:])   # extras are optional
 
 
 def test_state_dict_matches_reference_manifest():
@@ -166,16 +168,33 @@ ref = torch.cat([kc, tr, tf], -1)
 assert torch.equal(allp, ref), "gathered transforms differ"
 # a fake module that tags each scene so routing can be checked
 class Fake:
-    def __call__(self, pts, td, img):
+    real_cluster_num = Mk
+    def __call__(self, pts, td, img, return_transforms=False):
         f, m = td.values()
-        return [p + f[i, 0, 0] + img[i, 0, 0, 0, 0] for i, p in enumerate(pts)]
+        outs = [p + f[i, 0, 0] + img[i, 0, 0, 0, 0] for i, p in enumerate(pts)]
+        if not return_transforms:
+            return outs
+        sid = [int(p[0, 0]) for p in pts]
+        return outs, dict(kcenter=kc[sid], translate=tr[sid], transform=tf[sid])
 pts = [torch.full((4, 3), float(i)) for i in range(S)]
 td = {"text_feats": torch.arange(S).float().view(S, 1, 1) * 10, "text_token_mask": torch.ones(S, 1, dtype=torch.bool)}
 img = torch.arange(S).float().view(S, 1, 1, 1, 1) * 100
-lids, outs = ShardedPreshape(Fake())(pts, td, img)
+sp = ShardedPreshape(Fake())
+lids, outs = sp(pts, td, img)
 assert lids == ids
 for i, o in zip(lids, outs):
     assert torch.equal(o, torch.full((4, 3), float(i + 10 * i + 100 * i)))
+# rank-local inputs (what a per-rank dataloader hands over) + the transform gather
+sel = torch.tensor(ids)
+ltd = {"text_feats": td["text_feats"][sel], "text_token_mask": td["text_token_mask"][sel]}
+lids2, outs2, allt = sp([pts[i] for i in ids], ltd, img[sel], inputs="local", num_scenes=S, gather=True)
+assert lids2 == ids and all(torch.equal(a, b) for a, b in zip(outs, outs2))
+assert torch.equal(allt, ref), "gathered transforms (local inputs) differ"
+try:
+    sp(pts, td, img, inputs="local", num_scenes=S)
+    raise SystemExit("local inputs of the wrong length were accepted")
+except ValueError:
+    pass
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 '''
