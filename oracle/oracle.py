@@ -207,9 +207,11 @@ def img_proxy(sd, img_feat: torch.Tensor, heads: int) -> torch.Tensor:
 def slot_bias(sd, pre: str, C: int) -> torch.Tensor:
     """Per-kept-slot learned bias of ProxyAttention, PRE:212-215 -> (M',C)."""
     s = int(C ** 0.5)
+    if s * s != C:       # not runnable by the reference (SURVEY H6): next larger grid, first C entries
+        s += 1
     b1 = F.interpolate(sd[pre + ".pb_bias"], size=(s, s), mode="bilinear")
     n = b1.shape[1]
-    return b1.reshape(n, -1) + (sd[pre + ".pc_bias"] + sd[pre + ".pr_bias"]).reshape(n, -1)
+    return (b1.reshape(n, -1) + (sd[pre + ".pc_bias"] + sd[pre + ".pr_bias"]).reshape(n, -1))[:, :C]
 
 
 def proxy_block(sd, pre: str, x: torch.Tensor, proxy: torch.Tensor,

@@ -76,17 +76,18 @@ int validate_shape(const PtxShape &s)
     PTX_REQUIRE(s.grid_size >= 1 && M <= (1 << 20), "shape: grid_size=%d", s.grid_size);
     PTX_REQUIRE(s.K >= 1 && s.K <= 63, "shape: num_sub K=%d must be in [1,63]", s.K);
     PTX_REQUIRE(s.Mk >= 1 && s.Mk <= s.Mt && s.Mt <= M, "shape: need 1 <= Mk=%d <= Mt=%d <= M=%ld", s.Mk, s.Mt, M);
-    PTX_REQUIRE(s.C == kSlotHidden, "shape: embed_dim=%d; this build supports 256 (SimplifiedPointNet width, PRE:302)", s.C);
-    PTX_REQUIRE(s.heads >= 1 && s.heads <= 8 && s.C % s.heads == 0 && s.C / s.heads == 32,
-                "shape: heads=%d; head_dim must be 32", s.heads);
-    int sd = 1;
-    while (sd * sd < s.C) ++sd;
-    PTX_REQUIRE(sd * sd == s.C, "shape: embed_dim=%d is not a perfect square (PRE:196)", s.C);
+    PTX_REQUIRE(s.C == 256 || s.C == 512, "shape: embed_dim=%d; supported: 256 (the reference, PRE:302) and 512", s.C);
+    PTX_REQUIRE(s.heads == 8, "shape: num_heads=%d; the image-pool and attention kernels are built for 8 heads "
+                "(head_dim 32 or 64)", s.heads);
+    PTX_REQUIRE(s.Mt <= 4096, "shape: Mt=%d clusters after the empty-drop; the farthest point sampling holds at most 4096", s.Mt);
     PTX_REQUIRE(s.hidden >= 4 && s.hidden % 4 == 0, "shape: hidden=%d", s.hidden);
-    PTX_REQUIRE(s.in_dim >= 64 && s.in_dim % 64 == 0, "shape: in_dim=%d must be a multiple of 64", s.in_dim);
-    PTX_REQUIRE(s.hw >= 1 && s.L >= 1 && s.V >= 1, "shape: hw=%d L=%d V=%d", s.hw, s.L, s.V);
-    PTX_REQUIRE((long)s.Mk * s.K < (1l << 31) - 1, "shape: Mk*K overflows the ownership tag");
+    PTX_REQUIRE(s.in_dim >= 64 && s.in_dim % 64 == 0 && s.in_dim <= 512,
+                "shape: in_dim=%d must be a multiple of 64, at most 512", s.in_dim);
+    PTX_REQUIRE(s.L >= 1 && s.V >= 1, "shape: L=%d V=%d", s.L, s.V);
     PTX_REQUIRE(s.img_dtype >= 0 && s.img_dtype <= 2, "shape: img_dtype=%d (0 fp32, 1 bf16, 2 fp16)", s.img_dtype);
+    if (s.img_dtype == 0) PTX_REQUIRE(s.hw >= 4 && s.hw <= 256, "shape: H*W=%d (fp32 image features: 4..256 pixels)", s.hw);
+    else PTX_REQUIRE(s.hw >= 8 && s.hw <= 255, "shape: H*W=%d (16-bit image features: 8..255 pixels)", s.hw);
+    PTX_REQUIRE((long)s.Mk * s.K < (1l << 31) - 1, "shape: Mk*K overflows the ownership tag");
     return PTX_OK;
 }
 
@@ -98,7 +99,7 @@ PrepLayout prep_layout(const PtxShape &s)
     P.hd = s.C / s.heads;
     P.KT1 = s.in_dim + s.hw + 1;
     P.KT2p = (int)align_up((size_t)s.in_dim + s.hw + 1, 4);
-    P.off_ab = take(2 * kSlotHidden); P.enc_ab = take(2 * kSlotHidden);
+    P.off_ab = take(2 * kSlotHidden); P.enc_ab = take(2 * (size_t)s.C);
     P.ttn_ab = take(6); P.itn_ab = take(18);
     P.posb_t = take((size_t)s.Mk * s.C); P.posb_i = take((size_t)s.Mk * s.C);
     P.w3 = take((size_t)3 * s.C * s.in_dim); P.b3 = take((size_t)3 * s.C);
@@ -328,7 +329,7 @@ static int run_blocks(const PtxShape &s, const Branch *br, int nb, const float *
         if (g.n > 0) PTX_TIMED(KID_BLK_QKV, st, launch_gemm(g, st));
         if (phase == 1) return PTX_OK;
     }
-    AttnBatch a{}; a.n = nb; a.B = s.B; a.heads = s.heads; a.scale = attn_scale(C / s.heads);
+    AttnBatch a{}; a.n = nb; a.B = s.B; a.heads = s.heads; a.hd = C / s.heads; a.scale = attn_scale(C / s.heads);
     for (int i = 0; i < nb; ++i) {   // proxy as query (PRE:232-238): no mask
         const int sl = br[i].slot;
         float *qkv = at<float>(ws, L.qkv[sl]);
@@ -592,7 +593,7 @@ int ptx_pointnet(const PtxShape *s, const PtxWeights *w, const void *prep, const
     PTX_TRY(validate_shape(*s));
     const PrepLayout P = prep_layout(*s);
     return launch_pointnet(static_cast<const float *>(prep) + P.enc_ab, w->encoder, kcenter, kcluster,
-                           s->B * s->Mk, s->Mk, s->K, point_proxy, nullptr, nullptr, nullptr, nullptr, nullptr,
+                           s->B * s->Mk, s->Mk, s->K, s->C, point_proxy, nullptr, nullptr, nullptr, nullptr, nullptr,
                            nullptr, s->ln_eps, static_cast<hipStream_t>(stream));
 }
 
@@ -731,7 +732,7 @@ int ptx_forward(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, const v
     float *point_proxy = at<float>(ws, L.point_proxy);
     float *xin_t = at<float>(ws, L.x_in[0]), *xin_i = at<float>(ws, L.x_in[1]);
     PTX_TIMED(KID_POINTNET, cs, launch_pointnet(pf + P.enc_ab, w->encoder, kcenter, kcluster, B * S.Mk, S.Mk, K,
-                                                point_proxy, &w->text, &w->img, pf + P.posb_t, pf + P.posb_i, xin_t,
+                                                S.C, point_proxy, &w->text, &w->img, pf + P.posb_t, pf + P.posb_i, xin_t,
                                                 xin_i, S.ln_eps, cs));
 
     // ---- both proxy blocks + heads in shared launches (PRE:440-455); the input projections that

@@ -1,4 +1,4 @@
-// Proxy attention (PRE:230-250) on the matrix cores, head_dim = 32.
+// Proxy attention (PRE:230-250) on the matrix cores, head_dim = 32 (the reference's 256 / 8) or 64 (embed_dim = 512).
 //
 // One kernel serves both contractions of ProxyAttention:
 //   proxy as query : O = softmax_n((P*scale) K^T) V          queries = proxies, keys = cluster tokens
@@ -21,10 +21,11 @@ namespace ptx {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int HD = 32;
-
+template <int HD>      // 32 or 64: HD / 2 contraction steps for the scores, HD / 32 accumulators for O^T
 __global__ __launch_bounds__(256) void k_attn32(AttnBatch ab)
 {
+    constexpr int NS = HD / 2;          // MFMA steps of S^T = K Q^T (each contracts 2 dims: halves hh = 0, 1)
+    constexpr int NA = HD / 32;         // 32-row blocks of O^T
     const AttnProb p = ab.p[blockIdx.z];           // by value: fields live in SGPRs
     const int lane = lane_id();
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -39,50 +40,54 @@ __global__ __launch_bounds__(256) void k_attn32(AttnBatch ab)
     const float *Vp = p.V + (size_t)b * p.sV + h * HD;
     const uint8_t *mask = p.mask ? p.mask + (size_t)b * p.nk : nullptr;
 
-    // B operand of S^T: this lane's query row, dims hh*16 .. hh*16+15, pre-scaled (PRE:232, 241)
-    float qf[16];
+    // B operand of S^T: this lane's query row, dims hh*NS .. hh*NS+NS-1, pre-scaled (PRE:232, 241)
+    float qf[NS];
     {
         const int qi = q0 + li;
         if (qi < p.nq) {
-            const float4 *src = reinterpret_cast<const float4 *>(Q + (size_t)qi * p.ldq + hh * 16);
+            const float4 *src = reinterpret_cast<const float4 *>(Q + (size_t)qi * p.ldq + hh * NS);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NS / 4; ++i) {
                 const float4 t = src[i];
                 qf[4 * i] = t.x * ab.scale; qf[4 * i + 1] = t.y * ab.scale;
                 qf[4 * i + 2] = t.z * ab.scale; qf[4 * i + 3] = t.w * ab.scale;
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) qf[i] = 0.0f;
+            for (int i = 0; i < NS; ++i) qf[i] = 0.0f;
         }
     }
     float m_run = -INFINITY, l_run = 0.0f;
-    f32x16 o;
+    f32x16 o[NA];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) o[i] = 0.0f;
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[a][i] = 0.0f;
 
-    // key / value fragments of tile k0 (A operands): kf = K[k0 + li][hh*16 .. +15],
-    // vf[s] = V[k0 + key(s,hh)][li] with key(s,hh) = (s&3) + 8*(s>>2) + 4*hh
-    auto load_tile = [&](int k0, float (&kf)[16], float (&vf)[16]) {
+    // key / value fragments of tile k0 (A operands): kf = K[k0 + li][hh*NS .. +NS-1],
+    // vf[a*16 + s] = V[k0 + key(s,hh)][32 a + li] with key(s,hh) = (s&3) + 8*(s>>2) + 4*hh
+    auto load_tile = [&](int k0, float (&kf)[NS], float (&vf)[16 * NA]) {
         const int ki = k0 + li;
         if (ki < p.nk) {
-            const float4 *src = reinterpret_cast<const float4 *>(Kp + (size_t)ki * p.ldk + hh * 16);
+            const float4 *src = reinterpret_cast<const float4 *>(Kp + (size_t)ki * p.ldk + hh * NS);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NS / 4; ++i) {
                 const float4 t = src[i];
                 kf[4 * i] = t.x; kf[4 * i + 1] = t.y; kf[4 * i + 2] = t.z; kf[4 * i + 3] = t.w;
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) kf[i] = 0.0f;
+            for (int i = 0; i < NS; ++i) kf[i] = 0.0f;
         }
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int key = k0 + (s & 3) + 8 * (s >> 2) + 4 * hh;
-            vf[s] = key < p.nk ? Vp[(size_t)key * p.ldv + li] : 0.0f;
-        }
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int key = k0 + (s & 3) + 8 * (s >> 2) + 4 * hh;
+                vf[a * 16 + s] = key < p.nk ? Vp[(size_t)key * p.ldv + 32 * a + li] : 0.0f;
+            }
     };
-    float kf[16], vf[16], kn[16], vn[16];
+    float kf[NS], vf[16 * NA], kn[NS], vn[16 * NA];
     if (kbeg < kend) load_tile(kbeg, kf, vf);
     for (int k0 = kbeg; k0 < kend; k0 += 32) {
         // software pipeline: the next tile's loads are in flight while this tile is consumed
@@ -93,7 +98,7 @@ __global__ __launch_bounds__(256) void k_attn32(AttnBatch ab)
 #pragma unroll
         for (int i = 0; i < 16; ++i) sc[i] = 0.0f;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[s], sc, 0, 0, 0);
+        for (int s = 0; s < NS; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[s], sc, 0, 0, 0);
         // sc[r] = score(key = k0 + (r&3) + 8*(r>>2) + 4*hh, query = q0 + li)
         float tmax = -INFINITY;
 #pragma unroll
@@ -114,23 +119,30 @@ __global__ __launch_bounds__(256) void k_attn32(AttnBatch ab)
         psum += __shfl_xor(psum, 32, 64);
         l_run = fmaf(l_run, alpha, psum);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) o[i] *= alpha;
+        for (int a = 0; a < NA; ++a) {
 #pragma unroll
-        for (int s = 0; s < 16; ++s) o = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[s], sc[s], o, 0, 0, 0);
+            for (int i = 0; i < 16; ++i) o[a][i] *= alpha;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) o[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[a * 16 + s], sc[s], o[a], 0, 0, 0);
+        }
         m_run = m_new;
         if (more) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { kf[i] = kn[i]; vf[i] = vn[i]; }
+            for (int i = 0; i < NS; ++i) kf[i] = kn[i];
+#pragma unroll
+            for (int i = 0; i < 16 * NA; ++i) vf[i] = vn[i];
         }
     }
     // ---- merge the 4 key slices in fixed order: m = max m_w, O = sum_w O_w exp(m_w - m), l likewise
     __shared__ float s_ml[3][2][64];
-    __shared__ __attribute__((aligned(16))) float s_o[3][16][64];
+    __shared__ __attribute__((aligned(16))) float s_o[3][16 * NA][64];
     if (wv > 0) {
         s_ml[wv - 1][0][lane] = m_run;
         s_ml[wv - 1][1][lane] = l_run;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s_o[wv - 1][r][lane] = o[r];
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_o[wv - 1][a * 16 + r][lane] = o[a][r];
     }
     __syncthreads();
     if (wv > 0) return;
@@ -141,7 +153,9 @@ __global__ __launch_bounds__(256) void k_attn32(AttnBatch ab)
         const float a0 = expf(m_run - m_all);                       // wave 0 always owns >= 1 tile
         l_run *= a0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[r] *= a0;
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[a][r] *= a0;
     }
 #pragma unroll
     for (int w = 0; w < 3; ++w) {
@@ -149,18 +163,22 @@ __global__ __launch_bounds__(256) void k_attn32(AttnBatch ab)
         const float aw = mw == -INFINITY ? 0.0f : expf(mw - m_all);   // slice without keys
         l_run = fmaf(s_ml[w][1][lane], aw, l_run);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[r] = fmaf(s_o[w][r][lane], aw, o[r]);
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[a][r] = fmaf(s_o[w][a * 16 + r][lane], aw, o[a][r]);
     }
-    // o[r] = O^T[d = (r&3) + 8*(r>>2) + 4*hh][query = li]
+    // o[a][r] = O^T[d = 32 a + (r&3) + 8*(r>>2) + 4*hh][query = li]
     const int qi = q0 + li;
     if (qi < p.nq) {
         const float inv = 1.0f / l_run;
         float *dst = p.O + (size_t)b * p.sO + (size_t)qi * p.ldo + h * HD;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float4 t = make_float4(o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv);
-            *reinterpret_cast<float4 *>(dst + 8 * g + 4 * hh) = t;
-        }
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 t = make_float4(o[a][4 * g] * inv, o[a][4 * g + 1] * inv, o[a][4 * g + 2] * inv, o[a][4 * g + 3] * inv);
+                *reinterpret_cast<float4 *>(dst + 32 * a + 8 * g + 4 * hh) = t;
+            }
     }
 }
 
@@ -176,7 +194,10 @@ int launch_attn32(const AttnBatch &ab, hipStream_t st)
         nqmax = p.nq > nqmax ? p.nq : nqmax;
     }
     if (nqmax == 0) return PTX_OK;
-    hipLaunchKernelGGL(k_attn32, dim3(cdiv(nqmax, 32), ab.B * ab.heads, ab.n), dim3(256), 0, st, ab);
+    PTX_REQUIRE(ab.hd == 32 || ab.hd == 64, "attention: head_dim=%d (supported: 32, 64)", ab.hd);
+    const dim3 grid(cdiv(nqmax, 32), ab.B * ab.heads, ab.n);
+    if (ab.hd == 32) hipLaunchKernelGGL(k_attn32<32>, grid, dim3(256), 0, st, ab);
+    else             hipLaunchKernelGGL(k_attn32<64>, grid, dim3(256), 0, st, ab);
     PTX_LAUNCHED("k_attn32");
     return PTX_OK;
 }

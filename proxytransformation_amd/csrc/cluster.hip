@@ -191,19 +191,20 @@ struct SlotNetArgs {
     float ln_eps;
 };
 
-template <int MODE>
+template <int MODE, int Q>     // Q = hidden width / 64 channels per lane (4: the reference's 256; 8: 512)
 __global__ __launch_bounds__(256) void k_slot_net(SlotNetArgs a)
 {
+    constexpr int W = 64 * Q;
     const int lane = lane_id();
     const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (w >= a.BM) return;
-    float wt[4][6], bs[4], al[4], be[4];
+    float wt[Q][6], bs[Q], al[Q], be[Q];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < Q; ++q) {
         const int c = lane + 64 * q;
 #pragma unroll
         for (int i = 0; i < 6; ++i) wt[q][i] = a.conv_w[c * 6 + i];
-        bs[q] = a.conv_b[c]; al[q] = a.ab[c]; be[q] = a.ab[kSlotHidden + c];
+        bs[q] = a.conv_b[c]; al[q] = a.ab[c]; be[q] = a.ab[W + c];
     }
     const float cx = a.center[(size_t)w * 3], cy = a.center[(size_t)w * 3 + 1], cz = a.center[(size_t)w * 3 + 2];
     // lane k (< K) prepares slot k
@@ -215,15 +216,15 @@ __global__ __launch_bounds__(256) void k_slot_net(SlotNetArgs a)
         x[0] = pad ? 0.0f : px - cx; x[1] = pad ? 0.0f : py - cy; x[2] = pad ? 0.0f : pz - cz;
         x[3] = px; x[4] = py; x[5] = pz;
     }
-    float acc[4];
+    float acc[Q];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = MODE == 0 ? 0.0f : -INFINITY;
+    for (int q = 0; q < Q; ++q) acc[q] = MODE == 0 ? 0.0f : -INFINITY;
     for (int k = 0; k < a.K; ++k) {
         float s[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) s[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x[i]), k));
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < Q; ++q) {
             float h = bs[q];
 #pragma unroll
             for (int i = 0; i < 6; ++i) h = fmaf(wt[q][i], s[i], h);
@@ -235,11 +236,11 @@ __global__ __launch_bounds__(256) void k_slot_net(SlotNetArgs a)
         const float invK = 1.0f / (float)a.K;
         float o[3] = {0, 0, 0};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < Q; ++q) {
             const float hm = acc[q] * invK;
             const int c = lane + 64 * q;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) o[j] = fmaf(a.map_w[j * kSlotHidden + c], hm, o[j]);
+            for (int j = 0; j < 3; ++j) o[j] = fmaf(a.map_w[j * W + c], hm, o[j]);
         }
 #pragma unroll
         for (int j = 0; j < 3; ++j) o[j] = wave_sum(o[j]);
@@ -254,25 +255,28 @@ __global__ __launch_bounds__(256) void k_slot_net(SlotNetArgs a)
             if (a.offsets_out) a.offsets_out[(size_t)w * 3 + lane] = off;
         }
     } else {
-        float *pr = a.proxy + (size_t)w * kSlotHidden;
+        float *pr = a.proxy + (size_t)w * W;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) pr[lane + 64 * q] = acc[q];
+        for (int q = 0; q < Q; ++q) pr[lane + 64 * q] = acc[q];
         // LayerNorm1 (PRE:274) + per-slot bias (PRE:215-217) for the text / image ProxyBlock
-        float mean = wave_sum(acc[0] + acc[1] + acc[2] + acc[3]) * (1.0f / kSlotHidden);
+        float sum = 0.0f;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) sum += acc[q];
+        float mean = wave_sum(sum) * (1.0f / W);
         float var = 0.0f;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const float d = acc[q] - mean; var = fmaf(d, d, var); }
-        var = wave_sum(var) * (1.0f / kSlotHidden);
+        for (int q = 0; q < Q; ++q) { const float d = acc[q] - mean; var = fmaf(d, d, var); }
+        var = wave_sum(var) * (1.0f / W);
         const float rstd = 1.0f / sqrtf(var + a.ln_eps);
         const int j = w % a.Mper;                                                  // kept-slot position (Q9)
 #pragma unroll
         for (int br = 0; br < 2; ++br) {
             if (a.xin[br] == nullptr) continue;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < Q; ++q) {
                 const int c = lane + 64 * q;
                 const float xn = (acc[q] - mean) * rstd * a.n1w[br][c] + a.n1b[br][c];
-                a.xin[br][(size_t)w * kSlotHidden + c] = xn + a.posb[br][(size_t)j * kSlotHidden + c];
+                a.xin[br][(size_t)w * W + c] = xn + a.posb[br][(size_t)j * W + c];
             }
         }
     }
@@ -287,13 +291,13 @@ int launch_offset_net(const float *ab, const PtxSlotMlp &mlp, const float *map_w
     a.ab = ab; a.conv_w = mlp.conv_w; a.conv_b = mlp.conv_b; a.center = centers_in; a.cluster = cluster;
     a.BM = BM; a.Mper = M; a.K = K; a.map_w = map_w; a.minmax = minmax; a.margin = margin;
     a.centers_out = centers_out; a.offsets_out = offsets_out;
-    hipLaunchKernelGGL(k_slot_net<0>, dim3(cdiv(BM, 4)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_slot_net<0, kSlotHidden / 64>), dim3(cdiv(BM, 4)), dim3(256), 0, st, a);
     PTX_LAUNCHED("k_slot_net<offset>");
     return PTX_OK;
 }
 
 int launch_pointnet(const float *ab, const PtxSlotMlp &mlp, const float *kcenter,
-                    const float *kcluster, int BM, int Mk, int K, float *point_proxy,
+                    const float *kcluster, int BM, int Mk, int K, int width, float *point_proxy,
                     const PtxBlock *blk_t, const PtxBlock *blk_i, const float *posb_t,
                     const float *posb_i, float *xin_t, float *xin_i, float ln_eps, hipStream_t st)
 {
@@ -302,7 +306,9 @@ int launch_pointnet(const float *ab, const PtxSlotMlp &mlp, const float *kcenter
     a.BM = BM; a.Mper = Mk; a.K = K; a.proxy = point_proxy; a.ln_eps = ln_eps;
     if (blk_t && xin_t) { a.n1w[0] = blk_t->norm1_w; a.n1b[0] = blk_t->norm1_b; a.posb[0] = posb_t; a.xin[0] = xin_t; }
     if (blk_i && xin_i) { a.n1w[1] = blk_i->norm1_w; a.n1b[1] = blk_i->norm1_b; a.posb[1] = posb_i; a.xin[1] = xin_i; }
-    hipLaunchKernelGGL(k_slot_net<1>, dim3(cdiv(BM, 4)), dim3(256), 0, st, a);
+    PTX_REQUIRE(width == 256 || width == 512, "pointnet: width=%d (supported: 256, 512)", width);
+    if (width == 256) hipLaunchKernelGGL((k_slot_net<1, 4>), dim3(cdiv(BM, 4)), dim3(256), 0, st, a);
+    else              hipLaunchKernelGGL((k_slot_net<1, 8>), dim3(cdiv(BM, 4)), dim3(256), 0, st, a);
     PTX_LAUNCHED("k_slot_net<pointnet>");
     return PTX_OK;
 }

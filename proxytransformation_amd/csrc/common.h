@@ -44,7 +44,7 @@ void set_error(const char *fmt, ...);
     } while (0)
 
 constexpr int kWave = 64;
-constexpr int kSlotHidden = 256;   // OffsetNetwork / SimplifiedPointNet width is hard-coded (PRE:31,302)
+constexpr int kSlotHidden = 256;   // OffsetNetwork width (PRE:31); SimplifiedPointNet is as wide as embed_dim (PRE:302: 256)
 constexpr int kTilePts = 2048;     // points per compaction tile
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -95,7 +95,7 @@ __device__ __forceinline__ float dist2_nofma(float ax, float ay, float az, float
 // ---- parameter-only tables (ptx_prepare) ------------------------------------
 struct PrepLayout {
     // all offsets in floats from the start of `prep`
-    size_t off_ab, enc_ab;          // (2,256): alpha, beta of the folded eval BatchNorm2d
+    size_t off_ab, enc_ab;          // (2,256), (2,C): alpha, beta of the folded eval BatchNorm2d
     size_t ttn_ab, itn_ab;          // (2,3), (2,9) BatchNorm1d alpha/beta
     size_t posb_t, posb_i;          // (Mk,C) per-slot bias tables (PRE:212-215)
     size_t w3, b3;                  // (3C,in_dim), (3C): [q | k0 | v0] of token 0 from the image mean
@@ -161,7 +161,7 @@ struct AttnProb {
     int nq, nk, ldq, ldk, ldv, ldo;
     long sQ, sK, sV, sO;                                     // per-scene strides (elements)
 };
-struct AttnBatch { AttnProb p[2]; int n; int B, heads; float scale; };
+struct AttnBatch { AttnProb p[2]; int n; int B, heads, hd; float scale; };
 int launch_attn32(const AttnBatch &ab, hipStream_t st);
 
 // Per-scene base pointers of the point clouds, passed by value as a kernel argument: the caller's
@@ -182,7 +182,7 @@ int launch_offset_net(const float *ab, const PtxSlotMlp &mlp, const float *map_w
                       int BM, int M, int K, float margin, float *centers_out, float *offsets_out,
                       hipStream_t st);
 int launch_pointnet(const float *ab, const PtxSlotMlp &mlp, const float *kcenter,
-                    const float *kcluster, int BM, int Mk, int K, float *point_proxy,
+                    const float *kcluster, int BM, int Mk, int K, int width, float *point_proxy,
                     const PtxBlock *blk_t, const PtxBlock *blk_i, const float *posb_t,
                     const float *posb_i, float *xin_t, float *xin_i, float ln_eps, hipStream_t st);
 int launch_select(const PtxShape &s, const int32_t *idx, const float *centers, const float *cluster,

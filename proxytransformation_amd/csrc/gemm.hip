@@ -431,13 +431,14 @@ int launch_ln_rows(const LnBatch &lb, hipStream_t st)
 // of this kernel (measured: 12 of 20 us with one row per wave), not its arithmetic.
 constexpr int kHeadRows = 4;
 
+template <int Q>       // C / 64 values per lane
 __global__ __launch_bounds__(256) void k_heads(HeadBatch hb)
 {
     const HeadProb p = hb.p[blockIdx.y];
     const int row0 = __builtin_amdgcn_readfirstlane((blockIdx.x * 4 + (threadIdx.x >> 6)) * kHeadRows);
     if (row0 >= p.R) return;
     const int lane = lane_id();
-    constexpr int kMaxOut = 9, Q = 4;                      // C = 256: 4 values per lane
+    constexpr int kMaxOut = 9;
     float hbias = 0.0f, bn_a = 0.0f, bn_b = 0.0f;
     if (lane < p.nout) { hbias = p.hb[lane]; bn_a = p.ab[lane]; bn_b = p.ab[p.nout + lane]; }
     float nw[Q], nb[Q], hwt[kMaxOut][Q];
@@ -457,7 +458,10 @@ __global__ __launch_bounds__(256) void k_heads(HeadBatch hb)
     for (int r = 0; r < kHeadRows; ++r) {
         const int row = row0 + r;
         if (row >= p.R) break;                               // wave-uniform
-        const float mean = wave_sum((x[r][0] + x[r][1]) + (x[r][2] + x[r][3])) / (float)hb.C;
+        float rsum = (x[r][0] + x[r][1]) + (x[r][2] + x[r][3]);
+#pragma unroll
+        for (int q = 4; q < Q; ++q) rsum += x[r][q];
+        const float mean = wave_sum(rsum) / (float)hb.C;
         float var = 0.0f;
 #pragma unroll
         for (int q = 0; q < Q; ++q) { const float d = x[r][q] - mean; var = fmaf(d, d, var); }
@@ -485,14 +489,16 @@ __global__ __launch_bounds__(256) void k_heads(HeadBatch hb)
 
 int launch_heads(const HeadBatch &hb, hipStream_t st)
 {
-    PTX_REQUIRE(hb.C == 256, "heads: C=%d unsupported (256 only)", hb.C);
+    PTX_REQUIRE(hb.C == 256 || hb.C == 512, "heads: C=%d unsupported (256, 512)", hb.C);
     int rmax = 0;
     for (int g = 0; g < hb.n; ++g) {
         PTX_REQUIRE(hb.p[g].nout >= 1 && hb.p[g].nout <= 9, "heads: nout=%d", hb.p[g].nout);
         rmax = hb.p[g].R > rmax ? hb.p[g].R : rmax;
     }
     if (rmax == 0) return PTX_OK;
-    hipLaunchKernelGGL(k_heads, dim3(cdiv(rmax, 4 * kHeadRows), hb.n), dim3(256), 0, st, hb);
+    const dim3 grid(cdiv(rmax, 4 * kHeadRows), hb.n);
+    if (hb.C == 256) hipLaunchKernelGGL(k_heads<4>, grid, dim3(256), 0, st, hb);
+    else             hipLaunchKernelGGL(k_heads<8>, grid, dim3(256), 0, st, hb);
     PTX_LAUNCHED("k_heads");
     return PTX_OK;
 }

@@ -18,12 +18,14 @@ __global__ void k_prep_bn(const float *w, const float *b, const float *mean, con
 }
 
 // bias[j][y*s+x] = bilinear(pb[j] 4x4 -> s x s, align_corners=False)[y][x] + pc[j][y] + pr[j][x]
-__global__ void k_prep_posbias(const float *pb, const float *pc, const float *pr, int Mk, int s,
+// for the first C entries of the s x s grid: s = sqrt(C) for the reference's C = 256 (PRE:196, the whole grid);
+// for a C that is no perfect square (512: the reference cannot run it) s = ceil(sqrt(C)), cropped.
+__global__ void k_prep_posbias(const float *pb, const float *pc, const float *pr, int Mk, int s, int C,
                                float *out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= Mk * s * s) return;
-    const int j = i / (s * s), yx = i - j * s * s, y = yx / s, x = yx - y * s;
+    if (i >= Mk * C) return;
+    const int j = i / C, yx = i - j * C, y = yx / s, x = yx - y * s;
     const float sc = 4.0f / (float)s;
     float sy = sc * ((float)y + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
     float sx = sc * ((float)x + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
@@ -104,8 +106,8 @@ int run_prepare(const PtxShape &s, const PtxWeights &w, float *prep, hipStream_t
     const int C = s.C, T = 256;
     hipLaunchKernelGGL(k_prep_bn, dim3(1), dim3(T), 0, st, w.offset.bn_w, w.offset.bn_b,
                        w.offset.bn_mean, w.offset.bn_var, kSlotHidden, s.bn_eps, prep + P.off_ab);
-    hipLaunchKernelGGL(k_prep_bn, dim3(1), dim3(T), 0, st, w.encoder.bn_w, w.encoder.bn_b,
-                       w.encoder.bn_mean, w.encoder.bn_var, kSlotHidden, s.bn_eps, prep + P.enc_ab);
+    hipLaunchKernelGGL(k_prep_bn, dim3(cdiv(C, T)), dim3(T), 0, st, w.encoder.bn_w, w.encoder.bn_b,
+                       w.encoder.bn_mean, w.encoder.bn_var, C, s.bn_eps, prep + P.enc_ab);
     hipLaunchKernelGGL(k_prep_bn, dim3(1), dim3(T), 0, st, w.text_trans_norm.w, w.text_trans_norm.b,
                        w.text_trans_norm.mean, w.text_trans_norm.var, 3, s.bn_eps, prep + P.ttn_ab);
     hipLaunchKernelGGL(k_prep_bn, dim3(1), dim3(T), 0, st, w.img_trans_norm.w, w.img_trans_norm.b,
@@ -115,9 +117,9 @@ int run_prepare(const PtxShape &s, const PtxWeights &w, float *prep, hipStream_t
     while (sd * sd < C) ++sd;
     const int nb = s.Mk * C;
     hipLaunchKernelGGL(k_prep_posbias, dim3(cdiv(nb, T)), dim3(T), 0, st, w.text.pb_bias, w.text.pc_bias,
-                       w.text.pr_bias, s.Mk, sd, prep + P.posb_t);
+                       w.text.pr_bias, s.Mk, sd, C, prep + P.posb_t);
     hipLaunchKernelGGL(k_prep_posbias, dim3(cdiv(nb, T)), dim3(T), 0, st, w.img.pb_bias, w.img.pc_bias,
-                       w.img.pr_bias, s.Mk, sd, prep + P.posb_i);
+                       w.img.pr_bias, s.Mk, sd, C, prep + P.posb_i);
     PTX_LAUNCHED("k_prep_posbias");
     hipLaunchKernelGGL(k_prep_w3, dim3(cdiv(3 * C * (s.in_dim + 1), T)), dim3(T), 0, st, w.q_w, w.k_w, w.v_w,
                        w.q_b, w.cm_w, w.cm_b, w.pos, C, s.in_dim, prep + P.w3, prep + P.b3);

@@ -31,6 +31,16 @@ __all__ = ["ProxyTransformationNormReverse"]
 _RADIUS, _MARGIN = 3.0, 4.0          # PRE:23 (fixed, not reachable from the config)
 _EMPTY_DROP = 0.3                    # PRE:352
 _SLOT_WIDTH = 256                    # PRE:31, PRE:302 (hard-coded in the reference)
+_EMBED_DIMS = (256, 512)             # 256 = everything the reference can run; 512 = BASELINE's stress config
+
+
+def _bias_grid(dim: int) -> int:
+    """Side of the per-slot positional-bias grid: int(sqrt(dim)) for a perfect square (PRE:196); a dim that is
+    no perfect square -- which the reference cannot run at all (its reshape at PRE:217 fails) -- uses the
+    next larger grid, of which the first ``dim`` entries are taken."""
+    s = int(dim ** 0.5)
+    return s if s * s == dim else s + 1
+
 _IMG_DTYPES = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}   # PtxShape.img_dtype
 _COUNTS_TIMEOUT_US = 20_000_000         # then fall back to a stream synchronise
 _MAX_SCENES_PER_CALL = 32            # kMaxScenes of the C ABI (per-scene pointer table passed by value)
@@ -84,7 +94,7 @@ class _ProxyAttention(_Holder):                                       # PRE:179-
         self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
         self.proxy_proj = nn.Linear(dim, dim)
         self.proj = nn.Linear(dim, dim)
-        s = int(dim ** 0.5)
+        s = _bias_grid(dim)
         self.pb_bias = nn.Parameter(torch.zeros(1, kept, 4, 4))
         self.pc_bias = nn.Parameter(torch.zeros(1, kept, s, 1))
         self.pr_bias = nn.Parameter(torch.zeros(1, kept, 1, s))
@@ -124,6 +134,9 @@ class ProxyTransformationNormReverse(nn.Module):
         super().__init__()
         if act_layer is not nn.GELU or norm_layer is not nn.LayerNorm:
             raise NotImplementedError("the HIP path implements act_layer=nn.GELU, norm_layer=nn.LayerNorm")
+        if embed_dim not in _EMBED_DIMS or num_heads != 8:
+            raise NotImplementedError(f"the HIP path implements embed_dim in {_EMBED_DIMS} with num_heads=8 "
+                                      f"(got embed_dim={embed_dim}, num_heads={num_heads})")
         self.embed_dim = embed_dim
         self.num_heads = num_heads
         self.grid_size = grid_size
@@ -141,7 +154,9 @@ class ProxyTransformationNormReverse(nn.Module):
         self.real_cluster_num = kept
 
         self.get_deformable_cluster = _DeformablePointCluster(_SLOT_WIDTH)
-        self.simple_encoder = _SimplifiedPointNet(_SLOT_WIDTH)
+        # the reference hard-codes 256 output channels (PRE:302), which only works with embed_dim = 256;
+        # the point encoder is as wide as the tokens it feeds
+        self.simple_encoder = _SimplifiedPointNet(embed_dim)
         self.channel_mapper = nn.Conv2d(input_dim, embed_dim, kernel_size=1)
         self.attn_pool2d = _AttentionPool2d(img_spacial_dim, embed_dim)
         self.norm_img = nn.LayerNorm(embed_dim)
@@ -303,15 +318,16 @@ class ProxyTransformationNormReverse(nn.Module):
         return ctx
 
     def _release_context(self):
-        ctx, self._ctx = getattr(self, "_ctx", None), None
+        ctx = self.__dict__.get("_ctx")
+        self.__dict__["_ctx"] = None
         if ctx is not None:
-            try:
-                _abi.lib().ptx_context_destroy(ctx)
-            except Exception:      # interpreter shutdown
-                pass
+            _abi.lib().ptx_context_destroy(ctx)
 
     def __del__(self):
-        self._release_context()
+        try:
+            self._release_context()
+        except Exception:          # interpreter shutdown: modules may already be torn down
+            pass
 
     def _workspace(self, shape: _abi.PtxShape, device: torch.device) -> torch.Tensor:
         key = (shape.B, shape.N, shape.L, shape.V, str(device))           # layout does not depend on img_dtype

@@ -86,7 +86,7 @@ CONFIGS: Dict[str, PreshapeConfig] = {
                            L=20, V=50, text_blocks=3, img_blocks=3, seed_base=4000),
     # cfg5: stress / roofline run; the reference itself cannot run d=512
     "cfg5": PreshapeConfig("cfg5", B=1, N=500000, grid_size=16, dynamic_drop_radio=0.75,
-                           L=64, V=192, seed_base=5000),
+                           L=64, V=192, embed_dim=512, seed_base=5000),
 }
 
 

@@ -240,19 +240,13 @@ def test_forward_vs_oracle_fresh_scene(seed):
 
 
 # ------------------------------------------------------------------ full-size properties (cfg2 shape)
-def test_full_size_properties_cfg2():
-    """BASELINE config 2 shape (100k points, 512 -> 256 kept clusters, 64 + 196 proxies): the oracle
-    would take minutes here, so check size-independent properties of the result instead."""
-    from proxytransformation_amd.synth import CONFIGS, make_scene_batch
-    cfg = CONFIGS["cfg2"]
-    m, _ = _gpu_module(cfg)
-    batch = make_scene_batch(cfg, scene_ids=[0, 1])
-    d = m.forward_debug(*_inputs(batch))
-    pts = batch[0]
+def check_forward_properties(cfg, d, pts, scenes):
+    """Size-independent properties of one forward_debug result (used at BASELINE's full sizes, also where the
+    reference has no parity to offer: cfg5)."""
     idx2, kidx, drop = _i64(d["idx2"]), _i64(d["kidx"]), _i64(d["drop_idx"])
     tag = d["tag"].cpu().numpy().astype(np.int64) & 0xFFFFFFFF
     K = cfg.num_sub
-    for b in range(2):
+    for b in scenes:
         # ball query: hits ascending, inside the sphere, padding only at the tail
         c = d["centers"][b].cpu().numpy()
         for mi in range(0, cfg.M, 37):
@@ -291,3 +285,15 @@ def test_full_size_properties_cfg2():
                 cl = s_ // K
                 exp = T[cl].astype(np.float64) @ (pts[b, j] - kc[cl]).astype(np.float64) + kc[cl] + tr[cl]
                 assert np.abs(out[pos[j]] - exp).max() < 1e-4
+
+
+def test_full_size_properties_cfg2():
+    """BASELINE config 2 shape (100k points, 512 -> 256 kept clusters, 64 + 196 proxies), un-injected: the
+    size-independent properties of the result (the same workload is compared with the oracle value by value in
+    tests/test_gpu_workloads.py)."""
+    from proxytransformation_amd.synth import CONFIGS, make_scene_batch
+    cfg = CONFIGS["cfg2"]
+    m, _ = _gpu_module(cfg)
+    batch = make_scene_batch(cfg, scene_ids=[0, 1])
+    d = m.forward_debug(*_inputs(batch))
+    check_forward_properties(cfg, d, batch[0], range(2))

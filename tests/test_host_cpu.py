@@ -58,9 +58,19 @@ def test_shape_validation_and_sizes_on_host():
     assert lib.ptx_workspace_bytes(ctypes.byref(s)) > 4 * 100000 * 4
     assert lib.ptx_prep_bytes(ctypes.byref(s)) > 0
     bad = m._shape(4, 100000, 64, 196)
-    bad.C = 512                                   # not runnable by the reference either
+    bad.C = 384                                   # 256 (the reference) and 512 (BASELINE configs[4]) only
     assert lib.ptx_workspace_bytes(ctypes.byref(bad)) == 0
     assert b"embed_dim" in lib.ptx_last_error()
+    big = MODELS.build(dict(type="ProxyTransformationNormReverse", grid_size=16, dynamic_drop_radio=0.75,
+                            embed_dim=512))       # cfg5: the reference itself cannot run this
+    s5 = big._shape(1, 500000, 64, 192, 2)
+    assert (s5.Mt, s5.Mk, s5.C, s5.hidden) == (2868, 1024, 512, 2048)
+    assert lib.ptx_workspace_bytes(ctypes.byref(s5)) > 0 and lib.ptx_prep_bytes(ctypes.byref(s5)) > 0
+    assert big.textformer[0].attn.pc_bias.shape == (1, 1024, 23, 1)
+    assert big.simple_encoder.mlp[0].weight.shape == (512, 6, 1, 1)
+    bad = m._shape(4, 100000, 64, 196, 1)
+    bad.hw = 256                                  # 16-bit features: at most 255 pixels -- rejected before any enqueue
+    assert lib.ptx_workspace_bytes(ctypes.byref(bad)) == 0 and b"H*W" in lib.ptx_last_error()
     bad = m._shape(4, 100000, 64, 196)
     bad.K = 64
     assert lib.ptx_prep_bytes(ctypes.byref(bad)) == 0
