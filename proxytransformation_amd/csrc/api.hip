@@ -86,7 +86,7 @@ int validate_shape(const PtxShape &s)
     PTX_REQUIRE(s.L >= 1 && s.V >= 1, "shape: L=%d V=%d", s.L, s.V);
     PTX_REQUIRE(s.img_dtype >= 0 && s.img_dtype <= 2, "shape: img_dtype=%d (0 fp32, 1 bf16, 2 fp16)", s.img_dtype);
     if (s.img_dtype == 0) PTX_REQUIRE(s.hw >= 4 && s.hw <= 256, "shape: H*W=%d (fp32 image features: 4..256 pixels)", s.hw);
-    else PTX_REQUIRE(s.hw >= 8 && s.hw <= 255, "shape: H*W=%d (16-bit image features: 8..255 pixels)", s.hw);
+    else PTX_REQUIRE(s.hw >= 8 && s.hw <= 256, "shape: H*W=%d (16-bit image features: 8..256 pixels)", s.hw);
     PTX_REQUIRE((long)s.Mk * s.K < (1l << 31) - 1, "shape: Mk*K overflows the ownership tag");
     return PTX_OK;
 }

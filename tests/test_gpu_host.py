@@ -46,7 +46,7 @@ def test_every_kind_of_weight_change_is_picked_up():
     m.load_state_dict(alt)                                   # in-place copy: versions bump
     assert _same(m(*inp), want_alt)
     orig = {k: torch.from_numpy(v).cuda() for k, v in sd.items()}
-    m.load_state_dict(orig, assign=True)                     # new Parameter objects, old ones untouched
+    m.load_state_dict({k: v.clone() for k, v in orig.items()}, assign=True)   # new Parameter objects, old ones untouched
     assert _same(m(*inp), base)
     m.channel_mapper.weight = torch.nn.Parameter(alt["channel_mapper.weight"].clone())   # re-assigned Parameter
     mixed = dict(orig)

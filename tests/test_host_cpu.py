@@ -69,7 +69,7 @@ def test_shape_validation_and_sizes_on_host():
     assert big.textformer[0].attn.pc_bias.shape == (1, 1024, 23, 1)
     assert big.simple_encoder.mlp[0].weight.shape == (512, 6, 1, 1)
     bad = m._shape(4, 100000, 64, 196, 1)
-    bad.hw = 256                                  # 16-bit features: at most 255 pixels -- rejected before any enqueue
+    bad.hw = 289                                  # 16-bit features: at most 256 pixels -- rejected before any enqueue
     assert lib.ptx_workspace_bytes(ctypes.byref(bad)) == 0 and b"H*W" in lib.ptx_last_error()
     bad = m._shape(4, 100000, 64, 196)
     bad.K = 64
