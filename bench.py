@@ -1,31 +1,34 @@
 #!/usr/bin/env python3
 """Throughput of the preshape hot path on MI355X: scenes/sec at 1/2/4/8 GPUs.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (N > 1: re-launches itself under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A *step* is one eval forward of ``ProxyTransformationNormReverse`` over this rank's batch of
-synthetic scenes (BASELINE.json configs[1] shape: 100k points, 8^3 grid -> 256 kept clusters,
-64 text + 196 image proxies, d = 256, image features stored as bf16 as that config names; 4 scenes
-per GPU = the per-GPU shard of configs[2]).  All arithmetic is fp32; the rate with fp32-stored
-features is measured in the same run and reported as `value_f32_features`.
-Inputs are resident in HBM before the timed region; a step returns when the list of output
-tensors exists (the host waits for the per-scene lengths, which the clustering chain publishes
-early; the tensors' contents are stream-ordered like any torch result) and the timed region is
-closed by a full device synchronise, so every step's GPU work is inside it.
+A *step* is one eval forward of ``ProxyTransformationNormReverse`` over this rank's batch of synthetic scenes
+(BASELINE.json configs[1] shape: 100k points, 8^3 grid -> 256 kept clusters, 64 text + 196 image proxies, d = 256,
+image features stored as bf16 as that config names; 4 scenes per GPU = the per-GPU shard of configs[2]).  All
+arithmetic is fp32.  Inputs are resident in HBM before the timed region; consecutive steps use DIFFERENT input
+sets (``--sets``, default 3: together larger than the 256 MiB Infinity Cache), so every step streams its image
+features from HBM.  A step returns when the list of output tensors exists (the host waits for the per-scene
+lengths, which the clustering chain publishes early; the tensors' contents are stream-ordered like any torch result)
+and the timed region is closed by a full device synchronise, so every step's GPU work is inside it.
 Scenes are sharded by scene id with no data-path collective (weak scaling).
 
 Rank 0 prints ONE JSON line.  Extra objects:
-  roofline      dominant kernel (the one pass over img_feat after the means: k_img_pool for bf16-stored
-                features, k_img_scores for fp32): algorithmic
-                bytes per launch / average launch duration, timed with HIP events recorded by
-                the library on the kernel's own stream during the timed steps; `traffic` = HBM
-                bytes per launch from the committed rocprofv3 PMC pass (profiles/pmc_traffic.json,
-                FETCH_SIZE corrected as MI355X_MICROARCH.md prescribes, + WRITE_SIZE), null if the
-                file has no entry for this kernel / shape
-  cpu_baseline  the CPU oracle (torch CPU fp32 + C ball query / FPS, "port") on this box's
-                host cores, same workload, bounded sample (rank 0, N = 1 only)
+  roofline         dominant kernel (the pass over img_feat after the means: k_img_pool for 16-bit features, k_img_scores
+                   for fp32): algorithmic bytes per launch / average launch duration, timed with HIP events recorded by
+                   the library on the kernel's own stream during the timed steps; `traffic` = HBM bytes per launch from
+                   the committed rocprofv3 PMC passes (profiles/r02_pmc_traffic.json: FETCH_SIZE corrected as
+                   MI355X_MICROARCH.md prescribes, + WRITE_SIZE), null if that file has no entry for this shape
+  roofline_passes  per-pass figures of the north star, measured after the timed region with every launch site
+                   bracketed by events (which perturbs the step a little -- hence not inside it), at the benchmark's
+                   4 scenes per GPU and at 32 scenes per GPU: HBM fraction of the clustering / apply passes, fp32-MFMA
+                   fraction of proxy attention and of the block GEMMs
+  pipelined        the same steps issued round-robin on two torch streams (two independent batches in flight, as a
+                   serving loop would run them); `value` itself is single-stream
+  cpu_baseline     the CPU oracle (torch CPU fp32 + C ball query / FPS, "port") on this box's host cores, same
+                   workload, bounded sample (rank 0, N = 1 only)
 """
 from __future__ import annotations
 
@@ -36,7 +39,6 @@ import os
 import sys
 import time
 
-import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -47,22 +49,25 @@ from proxytransformation_amd import MODELS, _abi                                
 from proxytransformation_amd.synth import CONFIGS, fill_state_dict, make_scene_batch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix (v_mfma_f32_32x32x2_f32), 256 CUs
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=12)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--scenes-per-gpu", type=int, default=None)
-    ap.add_argument("--img-dtype", default="bf16", choices=["f32", "bf16", "f16"],
-                    help="storage type of the image features (BASELINE config 2 names bf16; arithmetic is fp32 "
-                         "either way); the fp32-feature rate is reported next to it")
-    ap.add_argument("--time-kernel", default="img_pass2",
-                    help="launch site timed for the roofline object (img_pass2 = the dominant stream over img_feat "
-                         "after the mean pass: k_img_pool for bf16 features, k_img_scores for fp32)")
+    ap.add_argument("--img-dtype", default=None, choices=["f32", "bf16", "f16"],
+                    help="storage type of the image features (cfg2: bf16 as BASELINE names it, cfg5: fp16, otherwise "
+                         "fp32; arithmetic is fp32 either way)")
+    ap.add_argument("--sets", type=int, default=3, help="distinct input sets rotated through the steps")
+    ap.add_argument("--streams", type=int, default=1, help="torch streams the timed steps are issued on (round-robin)")
+    ap.add_argument("--time-kernel", default="img_pass2", help="launch site timed inside the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-passes", action="store_true", help="skip roofline_passes / pipelined / fp32-feature extras")
     ap.add_argument("--cpu-scenes", type=int, default=None, help="scenes in the CPU baseline sample")
     ap.add_argument("--breakdown", action="store_true", help="print per-kernel event timings to stderr")
     return ap.parse_args()
@@ -73,26 +78,6 @@ def build_module(cfg, device):
     sd = fill_state_dict(mod.state_dict())
     mod.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     return mod.eval().to(device), sd
-
-
-def kernel_id(lib, name):
-    names = [lib.ptx_kernel_name(i).decode() for i in range(lib.ptx_kernel_count())]
-    if name not in names:
-        raise SystemExit(f"--time-kernel must be one of {names}")
-    return names.index(name), names
-
-
-def algorithmic_bytes(cfg, B, name, img_itemsize=4, dt="f32"):
-    """Algorithmic HBM bytes one launch of `name` must move (kernel table)."""
-    img = B * cfg.V * cfg.input_dim * cfg.img_spacial_dim ** 2 * img_itemsize
-    table = {
-        "k_img_mean": img, "img_pass2": img,
-        "img_pass3": None if dt in ("bf16", "f16") else img,
-        "k_minmax": B * cfg.N * 12,
-        "k_affine<compact>": B * cfg.N * (12 + 4 + 12),
-        "k_tile_count": B * cfg.N * 4,
-    }
-    return table.get(name)
 
 
 # the kernel behind a launch site depends on the storage type of the image features
@@ -110,7 +95,7 @@ def site_kernel(site, dt):
 def pmc_traffic(kernel, dt, cfg, B):
     """HBM bytes per launch of `kernel` from the committed PMC digest (tools/profile_round.sh)."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        d = json.load(open(PMC_FILE))
         if d.get("config") != cfg.name or d.get("scenes_per_gpu") != B:
             return None
         for name, v in d[dt].items():
@@ -119,6 +104,28 @@ def pmc_traffic(kernel, dt, cfg, B):
     except (OSError, KeyError, ValueError):
         pass
     return None
+
+
+def work_model(cfg, B, dt_bytes):
+    """Algorithmic bytes / flops of ONE launch of each site (DESIGN.md kernel table)."""
+    N, M, K, Mk, C, L, V, H = cfg.N, cfg.M, cfg.num_sub, cfg.M_keep, cfg.embed_dim, cfg.L, cfg.V, cfg.embed_dim * 4
+    R = B * Mk
+    img = B * V * cfg.input_dim * cfg.img_spacial_dim ** 2 * dt_bytes
+    byts = {
+        "k_img_mean": img, "img_pass2": img, "img_pass3": img if dt_bytes == 4 else None,
+        "k_minmax": B * N * 12,
+        # two ball-query passes (upper bound: every point read once per pass) + cluster writes of the second
+        "k_cluster": B * (2 * 12 * N + M * K * (4 + 12) + M * 16),
+        "k_tile_count": B * N * 4,
+        "k_affine<compact>": B * N * (12 + 4 + 12),
+    }
+    flops = {
+        "k_attn32[proxy_as_query]": 4.0 * R * (L + V) * C, "k_attn32[proxy_as_key]": 4.0 * R * (L + V) * C,
+        "k_gemm_nt[qkv+proxy_proj]": 2.0 * 2 * R * 3 * C * C + 2.0 * B * L * C * C,
+        "k_gemm_nt[pp_img]": 2.0 * B * V * C * C,
+        "k_gemm_nt[proj]": 2.0 * 2 * R * C * C, "k_gemm_nt[fc1]": 2.0 * 2 * R * H * C, "k_gemm_nt[fc2]": 2.0 * 2 * R * H * C,
+    }
+    return byts, flops
 
 
 def cpu_baseline(cfg, sd, n_scenes):
@@ -154,11 +161,99 @@ def cpu_baseline(cfg, sd, n_scenes):
                        f"single-thread C ball query / FPS")
 
 
+class InputSets:
+    """`nsets` device-resident input sets of B scenes each; set j of rank r holds scenes (j * world + r) * B ..."""
+
+    def __init__(self, cfg, B, nsets, rank, world, device, tdt):
+        self.sets = []
+        for j in range(nsets):
+            first = (j * world + rank) * B
+            pts, text, mask, img = make_scene_batch(cfg, scene_ids=range(first, first + B))
+            img_t = torch.from_numpy(img).to(device)
+            self.sets.append(dict(
+                points=[torch.from_numpy(p).to(device) for p in pts],
+                text={"text_feats": torch.from_numpy(text).to(device), "text_token_mask": torch.from_numpy(mask).to(device)},
+                img_f32=img_t, img=img_t if tdt is torch.float32 else img_t.to(tdt)))
+            del img
+        self.B = B
+
+    def args(self, i, f32=False):
+        s = self.sets[i % len(self.sets)]
+        return s["points"], s["text"], (s["img_f32"] if f32 else s["img"])
+
+    def widened(self, factor):
+        """B * factor scenes per set out of the resident ones (distinct addresses: copies, not views)."""
+        out = InputSets.__new__(InputSets)
+        out.B = self.B * factor
+        out.sets = []
+        n = len(self.sets)
+        for j in range(n):
+            src = [self.sets[(j + k) % n] for k in range(factor)]
+            out.sets.append(dict(
+                points=[p.clone() for s in src for p in s["points"]],
+                text={"text_feats": torch.cat([s["text"]["text_feats"] for s in src]),
+                      "text_token_mask": torch.cat([s["text"]["text_token_mask"] for s in src])},
+                img=torch.cat([s["img"] for s in src]), img_f32=None))
+        return out
+
+
+def timed_steps(mod, inputs, steps, barrier, streams=None, f32=False):
+    barrier()
+    t0 = time.perf_counter()
+    if streams is None:
+        for i in range(steps):
+            outs = mod(*inputs.args(i, f32))
+    else:
+        for i in range(steps):
+            with torch.cuda.stream(streams[i % len(streams)]):
+                outs = mod(*inputs.args(i, f32))
+    barrier()
+    return time.perf_counter() - t0, outs
+
+
+def site_times(lib, names, mod, inputs, steps):
+    """Average duration of every launch site over `steps` forwards (all sites bracketed by events)."""
+    lib.ptx_timing_select_mask((1 << len(names)) - 1)
+    for i in range(steps):
+        mod(*inputs.args(i))
+    torch.cuda.synchronize()
+    n = (ctypes.c_int * len(names))()
+    ms = (ctypes.c_float * len(names))()
+    lib.ptx_timing_read_sites(n, ms, len(names))
+    lib.ptx_timing_select(-1)
+    return {nm: 1e3 * ms[i] / n[i] for i, nm in enumerate(names) if n[i] > 0}
+
+
+def passes_report(cfg, B, us, dt_bytes):
+    byts, flops = work_model(cfg, B, dt_bytes)
+    rep = {"scenes_per_gpu": B}
+
+    def hbm(sites):
+        t = sum(us[s] for s in sites if s in us)
+        b = sum(byts[s] for s in sites if byts.get(s))
+        return dict(us=round(t, 2), algorithmic_MB=round(b / 1e6, 2), achieved_GBs=round(b / t / 1e3, 1),
+                    frac_of_hbm_peak=round(b / t / 1e3 / HBM_PEAK_GBS, 4)) if t > 0 else None
+
+    def mfma(sites):
+        t = sum(us[s] for s in sites if s in us)
+        f = sum(flops[s] for s in sites if s in us)
+        return dict(us=round(t, 2), GFLOP=round(f / 1e9, 3), achieved_TFLOPs=round(f / t / 1e6, 2),
+                    frac_of_f32_mfma_peak=round(f / t / 1e6 / MFMA_F32_PEAK_TFLOPS, 4)) if t > 0 else None
+    rep["clustering_pass_hbm"] = hbm(["k_minmax", "k_cluster"])
+    rep["apply_pass_hbm"] = hbm(["k_tile_count", "k_affine<compact>"])
+    rep["k_minmax"] = hbm(["k_minmax"])
+    rep["k_affine"] = hbm(["k_affine<compact>"])
+    rep["img_mean_pass_hbm"] = hbm(["k_img_mean"])
+    rep["img_pool_pass_hbm"] = hbm(["img_pass2"])
+    rep["proxy_attention_mfma"] = mfma(["k_attn32[proxy_as_query]", "k_attn32[proxy_as_key]"])
+    rep["block_gemms_mfma"] = mfma(["k_gemm_nt[qkv+proxy_proj]", "k_gemm_nt[pp_img]", "k_gemm_nt[proj]",
+                                    "k_gemm_nt[fc1]", "k_gemm_nt[fc2]"])
+    rep["site_us"] = {k: round(v, 2) for k, v in us.items()}
+    return rep
+
+
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and "RANK" not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher -- one rank per GPU over RCCL, same flags
         import socket
@@ -169,6 +264,9 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd))
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path to measure)"
@@ -181,88 +279,84 @@ def main():
 
     cfg = CONFIGS[args.config]
     B = args.scenes_per_gpu or cfg.B
-    scene_ids = range(rank * B, rank * B + B)                  # weak scaling: B scenes per GPU
+    img_dtype = args.img_dtype or {"cfg2": "bf16", "cfg5": "f16"}.get(cfg.name, "f32")
+    tdt = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[img_dtype]
     mod, sd = build_module(cfg, device)
-    pts, text, mask, img = make_scene_batch(cfg, scene_ids=scene_ids)
-    points = [torch.from_numpy(p).to(device) for p in pts]
-    text_dict = {"text_feats": torch.from_numpy(text).to(device),
-                 "text_token_mask": torch.from_numpy(mask).to(device)}
-    tdt = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[args.img_dtype]
-    img_f32 = torch.from_numpy(img).to(device)
-    img_feat = img_f32 if tdt is torch.float32 else img_f32.to(tdt)
+    inputs = InputSets(cfg, B, max(1, args.sets), rank, world, device, tdt)
     lib = _abi.lib()
-    kid, names = kernel_id(lib, args.time_kernel)
+    names = [lib.ptx_kernel_name(i).decode() for i in range(lib.ptx_kernel_count())]
+    if args.time_kernel not in names:
+        raise SystemExit(f"--time-kernel must be one of {names}")
+    kid = names.index(args.time_kernel)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    streams = [torch.cuda.Stream() for _ in range(args.streams)] if args.streams > 1 else None
+    extras = {}
     with torch.no_grad():
-        for _ in range(args.warmup):
-            outs = mod(points, text_dict, img_feat)
+        for i in range(args.warmup):
+            outs = mod(*inputs.args(i))
+        if streams:
+            for i in range(2 * len(streams)):
+                with torch.cuda.stream(streams[i % len(streams)]):
+                    mod(*inputs.args(i))
         n_out = sum(int(o.shape[0]) for o in outs) if args.warmup else None
         lib.ptx_timing_select(kid)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            outs = mod(points, text_dict, img_feat)
-        barrier()
-        elapsed = time.perf_counter() - t0
+        elapsed, outs = timed_steps(mod, inputs, args.steps, barrier, streams)
         launches, total_ms = ctypes.c_int(0), ctypes.c_float(0.0)
         lib.ptx_timing_read(ctypes.byref(launches), ctypes.byref(total_ms))
         lib.ptx_timing_select(-1)
 
-        # the same workload with fp32-stored image features (the reference's non-AMP layout)
-        elapsed_f32 = None
-        if tdt is not torch.float32:
-            for _ in range(max(2, args.warmup // 2)):
-                mod(points, text_dict, img_f32)
-            barrier()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                mod(points, text_dict, img_f32)
-            barrier()
-            elapsed_f32 = time.perf_counter() - t1
-
-        breakdown = None
+        if not args.no_passes:
+            steps2 = max(10, args.steps // 2)
+            if tdt is not torch.float32:        # the same workload with fp32-stored image features (non-AMP layout)
+                for i in range(4):
+                    mod(*inputs.args(i, True))
+                extras["f32"] = timed_steps(mod, inputs, steps2, barrier, None, True)[0] / steps2
+            two = [torch.cuda.Stream() for _ in range(2)]
+            for i in range(6):
+                with torch.cuda.stream(two[i % 2]):
+                    mod(*inputs.args(i))
+            extras["pipe"] = timed_steps(mod, inputs, args.steps, barrier, two)[0] / args.steps
+            if rank == 0:
+                extras["passes"] = [passes_report(cfg, B, site_times(lib, names, mod, inputs, 20), inputs.sets[0]["img"].element_size())]
+                if cfg.name == "cfg2" and B * 8 <= 32:
+                    wide = inputs.widened(8)
+                    for i in range(3):
+                        mod(*wide.args(i))
+                    extras["passes"].append(passes_report(cfg, wide.B, site_times(lib, names, mod, wide, 9),
+                                                          wide.sets[0]["img"].element_size()))
+                    del wide
         if args.breakdown and rank == 0:
-            breakdown = {}
-            for i, nm in enumerate(names):
-                lib.ptx_timing_select(i)
-                for _ in range(5):
-                    mod(points, text_dict, img_feat)
-                torch.cuda.synchronize()
-                n_, ms_ = ctypes.c_int(0), ctypes.c_float(0.0)
-                lib.ptx_timing_read(ctypes.byref(n_), ctypes.byref(ms_))
-                breakdown[nm] = round(1e3 * ms_.value / max(n_.value, 1), 2)
-            lib.ptx_timing_select(-1)
-            print("per-kernel us/launch:", json.dumps(breakdown), file=sys.stderr)
+            print("per-kernel us/launch:", json.dumps({k: round(v, 2) for k, v in site_times(lib, names, mod, inputs, 12).items()}),
+                  file=sys.stderr)
 
-    t = torch.tensor([elapsed, elapsed_f32 or 0.0], device=device, dtype=torch.float64)
+    vals = [elapsed, extras.get("f32", 0.0), extras.get("pipe", 0.0)]
+    t = torch.tensor(vals, device=device, dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t[0].item())
-    if elapsed_f32 is not None:
-        elapsed_f32 = float(t[1].item())
+    elapsed, f32_step, pipe_step = (float(x) for x in t.tolist())
 
     if rank == 0:
         total_scenes = world * B * args.steps
-        abytes = algorithmic_bytes(cfg, B, args.time_kernel, img_feat.element_size(), args.img_dtype)
+        byts, _ = work_model(cfg, B, inputs.sets[0]["img"].element_size())
+        abytes = byts.get(args.time_kernel)
         roof = None
-        if launches.value > 0 and not abytes:
-            roof = dict(kernel=site_kernel(args.time_kernel, args.img_dtype), avg_launch_us=round(total_ms.value / launches.value * 1e3, 2))
-        if launches.value > 0 and abytes:
-            # the image branch is launched once per slice of scenes (2 slices per forward): the
-            # algorithmic bytes of a step are spread over the launches actually recorded
-            abytes = abytes * args.steps // launches.value
+        if launches.value > 0:
             avg_s = total_ms.value / launches.value / 1e3
-            ach = abytes / avg_s / 1e9
-            roof = dict(bound="hbm", kernel=site_kernel(args.time_kernel, args.img_dtype), achieved=round(ach, 1), peak=HBM_PEAK_GBS,
-                        unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
-                        traffic=pmc_traffic(site_kernel(args.time_kernel, args.img_dtype), args.img_dtype, cfg, B),
-                        avg_launch_us=round(avg_s * 1e6, 2), launches=launches.value,
-                        algorithmic_bytes_per_launch=abytes)
+            roof = dict(kernel=site_kernel(args.time_kernel, img_dtype), avg_launch_us=round(avg_s * 1e6, 2),
+                        launches=launches.value)
+            if abytes:
+                ach = abytes / avg_s / 1e9
+                kern = site_kernel(args.time_kernel, img_dtype)
+                roof = dict(bound="hbm", kernel=kern, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=round(ach / HBM_PEAK_GBS, 4), traffic=pmc_traffic(kern, img_dtype, cfg, B),
+                            traffic_source="profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)",
+                            avg_launch_us=round(avg_s * 1e6, 2), launches=launches.value,
+                            algorithmic_bytes_per_launch=abytes)
         line = dict(metric="scenes/sec (100k pts, 256 clusters, 64 proxies)", value=round(total_scenes / elapsed, 2),
                     unit="scenes/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                     ms_per_step=round(1e3 * elapsed / args.steps, 4), higher_is_better=True, scaling="weak",
@@ -270,12 +364,18 @@ def main():
                     config=dict(workload=f"{cfg.name}: N={cfg.N} pts, gs={cfg.grid_size}->M'={cfg.M_keep} kept clusters, "
                                          f"L={cfg.L} text + V={cfg.V} image proxies, d={cfg.embed_dim}, eval forward",
                                 scenes_per_gpu=B, global_scenes_per_step=world * B, sharding="by scene, no collective",
-                                img_feat_dtype=args.img_dtype, arithmetic="fp32 (exact-fp32 MFMA / VALU; 16-bit matrix pipe only through exact 3-way operand splits, fp32 accumulate)",
+                                img_feat_dtype=img_dtype, input_sets_rotated=len(inputs.sets), streams=args.streams,
+                                arithmetic="fp32 (exact-fp32 MFMA / VALU; 16-bit matrix pipe only through exact 3-way operand splits, fp32 accumulate)",
                                 surviving_points_per_step=n_out),
                     roofline=roof)
-        if elapsed_f32 is not None:
-            line["value_f32_features"] = round(total_scenes / elapsed_f32, 2)
-            line["ms_per_step_f32_features"] = round(1e3 * elapsed_f32 / args.steps, 4)
+        if f32_step > 0:
+            line["value_f32_features"] = round(world * B / f32_step, 2)
+            line["ms_per_step_f32_features"] = round(1e3 * f32_step, 4)
+        if pipe_step > 0:
+            line["pipelined"] = dict(streams=2, value=round(world * B / pipe_step, 2), ms_per_step=round(1e3 * pipe_step, 4),
+                                     note="same steps, two independent batches in flight on two torch streams")
+        if "passes" in extras:
+            line["roofline_passes"] = extras["passes"]
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(cfg, sd, args.cpu_scenes or min(B, 2))

@@ -125,12 +125,22 @@ int         ptx_kernel_count(void);
 const char *ptx_kernel_name(int kid);
 int         ptx_timing_select(int kid);
 int         ptx_timing_read(int *launches, float *total_ms);
+/* Several launch sites at once (bit k of `mask` = site k); ptx_timing_read_sites fills two [host] arrays of
+ * ptx_kernel_count() entries.  The event records perturb the step a little: use the single-site form inside a
+ * timed region and the mask form for per-pass breakdowns. */
+int         ptx_timing_select_mask(uint64_t mask);
+int         ptx_timing_read_sites(int *launches, float *total_ms, int n);
 
 /* Bytes of the parameter-only tables derived once per set of weights (folded
  * BatchNorm scale/shift, per-slot bias tables PRE:212-215, folded attention-pool
  * matrices) and of the per-call scratch.  Both buffers are caller-owned. */
 size_t ptx_prep_bytes(const PtxShape *s);
 size_t ptx_workspace_bytes(const PtxShape *s);
+
+/* A workspace must be initialised ONCE after allocation (and again after a failed ptx_forward): ptx_forward finds
+ * the ownership tags, encoded bounding boxes and count accumulators zero and its kernels leave them zero -- there
+ * is no clearing launch on the per-call path. */
+int ptx_workspace_init(const PtxShape *s, void *workspace, size_t ws_bytes, void *stream);
 
 /* Build the derived tables in `prep`.  lin = torch.linspace(0,1,gs) (gs floats, device);
  * it is uploaded by the caller because torch's two-sided linspace formula is part of

@@ -70,8 +70,11 @@ SIGNATURES = {
     "ptx_kernel_name": (C.c_char_p, [_I]),
     "ptx_timing_select": (_I, [_I]),
     "ptx_timing_read": (_I, [C.POINTER(C.c_int), C.POINTER(C.c_float)]),
+    "ptx_timing_select_mask": (_I, [C.c_uint64]),
+    "ptx_timing_read_sites": (_I, [C.POINTER(C.c_int), C.POINTER(C.c_float), _I]),
     "ptx_prep_bytes": (_Z, [_SH]),
     "ptx_workspace_bytes": (_Z, [_SH]),
+    "ptx_workspace_init": (_I, [_SH, _P, _Z, _P]),
     "ptx_prepare": (_I, [_SH, _W, _P, _P, _Z, _P]),
     "ptx_grid_centers": (_I, [_P, _I, _I, _P, _I, _F, _P, _P, _P, _Z, _P]),
     "ptx_ball_query": (_I, [_P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P]),

@@ -28,23 +28,24 @@ void set_error(const char *fmt, ...)
 // img_pass2 / img_pass3 are the launch sites after the mean pass: k_img_pool (no third launch) for bf16 / fp16
 // features of the path's shape, k_img_scores / k_img_gather for fp32, k_img_scores16 / k_img_gather16 otherwise.
 static const char *const kKernelNames[] = {
-    "memset", "k_minmax", "k_ball_query<grid>", "k_slot_net<offset>", "k_ball_query", "k_select",
+    "k_minmax", "k_cluster", "k_select", "k_select_slots",
     "k_tile_count", "k_slot_net<pointnet>", "k_img_mean", "k_gemm_nt[qkv0]",
     "k_gemm_nt[we]", "img_pass2", "img_pass3", "k_gemm_nt[o]", "k_gemm_nt[c_proj]",
-    "k_ln_rows[norm_img]", "k_gemm_nt[qkv+proxy_proj]", "k_attn32[proxy_as_query]",
-    "k_attn32[proxy_as_key]", "k_gemm_nt[proj]", "k_ln_rows[norm2]", "k_gemm_nt[fc1]", "k_gemm_nt[fc2]",
+    "k_ln_rows[norm_img]", "k_gemm_nt[qkv+proxy_proj]", "k_gemm_nt[pp_img]", "k_attn32[proxy_as_query]",
+    "k_attn32[proxy_as_key]", "k_gemm_nt[proj]", "k_gemm_nt[fc1]", "k_gemm_nt[fc2]",
     "k_heads", "k_affine<compact>"};
 enum Kid : int {
-    KID_MEMSET = 0, KID_MINMAX, KID_BQ1, KID_OFFSET, KID_BQ2, KID_SELECT, KID_TILECOUNT, KID_POINTNET,
+    KID_MINMAX = 0, KID_CLUSTER, KID_SELECT, KID_SLOTS, KID_TILECOUNT, KID_POINTNET,
     KID_IMG_MEAN, KID_IMG_QKV0, KID_IMG_WE, KID_IMG_SCORES, KID_IMG_GATHER, KID_IMG_O, KID_IMG_C,
-    KID_IMG_LN, KID_BLK_QKV, KID_BLK_ATTN_A, KID_BLK_ATTN_B, KID_BLK_PROJ, KID_BLK_LN2, KID_BLK_FC1,
+    KID_IMG_LN, KID_BLK_QKV, KID_BLK_PP, KID_BLK_ATTN_A, KID_BLK_ATTN_B, KID_BLK_PROJ, KID_BLK_FC1,
     KID_BLK_FC2, KID_BLK_HEADS, KID_AFFINE, KID_COUNT};
 static_assert(sizeof(kKernelNames) / sizeof(kKernelNames[0]) == KID_COUNT, "kernel name table");
 
+struct TimingRec { int kid; hipEvent_t a, b; };
 struct TimingState {
     std::mutex mu;
-    int selected = -1;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    uint64_t mask = 0;                  // bit k = launch site k is bracketed by events
+    std::vector<TimingRec> pool;
     size_t used = 0;
 };
 static TimingState g_timing;
@@ -52,16 +53,17 @@ static TimingState g_timing;
 struct Timed {
     hipEvent_t stop = nullptr; hipStream_t st;
     Timed(int kid, hipStream_t s) : st(s) {
-        if (g_timing.selected != kid) return;
+        if (!((g_timing.mask >> kid) & 1u)) return;
         std::lock_guard<std::mutex> lk(g_timing.mu);
         if (g_timing.used == g_timing.pool.size()) {
             hipEvent_t a, b;
             if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
-            g_timing.pool.emplace_back(a, b);
+            g_timing.pool.push_back(TimingRec{kid, a, b});
         }
-        auto &pr = g_timing.pool[g_timing.used++];
-        (void)hipEventRecord(pr.first, st);
-        stop = pr.second;
+        TimingRec &pr = g_timing.pool[g_timing.used++];
+        pr.kid = kid;
+        (void)hipEventRecord(pr.a, st);
+        stop = pr.b;
     }
     ~Timed() { if (stop) (void)hipEventRecord(stop, st); }
 };
@@ -105,6 +107,10 @@ PrepLayout prep_layout(const PtxShape &s)
     P.w3 = take((size_t)3 * s.C * s.in_dim); P.b3 = take((size_t)3 * s.C);
     P.t1 = take((size_t)s.heads * P.KT1 * P.hd);
     P.t2 = take((size_t)s.heads * P.hd * P.KT2p);
+    P.ppg_w = take((size_t)s.C * s.C); P.ppg_s = take(s.C); P.ppg_c = take(s.C);
+    for (int i = 0; i < 2; ++i) {
+        P.fc1g_w[i] = take((size_t)s.hidden * s.C); P.fc1g_s[i] = take(s.hidden); P.fc1g_c[i] = take(s.hidden);
+    }
     P.total = o;
     return P;
 }
@@ -121,6 +127,7 @@ WsLayout ws_layout(const PtxShape &s)
     const size_t nimg = B * s.V, Lp = s.L > s.V ? s.L : s.V, R = B * Mk;
     L.zero_begin = o;
     L.mm_enc = take(B * 6 * 4);
+    L.scene_acc = take(B * 2 * 4);
     L.tag = take(B * N * 4);
     L.zero_bytes = o - L.zero_begin;
     L.minmax = take(B * 6 * 4);
@@ -144,7 +151,9 @@ WsLayout ws_layout(const PtxShape &s)
         L.ao[i] = take(R * C * 4); L.x1[i] = take(R * C * 4); L.xn2[i] = take(R * C * 4);
         L.hbuf[i] = take(R * (size_t)s.hidden * 4); L.x2[i] = take(R * C * 4); L.guide[i] = take(R * C * 4);
         L.head[i] = take(R * 9 * 4);
+        L.lnp_x1[i] = take(R * (C / 32) * 2 * 4);
     }
+    L.lnp_img = take(nimg * (C / 32) * 2 * 4);
     L.total = o;
     return L;
 }
@@ -158,7 +167,7 @@ WsLayout ws_layout(const PtxShape &s)
 struct PtxContext {
     int dev = -1;
     hipStream_t st = nullptr, lo = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr, aux = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr, aux = nullptr, tags = nullptr;
     std::mutex mu;                       // held for the whole enqueue section of a forward
 };
 namespace ptx {
@@ -175,6 +184,7 @@ static int context_init(PtxContext *c)
     PTX_HIP(hipEventCreateWithFlags(&c->fork, hipEventDisableTiming));
     PTX_HIP(hipEventCreateWithFlags(&c->join, hipEventDisableTiming));
     PTX_HIP(hipEventCreateWithFlags(&c->aux, hipEventDisableTiming));
+    PTX_HIP(hipEventCreateWithFlags(&c->tags, hipEventDisableTiming));
     return PTX_OK;
 }
 
@@ -183,9 +193,10 @@ static void context_release(PtxContext *c)
     if (c->fork) (void)hipEventDestroy(c->fork);
     if (c->join) (void)hipEventDestroy(c->join);
     if (c->aux) (void)hipEventDestroy(c->aux);
+    if (c->tags) (void)hipEventDestroy(c->tags);
     if (c->st) (void)hipStreamDestroy(c->st);
     if (c->lo) (void)hipStreamDestroy(c->lo);
-    c->fork = c->join = c->aux = nullptr; c->st = c->lo = nullptr;
+    c->fork = c->join = c->aux = c->tags = nullptr; c->st = c->lo = nullptr;
 }
 
 static std::mutex g_default_mu;
@@ -225,8 +236,10 @@ static inline T *at(void *base, size_t off) { return reinterpret_cast<T *>(stati
 // ---- image chain ---------------------------------------------------------------------------------
 // Image chain (PRE:335-342).  phase 0: everything; 1: only the first streaming pass (image means);
 // 2: everything after it.
+// need_ln: also write the normalised proxies (stage API, debug); the forward consumes c_proj's raw rows through
+// the LayerNorm fold of the image block's proxy_proj GEMM (partials L.lnp_img) and skips that launch.
 static int run_img_proxy(const PtxShape &s, const PtxWeights &w, const float *prep, const void *img_any,
-                         float *img_proxy, void *ws, hipStream_t st, int phase = 0)
+                         float *img_proxy, void *ws, hipStream_t st, int phase = 0, bool need_ln = true)
 {
     const PrepLayout P = prep_layout(s);
     const WsLayout L = ws_layout(s);
@@ -292,11 +305,14 @@ static int run_img_proxy(const PtxShape &s, const PtxWeights &w, const float *pr
         GemmBatch g{}; g.n = 1;
         g.p[0] = GemmProb{obuf, w.c_w, cbuf, w.c_b, nullptr, nullptr, nullptr,
                           nimg, C, C, C, C, C, 0, 0, 0, EPI_NONE};
+        g.p[0].lnp_out = at<float>(ws, L.lnp_img);
         PTX_TIMED(KID_IMG_C, st, launch_gemm(g, st));
     }
-    LnBatch lb{}; lb.n = 1; lb.C = C; lb.eps = s.ln_eps;
-    lb.p[0] = LnProb{cbuf, img_proxy, w.norm_img_w, w.norm_img_b, nullptr, nimg, 1};
-    PTX_TIMED(KID_IMG_LN, st, launch_ln_rows(lb, st));
+    if (need_ln) {
+        LnBatch lb{}; lb.n = 1; lb.C = C; lb.eps = s.ln_eps;
+        lb.p[0] = LnProb{cbuf, img_proxy, w.norm_img_w, w.norm_img_b, nullptr, nimg, 1};
+        PTX_TIMED(KID_IMG_LN, st, launch_ln_rows(lb, st));
+    }
     return PTX_OK;
 }
 
@@ -305,6 +321,9 @@ struct Branch {
     const PtxBlock *blk; const float *x_in; const float *proxy; int Lp; const uint8_t *mask;
     const float *head_w, *head_b, *head_ab; int nout; float *head_out; float *guide; int slot;
     bool late_proxy;     // the proxies of this branch are produced on the side stream (image proxies)
+    // proxies given as RAW rows + LayerNorm partials (the forward's image branch): proxy_proj folds the LayerNorm
+    const float *proxy_lnp, *pp_gw, *pp_gs, *pp_gc;
+    const float *fc1_gw, *fc1_gs, *fc1_gc;      // norm2 folded into fc1
 };
 
 // phase 0: everything; phase 1: only the projections that do not wait for late proxies
@@ -322,11 +341,18 @@ static int run_blocks(const PtxShape &s, const Branch *br, int nb, const float *
                 g.p[g.n++] = GemmProb{br[i].x_in, br[i].blk->qkv_w, at<float>(ws, L.qkv[sl]), br[i].blk->qkv_b,
                                       nullptr, nullptr, nullptr, R, 3 * C, C, C, C, 3 * C, 0, 0, 0, EPI_NONE};
             const bool now = phase == 0 || (phase == 1 && !br[i].late_proxy) || (phase == 2 && br[i].late_proxy);
-            if (now)
-                g.p[g.n++] = GemmProb{br[i].proxy, br[i].blk->pp_w, at<float>(ws, L.pt[sl]), br[i].blk->pp_b,
-                                      nullptr, nullptr, nullptr, s.B * br[i].Lp, C, C, C, C, C, 0, 0, 0, EPI_NONE};
+            if (now) {
+                GemmProb &q = g.p[g.n++];
+                q = GemmProb{br[i].proxy, br[i].blk->pp_w, at<float>(ws, L.pt[sl]), br[i].blk->pp_b,
+                             nullptr, nullptr, nullptr, s.B * br[i].Lp, C, C, C, C, C, 0, 0, 0, EPI_NONE};
+                if (br[i].proxy_lnp != nullptr) {       // LayerNorm(norm_img) folded into this GEMM
+                    q.W = br[i].pp_gw; q.bias = nullptr;
+                    q.lnp_in = br[i].proxy_lnp; q.ln_s = br[i].pp_gs; q.ln_c = br[i].pp_gc;
+                    q.ln_parts = C / 32; q.ln_C = C; q.ln_eps = s.ln_eps;
+                }
+            }
         }
-        if (g.n > 0) PTX_TIMED(KID_BLK_QKV, st, launch_gemm(g, st));
+        if (g.n > 0) PTX_TIMED(phase == 2 ? KID_BLK_PP : KID_BLK_QKV, st, launch_gemm(g, st));
         if (phase == 1) return PTX_OK;
     }
     AttnBatch a{}; a.n = nb; a.B = s.B; a.heads = s.heads; a.hd = C / s.heads; a.scale = attn_scale(C / s.heads);
@@ -346,31 +372,25 @@ static int run_blocks(const PtxShape &s, const Branch *br, int nb, const float *
                           (long)s.Mk * 3 * C, (long)br[i].Lp * C, (long)br[i].Lp * C, (long)s.Mk * C};
     }
     PTX_TIMED(KID_BLK_ATTN_B, st, launch_attn32(a, st));
-    {   // x1 = x + proj(attn) (PRE:255, 274)
+    {   // x1 = x + proj(attn) (PRE:255, 274); every tile also leaves the LayerNorm partials of its rows for fc1
         GemmBatch g{}; g.n = nb;
         for (int i = 0; i < nb; ++i) {
             const int sl = br[i].slot;
             g.p[i] = GemmProb{at<float>(ws, L.ao[sl]), br[i].blk->proj_w, at<float>(ws, L.x1[sl]),
                               br[i].blk->proj_b, point_proxy, nullptr, nullptr, R, C, C, C, C, C, C, 0, 0, EPI_NONE};
+            g.p[i].lnp_out = at<float>(ws, L.lnp_x1[sl]);
         }
         PTX_TIMED(KID_BLK_PROJ, st, launch_gemm(g, st));
     }
-    {   // norm2 (PRE:275)
-        LnBatch lb{}; lb.n = nb; lb.C = C; lb.eps = s.ln_eps;
-        for (int i = 0; i < nb; ++i) {
-            const int sl = br[i].slot;
-            lb.p[i] = LnProb{at<float>(ws, L.x1[sl]), at<float>(ws, L.xn2[sl]), br[i].blk->norm2_w,
-                             br[i].blk->norm2_b, nullptr, R, 1};
-        }
-        PTX_TIMED(KID_BLK_LN2, st, launch_ln_rows(lb, st));
-    }
-    {   // fc1 + GELU(erf)
+    {   // h = GELU(fc1(norm2(x1))) (PRE:275): norm2 folded into the GEMM (W1 diag(gamma), row statistics in the epilogue)
         GemmBatch g{}; g.n = nb;
         for (int i = 0; i < nb; ++i) {
             const int sl = br[i].slot;
-            g.p[i] = GemmProb{at<float>(ws, L.xn2[sl]), br[i].blk->fc1_w, at<float>(ws, L.hbuf[sl]),
-                              br[i].blk->fc1_b, nullptr, nullptr, nullptr, R, s.hidden, C, C, C, s.hidden,
+            g.p[i] = GemmProb{at<float>(ws, L.x1[sl]), br[i].fc1_gw, at<float>(ws, L.hbuf[sl]),
+                              nullptr, nullptr, nullptr, nullptr, R, s.hidden, C, C, C, s.hidden,
                               0, 0, 0, EPI_GELU};
+            g.p[i].lnp_in = at<float>(ws, L.lnp_x1[sl]); g.p[i].ln_s = br[i].fc1_gs; g.p[i].ln_c = br[i].fc1_gc;
+            g.p[i].ln_parts = C / 32; g.p[i].ln_C = C; g.p[i].ln_eps = s.ln_eps;
         }
         PTX_TIMED(KID_BLK_FC1, st, launch_gemm(g, st));
     }
@@ -407,6 +427,8 @@ static Branch make_branch(const PtxShape &s, const PtxWeights &w, const float *p
     b.head_ab = prep + (which == 0 ? P.ttn_ab : P.itn_ab);
     b.nout = which == 0 ? 3 : 9;
     b.head_out = head_out; b.guide = guide; b.slot = which; b.late_proxy = which == 1;
+    b.proxy_lnp = nullptr; b.pp_gw = prep + P.ppg_w; b.pp_gs = prep + P.ppg_s; b.pp_gc = prep + P.ppg_c;
+    b.fc1_gw = prep + P.fc1g_w[which]; b.fc1_gs = prep + P.fc1g_s[which]; b.fc1_gc = prep + P.fc1g_c[which];
     return b;
 }
 
@@ -436,7 +458,31 @@ int ptx_timing_select(int kid)
 {
     PTX_REQUIRE(kid >= -1 && kid < KID_COUNT, "ptx_timing_select: kid=%d", kid);
     std::lock_guard<std::mutex> lk(g_timing.mu);
-    g_timing.selected = kid;
+    g_timing.mask = kid < 0 ? 0 : (1ull << kid);
+    g_timing.used = 0;
+    return PTX_OK;
+}
+
+int ptx_timing_select_mask(uint64_t mask)
+{
+    static_assert(KID_COUNT <= 64, "timing mask is 64 bits");
+    std::lock_guard<std::mutex> lk(g_timing.mu);
+    g_timing.mask = mask & ((KID_COUNT >= 64) ? ~0ull : ((1ull << KID_COUNT) - 1));
+    g_timing.used = 0;
+    return PTX_OK;
+}
+
+static int timing_collect(int *launches, float *total_ms, int nsites)
+{
+    for (int k = 0; k < nsites; ++k) { launches[k] = 0; total_ms[k] = 0.0f; }
+    for (size_t i = 0; i < g_timing.used; ++i) {
+        const TimingRec &r = g_timing.pool[i];
+        PTX_HIP(hipEventSynchronize(r.b));
+        float ms = 0.0f;
+        PTX_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+        const int k = nsites == 1 ? 0 : r.kid;
+        if (k >= 0 && k < nsites) { launches[k] += 1; total_ms[k] += ms; }
+    }
     g_timing.used = 0;
     return PTX_OK;
 }
@@ -445,17 +491,14 @@ int ptx_timing_read(int *launches, float *total_ms)
 {
     PTX_REQUIRE(launches && total_ms, "ptx_timing_read: null argument");
     std::lock_guard<std::mutex> lk(g_timing.mu);
-    float sum = 0.0f;
-    for (size_t i = 0; i < g_timing.used; ++i) {
-        PTX_HIP(hipEventSynchronize(g_timing.pool[i].second));
-        float ms = 0.0f;
-        PTX_HIP(hipEventElapsedTime(&ms, g_timing.pool[i].first, g_timing.pool[i].second));
-        sum += ms;
-    }
-    *launches = (int)g_timing.used;
-    *total_ms = sum;
-    g_timing.used = 0;
-    return PTX_OK;
+    return timing_collect(launches, total_ms, 1);
+}
+
+int ptx_timing_read_sites(int *launches, float *total_ms, int n)
+{
+    PTX_REQUIRE(launches && total_ms && n == KID_COUNT, "ptx_timing_read_sites: need arrays of ptx_kernel_count() = %d entries", KID_COUNT);
+    std::lock_guard<std::mutex> lk(g_timing.mu);
+    return timing_collect(launches, total_ms, n);
 }
 const char *ptx_last_error(void) { return g_err; }
 
@@ -511,6 +554,14 @@ size_t ptx_workspace_bytes(const PtxShape *s)
 {
     if (s == nullptr || validate_shape(*s) != PTX_OK) return 0;
     return ws_layout(*s).total;
+}
+
+int ptx_workspace_init(const PtxShape *s, void *workspace, size_t ws_bytes, void *stream)
+{
+    PTX_TRY(check_bufs(s, workspace, ws_bytes));
+    const WsLayout L = ws_layout(*s);
+    PTX_HIP(hipMemsetAsync(at<char>(workspace, L.zero_begin), 0, L.zero_bytes, static_cast<hipStream_t>(stream)));
+    return PTX_OK;
 }
 
 int ptx_prepare(const PtxShape *s, const PtxWeights *w, const float *lin, void *prep, size_t prep_bytes,
@@ -594,7 +645,7 @@ int ptx_pointnet(const PtxShape *s, const PtxWeights *w, const void *prep, const
     const PrepLayout P = prep_layout(*s);
     return launch_pointnet(static_cast<const float *>(prep) + P.enc_ab, w->encoder, kcenter, kcluster,
                            s->B * s->Mk, s->Mk, s->K, s->C, point_proxy, nullptr, nullptr, nullptr, nullptr, nullptr,
-                           nullptr, s->ln_eps, static_cast<hipStream_t>(stream));
+                           nullptr, s->ln_eps, nullptr, nullptr, 0, 0, static_cast<hipStream_t>(stream));
 }
 
 int ptx_img_proxy(const PtxShape *s, const PtxWeights *w, const void *prep, const void *img_feat,
@@ -635,8 +686,8 @@ int ptx_affine_scatter(const PtxShape *s, const float *points, const uint32_t *t
     PTX_TRY(validate_shape(*s));
     ScenePts sp;
     PTX_TRY(make_scene_pts(points, nullptr, s->B, s->N, &sp));
-    return launch_affine(*s, sp, tag, kcenter, translate, transform, new_points, nullptr, nullptr, false,
-                         static_cast<hipStream_t>(stream));
+    return launch_affine(*s, sp, const_cast<uint32_t *>(tag), kcenter, translate, transform, new_points, nullptr, nullptr,
+                         false, false, static_cast<hipStream_t>(stream));
 }
 
 int ptx_affine_compact(const PtxShape *s, const float *points, const uint32_t *tag, const float *kcenter,
@@ -647,10 +698,10 @@ int ptx_affine_compact(const PtxShape *s, const float *points, const uint32_t *t
     PTX_TRY(check_bufs(s, workspace, ws_bytes));
     hipStream_t st = static_cast<hipStream_t>(stream);
     int32_t *tc = at<int32_t>(workspace, ws_layout(*s).tile_counts);
-    PTX_TRY(launch_tile_count(tag, s->B, s->N, tc, counts, st));
+    PTX_TRY(launch_tile_count(tag, s->B, s->N, tc, counts, nullptr, st));
     ScenePts sp;
     PTX_TRY(make_scene_pts(points, nullptr, s->B, s->N, &sp));
-    return launch_affine(*s, sp, tag, kcenter, translate, transform, out, counts, tc, true, st);
+    return launch_affine(*s, sp, const_cast<uint32_t *>(tag), kcenter, translate, transform, out, counts, tc, true, false, st);
 }
 
 #define PTX_DBG(field, src, bytes)                                                                         do {                                                                                                       if (debug && debug->field)                                                                                 PTX_HIP(hipMemcpyAsync(debug->field, src, bytes, hipMemcpyDeviceToDevice, st));                } while (0)
@@ -690,50 +741,50 @@ int ptx_forward(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, const v
         PTX_REQUIRE(dev == side->dev, "ptx_forward: context belongs to device %d, current device is %d", side->dev, dev);
     }
     std::lock_guard<std::mutex> enqueue_lock(side->mu);
-    static const int mode = getenv("PTX_STREAM_MODE") ? atoi(getenv("PTX_STREAM_MODE")) : 0;
-    // mode 0: image branch on the caller's stream, clustering on the high-priority stream
-    // mode 1: image branch on the low-priority stream, clustering on the caller's stream
-    hipStream_t cs = mode == 0 ? side->st : st;
-    hipStream_t is = mode == 0 ? st : side->lo;
-    hipStream_t other = mode == 0 ? cs : is;
+    hipStream_t cs = side->st, is = st;
     PTX_HIP(hipEventRecord(side->fork, st));
-    PTX_HIP(hipStreamWaitEvent(other, side->fork, 0));
+    PTX_HIP(hipStreamWaitEvent(cs, side->fork, 0));
     float *img_proxy = at<float>(ws, L.img_proxy);
     PTX_TRY(run_img_proxy(S, *w, pf, img_feat, img_proxy, ws, is, 1));      // first pass starts at once
 
-    // ---- clustering (PRE:430)
+    // ---- clustering (PRE:430): bounding boxes, then everything per centre in one launch
+    // The words of the workspace's zero region (encoded boxes, tags, count accumulators) are clean on entry and are
+    // re-zeroed by their last readers (k_select, k_affine, k_tile_count): no memset launch per call.
     uint32_t *mm_enc = at<uint32_t>(ws, L.mm_enc), *tag = at<uint32_t>(ws, L.tag);
-    float *minmax = at<float>(ws, L.minmax), *centers0 = at<float>(ws, L.centers0);
-    float *cluster1 = at<float>(ws, L.cluster1), *offsets = at<float>(ws, L.offsets);
+    const bool dbg = debug != nullptr;
+    float *centers0 = dbg && debug->centers0 ? at<float>(ws, L.centers0) : nullptr;
+    float *cluster1 = dbg && debug->cluster1 ? at<float>(ws, L.cluster1) : nullptr;
+    float *offsets = dbg && debug->offsets ? at<float>(ws, L.offsets) : nullptr;
     float *centers = at<float>(ws, L.centers), *cluster2 = at<float>(ws, L.cluster2);
     int32_t *idx2 = at<int32_t>(ws, L.idx2), *pad_count = at<int32_t>(ws, L.pad_count);
-    { Timed t_(KID_MEMSET, cs); PTX_HIP(hipMemsetAsync(at<char>(ws, L.zero_begin), 0, L.zero_bytes, cs)); }
     PTX_TIMED(KID_MINMAX, cs, launch_minmax(sp, B, S.N, mm_enc, cs));
-    // ball query #1 on the unclamped grid centres; only the gathered xyz is used (PRE:56, Q3)
-    PTX_TIMED(KID_BQ1, cs, launch_ball_query(nullptr, mm_enc, lin, S.grid_size, S.margin, minmax, centers0, sp,
-                                             B, M, S.N, K, S.radius, idx2, cluster1, nullptr, cs));
-    PTX_TIMED(KID_OFFSET, cs, launch_offset_net(pf + P.off_ab, w->offset, w->offset_map_w, centers0, cluster1,
-                                                minmax, B * M, M, K, S.margin, centers, offsets, cs));
-    if (centers_override)
-        PTX_HIP(hipMemcpyAsync(centers, centers_override, (size_t)B * M * 3 * 4, hipMemcpyDeviceToDevice, cs));
-    PTX_TIMED(KID_BQ2, cs, launch_ball_query(centers, nullptr, nullptr, 0, 0.0f, nullptr, nullptr, sp, B, M,
-                                             S.N, K, S.radius, idx2, cluster2, pad_count, cs));   // PRE:65
+    PTX_TIMED(KID_CLUSTER, cs, launch_cluster(S, mm_enc, lin, sp, pf + P.off_ab, w->offset, w->offset_map_w,
+                                              centers_override, nullptr, centers0, cluster1, offsets, centers, idx2,
+                                              cluster2, pad_count, cs));
 
-    // ---- dynamic cluster dropout (PRE:433)
+    // ---- dynamic cluster dropout (PRE:433): ordering + FPS + keep list on the chain; the slot tags and the survivor
+    // counts (only k_affine and the host need them) on the low-priority stream next to it
     int32_t *order = at<int32_t>(ws, L.order), *picks = at<int32_t>(ws, L.picks), *keep = at<int32_t>(ws, L.keep);
-    float *kcenter = at<float>(ws, L.kcenter), *kcluster = at<float>(ws, L.kcluster);
-    int32_t *kidx = at<int32_t>(ws, L.kidx), *drop_idx = at<int32_t>(ws, L.drop_idx);
-    PTX_TIMED(KID_SELECT, cs, launch_select(S, idx2, centers, cluster2, pad_count, order_override, order, picks,
-                                            keep, kcenter, kcluster, kidx, drop_idx, tag, cs));
+    float *kcenter = at<float>(ws, L.kcenter);
+    float *kcluster = dbg && debug->kcluster ? at<float>(ws, L.kcluster) : nullptr;
+    int32_t *kidx = dbg && debug->kidx ? at<int32_t>(ws, L.kidx) : nullptr;
+    int32_t *drop_idx = dbg && debug->drop_idx ? at<int32_t>(ws, L.drop_idx) : nullptr;
+    PTX_TIMED(KID_SELECT, cs, launch_select_order(S, centers, pad_count, order_override, order, picks, keep, kcenter,
+                                                  mm_enc, cs));
     int32_t *tile_counts = at<int32_t>(ws, L.tile_counts);
-    PTX_TIMED(KID_TILECOUNT, cs, launch_tile_count(tag, B, S.N, tile_counts, counts, cs));   // publishes counts early
+    hipStream_t ts = side->lo;
+    PTX_HIP(hipEventRecord(side->aux, cs));
+    PTX_HIP(hipStreamWaitEvent(ts, side->aux, 0));
+    PTX_TIMED(KID_SLOTS, ts, launch_select_slots(S, idx2, cluster2, order, picks, keep, kcluster, kidx, drop_idx, tag, ts));
+    PTX_TIMED(KID_TILECOUNT, ts, launch_tile_count(tag, B, S.N, tile_counts, counts, at<int32_t>(ws, L.scene_acc), ts));   // publishes counts early
+    PTX_HIP(hipEventRecord(side->tags, ts));
 
-    // ---- point proxies (PRE:437) + norm1 / slot bias of both blocks
+    // ---- point proxies (PRE:437) + norm1 / slot bias of both blocks; the kept clusters are read through the selection
     float *point_proxy = at<float>(ws, L.point_proxy);
     float *xin_t = at<float>(ws, L.x_in[0]), *xin_i = at<float>(ws, L.x_in[1]);
-    PTX_TIMED(KID_POINTNET, cs, launch_pointnet(pf + P.enc_ab, w->encoder, kcenter, kcluster, B * S.Mk, S.Mk, K,
+    PTX_TIMED(KID_POINTNET, cs, launch_pointnet(pf + P.enc_ab, w->encoder, centers, cluster2, B * S.Mk, S.Mk, K,
                                                 S.C, point_proxy, &w->text, &w->img, pf + P.posb_t, pf + P.posb_i, xin_t,
-                                                xin_i, S.ln_eps, cs));
+                                                xin_i, S.ln_eps, order, keep, M, S.Mt, cs));
 
     // ---- both proxy blocks + heads in shared launches (PRE:440-455); the input projections that
     // do not need the image proxies still run on the clustering stream
@@ -741,20 +792,23 @@ int ptx_forward(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, const v
     float *guide_t = (debug && debug->text_guide) ? at<float>(ws, L.guide[0]) : nullptr;
     float *guide_i = (debug && debug->img_guide) ? at<float>(ws, L.guide[1]) : nullptr;
     Branch br[2] = {make_branch(S, *w, pf, 0, xin_t, text_feats, S.L, text_mask, translate, guide_t),
-                    make_branch(S, *w, pf, 1, xin_i, img_proxy, S.V, nullptr, transform, guide_i)};
+                    make_branch(S, *w, pf, 1, xin_i, at<float>(ws, L.cbuf), S.V, nullptr, transform, guide_i)};
+    br[1].proxy_lnp = at<float>(ws, L.lnp_img);       // norm_img is applied inside the image block's proxy_proj
+    const bool want_img_proxy = debug != nullptr && debug->img_proxy != nullptr;
     // (The whole text branch on a third stream while the image chain finishes, leaving only the image
     // branch after the join, was measured slower: 12.6k vs 13.7k scenes/s -- eight more launches, and its
     // small kernels take CUs from the image passes that are on the critical path.)
     PTX_TRY(run_blocks(S, br, 2, point_proxy, ws, cs, 1));
-    if (mode == 0) PTX_HIP(hipEventRecord(side->join, cs));
-    PTX_TRY(run_img_proxy(S, *w, pf, img_feat, img_proxy, ws, is, 2));      // rest of the image chain
-    if (mode != 0) PTX_HIP(hipEventRecord(side->join, is));
+    PTX_HIP(hipEventRecord(side->join, cs));
+    PTX_TRY(run_img_proxy(S, *w, pf, img_feat, img_proxy, ws, is, 2, want_img_proxy));      // rest of the image chain
     PTX_HIP(hipStreamWaitEvent(st, side->join, 0));
     PTX_TRY(run_blocks(S, br, 2, point_proxy, ws, st, 2));
 
-    // ---- submanifold reshape + scatter + drop (PRE:459-467)
+    // ---- submanifold reshape + scatter + drop (PRE:459-467); k_affine is the last reader of the tags and clears them
+    PTX_HIP(hipStreamWaitEvent(st, side->tags, 0));
+    PTX_DBG(tag, tag, (size_t)B * S.N * 4);
     PTX_TIMED(KID_AFFINE, st, launch_affine(S, sp, tag, kcenter, translate, transform, out, counts, tile_counts,
-                                            true, st));
+                                            true, true, st));
 
     PTX_DBG(centers0, centers0, (size_t)B * M * 3 * 4);
     PTX_DBG(cluster1, cluster1, (size_t)B * M * K * 3 * 4);
@@ -776,7 +830,6 @@ int ptx_forward(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, const v
     PTX_DBG(img_guide, guide_i, (size_t)B * S.Mk * S.C * 4);
     PTX_DBG(translate, translate, (size_t)B * S.Mk * 3 * 4);
     PTX_DBG(transform, transform, (size_t)B * S.Mk * 9 * 4);
-    PTX_DBG(tag, tag, (size_t)B * S.N * 4);
     return PTX_OK;
 }
 

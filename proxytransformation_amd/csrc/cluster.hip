@@ -83,42 +83,29 @@ int launch_minmax(const ScenePts &points, int B, int N, uint32_t *mm_enc, hipStr
 // walk the same short prefix of the point array, which stays in L2.
 constexpr int kBqUnroll = 4;   // 256 points per outer step
 
-template <bool GRID>
-__global__ __launch_bounds__(256) void k_ball_query(
-    const float *__restrict__ centers, const uint32_t *__restrict__ mm_enc,
-    const float *__restrict__ lin, int gs, float margin, float *__restrict__ minmax_out,
-    float *__restrict__ centers_out, ScenePts points, int BM, int M, int N, int K,
-    float radius, int32_t *__restrict__ idx, float *__restrict__ cluster,
-    int32_t *__restrict__ pad_count)
+// PRE:48: (min + margin) + lin * ((max - min) - 2*margin), python operator order; meshgrid 'ij' (PRE:44)
+__device__ __forceinline__ void grid_centre(const uint32_t *__restrict__ mm_enc, const float *__restrict__ lin, int gs,
+                                            float margin, int b, int m, float (&mn)[3], float (&mx)[3], float (&c)[3])
+{
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { mn[d] = ord2f(~mm_enc[b * 6 + d]); mx[d] = ord2f(mm_enc[b * 6 + 3 + d]); }
+    const int ijk[3] = {m / (gs * gs), (m / gs) % gs, m % gs};
+    const float two_margin = __fmul_rn(2.0f, margin);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float base = __fadd_rn(mn[d], margin);
+        const float span = __fsub_rn(__fsub_rn(mx[d], mn[d]), two_margin);
+        c[d] = __fadd_rn(base, __fmul_rn(lin[ijk[d]], span));
+    }
+}
+
+// One wave scans the scene for the first K points with dist2 < r2 around (cx,cy,cz), in index order.  Hit number
+// `pos` goes to oi[pos] (point index, may be null) and oc[3 pos ..] (xyz; global or wave-private LDS); slots
+// beyond the hit count are padded with -1 / 0.0 (masked_gather, PRE:664-671).  Returns the hit count (<= K).
+__device__ __forceinline__ int bq_scan(const float *__restrict__ p, int N, int K, float cx, float cy, float cz, float r2,
+                                       int32_t *oi, float *oc)
 {
     const int lane = lane_id();
-    const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (w >= BM) return;
-    const int b = w / M, m = w - b * M;
-    float cx, cy, cz;
-    if (GRID) {
-        // PRE:48: (min + margin) + lin * ((max - min) - 2*margin), python operator order
-        float mn[3], mx[3], c[3];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) { mn[d] = ord2f(~mm_enc[b * 6 + d]); mx[d] = ord2f(mm_enc[b * 6 + 3 + d]); }
-        const int ijk[3] = {m / (gs * gs), (m / gs) % gs, m % gs};   // meshgrid 'ij' (PRE:44)
-        const float two_margin = __fmul_rn(2.0f, margin);
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            float base = __fadd_rn(mn[d], margin);
-            float span = __fsub_rn(__fsub_rn(mx[d], mn[d]), two_margin);
-            c[d] = __fadd_rn(base, __fmul_rn(lin[ijk[d]], span));
-        }
-        cx = c[0]; cy = c[1]; cz = c[2];
-        if (lane < 3) centers_out[(size_t)w * 3 + lane] = c[lane];
-        if (m == 0 && lane < 3) { minmax_out[b * 6 + lane] = mn[lane]; minmax_out[b * 6 + 3 + lane] = mx[lane]; }
-    } else {
-        cx = centers[(size_t)w * 3 + 0]; cy = centers[(size_t)w * 3 + 1]; cz = centers[(size_t)w * 3 + 2];
-    }
-    const float r2 = __fmul_rn(radius, radius);
-    const float *__restrict__ p = points.p[b];
-    int32_t *oi = idx + (size_t)w * K;
-    float *oc = cluster + (size_t)w * K * 3;
     const unsigned long long lt = (1ull << lane) - 1ull;
     int count = 0;
     for (int base = 0; base < N && count < K; base += 64 * kBqUnroll) {
@@ -138,7 +125,7 @@ __global__ __launch_bounds__(256) void k_ball_query(
                 const unsigned long long mask = __ballot(hit);
                 const int pos = count + __popcll(mask & lt);
                 if (hit && pos < K) {
-                    oi[pos] = j;
+                    if (oi) oi[pos] = j;
                     oc[pos * 3] = px[u]; oc[pos * 3 + 1] = py[u]; oc[pos * 3 + 2] = pz[u];
                 }
                 count += __popcll(mask);
@@ -147,9 +134,36 @@ __global__ __launch_bounds__(256) void k_ball_query(
     }
     if (count > K) count = K;
     for (int k = count + lane; k < K; k += 64) {               // masked_gather padding (PRE:664-671)
-        oi[k] = -1;
+        if (oi) oi[k] = -1;
         oc[k * 3] = 0.0f; oc[k * 3 + 1] = 0.0f; oc[k * 3 + 2] = 0.0f;
     }
+    return count;
+}
+
+template <bool GRID>
+__global__ __launch_bounds__(256) void k_ball_query(
+    const float *__restrict__ centers, const uint32_t *__restrict__ mm_enc,
+    const float *__restrict__ lin, int gs, float margin, float *__restrict__ minmax_out,
+    float *__restrict__ centers_out, ScenePts points, int BM, int M, int N, int K,
+    float radius, int32_t *__restrict__ idx, float *__restrict__ cluster,
+    int32_t *__restrict__ pad_count)
+{
+    const int lane = lane_id();
+    const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (w >= BM) return;
+    const int b = w / M, m = w - b * M;
+    float cx, cy, cz;
+    if (GRID) {
+        float mn[3], mx[3], c[3];
+        grid_centre(mm_enc, lin, gs, margin, b, m, mn, mx, c);
+        cx = c[0]; cy = c[1]; cz = c[2];
+        if (lane < 3) centers_out[(size_t)w * 3 + lane] = c[lane];
+        if (m == 0 && lane < 3) { minmax_out[b * 6 + lane] = mn[lane]; minmax_out[b * 6 + 3 + lane] = mx[lane]; }
+    } else {
+        cx = centers[(size_t)w * 3 + 0]; cy = centers[(size_t)w * 3 + 1]; cz = centers[(size_t)w * 3 + 2];
+    }
+    const float r2 = __fmul_rn(radius, radius);
+    const int count = bq_scan(points.p[b], N, K, cx, cy, cz, r2, idx + (size_t)w * K, cluster + (size_t)w * K * 3);
     if (pad_count != nullptr && lane == 0) pad_count[w] = K - count;
 }
 
@@ -189,37 +203,28 @@ struct SlotNetArgs {
     // MODE 1
     float *proxy; const float *n1w[2]; const float *n1b[2]; const float *posb[2]; float *xin[2];
     float ln_eps;
+    const int32_t *order, *keep; int Msrc, Mt;      // MODE 1: gather through the selection when keep != null
 };
 
-template <int MODE, int Q>     // Q = hidden width / 64 channels per lane (4: the reference's 256; 8: 512)
-__global__ __launch_bounds__(256) void k_slot_net(SlotNetArgs a)
+// pooled hidden features of one cluster: lane k (< K) holds slot k's input x[6]; returns acc[q] = channel
+// lane + 64 q of  sum_k / max_k relu(alpha (W x_k + b) + beta)
+template <bool MAXPOOL, int Q>     // Q = hidden width / 64 channels per lane (4: the reference's 256; 8: 512)
+__device__ __forceinline__ void slot_pool(const float *__restrict__ conv_w, const float *__restrict__ conv_b,
+                                          const float *__restrict__ ab, int K, const float (&x)[6], float (&acc)[Q])
 {
     constexpr int W = 64 * Q;
     const int lane = lane_id();
-    const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (w >= a.BM) return;
     float wt[Q][6], bs[Q], al[Q], be[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
         const int c = lane + 64 * q;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) wt[q][i] = a.conv_w[c * 6 + i];
-        bs[q] = a.conv_b[c]; al[q] = a.ab[c]; be[q] = a.ab[W + c];
+        for (int i = 0; i < 6; ++i) wt[q][i] = conv_w[c * 6 + i];
+        bs[q] = conv_b[c]; al[q] = ab[c]; be[q] = ab[W + c];
     }
-    const float cx = a.center[(size_t)w * 3], cy = a.center[(size_t)w * 3 + 1], cz = a.center[(size_t)w * 3 + 2];
-    // lane k (< K) prepares slot k
-    float x[6] = {0, 0, 0, 0, 0, 0};
-    if (lane < a.K) {
-        const float *pk = a.cluster + ((size_t)w * a.K + lane) * 3;
-        const float px = pk[0], py = pk[1], pz = pk[2];
-        const bool pad = (px == 0.0f) && (py == 0.0f) && (pz == 0.0f);     // PRE:94 / PRE:132
-        x[0] = pad ? 0.0f : px - cx; x[1] = pad ? 0.0f : py - cy; x[2] = pad ? 0.0f : pz - cz;
-        x[3] = px; x[4] = py; x[5] = pz;
-    }
-    float acc[Q];
 #pragma unroll
-    for (int q = 0; q < Q; ++q) acc[q] = MODE == 0 ? 0.0f : -INFINITY;
-    for (int k = 0; k < a.K; ++k) {
+    for (int q = 0; q < Q; ++q) acc[q] = MAXPOOL ? -INFINITY : 0.0f;
+    for (int k = 0; k < K; ++k) {
         float s[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) s[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x[i]), k));
@@ -229,28 +234,73 @@ __global__ __launch_bounds__(256) void k_slot_net(SlotNetArgs a)
 #pragma unroll
             for (int i = 0; i < 6; ++i) h = fmaf(wt[q][i], s[i], h);
             h = fmaxf(fmaf(h, al[q], be[q]), 0.0f);
-            acc[q] = MODE == 0 ? acc[q] + h : fmaxf(acc[q], h);
+            acc[q] = MAXPOOL ? fmaxf(acc[q], h) : acc[q] + h;
         }
     }
+}
+
+// slot k's input from its xyz and the centre: [rel (zeroed on padded slots), p]   PRE:93-99 / 131-137
+__device__ __forceinline__ void slot_input(float px, float py, float pz, float cx, float cy, float cz, float (&x)[6])
+{
+    const bool pad = (px == 0.0f) && (py == 0.0f) && (pz == 0.0f);     // PRE:94 / PRE:132
+    x[0] = pad ? 0.0f : px - cx; x[1] = pad ? 0.0f : py - cy; x[2] = pad ? 0.0f : pz - cz;
+    x[3] = px; x[4] = py; x[5] = pz;
+}
+
+// OffsetNetwork tail: mean_K -> 256->3 map -> tanh*margin -> add -> clamp (PRE:59-62, 102-103).  Lanes 0..2 return
+// component `lane` of the new centre in `nc` and of the offset in `off`.
+template <int Q>
+__device__ __forceinline__ void offset_tail(const float (&acc)[Q], const float *__restrict__ map_w, int K, float margin,
+                                            float cen, float mn, float mx, float &nc, float &off)
+{
+    constexpr int W = 64 * Q;
+    const int lane = lane_id();
+    const float invK = 1.0f / (float)K;
+    float o[3] = {0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const float hm = acc[q] * invK;
+        const int c = lane + 64 * q;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) o[j] = fmaf(map_w[j * W + c], hm, o[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) o[j] = wave_sum(o[j]);
+    const float raw = lane == 0 ? o[0] : (lane == 1 ? o[1] : o[2]);
+    off = tanhf(raw) * margin;                                 // PRE:59
+    nc = fmaxf(fminf(cen + off, mx), mn);                      // PRE:61-62
+}
+
+template <int MODE, int Q>
+__global__ __launch_bounds__(256) void k_slot_net(SlotNetArgs a)
+{
+    constexpr int W = 64 * Q;
+    const int lane = lane_id();
+    const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (w >= a.BM) return;
+    // MODE 1 may gather its cluster through the selection (src = order[keep[j]]) instead of reading the
+    // gathered copies: the gathers are then off the chain that leads to the proxy blocks
+    int src = w;
+    if (MODE == 1 && a.keep != nullptr) {
+        const int b = w / a.Mper, j = w - b * a.Mper;
+        src = b * a.Msrc + a.order[(size_t)b * a.Mt + a.keep[(size_t)b * a.Mper + j]];
+    }
+    const float cx = a.center[(size_t)src * 3], cy = a.center[(size_t)src * 3 + 1], cz = a.center[(size_t)src * 3 + 2];
+    // lane k (< K) prepares slot k
+    float x[6] = {0, 0, 0, 0, 0, 0};
+    if (lane < a.K) {
+        const float *pk = a.cluster + ((size_t)src * a.K + lane) * 3;
+        slot_input(pk[0], pk[1], pk[2], cx, cy, cz, x);
+    }
+    float acc[Q];
+    slot_pool<MODE == 1, Q>(a.conv_w, a.conv_b, a.ab, a.K, x, acc);
     if (MODE == 0) {
-        const float invK = 1.0f / (float)a.K;
-        float o[3] = {0, 0, 0};
-#pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            const float hm = acc[q] * invK;
-            const int c = lane + 64 * q;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) o[j] = fmaf(a.map_w[j * W + c], hm, o[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < 3; ++j) o[j] = wave_sum(o[j]);
+        const int b = w / a.Mper;
+        const int l3 = lane < 3 ? lane : 0;
+        const float cen = lane == 0 ? cx : (lane == 1 ? cy : cz);
+        float nc, off;
+        offset_tail<Q>(acc, a.map_w, a.K, a.margin, cen, a.minmax[b * 6 + l3], a.minmax[b * 6 + 3 + l3], nc, off);
         if (lane < 3) {
-            const int b = w / a.Mper;
-            const float cen = lane == 0 ? cx : (lane == 1 ? cy : cz);
-            const float raw = lane == 0 ? o[0] : (lane == 1 ? o[1] : o[2]);
-            const float off = tanhf(raw) * a.margin;                              // PRE:59
-            const float mn = a.minmax[b * 6 + lane], mx = a.minmax[b * 6 + 3 + lane];
-            const float nc = fmaxf(fminf(cen + off, mx), mn);                     // PRE:61-62
             a.centers_out[(size_t)w * 3 + lane] = nc;
             if (a.offsets_out) a.offsets_out[(size_t)w * 3 + lane] = off;
         }
@@ -282,6 +332,75 @@ __global__ __launch_bounds__(256) void k_slot_net(SlotNetArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------ fused clustering
+// get_point_cluster (PRE:53-67) per centre in ONE launch: grid centre -> ball query #1 (gathered xyz only, Q3) ->
+// OffsetNetwork + tanh*margin + clamp -> ball query #2.  Every step of a centre depends only on that centre, so
+// one wave carries it from the bounding box to its final cluster; the K slots of query #1 never leave the CU
+// (wave-private LDS), and three launches with their cold starts become one.  Arithmetic is exactly that of the
+// separate kernels (same device functions).
+struct ClusterArgs {
+    const uint32_t *mm_enc; const float *lin; int gs; float margin, radius;
+    ScenePts points; int BM, M, N, K;
+    const float *ab, *conv_w, *conv_b, *map_w;         // OffsetNetwork
+    const float *centers_override;                     // test hook or null
+    float *minmax_out, *centers0, *cluster1, *offsets; // optional outputs (debug / stage parity)
+    float *centers; int32_t *idx2; float *cluster2; int32_t *pad_count;
+};
+
+__global__ __launch_bounds__(256) void k_cluster(ClusterArgs a)
+{
+    __shared__ float s_slots[4][64 * 3];
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);
+    if (w >= a.BM) return;
+    const int b = w / a.M, m = w - b * a.M;
+    float mn[3], mx[3], c[3];
+    grid_centre(a.mm_enc, a.lin, a.gs, a.margin, b, m, mn, mx, c);
+    if (a.centers0 && lane < 3) a.centers0[(size_t)w * 3 + lane] = c[lane];
+    if (a.minmax_out && m == 0 && lane < 3) { a.minmax_out[b * 6 + lane] = mn[lane]; a.minmax_out[b * 6 + 3 + lane] = mx[lane]; }
+    const float r2 = __fmul_rn(a.radius, a.radius);
+    const float *__restrict__ p = a.points.p[b];
+    float *slots = s_slots[wv];
+    bq_scan(p, a.N, a.K, c[0], c[1], c[2], r2, nullptr, slots);                 // PRE:56
+    float x[6] = {0, 0, 0, 0, 0, 0};
+    if (lane < a.K) {
+        const float px = slots[lane * 3], py = slots[lane * 3 + 1], pz = slots[lane * 3 + 2];
+        slot_input(px, py, pz, c[0], c[1], c[2], x);
+        if (a.cluster1) {
+            float *o = a.cluster1 + ((size_t)w * a.K + lane) * 3;
+            o[0] = px; o[1] = py; o[2] = pz;
+        }
+    }
+    constexpr int Q = kSlotHidden / 64;
+    float acc[Q];
+    slot_pool<false, Q>(a.conv_w, a.conv_b, a.ab, a.K, x, acc);
+    const float cen = lane == 0 ? c[0] : (lane == 1 ? c[1] : c[2]);
+    const float lo = lane == 0 ? mn[0] : (lane == 1 ? mn[1] : mn[2]);
+    const float hi = lane == 0 ? mx[0] : (lane == 1 ? mx[1] : mx[2]);
+    float nc, off;
+    offset_tail<Q>(acc, a.map_w, a.K, a.margin, cen, lo, hi, nc, off);
+    if (a.offsets && lane < 3) a.offsets[(size_t)w * 3 + lane] = off;
+    if (a.centers_override && lane < 3) nc = a.centers_override[(size_t)w * 3 + lane];
+    if (lane < 3) a.centers[(size_t)w * 3 + lane] = nc;
+    const float cx = PTX_LANE_F(nc, 0), cy = PTX_LANE_F(nc, 1), cz = PTX_LANE_F(nc, 2);
+    const int count = bq_scan(p, a.N, a.K, cx, cy, cz, r2, a.idx2 + (size_t)w * a.K, a.cluster2 + (size_t)w * a.K * 3);   // PRE:65
+    if (lane == 0) a.pad_count[w] = a.K - count;
+}
+
+int launch_cluster(const PtxShape &s, const uint32_t *mm_enc, const float *lin, const ScenePts &points,
+                   const float *off_ab, const PtxSlotMlp &mlp, const float *map_w, const float *centers_override,
+                   float *minmax_out, float *centers0, float *cluster1, float *offsets, float *centers,
+                   int32_t *idx2, float *cluster2, int32_t *pad_count, hipStream_t st)
+{
+    const int M = s.grid_size * s.grid_size * s.grid_size;
+    ClusterArgs a{mm_enc, lin, s.grid_size, s.margin, s.radius, points, s.B * M, M, s.N, s.K,
+                  off_ab, mlp.conv_w, mlp.conv_b, map_w, centers_override,
+                  minmax_out, centers0, cluster1, offsets, centers, idx2, cluster2, pad_count};
+    hipLaunchKernelGGL(k_cluster, dim3(cdiv(s.B * M, 4)), dim3(256), 0, st, a);
+    PTX_LAUNCHED("k_cluster");
+    return PTX_OK;
+}
+
 int launch_offset_net(const float *ab, const PtxSlotMlp &mlp, const float *map_w,
                       const float *centers_in, const float *cluster, const float *minmax,
                       int BM, int M, int K, float margin, float *centers_out, float *offsets_out,
@@ -299,11 +418,15 @@ int launch_offset_net(const float *ab, const PtxSlotMlp &mlp, const float *map_w
 int launch_pointnet(const float *ab, const PtxSlotMlp &mlp, const float *kcenter,
                     const float *kcluster, int BM, int Mk, int K, int width, float *point_proxy,
                     const PtxBlock *blk_t, const PtxBlock *blk_i, const float *posb_t,
-                    const float *posb_i, float *xin_t, float *xin_i, float ln_eps, hipStream_t st)
+                    const float *posb_i, float *xin_t, float *xin_i, float ln_eps,
+                    const int32_t *order, const int32_t *keep, int Msrc, int Mt, hipStream_t st)
 {
+    // order / keep given: kcenter / kcluster are the UN-gathered (B,Msrc,..) arrays and kept cluster j of scene b
+    // reads row order[b][keep[b][j]] itself
     SlotNetArgs a{};
     a.ab = ab; a.conv_w = mlp.conv_w; a.conv_b = mlp.conv_b; a.center = kcenter; a.cluster = kcluster;
     a.BM = BM; a.Mper = Mk; a.K = K; a.proxy = point_proxy; a.ln_eps = ln_eps;
+    a.order = order; a.keep = keep; a.Msrc = Msrc; a.Mt = Mt;
     if (blk_t && xin_t) { a.n1w[0] = blk_t->norm1_w; a.n1b[0] = blk_t->norm1_b; a.posb[0] = posb_t; a.xin[0] = xin_t; }
     if (blk_i && xin_i) { a.n1w[1] = blk_i->norm1_w; a.n1b[1] = blk_i->norm1_b; a.posb[1] = posb_i; a.xin[1] = xin_i; }
     PTX_REQUIRE(width == 256 || width == 512, "pointnet: width=%d (supported: 256, 512)", width);
@@ -325,6 +448,8 @@ struct SelectArgs {
     const int32_t *order_override;
     int32_t *order, *picks, *keep; float *kcenter, *kcluster; int32_t *kidx, *drop_idx; uint32_t *tag;
     int M, K, Mt, Mk, Kd, N;
+    uint32_t *mm_clear;      // forward only: the encoded bounding boxes (B,6), last read before this launch, are
+                             // zeroed here so that the next call finds them clean (no memset launch per call)
 };
 
 template <int P>   // points per thread of the FPS (256 * P >= Mt)
@@ -467,6 +592,7 @@ __global__ __launch_bounds__(256) void k_select(SelectArgs a)
     // ---- 4. kept centres; the slot gathers, drop list and tags are spread over the chip by
     // k_select_slots (they are dependent-load chains: one work-group per scene made them the
     // longest part of this kernel once the image branch loads the memory system)
+    if (a.mm_clear != nullptr && tid < 6) a.mm_clear[b * 6 + tid] = 0u;
     for (int j = tid; j < Mk; j += T) {
         const int t = s_keep[j];
         a.keep[(size_t)b * Mk + j] = t;
@@ -493,11 +619,12 @@ __global__ __launch_bounds__(256) void k_select_slots(SelectArgs a)
         const int j = e / K, k = e - j * K;
         const int src = order[a.keep[(size_t)b * Mk + j]];
         const int id = a.idx[((size_t)b * M + src) * K + k];
-        const float *cp = a.cluster + (((size_t)b * M + src) * K + k) * 3;
-        const float x = cp[0], y = cp[1], z = cp[2];
-        a.kidx[(size_t)b * Mk * K + e] = id;
-        float *op = a.kcluster + ((size_t)b * Mk * K + e) * 3;
-        op[0] = x; op[1] = y; op[2] = z;
+        if (a.kidx) a.kidx[(size_t)b * Mk * K + e] = id;
+        if (a.kcluster) {
+            const float *cp = a.cluster + (((size_t)b * M + src) * K + k) * 3;
+            float *op = a.kcluster + ((size_t)b * Mk * K + e) * 3;
+            op[0] = cp[0]; op[1] = cp[1]; op[2] = cp[2];
+        }
         if (tag && id >= 0) {
             const uint32_t v = (uint32_t)(e + 1);
             const uint32_t old = atomicMax(&tag[id], v);
@@ -509,7 +636,7 @@ __global__ __launch_bounds__(256) void k_select_slots(SelectArgs a)
         const int pk = kk < kn ? a.picks[(size_t)b * Kd + kk] : -1;
         int id = -1;
         if (pk >= 0) id = a.idx[((size_t)b * M + order[pk]) * K + k];
-        a.drop_idx[(size_t)b * Kd * K + ed] = id;
+        if (a.drop_idx) a.drop_idx[(size_t)b * Kd * K + ed] = id;
         if (tag && id >= 0) atomicOr(&tag[id], 0x80000000u);
     }
 }
@@ -520,14 +647,23 @@ static size_t select_lds_bytes(const PtxShape &s)
     return sizeof(int) * ((size_t)s.Mt * 5 + s.Mk + (Kd > 0 ? Kd : 1) + 64 + 16 + 16);
 }
 
-int launch_select(const PtxShape &s, const int32_t *idx, const float *centers, const float *cluster,
-                  const int32_t *pad_count, const int32_t *order_override, int32_t *order,
-                  int32_t *picks, int32_t *keep, float *kcenter, float *kcluster, int32_t *kidx,
-                  int32_t *drop_idx, uint32_t *tag, hipStream_t st)
+static SelectArgs select_args(const PtxShape &s, const int32_t *idx, const float *centers, const float *cluster,
+                              const int32_t *pad_count, const int32_t *order_override, int32_t *order,
+                              int32_t *picks, int32_t *keep, float *kcenter, float *kcluster, int32_t *kidx,
+                              int32_t *drop_idx, uint32_t *tag, uint32_t *mm_clear)
 {
-    SelectArgs a{idx, centers, cluster, pad_count, order_override, order, picks, keep, kcenter,
-                 kcluster, kidx, drop_idx, tag, s.grid_size * s.grid_size * s.grid_size, s.K, s.Mt,
-                 s.Mk, s.Mt - s.Mk, s.N};
+    return SelectArgs{idx, centers, cluster, pad_count, order_override, order, picks, keep, kcenter,
+                      kcluster, kidx, drop_idx, tag, s.grid_size * s.grid_size * s.grid_size, s.K, s.Mt,
+                      s.Mk, s.Mt - s.Mk, s.N, mm_clear};
+}
+
+// ordering + FPS + keep list + kept centres (one work-group per scene)
+int launch_select_order(const PtxShape &s, const float *centers, const int32_t *pad_count,
+                        const int32_t *order_override, int32_t *order, int32_t *picks, int32_t *keep,
+                        float *kcenter, uint32_t *mm_clear, hipStream_t st)
+{
+    SelectArgs a = select_args(s, nullptr, centers, nullptr, pad_count, order_override, order, picks, keep, kcenter,
+                               nullptr, nullptr, nullptr, nullptr, mm_clear);
     const size_t lds = select_lds_bytes(s);
     PTX_REQUIRE(lds <= 160 * 1024, "select: Mt=%d needs %zu B of LDS (> 160 KiB)", s.Mt, lds);
     const int per = cdiv(s.Mt, 256);
@@ -551,16 +687,37 @@ int launch_select(const PtxShape &s, const int32_t *idx, const float *centers, c
     else { set_error("select: Mt=%d too large (max %d)", s.Mt, 256 * 16); return PTX_EINVAL; }
 #undef PTX_SEL
     PTX_LAUNCHED("k_select");
+    return PTX_OK;
+}
+
+// ownership / drop tags of every slot (+ the gathered copies kidx / kcluster / drop_idx where asked for), chip-wide
+int launch_select_slots(const PtxShape &s, const int32_t *idx, const float *cluster, const int32_t *order,
+                        const int32_t *picks, const int32_t *keep, float *kcluster, int32_t *kidx,
+                        int32_t *drop_idx, uint32_t *tag, hipStream_t st)
+{
+    SelectArgs a = select_args(s, idx, nullptr, cluster, nullptr, nullptr, const_cast<int32_t *>(order),
+                               const_cast<int32_t *>(picks), const_cast<int32_t *>(keep), nullptr, kcluster, kidx,
+                               drop_idx, tag, nullptr);
     hipLaunchKernelGGL(k_select_slots, dim3(cdiv(s.Mt * s.K, 256), s.B), dim3(256), 0, st, a);
     PTX_LAUNCHED("k_select_slots");
     return PTX_OK;
+}
+
+int launch_select(const PtxShape &s, const int32_t *idx, const float *centers, const float *cluster,
+                  const int32_t *pad_count, const int32_t *order_override, int32_t *order,
+                  int32_t *picks, int32_t *keep, float *kcenter, float *kcluster, int32_t *kidx,
+                  int32_t *drop_idx, uint32_t *tag, hipStream_t st)
+{
+    PTX_TRY(launch_select_order(s, centers, pad_count, order_override, order, picks, keep, kcenter, nullptr, st));
+    return launch_select_slots(s, idx, cluster, order, picks, keep, kcluster, kidx, drop_idx, tag, st);
 }
 
 // ------------------------------------------------------------------------------ apply
 // tag word per point: bit 31 = dropped (PRE:516-523), low 31 bits = 1 + owning flat (m,k) slot
 // (last writer in flat order, PRE:495 single-thread semantics), 0 = untouched.
 __global__ __launch_bounds__(256) void k_tile_count(const uint32_t *__restrict__ tag, int N,
-                                                    int32_t *__restrict__ tile_counts)
+                                                    int32_t *__restrict__ tile_counts, int32_t *scene_acc,
+                                                    int32_t *counts)
 {
     const int b = blockIdx.y, tile = blockIdx.x;
     const uint32_t *tg = tag + (size_t)b * N;
@@ -574,12 +731,26 @@ __global__ __launch_bounds__(256) void k_tile_count(const uint32_t *__restrict__
     __shared__ int red[4];
     if (lane_id() == 0) red[threadIdx.x >> 6] = c;
     __syncthreads();
-    if (threadIdx.x == 0) tile_counts[b * gridDim.x + tile] = red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) {
+        const int total = red[0] + red[1] + red[2] + red[3];
+        tile_counts[b * gridDim.x + tile] = total;
+        if (scene_acc != nullptr) {
+            // Surviving points per scene, published as soon as the drop tags are final so that the host can size
+            // its output views (PRE:467 masked_select lengths) long before the forward has drained: the last tile
+            // of a scene to arrive (ticket) stores the sum with system scope -- `counts` is normally pinned host
+            // memory that the caller polls -- and leaves the two accumulators zero for the next call.
+            __hip_atomic_fetch_add(scene_acc + 2 * b, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int ticket = __hip_atomic_fetch_add(scene_acc + 2 * b + 1, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (ticket == (int)gridDim.x - 1) {
+                const int sum = __hip_atomic_exchange(scene_acc + 2 * b, 0, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(scene_acc + 2 * b + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(counts + b, sum, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
 }
 
-// Surviving points per scene, published as soon as the drop tags are final so that the host can
-// size its output views (PRE:467 masked_select lengths) long before the forward has drained. The
-// store is system scope: `counts` is normally pinned host memory that the caller polls.
+// stand-alone form of the per-scene sum (stage API without accumulators)
 __global__ __launch_bounds__(64) void k_scene_counts(const int32_t *tile_counts, int ntiles, int32_t *counts)
 {
     const int b = blockIdx.x;
@@ -591,12 +762,15 @@ __global__ __launch_bounds__(64) void k_scene_counts(const int32_t *tile_counts,
     }
 }
 
-int launch_tile_count(const uint32_t *tag, int B, int N, int32_t *tile_counts, int32_t *counts, hipStream_t st)
+// scene_acc (B,2) int32, zero on entry, left zero: per-scene sum + arrival ticket; null = separate k_scene_counts launch
+int launch_tile_count(const uint32_t *tag, int B, int N, int32_t *tile_counts, int32_t *counts, int32_t *scene_acc,
+                      hipStream_t st)
 {
     const int ntiles = cdiv(N, kTilePts);
-    hipLaunchKernelGGL(k_tile_count, dim3(ntiles, B), dim3(256), 0, st, tag, N, tile_counts);
+    hipLaunchKernelGGL(k_tile_count, dim3(ntiles, B), dim3(256), 0, st, tag, N, tile_counts,
+                       counts ? scene_acc : nullptr, counts);
     PTX_LAUNCHED("k_tile_count");
-    if (counts) {
+    if (counts && scene_acc == nullptr) {
         hipLaunchKernelGGL(k_scene_counts, dim3(B), dim3(64), 0, st, tile_counts, ntiles, counts);
         PTX_LAUNCHED("k_scene_counts");
     }
@@ -604,8 +778,9 @@ int launch_tile_count(const uint32_t *tag, int B, int N, int32_t *tile_counts, i
 }
 
 struct AffineArgs {
-    ScenePts points; const uint32_t *tag; const float *kcenter, *translate, *transform;
+    ScenePts points; uint32_t *tag; const float *kcenter, *translate, *transform;
     float *out; int32_t *counts; const int32_t *tile_counts; int N, Mk, K;
+    int clear_tag;      // forward only: this is the last reader of the tags; leave them zero for the next call
 };
 
 template <bool COMPACT>
@@ -613,7 +788,7 @@ __global__ __launch_bounds__(256) void k_affine(AffineArgs a)
 {
     const int b = blockIdx.y, tile = blockIdx.x, ntiles = gridDim.x;
     const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
-    const uint32_t *tg = a.tag + (size_t)b * a.N;
+    uint32_t *tg = a.tag + (size_t)b * a.N;
     const float *__restrict__ pts = a.points.p[b];
     float *out = a.out + (size_t)b * a.N * 3;
     constexpr int R = kTilePts / 256;
@@ -638,6 +813,7 @@ __global__ __launch_bounds__(256) void k_affine(AffineArgs a)
         keep[r] = false;
         if (n < a.N) {
             const uint32_t t = tg[n];
+            if (a.clear_tag && t != 0u) tg[n] = 0u;
             float x = pts[(size_t)n * 3], y = pts[(size_t)n * 3 + 1], z = pts[(size_t)n * 3 + 2];
             keep[r] = !COMPACT || (t >> 31) == 0;
             const uint32_t own = t & 0x7fffffffu;
@@ -682,11 +858,11 @@ __global__ __launch_bounds__(256) void k_affine(AffineArgs a)
     }
 }
 
-int launch_affine(const PtxShape &s, const ScenePts &points, const uint32_t *tag, const float *kcenter,
+int launch_affine(const PtxShape &s, const ScenePts &points, uint32_t *tag, const float *kcenter,
                   const float *translate, const float *transform, float *out, int32_t *counts,
-                  const int32_t *tile_counts, bool compact, hipStream_t st)
+                  const int32_t *tile_counts, bool compact, bool clear_tag, hipStream_t st)
 {
-    AffineArgs a{points, tag, kcenter, translate, transform, out, counts, tile_counts, s.N, s.Mk, s.K};
+    AffineArgs a{points, tag, kcenter, translate, transform, out, counts, tile_counts, s.N, s.Mk, s.K, clear_tag ? 1 : 0};
     const dim3 grid(cdiv(s.N, kTilePts), s.B), block(256);
     if (compact) hipLaunchKernelGGL(k_affine<true>, grid, block, 0, st, a);
     else         hipLaunchKernelGGL(k_affine<false>, grid, block, 0, st, a);

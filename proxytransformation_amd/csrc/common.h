@@ -101,6 +101,9 @@ struct PrepLayout {
     size_t w3, b3;                  // (3C,in_dim), (3C): [q | k0 | v0] of token 0 from the image mean
     size_t t1;                      // (heads, KT1, hd): scale * [WkWc | K-proj of (bc+pos_i)]
     size_t t2;                      // (heads, hd, KT2p): [WvWc | V-proj of (bc+pos_i)] (transposed)
+    // LayerNorm folds (GemmProb::lnp_in): norm_img -> proxy_proj of the image block; norm2 -> fc1 of both blocks
+    size_t ppg_w, ppg_s, ppg_c;     // (C,C), (C), (C)
+    size_t fc1g_w[2], fc1g_s[2], fc1g_c[2];   // (hidden,C), (hidden), (hidden) for the text / image block
     size_t total;                   // floats
     int KT1, KT2p, hd;
 };
@@ -109,14 +112,17 @@ PrepLayout prep_layout(const PtxShape &s);
 // ---- per-call scratch ---------------------------------------------------------
 struct WsLayout {
     // byte offsets from the start of the workspace
-    size_t zero_begin, zero_bytes;  // region cleared by one memset per call
+    size_t zero_begin, zero_bytes;  // region that every forward finds zero and leaves zero (cleared once, by
+                                    // ptx_workspace_init; the kernels that read these words last re-zero them)
     size_t mm_enc;                  // (B,6) uint32 encoded min / max
+    size_t scene_acc;               // (B,2) int32 survivor-count accumulator + arrival ticket
     size_t tag;                     // (B,N) uint32
     size_t minmax, centers0, cluster1, offsets, centers, idx2, cluster2, pad_count;
     size_t order, picks, keep, kcenter, kcluster, kidx, drop_idx, tile_counts;
     size_t point_proxy, x_in[2];    // x_in: LN1(x)+slot bias per branch (B*Mk,C)
     size_t fm, qkv0, we, pool, gbuf, obuf, cbuf, img_proxy;
     size_t qkv[2], pt[2], pv[2], ao[2], x1[2], xn2[2], hbuf[2], x2[2], guide[2], head[2];
+    size_t lnp_img, lnp_x1[2];      // LayerNorm partials (rows, C/32, 2) of c_proj's / proj's output
     size_t total;
 };
 WsLayout ws_layout(const PtxShape &s);
@@ -137,6 +143,14 @@ struct GemmProb {
     // with the split-softmax factors of row r computed from ML[r] = (m0, l0, m1, l1, s(0)); the row scalar
     // `rs` is then a_h(0) = ct (gemm.hip, k_gemm32<SK, 1>)
     const float *pg, *pe, *pml; int ldg, gslab, lde, ldml, kg;
+    // LayerNorm folded across a GEMM -> GEMM seam (no LayerNorm launch, no normalised copy of the rows):
+    //   producer (lnp_out != null): besides C, every 32-column tile writes the partial (sum, sum of squares) of its
+    //     rows' FINAL values to lnp_out[(row * ceil(N/32) + tile) * 2 + {0,1}];
+    //   consumer (lnp_in != null): A holds the RAW rows of the producer (width ln_C), W = W' diag(gamma), and the
+    //     epilogue applies  y = rstd_r (acc - mean_r s_n) + c_n  with s_n = sum_k W[n][k], c_n = W' beta + bias
+    //     (mean_r, rstd_r from the ln_parts partials of row r; `bias` must be null) -- LN(x) W'^T + b, reassociated.
+    float *lnp_out;
+    const float *lnp_in, *ln_s, *ln_c; int ln_parts, ln_C; float ln_eps;
 };
 constexpr int kMaxGroups = 8;
 struct GemmBatch { GemmProb p[kMaxGroups]; int n; int rotate; };
@@ -184,15 +198,27 @@ int launch_offset_net(const float *ab, const PtxSlotMlp &mlp, const float *map_w
 int launch_pointnet(const float *ab, const PtxSlotMlp &mlp, const float *kcenter,
                     const float *kcluster, int BM, int Mk, int K, int width, float *point_proxy,
                     const PtxBlock *blk_t, const PtxBlock *blk_i, const float *posb_t,
-                    const float *posb_i, float *xin_t, float *xin_i, float ln_eps, hipStream_t st);
+                    const float *posb_i, float *xin_t, float *xin_i, float ln_eps,
+                    const int32_t *order, const int32_t *keep, int Msrc, int Mt, hipStream_t st);
+int launch_cluster(const PtxShape &s, const uint32_t *mm_enc, const float *lin, const ScenePts &points,
+                   const float *off_ab, const PtxSlotMlp &mlp, const float *map_w, const float *centers_override,
+                   float *minmax_out, float *centers0, float *cluster1, float *offsets, float *centers,
+                   int32_t *idx2, float *cluster2, int32_t *pad_count, hipStream_t st);
 int launch_select(const PtxShape &s, const int32_t *idx, const float *centers, const float *cluster,
                   const int32_t *pad_count, const int32_t *order_override, int32_t *order,
                   int32_t *picks, int32_t *keep, float *kcenter, float *kcluster, int32_t *kidx,
                   int32_t *drop_idx, uint32_t *tag, hipStream_t st);
-int launch_tile_count(const uint32_t *tag, int B, int N, int32_t *tile_counts, int32_t *counts, hipStream_t st);
-int launch_affine(const PtxShape &s, const ScenePts &points, const uint32_t *tag, const float *kcenter,
+int launch_select_order(const PtxShape &s, const float *centers, const int32_t *pad_count,
+                        const int32_t *order_override, int32_t *order, int32_t *picks, int32_t *keep,
+                        float *kcenter, uint32_t *mm_clear, hipStream_t st);
+int launch_select_slots(const PtxShape &s, const int32_t *idx, const float *cluster, const int32_t *order,
+                        const int32_t *picks, const int32_t *keep, float *kcluster, int32_t *kidx,
+                        int32_t *drop_idx, uint32_t *tag, hipStream_t st);
+int launch_tile_count(const uint32_t *tag, int B, int N, int32_t *tile_counts, int32_t *counts, int32_t *scene_acc,
+                      hipStream_t st);
+int launch_affine(const PtxShape &s, const ScenePts &points, uint32_t *tag, const float *kcenter,
                   const float *translate, const float *transform, float *out, int32_t *counts,
-                  const int32_t *tile_counts, bool compact, hipStream_t st);
+                  const int32_t *tile_counts, bool compact, bool clear_tag, hipStream_t st);
 
 // ---- image proxy (imgproxy.hip) ------------------------------------------------------------
 int launch_img_mean(const float *img, int nimg, int in_dim, int hw, float *fm, hipStream_t st);

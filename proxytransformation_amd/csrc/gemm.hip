@@ -19,6 +19,39 @@ constexpr int BK = 32, LDT = BK + 4;   // 144-B LDS rows: 16-B aligned, b128 fra
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+// ---- LayerNorm fold helpers (GemmProb::lnp_out / lnp_in) ----------------------------------------------------------
+// consumer: mean / rstd of row `row` from the producer's per-tile partials
+__device__ __forceinline__ void ln_row_stats(const GemmProb &pr, int row, float &mu, float &rstd)
+{
+    const float2 *pp = reinterpret_cast<const float2 *>(pr.lnp_in) + (size_t)row * pr.ln_parts;
+    float s1 = 0.0f, s2 = 0.0f;
+    for (int t = 0; t < pr.ln_parts; ++t) { const float2 v = pp[t]; s1 += v.x; s2 += v.y; }
+    const float inv = 1.0f / (float)pr.ln_C;
+    mu = s1 * inv;
+    const float var = fmaxf(fmaf(-mu, mu, s2 * inv), 0.0f);
+    rstd = 1.0f / sqrtf(var + pr.ln_eps);
+}
+// producer: one wave holds the final values v[r] of a 32x32 tile in the MFMA C layout (col = lane & 31,
+// row = (r&3) + 8 (r>>2) + 4 (lane>>5)); scratch = 32 x 33 floats of wave-private LDS.  Writes the (sum, sum of
+// squares) of each row's 32 columns (invalid columns / rows contribute 0) to lnp_out[(row * parts + part) * 2].
+__device__ __forceinline__ void ln_tile_partials(const GemmProb &pr, const float (&v)[16], float *scratch, int row0,
+                                                 int part, int parts)
+{
+    const int lane = threadIdx.x & 63, li = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) scratch[((r & 3) + 8 * (r >> 2) + 4 * hh) * 33 + li] = v[r];
+    // same wave: LDS operations complete in order, no barrier needed
+    const float *rowp = scratch + li * 33 + 16 * hh;       // lane (li, hh) sums columns 16 hh .. 16 hh + 15 of row li
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { const float x = rowp[c]; s1 += x; s2 = fmaf(x, x, s2); }
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    const int row = row0 + li;
+    if (hh == 0 && row < pr.R)
+        *reinterpret_cast<float2 *>(pr.lnp_out + ((size_t)row * parts + part) * 2) = make_float2(s1, s2);
+}
+
 // Throughput-regime kernel: 64x64 output tile per 4-wave work-group, one 32x32 MFMA accumulator
 // per wave.  K loop, BK = 32 per step, three stages: tile it is consumed from LDS, tile it+1
 // sits in the other LDS buffer, tile it+2 is in flight in registers (two register sets, loop
@@ -60,7 +93,13 @@ __global__ __launch_bounds__(256) void k_gemm64(GemmBatch gb)
     if (row0 >= pr.R || col0 >= pr.N) return;
     __shared__ __attribute__((aligned(16))) float As[2][64][LDT];
     __shared__ __attribute__((aligned(16))) float Ws[2][64][LDT];
+    __shared__ float s_mu[64], s_rs[64];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (pr.lnp_in != nullptr && tid < 64) {
+        float mu, rs;
+        ln_row_stats(pr, min(row0 + tid, pr.R - 1), mu, rs);
+        s_mu[tid] = mu; s_rs[tid] = rs;                    // read after the barriers of the K loop
+    }
     const int wr = wid >> 1, wc = wid & 1;
     const int li = lane & 31, hh = lane >> 5;
     const int sr = tid >> 3, kq = (tid & 7) * 4;        // staging: rows sr and sr + 32
@@ -97,18 +136,26 @@ __global__ __launch_bounds__(256) void k_gemm64(GemmBatch gb)
         __syncthreads();
     }
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-    if (n >= pr.N) return;
+    const bool ncol = n < pr.N;
+    float lns = 0.0f, lnc = 0.0f;
+    if (pr.lnp_in != nullptr && ncol) { lns = pr.ln_s[n]; lnc = pr.ln_c[n]; }
+    float fin[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int row = row0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (row < pr.R) {
-            float v = acc[r] + bias;
-            if (pr.epi == EPI_GELU) v = gelu_erf(v);
+        const int rl = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh, row = row0 + rl;
+        float v = acc[r] + bias;
+        if (pr.lnp_in != nullptr) v = fmaf(s_rs[rl], fmaf(-s_mu[rl], lns, acc[r]), lnc);
+        if (pr.epi == EPI_GELU) v = gelu_erf(v);
+        const bool ok = ncol && row < pr.R;
+        if (ok) {
             if (pr.rs) v = fmaf(pr.rs[(size_t)row * pr.rs_stride], pr.ad[(size_t)row * pr.ldad + n], v);
             if (pr.res) v += resv[r];
             pr.C[(size_t)row * pr.ldc + n] = v;
         }
+        fin[r] = ok ? v : 0.0f;
     }
+    if (pr.lnp_out != nullptr)      // every wave is past its last LDS read (barrier after the last stash)
+        ln_tile_partials(pr, fin, &As[0][0][0] + wid * (32 * 33), row0 + wr * 32, (col0 >> 5) + wc, (pr.N + 31) >> 5);
 }
 #undef PTX_G64_FETCH
 #undef PTX_G64_STASH
@@ -151,6 +198,12 @@ __global__ __launch_bounds__(SK * 64) void k_gemm32(GemmBatch gb)
     size_t g0 = 0, g1 = 0, g2 = 0, g3 = 0, e0 = 0, e1 = 0, e2 = 0, e3 = 0;
     float fc0[4] = {0.f, 0.f, 0.f, 0.f}, fc1[4] = {0.f, 0.f, 0.f, 0.f}, fct[4] = {0.f, 0.f, 0.f, 0.f};
     float *cts = lds + (size_t)SK * (4 * 32 * LDT);         // [32] a_h(0) of the tile's rows (AMODE 1)
+    float *lnst = cts + 32;                                 // [32][2] mean, rstd of the tile's rows (LayerNorm consumer)
+    if (pr.lnp_in != nullptr && wv == 0 && lane < 32) {     // written and read by wave 0 only
+        float mu, rs;
+        ln_row_stats(pr, min(row0 + lane, pr.R - 1), mu, rs);
+        lnst[2 * lane] = mu; lnst[2 * lane + 1] = rs;
+    }
     if (AMODE == 1) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -297,25 +350,33 @@ __global__ __launch_bounds__(SK * 64) void k_gemm32(GemmBatch gb)
             for (int r = 0; r < 16; ++r) acc[r] += o[r * 64 + lane];
         }
     }
-    if (n >= pr.N) return;
+    const bool ncol = n < pr.N;
+    float lns = 0.0f, lnc = 0.0f;
+    if (pr.lnp_in != nullptr && ncol) { lns = pr.ln_s[n]; lnc = pr.ln_c[n]; }
+    float fin[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (row < pr.R) {
-            float v = acc[r] + bias;
-            if (pr.epi == EPI_GELU) v = gelu_erf(v);
-            if (AMODE == 1) v = fmaf(cts[row - row0], pr.ad[(size_t)row * pr.ldad + n], v);
+        const int rl = (r & 3) + 8 * (r >> 2) + 4 * hh, row = row0 + rl;
+        float v = acc[r] + bias;
+        if (pr.lnp_in != nullptr) v = fmaf(lnst[2 * rl + 1], fmaf(-lnst[2 * rl], lns, acc[r]), lnc);
+        if (pr.epi == EPI_GELU) v = gelu_erf(v);
+        const bool ok = ncol && row < pr.R;
+        if (ok) {
+            if (AMODE == 1) v = fmaf(cts[rl], pr.ad[(size_t)row * pr.ldad + n], v);
             else if (pr.rs) v = fmaf(pr.rs[(size_t)row * pr.rs_stride], pr.ad[(size_t)row * pr.ldad + n], v);
             if (pr.res) v += resv[r];
             pr.C[(size_t)row * pr.ldc + n] = v;
         }
+        fin[r] = ok ? v : 0.0f;
     }
+    if (pr.lnp_out != nullptr)      // wave 0's staging area is free: its K loop is over, the other slices parked elsewhere
+        ln_tile_partials(pr, fin, lds, row0, col0 >> 5, (pr.N + 31) >> 5);
 }
 
 template <int SK, int AMODE>
 static int launch_gemm32(const GemmBatch &gb, int rmax, int nmax, hipStream_t st)
 {
-    const size_t lds = sizeof(float) * (SK * 4 * 32 * LDT + (AMODE ? 32 : 0));
+    const size_t lds = sizeof(float) * (SK * 4 * 32 * LDT + 32 + 64);
     if (lds > 64 * 1024)
         PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm32<SK, AMODE>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -345,6 +406,8 @@ int launch_gemm(const GemmBatch &gb_in, hipStream_t st)
                       reinterpret_cast<uintptr_t>(p.pe)) & 15) == 0,
                     "gemm: operands of group %d are not 16-byte aligned", g);
         PTX_REQUIRE(p.rs == nullptr || p.ad != nullptr, "gemm: row scale without addend");
+        PTX_REQUIRE(p.lnp_in == nullptr || (p.ln_s && p.ln_c && p.ln_parts >= 1 && p.ln_C >= 1 && p.bias == nullptr),
+                    "gemm: bad LayerNorm-consumer description in group %d", g);
         rmax = p.R > rmax ? p.R : rmax;
         nmax = p.N > nmax ? p.N : nmax;
         kmin = p.K < kmin ? p.K : kmin;

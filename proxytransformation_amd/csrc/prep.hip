@@ -100,6 +100,25 @@ __global__ void k_prep_t2(const float *vw, const float *cw, const float *cb, con
     t2[i] = s;
 }
 
+// LayerNorm fold (GemmProb::lnp_in): Wg[n][k] = W[n][k] gamma[k];  s[n] = sum_k Wg[n][k] (of the ROUNDED products, the
+// values the GEMM multiplies);  c[n] = sum_k W[n][k] beta[k] + bias[n].  One wave per output row.
+__global__ void k_prep_lnfold(const float *W, const float *gamma, const float *beta, const float *bias, int N, int K,
+                              float *Wg, float *sv, float *cv)
+{
+    const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const int lane = threadIdx.x & 63;
+    float s1 = 0.0f, c1 = 0.0f;
+    for (int k = lane; k < K; k += 64) {
+        const float wv = W[(size_t)n * K + k], g = wv * gamma[k];
+        Wg[(size_t)n * K + k] = g;
+        s1 += g;
+        c1 = fmaf(wv, beta[k], c1);
+    }
+    s1 = wave_sum(s1); c1 = wave_sum(c1);
+    if (lane == 0) { sv[n] = s1; cv[n] = c1 + (bias ? bias[n] : 0.0f); }
+}
+
 int run_prepare(const PtxShape &s, const PtxWeights &w, float *prep, hipStream_t st)
 {
     const PrepLayout P = prep_layout(s);
@@ -131,6 +150,14 @@ int run_prepare(const PtxShape &s, const PtxWeights &w, float *prep, hipStream_t
     hipLaunchKernelGGL(k_prep_t2, dim3(cdiv(s.heads * P.hd * P.KT2p, T)), dim3(T), 0, st, w.v_w, w.cm_w,
                        w.cm_b, w.pos, C, s.in_dim, s.hw, s.heads, P.KT2p, prep + P.t2);
     PTX_LAUNCHED("k_prep_t2");
+    hipLaunchKernelGGL(k_prep_lnfold, dim3(cdiv(C, 4)), dim3(T), 0, st, w.img.pp_w, w.norm_img_w, w.norm_img_b, w.img.pp_b,
+                       C, C, prep + P.ppg_w, prep + P.ppg_s, prep + P.ppg_c);
+    const PtxBlock *blk[2] = {&w.text, &w.img};
+    for (int i = 0; i < 2; ++i)
+        hipLaunchKernelGGL(k_prep_lnfold, dim3(cdiv(s.hidden, 4)), dim3(T), 0, st, blk[i]->fc1_w, blk[i]->norm2_w,
+                           blk[i]->norm2_b, blk[i]->fc1_b, s.hidden, C, prep + P.fc1g_w[i], prep + P.fc1g_s[i],
+                           prep + P.fc1g_c[i]);
+    PTX_LAUNCHED("k_prep_lnfold");
     return PTX_OK;
 }
 

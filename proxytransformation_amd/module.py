@@ -118,6 +118,30 @@ class _ProxyBlock(_Holder):                                            # PRE:259
         self.mlp = _Mlp(dim, hidden)
 
 
+class _Lane:
+    """Per-(device, stream) call state: the library context (side streams / events), one workspace and the pinned
+    count buffer.  Calls on different torch streams use different lanes, so independent batches can be in flight
+    on the GPU at the same time (a serving loop alternating between two streams overlaps the bandwidth-bound
+    image passes of one batch with the latency-bound proxy blocks of the other)."""
+    __slots__ = ("ctx", "ws", "ws_key", "ws_dirty", "counts", "counts_np", "stream")
+
+    def __init__(self, stream):
+        self.stream = stream
+        self.ctx = ctypes.c_void_p()
+        _abi.check(_abi.lib().ptx_context_create(ctypes.byref(self.ctx)), "ptx_context_create")
+        self.ws, self.ws_key, self.ws_dirty = None, None, True
+        self.counts = self.counts_np = None
+
+    def release(self):
+        ctx, self.ctx = self.ctx, None
+        if ctx is not None:
+            _abi.lib().ptx_context_destroy(ctx)
+        self.ws = None
+
+
+_MAX_LANES = 4                       # streams served concurrently by one module (least recently used is retired)
+
+
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -174,12 +198,8 @@ class ProxyTransformationNormReverse(nn.Module):
         # host-side caches (not part of the state_dict)
         self._tensors = None
         self._slots = None
-        self._ctx: Optional[ctypes.c_void_p] = None
-        self._ctx_dev = None
+        self._lanes: Dict[tuple, _Lane] = {}
         self.register_load_state_dict_post_hook(lambda mod, _keys: mod.invalidate_weights())
-        self._counts_host: Optional[torch.Tensor] = None
-        self._counts_np = None
-        self._last_stream = None
         #: True = block until the whole forward has drained (the pre-ABI-3 behaviour); default is
         #: to return once the output lengths are known, like any asynchronous torch op
         self.sync_outputs = os.environ.get("PTX_SYNC_OUTPUTS", "0") == "1"
@@ -187,7 +207,6 @@ class ProxyTransformationNormReverse(nn.Module):
         self._wstruct: Optional[_abi.PtxWeights] = None
         self._prep: Optional[torch.Tensor] = None
         self._lin: Optional[torch.Tensor] = None
-        self._ws: Dict[tuple, torch.Tensor] = {}
         self._shapes: Dict[tuple, _abi.PtxShape] = {}
         # test-only hooks: replay a captured argsort / inject clamped centres
         self._order_override: Optional[torch.Tensor] = None
@@ -300,45 +319,60 @@ class ProxyTransformationNormReverse(nn.Module):
         nbytes = lib.ptx_prep_bytes(ctypes.byref(shape))
         if nbytes == 0:
             raise RuntimeError("unsupported configuration: " + lib.ptx_last_error().decode())
+        multi = len(self._lanes) > 1
+        if multi:                       # other streams may still be reading the old tables
+            torch.cuda.synchronize(device)
         prep = torch.empty(nbytes, dtype=torch.uint8, device=device)
         # torch.linspace is part of the reference's arithmetic (PRE:41)
         lin = torch.linspace(0, 1, self.grid_size, device="cpu").to(device)
         _abi.check(lib.ptx_prepare(ctypes.byref(shape), ctypes.byref(w), lin.data_ptr(),
                                    prep.data_ptr(), nbytes, stream), "ptx_prepare")
+        # ... and no stream may start on the new ones before they are built (weights change rarely in eval)
+        torch.cuda.current_stream(device).synchronize()
         self._wstruct, self._prep, self._lin, self._wkey = w, prep, lin, key
 
-    def _context(self, device: torch.device):
-        """This instance's library-side streams / events (PtxContext), created on first use per device."""
-        if self._ctx is not None and self._ctx_dev == device:
-            return self._ctx
-        self._release_context()
-        ctx = ctypes.c_void_p()
-        _abi.check(_abi.lib().ptx_context_create(ctypes.byref(ctx)), "ptx_context_create")
-        self._ctx, self._ctx_dev = ctx, device
-        return ctx
+    def _lane(self, device: torch.device, tstream) -> _Lane:
+        """The call state of (device, stream), created on first use; at most ``_MAX_LANES`` are kept."""
+        key = (str(device), tstream.cuda_stream)
+        lane = self._lanes.get(key)
+        if lane is None:
+            if len(self._lanes) >= _MAX_LANES:
+                old_key = next(iter(self._lanes))
+                old = self._lanes.pop(old_key)
+                old.stream.synchronize()           # its workspace may still be in use
+                old.release()
+            lane = self._lanes[key] = _Lane(tstream)
+        else:
+            self._lanes[key] = self._lanes.pop(key)   # most recently used last
+        return lane
 
-    def _release_context(self):
-        ctx = self.__dict__.get("_ctx")
-        self.__dict__["_ctx"] = None
-        if ctx is not None:
-            _abi.lib().ptx_context_destroy(ctx)
+    def _release_lanes(self):
+        lanes = self.__dict__.get("_lanes") or {}
+        self.__dict__["_lanes"] = {}
+        for lane in lanes.values():
+            lane.release()
 
     def __del__(self):
         try:
-            self._release_context()
+            self._release_lanes()
         except Exception:          # interpreter shutdown: modules may already be torn down
             pass
 
-    def _workspace(self, shape: _abi.PtxShape, device: torch.device) -> torch.Tensor:
+    def _workspace(self, lane: _Lane, shape: _abi.PtxShape, device: torch.device, stream: int) -> torch.Tensor:
         key = (shape.B, shape.N, shape.L, shape.V, str(device))           # layout does not depend on img_dtype
-        ws = self._ws.get(key)
-        if ws is None:
+        if lane.ws is None or lane.ws_key != key:
             nbytes = _abi.lib().ptx_workspace_bytes(ctypes.byref(shape))
             if nbytes == 0:
                 raise RuntimeError("unsupported configuration: " + _abi.lib().ptx_last_error().decode())
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-            self._ws = {key: ws}          # one live workspace per module
-        return ws
+            lane.ws = None                          # one live workspace per lane
+            lane.ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            lane.ws_key, lane.ws_dirty = key, True
+        if lane.ws_dirty:
+            # tags / encoded boxes / count accumulators: zero once, the kernels keep them zero (no per-call memset)
+            _abi.check(_abi.lib().ptx_workspace_init(ctypes.byref(shape), lane.ws.data_ptr(), lane.ws.numel(), stream),
+                       "ptx_workspace_init")
+            lane.ws_dirty = False
+        return lane.ws
 
     # ------------------------------------------------------------------ forward
     def _check_inputs(self, points, text_dict, img_feat):
@@ -410,22 +444,17 @@ class ProxyTransformationNormReverse(nn.Module):
         tstream = torch.cuda.current_stream(dev)
         stream = tstream.cuda_stream
         self._ensure_prepared(shape, dev, stream)
-        ws = self._workspace(shape, dev)
+        lane = self._lane(dev, tstream)
+        ws = self._workspace(lane, shape, dev, stream)
         out = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
         # per-scene survivor counts land directly in pinned (device-mapped) host memory, published
         # by the clustering chain as soon as the drop tags are final: the host only waits for
         # those B integers (the list lengths of PRE:467), not for the forward to drain
-        counts = self._counts_host
-        if counts is None or counts.numel() < B:
-            counts = torch.empty((max(B, 64),), dtype=torch.int32).pin_memory()
-            self._counts_host, self._counts_np = counts, counts.numpy()
-        self._counts_np[:B] = -1
-        # the workspace is reused call to call: a call on a different stream must not overtake
-        # the previous one, which may still be running
-        last = self._last_stream
-        if last is not None and last.cuda_stream != stream:
-            last.synchronize()
-        self._last_stream = tstream
+        if lane.counts is None or lane.counts.numel() < B:
+            lane.counts = torch.empty((max(B, 64),), dtype=torch.int32).pin_memory()
+            lane.counts_np = lane.counts.numpy()
+        counts = lane.counts
+        lane.counts_np[:B] = -1
         dbg_struct, dbg = None, {}
         if debug:
             dbg = self._alloc_debug(shape, dev)
@@ -440,15 +469,17 @@ class ProxyTransformationNormReverse(nn.Module):
             oo = oo.to(device=dev, dtype=torch.int32).contiguous()
         if co is not None:
             co = co.to(device=dev, dtype=torch.float32).contiguous()
+        lane.ws_dirty = True              # until the call has been enqueued completely
         _abi.check(lib.ptx_forward(
-            self._context(dev), ctypes.byref(shape), ctypes.byref(self._wstruct), self._prep.data_ptr(),
+            lane.ctx, ctypes.byref(shape), ctypes.byref(self._wstruct), self._prep.data_ptr(),
             self._lin.data_ptr(), _ptr(pts), plist, text_feats.data_ptr(), mask_u8.data_ptr(),
             img.data_ptr(), _ptr(oo), _ptr(co), out.data_ptr(), counts.data_ptr(),
             ws.data_ptr(), ws.numel(), ctypes.byref(dbg_struct) if dbg_struct else None, stream),
             "ptx_forward")
+        lane.ws_dirty = False
         if debug or self.sync_outputs or lib.ptx_wait_counts(counts.data_ptr(), B, _COUNTS_TIMEOUT_US) != 0:
             tstream.synchronize()                          # full drain; also surfaces device faults
-        n_keep = self._counts_np[:B].tolist()
+        n_keep = lane.counts_np[:B].tolist()
         if min(n_keep) < 0:
             raise RuntimeError("ptx_forward finished without publishing the survivor counts")
         outs = [out[b, :n_keep[b]] for b in range(B)]

@@ -27,7 +27,7 @@ class Stages:
         self.shape = module._shape(B, N, L, V)
         self.stream = torch.cuda.current_stream().cuda_stream
         module._ensure_prepared(self.shape, dev(), self.stream)
-        self.ws = module._workspace(self.shape, dev())
+        self.ws = module._workspace(module._lane(dev(), torch.cuda.current_stream()), self.shape, dev(), self.stream)
         self.w, self.prep, self.lin = module._wstruct, module._prep, module._lin
         self.M = module.num_cluster
         self.K = module.num_sub
