@@ -25,8 +25,6 @@ Rank 0 prints ONE JSON line.  Extra objects:
                    bracketed by events (which perturbs the step a little -- hence not inside it), at the benchmark's
                    4 scenes per GPU and at 32 scenes per GPU: HBM fraction of the clustering / apply passes, fp32-MFMA
                    fraction of proxy attention and of the block GEMMs
-  pipelined        the same steps issued round-robin on two torch streams (two independent batches in flight, as a
-                   serving loop would run them); `value` itself is single-stream
   cpu_baseline     the CPU oracle (torch CPU fp32 + C ball query / FPS, "port") on this box's host cores, same
                    workload, bounded sample (rank 0, N = 1 only)
 """
@@ -67,7 +65,7 @@ def parse():
     ap.add_argument("--streams", type=int, default=1, help="torch streams the timed steps are issued on (round-robin)")
     ap.add_argument("--time-kernel", default="img_pass2", help="launch site timed inside the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-passes", action="store_true", help="skip roofline_passes / pipelined / fp32-feature extras")
+    ap.add_argument("--no-passes", action="store_true", help="skip roofline_passes / fp32-feature extras")
     ap.add_argument("--cpu-scenes", type=int, default=None, help="scenes in the CPU baseline sample")
     ap.add_argument("--breakdown", action="store_true", help="print per-kernel event timings to stderr")
     return ap.parse_args()
@@ -316,11 +314,6 @@ def main():
                 for i in range(4):
                     mod(*inputs.args(i, True))
                 extras["f32"] = timed_steps(mod, inputs, steps2, barrier, None, True)[0] / steps2
-            two = [torch.cuda.Stream() for _ in range(2)]
-            for i in range(6):
-                with torch.cuda.stream(two[i % 2]):
-                    mod(*inputs.args(i))
-            extras["pipe"] = timed_steps(mod, inputs, args.steps, barrier, two)[0] / args.steps
             if rank == 0:
                 extras["passes"] = [passes_report(cfg, B, site_times(lib, names, mod, inputs, 20), inputs.sets[0]["img"].element_size())]
                 if cfg.name == "cfg2" and B * 8 <= 32:
@@ -334,11 +327,11 @@ def main():
             print("per-kernel us/launch:", json.dumps({k: round(v, 2) for k, v in site_times(lib, names, mod, inputs, 12).items()}),
                   file=sys.stderr)
 
-    vals = [elapsed, extras.get("f32", 0.0), extras.get("pipe", 0.0)]
+    vals = [elapsed, extras.get("f32", 0.0)]
     t = torch.tensor(vals, device=device, dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed, f32_step, pipe_step = (float(x) for x in t.tolist())
+    elapsed, f32_step = (float(x) for x in t.tolist())
 
     if rank == 0:
         total_scenes = world * B * args.steps
@@ -371,9 +364,6 @@ def main():
         if f32_step > 0:
             line["value_f32_features"] = round(world * B / f32_step, 2)
             line["ms_per_step_f32_features"] = round(1e3 * f32_step, 4)
-        if pipe_step > 0:
-            line["pipelined"] = dict(streams=2, value=round(world * B / pipe_step, 2), ms_per_step=round(1e3 * pipe_step, 4),
-                                     note="same steps, two independent batches in flight on two torch streams")
         if "passes" in extras:
             line["roofline_passes"] = extras["passes"]
         if world == 1 and not args.no_cpu_baseline:

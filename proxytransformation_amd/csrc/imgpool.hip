@@ -47,6 +47,11 @@
 //   * persistent, double-buffered variants (64-pixel tiles, or 16 waves x 32 channels) in isolation: the loads
 //     alone take 57 / 43 us instead of 33 (128-B runs per row; one work-group per CU), and time spent between
 //     issuing a prefetch and using it is simply added on top (scratch/pattern_bench.hip Q*/R*) -- not pursued
+//   * r02, cold inputs (three input sets rotated, > Infinity Cache): cache policy of the mean pass and of this pass
+//     (nt / default, all four combinations) and the image order (same / reverse of the mean pass): 61.4-64.0 us in
+//     every case -- the second read gets nothing from the 256 MiB cache; the kernel waits on its own load / compute
+//     phases, not on DRAM.  Two independent batches in flight on two streams: no gain either (12.7-13.9k scenes/s):
+//     the resident pooling work-groups fill the register files and the other batch's small kernels stretch 3-5x
 #include <cstdlib>
 
 #include "common.h"

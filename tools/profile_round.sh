@@ -1,21 +1,21 @@
 #!/bin/bash
 # Run ON THE GPU BOX (through gpurun): produces the rocprofv3 evidence that profiles/ keeps.
-#   tools/profile_round.sh r01_final
+#   tools/profile_round.sh r02
 # Writes gpurun_out/<tag>/{bench.json, bench_f32.json, stats_*/, pmc_fetch_*/, pmc_write_*/} and the
 # digests <tag>_kernel_stats[_f32].csv / <tag>_pmc_traffic.json next to them.  Counter passes are
 # separate runs with --kernel-trace only, FETCH_SIZE and WRITE_SIZE in different passes
 # (MI355X_MICROARCH.md: TCC slot budget; no trace domains mixed with --pmc).
 set -u
-TAG=${1:-r01_final}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p "$O"
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $R/bench.py --steps 100 --warmup 10"
+BENCH="python $R/bench.py --steps 100 --warmup 10 --no-passes"
 # 1. the bench lines themselves (default = bf16-stored features; then fp32 features), with the CPU baseline once
 python $R/bench.py > "$O/bench.json" 2> "$O/bench.err"
-python $R/bench.py --img-dtype f32 --no-cpu-baseline > "$O/bench_f32.json" 2>> "$O/bench.err"
+python $R/bench.py --img-dtype f32 --no-cpu-baseline --no-passes > "$O/bench_f32.json" 2>> "$O/bench.err"
 # 2. kernel-trace + stats of the same command
 for dt in bf16 f32; do
   rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_$dt" -o k -- \
@@ -25,8 +25,11 @@ done
 for dt in bf16 f32; do
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$O/pmc_${c}_$dt" -o p -- \
-        python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --img-dtype $dt > "$O/pmc_${c}_$dt.log" 2>&1
+        python $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-passes --img-dtype $dt > "$O/pmc_${c}_$dt.log" 2>&1
   done
 done
 python $R/tools/profile_digest.py "$O" "$TAG"
+for dt in bf16 f32; do
+  python $R/tools/timeline.py "$(find "$O/stats_$dt" -name '*kernel_trace.csv' | head -1)" 60 > "$O/${TAG}_timeline_$dt.txt" 2>/dev/null
+done
 ls "$O"
