@@ -251,6 +251,78 @@ int ptx_forward(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, const v
  * (the caller then falls back to a stream synchronise, which also surfaces device faults). */
 int ptx_wait_counts(const int32_t *counts_host, int B, int64_t timeout_us);
 
+/* ------------------------------------------------------------------ train-mode operators
+ * The differentiable half of the path in train mode -- batch-statistics BatchNorm2d / BatchNorm1d (PRE:74, 114,
+ * 329-330), Dropout (PRE:189-191, timm Mlp), DropPath (PRE:268) and the gradients of everything between the ball
+ * queries and the scatter -- as forward / backward kernel pairs.  The index half (ball query, FPS, selection, tags:
+ * ptx_grid_centers, ptx_ball_query, ptx_select_clusters, ptx_affine_compact above) is shared with eval mode and is not
+ * differentiable, as in the reference.  proxytransformation_amd/train.py chains these with torch.autograd.Function
+ * nodes (torch keeps the graph and the buffers; every arithmetic step is one of these kernels).  All tensors dense
+ * row-major fp32 unless noted; nothing synchronises the host. */
+
+/* C[z][m][n] (+)= alpha * sum_k A[z][m][k] B[z][k][n] with arbitrary element strides (NN / NT / TN, head-split views,
+ * channels-first image features: a_dtype / b_dtype 0 fp32, 1 bf16, 2 fp16); z = z1 * inner + z2, one stride per batch
+ * digit.  ksplit > 1: K is cut into slices whose partial products land c_sk elements apart (summed by the caller with
+ * ptx_op_colsum) -- weight gradients contract over every slot / token of the batch with a tiny M x N. */
+int ptx_op_gemm(const void *A, const void *B, float *C, int M, int N, int K, long a_rs, long a_cs, long b_rs, long b_cs,
+                long c_rs, long c_cs, int batch, int inner, long a_s1, long a_s2, long b_s1, long b_s2, long c_s1, long c_s2,
+                int a_dtype, int b_dtype, float alpha, int accumulate, int ksplit, long c_sk, void *stream);
+/* out[n] (+)= scale * sum_r f(x[r][n]), accumulated in double; mode 0: x, 1: x*y, 2: x*x, 3: (x - y[n])^2 with y a
+ * per-column vector (bias / LayerNorm / BatchNorm parameter gradients, batch statistics) */
+int ptx_op_colsum(const float *x, const float *y, int R, int N, int mode, float scale, int accumulate, float *out,
+                  double *scratch /* nsplit * N doubles */, int nsplit, void *stream);
+/* op 0: a+b  1: a*s  2: gelu(a)  3: b*gelu'(a)  4: relu(a)  5: b*(a>0)  6: a+bias[col]  7: a+s*b  8: a*b */
+int ptx_op_eltwise(int op, const float *a, const float *b, float s, long n, int ncol, float *y, void *stream);
+/* y = x * keep / (1-p), keep = hash(seed, i / group) >= p: Dropout (group 1) / DropPath (group = elements per sample);
+ * the backward pass is the same call on dy */
+int ptx_op_dropout(const float *x, long n, long group, float p, uint64_t seed, float *y, void *stream);
+/* LayerNorm over C (+ optional per-slot bias table add[(row % add_rows)], PRE:215-217); stats (R,2) = mean, rstd */
+int ptx_op_layernorm_fwd(const float *x, const float *w, const float *b, const float *add, int add_rows, int R, int C,
+                         float eps, float *y, float *stats, void *stream);
+int ptx_op_layernorm_bwd(const float *x, const float *w, const float *dy, const float *stats, int R, int C, float *dx,
+                         float *xhat, void *stream);
+/* BatchNorm over the rows of (R,C) with batch statistics: mean = colsum / R, centred sum of squares (colsum mode 3) ->
+ * mean / rstd (+ running-stat update with momentum, unbiased variance) -> apply (optionally fused ReLU); backward in
+ * three steps (see train_ops.hip) */
+int ptx_op_bn_stats(const float *mean, const float *sumsq_centred, int C, long R, float eps, float momentum, float *mean_rstd,
+                    float *run_mean, float *run_var, void *stream);
+int ptx_op_bn_apply(const float *x, const float *mean_rstd, const float *w, const float *b, long R, int C, int relu, float *y,
+                    void *stream);
+int ptx_op_bn_bwd_prep(const float *x, const float *y, const float *dy, const float *mean_rstd, long R, int C, int relu,
+                       float *g, float *gx, void *stream);
+int ptx_op_bn_bwd_dx(const float *x, const float *g, const float *mean_rstd, const float *w, const float *dbeta,
+                     const float *dgamma, long R, int C, float *dx, void *stream);
+/* softmax over the last dim of (rows, L); mask (B,L) uint8 (1 = valid) fills -1e9 (PRE:247), row r -> scene r / rows_per_scene */
+int ptx_op_softmax_fwd(const float *s, const uint8_t *mask, long rows, int L, long rows_per_scene, float *p, void *stream);
+int ptx_op_softmax_bwd(const float *p, const float *dp, const uint8_t *mask, long rows, int L, long rows_per_scene, float *ds,
+                       void *stream);
+/* OffsetNetwork / SimplifiedPointNet pieces (PRE:87-107, 126-142): slot inputs [rel | p] with padded slots zeroed,
+ * pooling over the K slots (mode 0 mean, 1 max), tanh * margin + add + clamp (dcoef = d centre / d raw) */
+int ptx_op_slot_inputs(const float *center, const float *cluster, const int32_t *src, long nclus, int K, float *x6,
+                       uint8_t *padmask, void *stream);
+int ptx_op_slot_inputs_bwd(const float *dx6, const uint8_t *padmask, long nclus, int K, float *dcenter, void *stream);
+int ptx_op_slot_pool(const float *h, long nclus, int K, int C, int mode, float *out, int32_t *arg, void *stream);
+int ptx_op_slot_pool_bwd(const float *dout, const int32_t *arg, long nclus, int K, int C, int mode, float *dh, void *stream);
+int ptx_op_offset_apply(const float *c0, const float *raw, const float *minmax, long nclus, int M, float margin, float *cout,
+                        float *dcoef, void *stream);
+/* per-slot bias table of ProxyAttention (PRE:212-215) and its parameter gradients */
+int ptx_op_slotbias_fwd(const float *pb, const float *pc, const float *pr, int Mk, int s, int C, float *table, void *stream);
+int ptx_op_slotbias_bwd(const float *dtable, int Mk, int s, int C, float *dpb, float *dpc, float *dpr, void *stream);
+/* rows of the kept clusters: src[b*Mk+j] = b*M + order[b][keep[b][j]]; gather / scatter of (rows,C) by src */
+int ptx_op_keep_rows(const int32_t *order, const int32_t *keep, int B, int M, int Mt, int Mk, int32_t *src, void *stream);
+int ptx_op_rows_gather(const float *x, const int32_t *src, long rows, int C, float *y, void *stream);
+int ptx_op_rows_scatter(const float *dy, const int32_t *src, long rows, int C, float *dx, void *stream);
+/* output position of every input point after remove_points_by_index (PRE:516-523), -1 = dropped, + survivor counts */
+int ptx_op_out_positions(const uint32_t *tag, int B, int N, int32_t *tile_counts, int32_t *opos, int32_t *counts, void *stream);
+/* gradients of the per-cluster affine + pt_replace (PRE:459-465): every valid slot whose target point survives receives
+ * that point's output gradient (index_put_ backward gathers; duplicates included) */
+int ptx_op_affine_bwd(const float *dout, const int32_t *opos, const int32_t *kidx, const float *kcluster,
+                      const float *kcenter, const float *transform, int B, int N, int Mk, int K, float *dtranslate,
+                      float *dtransform, float *dkcenter, void *stream);
+/* AttentionPool2d tokens (PRE:155-157): token 0 = mean of the pixel tokens, then + positional embedding; backward of the mean */
+int ptx_op_tokens_finish(float *tok, const float *pos, int nimg, int hw, int C, void *stream);
+int ptx_op_tokens_finish_bwd(float *dtok, int nimg, int hw, int C, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -152,9 +152,10 @@ def _t(x) -> torch.Tensor:
     return x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x))
 
 
-def _slot_mlp(sd, prefix: str, center: torch.Tensor, cluster: torch.Tensor) -> torch.Tensor:
+def _slot_mlp(sd, prefix: str, center: torch.Tensor, cluster: torch.Tensor, training: bool = False) -> torch.Tensor:
     """Shared front of OffsetNetwork / SimplifiedPointNet (PRE:93-100, 131-138):
-    per-slot 6 -> 256 point-wise conv + BatchNorm(eval) + ReLU -> (B,M,K,256)."""
+    per-slot 6 -> 256 point-wise conv + BatchNorm (eval: running statistics; training: batch statistics over all
+    B*M*K slots, running statistics updated in ``sd``) + ReLU -> (B,M,K,256)."""
     rel = cluster - center[:, :, None, :]
     pad = (cluster == 0).all(dim=-1)                  # padded slot <=> xyz all zero (PRE:94)
     rel = torch.where(pad[..., None], torch.zeros_like(rel), rel)
@@ -163,20 +164,20 @@ def _slot_mlp(sd, prefix: str, center: torch.Tensor, cluster: torch.Tensor) -> t
     h = F.linear(x, w, sd[prefix + ".mlp.0.bias"])
     h = F.batch_norm(h.permute(0, 3, 1, 2), sd[prefix + ".mlp.1.running_mean"],
                      sd[prefix + ".mlp.1.running_var"], sd[prefix + ".mlp.1.weight"],
-                     sd[prefix + ".mlp.1.bias"], training=False, eps=BN_EPS)
+                     sd[prefix + ".mlp.1.bias"], training=training, momentum=0.1, eps=BN_EPS)
     return F.relu(h).permute(0, 2, 3, 1)
 
 
-def offset_net(sd, center, cluster) -> torch.Tensor:
+def offset_net(sd, center, cluster, training: bool = False) -> torch.Tensor:
     """OffsetNetwork.forward, PRE:87-107 -> raw offsets (B,M,3) (before tanh)."""
     pre = "get_deformable_cluster.get_offsets"
-    h = _slot_mlp(sd, pre, center, cluster).mean(dim=2)            # mean over K (PRE:102)
+    h = _slot_mlp(sd, pre, center, cluster, training).mean(dim=2)  # mean over K (PRE:102)
     return F.linear(h, sd[pre + ".channel_mapper.weight"].reshape(3, -1))
 
 
-def point_encoder(sd, center, cluster) -> torch.Tensor:
+def point_encoder(sd, center, cluster, training: bool = False) -> torch.Tensor:
     """SimplifiedPointNet.forward, PRE:126-142 -> (B,M',256); max over all K slots."""
-    return _slot_mlp(sd, "simple_encoder", center, cluster).max(dim=2)[0]
+    return _slot_mlp(sd, "simple_encoder", center, cluster, training).max(dim=2)[0]
 
 
 def img_proxy(sd, img_feat: torch.Tensor, heads: int) -> torch.Tensor:
@@ -244,10 +245,11 @@ def proxy_block(sd, pre: str, x: torch.Tensor, proxy: torch.Tensor,
     return dict(qkv=qkv, pt=pt, pv=pv, attn=o, x1=x1, out=x2)
 
 
-def _bn1d_eval(sd, pre: str, x: torch.Tensor) -> torch.Tensor:
-    """BatchNorm1d over the channel (last) dim of (B,m,c) in eval mode, PRE:446, 455."""
+def _bn1d_eval(sd, pre: str, x: torch.Tensor, training: bool = False) -> torch.Tensor:
+    """BatchNorm1d over the channel (last) dim of (B,m,c), PRE:446, 455 (eval: running statistics; training: batch
+    statistics over the B*m rows)."""
     return F.batch_norm(x.transpose(-2, -1), sd[pre + ".running_mean"], sd[pre + ".running_var"],
-                        sd[pre + ".weight"], sd[pre + ".bias"], training=False,
+                        sd[pre + ".weight"], sd[pre + ".bias"], training=training, momentum=0.1,
                         eps=BN_EPS).transpose(-2, -1)
 
 
@@ -331,4 +333,100 @@ def forward(sd_np: Dict[str, np.ndarray], *, grid_size: int, dynamic_drop_radio:
         new_points = pt_replace(pts, kidx, newcl.numpy())                  # PRE:465
         out["new_points"] = new_points
         out["outputs"] = remove_points(new_points, drop_idx)               # PRE:467
+    return out
+
+
+# --------------------------------------------------------------------------
+# train-mode forward + backward -- dropout / drop-path rates 0
+# --------------------------------------------------------------------------
+def loss_weights(b: int, n: int) -> np.ndarray:
+    """Upstream gradient of output b used by the train-mode parity tests (same formula as tests/golden/gen_golden.py)."""
+    i = np.arange(n, dtype=np.float64)[:, None]
+    d = np.arange(3, dtype=np.float64)[None, :]
+    return np.sin(0.37 * i + 1.3 * d + 0.7 * b).astype(np.float32)
+
+
+def forward_train(sd_np: Dict[str, np.ndarray], *, grid_size: int, dynamic_drop_radio: float, num_sub: int,
+                  num_heads: int, text_blocks: int, img_blocks: int, points: np.ndarray, text_feats: np.ndarray,
+                  text_mask: np.ndarray, img_feat: np.ndarray, centers_override: Optional[np.ndarray] = None,
+                  backward: bool = True, num_threads: Optional[int] = 1, float64: bool = False) -> Dict[str, object]:
+    """One training step of the reference module without the optimiser: train-mode forward (batch-statistics
+    BatchNorm2d / BatchNorm1d with running-stat update, PRE:74, 114, 329-330; Dropout / DropPath at rate 0),
+    loss = sum_b <out_b, loss_weights(b)>, backward through torch autograd.  The index steps are the C functions of
+    the eval oracle (not differentiable, like pytorch3d's); pt_replace is torch's index_put_ (PRE:495), whose backward
+    hands every valid slot the gradient of the point it targeted.  ``float64=True`` evaluates the float half in double
+    (same formulas; the index half stays the fp32 C code): the gradients are then accurate far beyond what two fp32
+    evaluations agree on, which is what the GPU gradients are held against.  Returns outputs, intermediates, ``grads``
+    (name -> array, inputs as ``input.text_feats`` / ``input.img_feat``), ``none_grads`` and the updated buffers."""
+    if num_threads is not None:
+        torch.set_num_threads(num_threads)                        # index_put_ with duplicates: single thread (H1)
+    ft = torch.float64 if float64 else torch.float32
+    sd = {k: (_t(v).clone().to(ft) if np.asarray(v).dtype.kind == "f" else _t(v).clone()) for k, v in sd_np.items()}
+    params = {k: v.requires_grad_(True) for k, v in sd.items()
+              if v.is_floating_point() and not k.endswith(("running_mean", "running_var"))}
+    gs, K = grid_size, num_sub
+    M = gs ** 3
+    Mt = M - int(M * EMPTY_DROP)
+    Mk = int(M * (1 - dynamic_drop_radio))
+    pts = _f32(points)
+    B, N, _ = pts.shape
+    tf = _t(_f32(text_feats)).clone().to(ft).requires_grad_(True)
+    im = _t(_f32(img_feat)).clone().to(ft).requires_grad_(True)
+    out: Dict[str, object] = {}
+
+    centers0, mn, mx = grid_centers(pts, gs)
+    _, cluster1 = ball_query(centers0, pts, K)
+    raw = offset_net(sd, _t(centers0).to(ft), _t(cluster1).to(ft), training=True)
+    newc = _t(centers0).to(ft) + raw.tanh() * MARGIN
+    clamped = torch.max(torch.min(newc, _t(mx).to(ft)[:, None]), _t(mn).to(ft)[:, None])          # PRE:62
+    cq = _f32(clamped.detach().numpy()) if centers_override is None else _f32(centers_override)
+    idx2, cluster2 = ball_query(cq, pts, K)
+    sel = select_clusters(idx2, cq, Mt, Mk)
+    order, picks, keep = sel["order"], sel["picks"], sel["keep"]
+    bidx = np.arange(B)[:, None]
+    keep_src, pick_src = order[bidx, keep], order[bidx, picks]
+    kcenter = clamped[torch.from_numpy(bidx), torch.from_numpy(keep_src)]           # differentiable gather (PRE:414)
+    kcluster = _t(cluster2[bidx, keep_src]).to(ft)
+    kidx = idx2[bidx, keep_src]
+    drop_idx = idx2[bidx, pick_src].reshape(B, -1)
+
+    pp = point_encoder(sd, kcenter, kcluster, training=True)
+    tb = proxy_block(sd, f"textformer.{text_blocks - 1}", pp, tf, _t(np.asarray(text_mask, bool)), num_heads)
+    C = pp.shape[-1]
+    tg = F.layer_norm(tb["out"], (C,), sd[f"text_norm.{text_blocks - 1}.weight"], sd[f"text_norm.{text_blocks - 1}.bias"], LN_EPS)
+    translate = _bn1d_eval(sd, "text_trans_norm", F.linear(tg, sd["text_trans.weight"], sd["text_trans.bias"]), True)
+    ip = img_proxy(sd, im, num_heads)
+    ib = proxy_block(sd, f"imgformer.{img_blocks - 1}", pp, ip, None, num_heads)
+    ig = F.layer_norm(ib["out"], (C,), sd[f"img_norm.{img_blocks - 1}.weight"], sd[f"img_norm.{img_blocks - 1}.bias"], LN_EPS)
+    transform = _bn1d_eval(sd, "img_trans_norm", F.linear(ig, sd["img_trans.weight"], sd["img_trans.bias"]), True)
+    T = transform.reshape(B, Mk, 3, 3)
+    c = kcenter[:, :, None, :]
+    newcl = (T @ (kcluster - c).transpose(-2, -1)).transpose(-2, -1) + c + translate[:, :, None, :]   # PRE:459-462
+    # pt_replace (PRE:478-495) with torch's own index_put_ + remove_points_by_index (PRE:516-523)
+    new_points = _t(pts).clone().to(ft)
+    kidx_t = torch.from_numpy(kidx)
+    valid = kidx_t != -1
+    bi = torch.arange(B).reshape(B, 1, 1).expand(B, Mk, K)
+    new_points[bi[valid], kidx_t[valid], :] = newcl[valid]
+    outs = []
+    for b in range(B):
+        dropset = np.unique(drop_idx[b][drop_idx[b] >= 0])
+        keepmask = np.ones(N, bool)
+        keepmask[dropset] = False
+        outs.append(new_points[b][torch.from_numpy(np.nonzero(keepmask)[0])])
+    out.update(centers=clamped.detach().numpy(), idx2=idx2, order=order, picks=picks, keep=keep, kidx=kidx,
+               drop_idx=drop_idx, point_proxy=pp.detach().numpy(), img_proxy=ip.detach().numpy(),
+               translate=translate.detach().numpy(), transform=transform.detach().numpy(),
+               outputs=[o.detach().numpy() for o in outs])
+    if backward:
+        loss = sum((o * torch.from_numpy(loss_weights(b, o.shape[0])).to(ft)).sum() for b, o in enumerate(outs))
+        loss.backward()
+        grads, none = {}, []
+        for name, p_ in list(params.items()) + [("input.text_feats", tf), ("input.img_feat", im)]:
+            if p_.grad is None:
+                none.append(name)
+            else:
+                grads[name] = p_.grad.numpy()
+        out.update(loss=float(loss.item()), grads=grads, none_grads=none)
+    out["buffers"] = {k: v.detach().numpy() for k, v in sd.items() if k.endswith(("running_mean", "running_var"))}
     return out

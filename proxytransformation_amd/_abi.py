@@ -93,6 +93,36 @@ SIGNATURES = {
                          C.POINTER(PtxDebug), _P]),
 }
 
+_L, _U64 = C.c_long, C.c_uint64
+SIGNATURES.update({
+    "ptx_op_gemm": (_I, [_P, _P, _P, _I, _I, _I, _L, _L, _L, _L, _L, _L, _I, _I, _L, _L, _L, _L, _L, _L, _I, _I, _F, _I, _I, _L, _P]),
+    "ptx_op_colsum": (_I, [_P, _P, _I, _I, _I, _F, _I, _P, _P, _I, _P]),
+    "ptx_op_eltwise": (_I, [_I, _P, _P, _F, _L, _I, _P, _P]),
+    "ptx_op_dropout": (_I, [_P, _L, _L, _F, _U64, _P, _P]),
+    "ptx_op_layernorm_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P]),
+    "ptx_op_layernorm_bwd": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P]),
+    "ptx_op_bn_stats": (_I, [_P, _P, _I, _L, _F, _F, _P, _P, _P, _P]),
+    "ptx_op_bn_apply": (_I, [_P, _P, _P, _P, _L, _I, _I, _P, _P]),
+    "ptx_op_bn_bwd_prep": (_I, [_P, _P, _P, _P, _L, _I, _I, _P, _P, _P]),
+    "ptx_op_bn_bwd_dx": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _P, _P]),
+    "ptx_op_softmax_fwd": (_I, [_P, _P, _L, _I, _L, _P, _P]),
+    "ptx_op_softmax_bwd": (_I, [_P, _P, _P, _L, _I, _L, _P, _P]),
+    "ptx_op_slot_inputs": (_I, [_P, _P, _P, _L, _I, _P, _P, _P]),
+    "ptx_op_slot_inputs_bwd": (_I, [_P, _P, _L, _I, _P, _P]),
+    "ptx_op_slot_pool": (_I, [_P, _L, _I, _I, _I, _P, _P, _P]),
+    "ptx_op_slot_pool_bwd": (_I, [_P, _P, _L, _I, _I, _I, _P, _P]),
+    "ptx_op_offset_apply": (_I, [_P, _P, _P, _L, _I, _F, _P, _P, _P]),
+    "ptx_op_slotbias_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
+    "ptx_op_slotbias_bwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _P]),
+    "ptx_op_keep_rows": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    "ptx_op_rows_gather": (_I, [_P, _P, _L, _I, _P, _P]),
+    "ptx_op_rows_scatter": (_I, [_P, _P, _L, _I, _P, _P]),
+    "ptx_op_out_positions": (_I, [_P, _I, _I, _P, _P, _P, _P]),
+    "ptx_op_affine_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "ptx_op_tokens_finish": (_I, [_P, _P, _I, _I, _I, _P]),
+    "ptx_op_tokens_finish_bwd": (_I, [_P, _I, _I, _I, _P]),
+})
+
 _lib: Optional[C.CDLL] = None
 
 

@@ -199,6 +199,11 @@ class ProxyTransformationNormReverse(nn.Module):
         self._tensors = None
         self._slots = None
         self._lanes: Dict[tuple, _Lane] = {}
+        self._train_calls = 0
+        self._lin_t = None
+        # stochastic-depth rate of the blocks that are live (the last of each list; PRE:298-299)
+        self._text_dpr = float(torch.linspace(0, drop_path_rate, text_blocks)[-1])
+        self._img_dpr = float(torch.linspace(0, drop_path_rate, img_blocks)[-1])
         self.register_load_state_dict_post_hook(lambda mod, _keys: mod.invalidate_weights())
         #: True = block until the whole forward has drained (the pre-ABI-3 behaviour); default is
         #: to return once the output lengths are known, like any asynchronous torch op
@@ -211,6 +216,14 @@ class ProxyTransformationNormReverse(nn.Module):
         # test-only hooks: replay a captured argsort / inject clamped centres
         self._order_override: Optional[torch.Tensor] = None
         self._centers_override: Optional[torch.Tensor] = None
+
+    def _dpr_last(self, blk) -> float:
+        return self._text_dpr if blk is self.textformer[-1] else self._img_dpr
+
+    def _train_lin(self, device):
+        if self._lin_t is None or self._lin_t.device != device:
+            self._lin_t = torch.linspace(0, 1, self.grid_size, device="cpu").to(device)      # PRE:41
+        return self._lin_t
 
     # ------------------------------------------------------------------ reference-named helpers
     def get_text_proxy(self, text_dict):                                       # PRE:332-333
@@ -382,10 +395,6 @@ class ProxyTransformationNormReverse(nn.Module):
         writes to its input; the reference's stacked copy, PRE:426-427, exists only because its
         scatter is in-place).  Only irregular inputs (non-fp32, non-contiguous, > 32 scenes)
         are stacked into a fresh tensor."""
-        if self.training:
-            raise NotImplementedError(
-                "train-mode forward (batch-stat BatchNorm, dropout, autograd) is not built yet; "
-                "call .eval() -- see DESIGN.md 'next'")
         if not isinstance(points, (list, tuple)) or len(points) == 0:
             raise ValueError("points must be a non-empty list of (N,3) tensors")
         p0 = points[0]
@@ -511,6 +520,12 @@ class ProxyTransformationNormReverse(nn.Module):
         ``return_transforms=True`` (not in the reference) additionally returns the per-cluster affine
         parameters ``dict(kcenter (B,M',3), translate (B,M',3), transform (B,M',9))`` -- what
         ``shard.gather_cluster_transforms`` exchanges between ranks -- as stream-ordered tensors."""
+        if self.training:
+            if return_transforms:
+                outs, aux = self._run_train(points, text_dict, img_feat)
+                return outs, {k: aux[k].view(len(points), self.real_cluster_num, -1)
+                              for k in ("kcenter", "translate", "transform")}
+            return self._run_train(points, text_dict, img_feat)[0]
         chunks = [(0, len(points))]
         if isinstance(points, (list, tuple)) and len(points) > _MAX_SCENES_PER_CALL:
             # scenes are independent in eval mode: larger batches run as consecutive calls
@@ -530,6 +545,25 @@ class ProxyTransformationNormReverse(nn.Module):
         if return_transforms:
             return outs, {k: torch.cat([e[k] for e in extras]) for k in extras[0]}
         return outs
+
+    def _run_train(self, points, text_dict, img_feat):
+        """Train-mode forward (batch-statistics BatchNorm, Dropout / DropPath, autograd graph of HIP kernels):
+        see ``train.py``.  One scene list of at most 32 scenes per call (the reference trains with 6, CFG:145)."""
+        from . import train
+        (B, N, dev), pts, plist, text_feats, mask_u8, img = self._check_inputs(points, text_dict, img_feat)
+        if B > _MAX_SCENES_PER_CALL:
+            raise RuntimeError(f"train mode takes at most {_MAX_SCENES_PER_CALL} scenes per call (got {B})")
+        for name, t in self.state_dict(keep_vars=True).items():
+            if t.device != dev or (t.is_floating_point() and (t.dtype != torch.float32 or not t.is_contiguous())):
+                raise RuntimeError(f"parameter {name} must be contiguous float32 on {dev}")
+        shape = self._shape(B, N, text_feats.shape[1], img.shape[1], _IMG_DTYPES[img.dtype])
+        tstream = torch.cuda.current_stream(dev)
+        lane = self._lane(dev, tstream)
+        ws = self._workspace(lane, shape, dev, tstream.cuda_stream)
+        # _check_inputs hands back the caller's own tensors when their layout is already right, so gradients w.r.t.
+        # text_feats / img_feat reach them directly
+        tf, im = text_feats, img
+        return train.forward_train(self, list(points), tf, mask_u8, im, shape, ws, self._order_override)
 
     @torch.no_grad()
     def forward_debug(self, points, text_dict, img_feat):

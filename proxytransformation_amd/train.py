@@ -1,0 +1,733 @@
+"""Train-mode forward + backward of ``ProxyTransformationNormReverse``.
+
+The reference neck is trained (``runner.train()``, configs/grounding/proxy-tiblock33-gs12-wbias-ddr0.6-clip.py:200):
+in train mode its BatchNorms use batch statistics (PRE:74, 114, 329-330), ProxyAttention / Mlp apply Dropout
+(PRE:189-191, timm Mlp) and ProxyBlock applies DropPath (PRE:268), and gradients flow from the transformed points
+back to every live parameter, to ``text_feats`` and to ``img_feat``.
+
+How this file is built:
+
+* the INDEX half of the path (grid centres, both ball queries, padding-count ordering, farthest point sampling, keep /
+  drop lists, ownership tags, ordered compaction) runs through the same HIP stage entry points as eval mode and is not
+  differentiable -- as in the reference, where pytorch3d returns integer indices (PRE:56, 65, 393);
+* the FLOAT half is a chain of ``torch.autograd.Function`` nodes whose forward and backward bodies only launch
+  hand-written HIP kernels through the C ABI (``ptx_op_*``, csrc/train_ops.hip).  torch owns the buffers and the graph
+  (plumbing); no torch arithmetic operator is on the data path.  Fan-out is explicit (``_fork``) so that gradient
+  sums are HIP launches too, and every parameter enters exactly one node whole;
+* dead blocks (``textformer[:-1]``, ``imgformer[:-1]`` and their norms: PRE:441-443 feeds ``point_proxy`` to every
+  block and keeps only the last output) are not executed: their parameters get ``grad = None`` exactly like
+  in the reference (``find_unused_parameters=True``, CFG:246);
+* gradients of ``pt_replace`` follow ``index_put_``'s backward (PRE:495): every valid slot whose target point survives
+  the drop receives that point's output gradient, duplicates included.
+
+Dropout masks come from a counter-based hash of (seed, call, site, element); torch's Philox stream is not reproduced
+(not reproducible across devices anyway).  With all three rates at 0 the pass is deterministic and is
+checked against gradients captured from the reference itself (tests/golden/g4_train.npz).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional
+
+import torch
+
+from . import _abi
+
+_F32 = torch.float32
+
+
+def _st() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ck(rc: int, what: str) -> None:
+    _abi.check(rc, what)
+
+
+def _p(t: Optional[torch.Tensor], off: int = 0) -> Optional[int]:
+    if t is None:
+        return None
+    return t.data_ptr() + off * t.element_size()
+
+
+def _c(t: torch.Tensor) -> torch.Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# --------------------------------------------------------------------------- thin kernel wrappers
+def gemm(A, B, C, M, N, K, a=(0, 1), b=(0, 1), c=(0, 1), batch=1, inner=1, a_bs=(0, 0), b_bs=(0, 0), c_bs=(0, 0),
+         a_off=0, b_off=0, c_off=0, a_dtype=0, b_dtype=0, alpha=1.0, accumulate=False, ksplit=1, c_sk=0):
+    """C[z][m][n] (+)= alpha sum_k A[z][m][k] B[z][k][n]; a / b / c = (row stride, col stride) in elements."""
+    _ck(_abi.lib().ptx_op_gemm(_p(A, a_off), _p(B, b_off), _p(C, c_off), M, N, K, a[0], a[1], b[0], b[1], c[0], c[1],
+                               batch, inner, a_bs[0], a_bs[1], b_bs[0], b_bs[1], c_bs[0], c_bs[1], a_dtype, b_dtype, alpha,
+                               1 if accumulate else 0, ksplit, c_sk, _st()), "ptx_op_gemm")
+
+
+def mm(a2, b2, ta=False, tb=False, out=None, alpha=1.0, accumulate=False):
+    """Dense 2-D product of contiguous matrices: op(a2) @ op(b2)."""
+    ar, ac = a2.shape
+    br, bc = b2.shape
+    M, K = (ac, ar) if ta else (ar, ac)
+    K2, N = (bc, br) if tb else (br, bc)
+    assert K == K2, (a2.shape, b2.shape, ta, tb)
+    if out is None:
+        out = torch.empty((M, N), dtype=_F32, device=a2.device)
+    kw = dict(a=(1, ac) if ta else (ac, 1), b=(1, bc) if tb else (bc, 1), c=(N, 1), alpha=alpha)
+    tiles = ((M + 63) // 64) * ((N + 63) // 64)
+    if K >= 4096 and tiles < 512 and not accumulate:
+        # a long contraction into a small result (weight gradients): slices of K across the chip, summed in order
+        ks = int(min(256, max(2, 1024 // tiles), K // 1024))
+        part = torch.empty((ks, M * N), dtype=_F32, device=a2.device)
+        gemm(a2, b2, part, M, N, K, ksplit=ks, c_sk=M * N, **kw)
+        colsum(part, out=out.view(-1))
+        return out
+    gemm(a2, b2, out, M, N, K, accumulate=accumulate, **kw)
+    return out
+
+
+def colsum(x2, y2=None, mode=0, scale=1.0, out=None, accumulate=False):
+    R, N = x2.shape
+    if out is None:
+        out = torch.empty((N,), dtype=_F32, device=x2.device)
+    # enough (column tile, row split) blocks to fill the chip; every split walks >= ~64 rows per slice
+    nsplit = int(max(1, min(1024, R // 256, 2048 // ((N + 63) // 64))))
+    scratch = torch.empty((nsplit, N), dtype=torch.float64, device=x2.device)
+    _ck(_abi.lib().ptx_op_colsum(_p(x2), _p(y2), R, N, mode, scale, 1 if accumulate else 0, _p(out), _p(scratch), nsplit,
+                                 _st()), "ptx_op_colsum")
+    return out
+
+
+def eltwise(op, a, b=None, s=0.0, ncol=1, out=None):
+    if out is None:
+        out = torch.empty_like(a)
+    _ck(_abi.lib().ptx_op_eltwise(op, _p(a), _p(b), s, a.numel(), ncol, _p(out), _st()), "ptx_op_eltwise")
+    return out
+
+
+def add_(a, b):
+    return eltwise(0, a, b)
+
+
+def dropout_k(x, p, seed, group=1):
+    y = torch.empty_like(x)
+    _ck(_abi.lib().ptx_op_dropout(_p(x), x.numel(), group, p, seed & 0xFFFFFFFFFFFFFFFF, _p(y), _st()), "ptx_op_dropout")
+    return y
+
+
+# --------------------------------------------------------------------------- autograd nodes
+class _Fork(torch.autograd.Function):
+    """n handles of one tensor; the backward sums the n gradients with HIP launches (no torch add)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n = n
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        live = [_c(g) for g in grads if g is not None]
+        if not live:
+            return None, None
+        acc = live[0]
+        for g in live[1:]:
+            acc = add_(acc, g)
+        return acc, None
+
+
+def fork(x, n):
+    return _Fork.apply(x, n)
+
+
+class _Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return add_(_c(a), _c(b))
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+class _Linear(torch.autograd.Function):
+    """y = x w^T + b (nn.Linear / 1x1 convolutions); w may be any contiguous tensor whose leading dim is n_out."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = _c(x)
+        R, K = x.shape
+        w2 = w.reshape(w.shape[0], -1)
+        y = mm(x, w2, tb=True)
+        if b is not None:
+            eltwise(6, y, b, ncol=w2.shape[0], out=y)
+        ctx.save_for_backward(x, w)
+        ctx.has_b = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _c(dy)
+        w2 = w.reshape(w.shape[0], -1)
+        dx = mm(dy, w2) if ctx.needs_input_grad[0] else None
+        dw = mm(dy, x, ta=True).view_as(w) if ctx.needs_input_grad[1] else None
+        db = colsum(dy) if (ctx.has_b and ctx.needs_input_grad[2]) else None
+        return dx, dw, db
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        x = _c(x)
+        R, C = x.shape
+        y = torch.empty_like(x)
+        stats = torch.empty((R, 2), dtype=_F32, device=x.device)
+        _ck(_abi.lib().ptx_op_layernorm_fwd(_p(x), _p(w), _p(b), None, 1, R, C, eps, _p(y), _p(stats), _st()), "layernorm_fwd")
+        ctx.save_for_backward(x, w, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, stats = ctx.saved_tensors
+        dy = _c(dy)
+        R, C = x.shape
+        dx = torch.empty_like(x)
+        xhat = torch.empty_like(x)
+        _ck(_abi.lib().ptx_op_layernorm_bwd(_p(x), _p(w), _p(dy), _p(stats), R, C, _p(dx), _p(xhat), _st()), "layernorm_bwd")
+        return dx, colsum(dy, xhat, mode=1), colsum(dy), None
+
+
+class _SlotBiasAdd(torch.autograd.Function):
+    """x + bias[j] with the learned per-slot table of ProxyAttention (PRE:212-217); j = row % Mk."""
+
+    @staticmethod
+    def forward(ctx, x, pb, pc, pr, Mk, s):
+        x = _c(x)
+        C = x.shape[1]
+        table = torch.empty((Mk, C), dtype=_F32, device=x.device)
+        _ck(_abi.lib().ptx_op_slotbias_fwd(_p(pb), _p(pc), _p(pr), Mk, s, C, _p(table), _st()), "slotbias_fwd")
+        ctx.dims = (Mk, s, C)
+        ctx.shapes = (pb.shape, pc.shape, pr.shape)
+        return eltwise(6, x, table, ncol=Mk * C)
+
+    @staticmethod
+    def backward(ctx, dy):
+        Mk, s, C = ctx.dims
+        dy = _c(dy)
+        dtab = colsum(dy.view(-1, Mk * C))
+        dpb = torch.empty(ctx.shapes[0], dtype=_F32, device=dy.device)
+        dpc = torch.empty(ctx.shapes[1], dtype=_F32, device=dy.device)
+        dpr = torch.empty(ctx.shapes[2], dtype=_F32, device=dy.device)
+        _ck(_abi.lib().ptx_op_slotbias_bwd(_p(dtab), Mk, s, C, _p(dpb), _p(dpc), _p(dpr), _st()), "slotbias_bwd")
+        return dy, dpb, dpc, dpr, None, None
+
+
+class _Gelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        ctx.save_for_backward(x)
+        return eltwise(2, x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return eltwise(3, x, _c(dy))
+
+
+class _Dropout(torch.autograd.Function):
+    """Dropout (group 1) / DropPath (group = elements per sample); identity node when p == 0."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed, group):
+        ctx.cfg = (p, seed, group)
+        return dropout_k(_c(x), p, seed, group)
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed, group = ctx.cfg
+        return dropout_k(_c(dy), p, seed, group), None, None, None
+
+
+def dropout(x, p, seed, group=1):
+    return x if p <= 0.0 else _Dropout.apply(x, float(p), int(seed), int(group))
+
+
+class _BatchNormRows(torch.autograd.Function):
+    """BatchNorm over the rows of (R,C) with batch statistics (+ optional fused ReLU); updates the running stats."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, run_mean, run_var, eps, momentum, relu):
+        x = _c(x)
+        R, C = x.shape
+        lib = _abi.lib()
+        s1 = colsum(x, scale=1.0 / R)                           # mean, then the sum of squares around it
+        s2 = colsum(x, s1, mode=3)
+        mr = torch.empty((2, C), dtype=_F32, device=x.device)
+        _ck(lib.ptx_op_bn_stats(_p(s1), _p(s2), C, R, eps, momentum, _p(mr), _p(run_mean), _p(run_var), _st()), "bn_stats")
+        y = torch.empty_like(x)
+        _ck(lib.ptx_op_bn_apply(_p(x), _p(mr), _p(w), _p(b), R, C, 1 if relu else 0, _p(y), _st()), "bn_apply")
+        ctx.save_for_backward(x, y if relu else x, mr, w)
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, mr, w = ctx.saved_tensors
+        dy = _c(dy)
+        R, C = x.shape
+        lib = _abi.lib()
+        g, gx = torch.empty_like(x), torch.empty_like(x)
+        _ck(lib.ptx_op_bn_bwd_prep(_p(x), _p(y), _p(dy), _p(mr), R, C, 1 if ctx.relu else 0, _p(g), _p(gx), _st()), "bn_bwd_prep")
+        dbeta, dgamma = colsum(g), colsum(gx)
+        dx = torch.empty_like(x)
+        _ck(lib.ptx_op_bn_bwd_dx(_p(x), _p(g), _p(mr), _p(w), _p(dbeta), _p(dgamma), R, C, _p(dx), _st()), "bn_bwd_dx")
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
+class _SlotNet(torch.autograd.Function):
+    """Shared body of OffsetNetwork / SimplifiedPointNet (PRE:87-102, 126-140): slot inputs -> Conv2d(6,W,1) ->
+    BatchNorm2d (batch statistics over all B*M*K slots) -> ReLU -> mean / max over the K slots."""
+
+    @staticmethod
+    def forward(ctx, center, cluster, conv_w, conv_b, bn_w, bn_b, run_mean, run_var, eps, momentum, maxpool):
+        lib = _abi.lib()
+        center = _c(center)
+        n, K = center.shape[0], cluster.shape[-2]
+        W = conv_w.shape[0]
+        dev = center.device
+        x6 = torch.empty((n * K, 6), dtype=_F32, device=dev)
+        pad = torch.empty((n * K,), dtype=torch.uint8, device=dev)
+        _ck(lib.ptx_op_slot_inputs(_p(center), _p(cluster), None, n, K, _p(x6), _p(pad), _st()), "slot_inputs")
+        w2 = conv_w.reshape(W, 6)
+        h = mm(x6, w2, tb=True)
+        eltwise(6, h, conv_b, ncol=W, out=h)
+        s1 = colsum(h, scale=1.0 / (n * K))
+        s2 = colsum(h, s1, mode=3)
+        mr = torch.empty((2, W), dtype=_F32, device=dev)
+        _ck(lib.ptx_op_bn_stats(_p(s1), _p(s2), W, n * K, eps, momentum, _p(mr), _p(run_mean), _p(run_var), _st()), "bn_stats")
+        act = torch.empty_like(h)
+        _ck(lib.ptx_op_bn_apply(_p(h), _p(mr), _p(bn_w), _p(bn_b), n * K, W, 1, _p(act), _st()), "bn_apply")
+        out = torch.empty((n, W), dtype=_F32, device=dev)
+        arg = torch.empty((n, W), dtype=torch.int32, device=dev) if maxpool else None
+        _ck(lib.ptx_op_slot_pool(_p(act), n, K, W, 1 if maxpool else 0, _p(out), _p(arg), _st()), "slot_pool")
+        ctx.save_for_backward(x6, pad, h, act, mr, bn_w, conv_w, arg if maxpool else pad)
+        ctx.cfg = (n, K, W, maxpool)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x6, pad, h, act, mr, bn_w, conv_w, arg = ctx.saved_tensors
+        n, K, W, maxpool = ctx.cfg
+        lib = _abi.lib()
+        dout = _c(dout)
+        dact = torch.empty_like(h)
+        _ck(lib.ptx_op_slot_pool_bwd(_p(dout), _p(arg) if maxpool else None, n, K, W, 1 if maxpool else 0, _p(dact), _st()), "slot_pool_bwd")
+        g, gx = torch.empty_like(h), torch.empty_like(h)
+        _ck(lib.ptx_op_bn_bwd_prep(_p(h), _p(act), _p(dact), _p(mr), n * K, W, 1, _p(g), _p(gx), _st()), "bn_bwd_prep")
+        dbeta, dgamma = colsum(g), colsum(gx)
+        dh = dact                                               # reuse
+        _ck(lib.ptx_op_bn_bwd_dx(_p(h), _p(g), _p(mr), _p(bn_w), _p(dbeta), _p(dgamma), n * K, W, _p(dh), _st()), "bn_bwd_dx")
+        w2 = conv_w.reshape(W, 6)
+        dconv_w = mm(dh, x6, ta=True).view_as(conv_w)
+        dconv_b = colsum(dh)
+        dcenter = None
+        if ctx.needs_input_grad[0]:
+            dx6 = mm(dh, w2)
+            dcenter = torch.empty((n, 3), dtype=_F32, device=dout.device)
+            _ck(lib.ptx_op_slot_inputs_bwd(_p(dx6), _p(pad), n, K, _p(dcenter), _st()), "slot_inputs_bwd")
+        return dcenter, None, dconv_w, dconv_b, dgamma, dbeta, None, None, None, None, None
+
+
+class _OffsetHead(torch.autograd.Function):
+    """mean-pooled features -> Conv1d(256,3,1,bias=False) -> tanh * margin -> + grid centre -> clamp (PRE:59-62, 103)."""
+
+    @staticmethod
+    def forward(ctx, pooled, map_w, c0, minmax, M, margin):
+        pooled = _c(pooled)
+        n = pooled.shape[0]
+        raw = mm(pooled, map_w.reshape(3, -1), tb=True)
+        cout = torch.empty((n, 3), dtype=_F32, device=pooled.device)
+        dcoef = torch.empty_like(cout)
+        _ck(_abi.lib().ptx_op_offset_apply(_p(c0), _p(raw), _p(minmax), n, M, margin, _p(cout), _p(dcoef), _st()), "offset_apply")
+        ctx.save_for_backward(pooled, map_w, dcoef)
+        return cout
+
+    @staticmethod
+    def backward(ctx, dc):
+        pooled, map_w, dcoef = ctx.saved_tensors
+        draw = eltwise(8, _c(dc), dcoef)
+        w2 = map_w.reshape(3, -1)
+        return mm(draw, w2), mm(draw, pooled, ta=True).view_as(map_w), None, None, None, None
+
+
+class _GatherRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, src):
+        x = _c(x)
+        rows, C = src.shape[0], x.shape[1]
+        y = torch.empty((rows, C), dtype=_F32, device=x.device)
+        _ck(_abi.lib().ptx_op_rows_gather(_p(x), _p(src), rows, C, _p(y), _st()), "rows_gather")
+        ctx.save_for_backward(src)
+        ctx.shape = x.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (src,) = ctx.saved_tensors
+        dx = torch.zeros(ctx.shape, dtype=_F32, device=dy.device)          # memset, rows that were not kept get 0
+        _ck(_abi.lib().ptx_op_rows_scatter(_p(_c(dy)), _p(src), src.shape[0], ctx.shape[1], _p(dx), _st()), "rows_scatter")
+        return dx, None
+
+
+class _ProxyAttnCore(torch.autograd.Function):
+    """Both contractions of ProxyAttention (PRE:230-252) on head-split views of qkv (B*n,3C) and the projected proxies
+    (B*L,C): proxy-as-query softmax over the n tokens (unmasked), proxy-as-key softmax over the L proxies (padded text
+    tokens filled with -1e9), attention dropout on both maps."""
+
+    @staticmethod
+    def forward(ctx, qkv, pt, mask, B, n, L, heads, p_drop, seed):
+        qkv, pt = _c(qkv), _c(pt)
+        C = pt.shape[1]
+        hd = C // heads
+        scale = float(hd) ** -0.5
+        dev = qkv.device
+        lib = _abi.lib()
+        Z = B * heads
+        q = dict(a=(3 * C, 1), a_bs=(n * 3 * C, hd))            # views of qkv as the A operand
+        # S1[b,h,l,i] = scale Pt[b,l,h,:] . K[b,i,h,:]
+        S1 = torch.empty((B, heads, L, n), dtype=_F32, device=dev)
+        gemm(pt, qkv, S1, L, n, hd, a=(C, 1), b=(1, 3 * C), c=(n, 1), batch=Z, inner=heads, a_bs=(L * C, hd),
+             b_bs=(n * 3 * C, hd), c_bs=(heads * L * n, L * n), b_off=C, alpha=scale)
+        P1 = torch.empty_like(S1)
+        _ck(lib.ptx_op_softmax_fwd(_p(S1), None, Z * L, n, 1, _p(P1), _st()), "softmax_fwd")
+        D1 = P1 if p_drop <= 0 else dropout_k(P1, p_drop, seed)
+        PV = torch.empty((B, heads, L, hd), dtype=_F32, device=dev)
+        gemm(D1, qkv, PV, L, hd, n, a=(n, 1), b=(3 * C, 1), c=(hd, 1), batch=Z, inner=heads, a_bs=(heads * L * n, L * n),
+             b_bs=(n * 3 * C, hd), c_bs=(heads * L * hd, L * hd), b_off=2 * C)
+        # S2[b,h,i,l] = scale Q[b,i,h,:] . Pt[b,l,h,:]
+        S2 = S1.view(B, heads, n, L)                              # same size, reused
+        gemm(qkv, pt, S2, n, L, hd, a=q["a"], b=(1, C), c=(L, 1), batch=Z, inner=heads, a_bs=q["a_bs"],
+             b_bs=(L * C, hd), c_bs=(heads * n * L, n * L), alpha=scale)
+        P2 = torch.empty((B, heads, n, L), dtype=_F32, device=dev)
+        _ck(lib.ptx_op_softmax_fwd(_p(S2), _p(mask), Z * n, L, heads * n, _p(P2), _st()), "softmax_fwd")
+        D2 = P2 if p_drop <= 0 else dropout_k(P2, p_drop, seed + 1)
+        O = torch.empty((B * n, C), dtype=_F32, device=dev)
+        gemm(D2, PV, O, n, hd, L, a=(L, 1), b=(hd, 1), c=(C, 1), batch=Z, inner=heads, a_bs=(heads * n * L, n * L),
+             b_bs=(heads * L * hd, L * hd), c_bs=(n * C, hd))
+        ctx.save_for_backward(qkv, pt, P1, D1, PV, P2, D2, mask if mask is not None else P1)
+        ctx.cfg = (B, n, L, heads, C, hd, scale, p_drop, seed, mask is not None)
+        return O
+
+    @staticmethod
+    def backward(ctx, dO):
+        qkv, pt, P1, D1, PV, P2, D2, mask = ctx.saved_tensors
+        B, n, L, heads, C, hd, scale, p_drop, seed, has_mask = ctx.cfg
+        dO = _c(dO)
+        dev = dO.device
+        lib = _abi.lib()
+        Z = B * heads
+        dqkv = torch.empty_like(qkv)
+        dpt = torch.empty_like(pt)
+        # dD2[b,h,i,l] = dO[b,i,h,:] . PV[b,h,l,:] ;  dPV[b,h,l,:] = sum_i D2[b,h,i,l] dO[b,i,h,:]
+        dD2 = torch.empty_like(P2)
+        gemm(dO, PV, dD2, n, L, hd, a=(C, 1), b=(1, hd), c=(L, 1), batch=Z, inner=heads, a_bs=(n * C, hd),
+             b_bs=(heads * L * hd, L * hd), c_bs=(heads * n * L, n * L))
+        dPV = torch.empty_like(PV)
+        gemm(D2, dO, dPV, L, hd, n, a=(1, L), b=(C, 1), c=(hd, 1), batch=Z, inner=heads, a_bs=(heads * n * L, n * L),
+             b_bs=(n * C, hd), c_bs=(heads * L * hd, L * hd))
+        dP2 = dD2 if p_drop <= 0 else dropout_k(dD2, p_drop, seed + 1)
+        dS2 = torch.empty_like(P2)
+        _ck(lib.ptx_op_softmax_bwd(_p(P2), _p(dP2), _p(mask) if has_mask else None, Z * n, L, heads * n, _p(dS2), _st()), "softmax_bwd")
+        # dQ[b,i,h,:] = scale sum_l dS2[b,h,i,l] Pt[b,l,h,:]  -> columns 0..C of dqkv
+        gemm(dS2, pt, dqkv, n, hd, L, a=(L, 1), b=(C, 1), c=(3 * C, 1), batch=Z, inner=heads, a_bs=(heads * n * L, n * L),
+             b_bs=(L * C, hd), c_bs=(n * 3 * C, hd), alpha=scale)
+        # dPt[b,l,h,:] = scale sum_i dS2[b,h,i,l] Q[b,i,h,:]
+        gemm(dS2, qkv, dpt, L, hd, n, a=(1, L), b=(3 * C, 1), c=(C, 1), batch=Z, inner=heads, a_bs=(heads * n * L, n * L),
+             b_bs=(n * 3 * C, hd), c_bs=(L * C, hd), alpha=scale)
+        # dD1[b,h,l,i] = dPV[b,h,l,:] . V[b,i,h,:] ;  dV[b,i,h,:] = sum_l D1[b,h,l,i] dPV[b,h,l,:]  -> columns 2C..3C
+        dD1 = torch.empty_like(P1)
+        gemm(dPV, qkv, dD1, L, n, hd, a=(hd, 1), b=(1, 3 * C), c=(n, 1), batch=Z, inner=heads, a_bs=(heads * L * hd, L * hd),
+             b_bs=(n * 3 * C, hd), c_bs=(heads * L * n, L * n), b_off=2 * C)
+        gemm(D1, dPV, dqkv, n, hd, L, a=(1, n), b=(hd, 1), c=(3 * C, 1), batch=Z, inner=heads, a_bs=(heads * L * n, L * n),
+             b_bs=(heads * L * hd, L * hd), c_bs=(n * 3 * C, hd), c_off=2 * C)
+        dP1 = dD1 if p_drop <= 0 else dropout_k(dD1, p_drop, seed)
+        dS1 = torch.empty_like(P1)
+        _ck(lib.ptx_op_softmax_bwd(_p(P1), _p(dP1), None, Z * L, n, 1, _p(dS1), _st()), "softmax_bwd")
+        # dPt += scale sum_i dS1[b,h,l,i] K[b,i,h,:] ;  dK[b,i,h,:] = scale sum_l dS1[b,h,l,i] Pt[b,l,h,:]  -> columns C..2C
+        gemm(dS1, qkv, dpt, L, hd, n, a=(n, 1), b=(3 * C, 1), c=(C, 1), batch=Z, inner=heads, a_bs=(heads * L * n, L * n),
+             b_bs=(n * 3 * C, hd), c_bs=(L * C, hd), b_off=C, alpha=scale, accumulate=True)
+        gemm(dS1, pt, dqkv, n, hd, L, a=(1, n), b=(C, 1), c=(3 * C, 1), batch=Z, inner=heads, a_bs=(heads * L * n, L * n),
+             b_bs=(L * C, hd), c_bs=(n * 3 * C, hd), c_off=C, alpha=scale)
+        return dqkv, dpt, None, None, None, None, None, None, None
+
+
+class _ImgTokens(torch.autograd.Function):
+    """Conv2d(in_dim,C,1) over every pixel + mean token + positional embedding (PRE:338, 155-157) -> (nimg, hw+1, C)."""
+
+    @staticmethod
+    def forward(ctx, img, wc, bc, pos):
+        # img (nimg, Cin, hw) in its storage type (fp32 / bf16 / fp16)
+        nimg, Cin, hw = img.shape
+        C = wc.shape[0]
+        a_dt = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[img.dtype]
+        tok = torch.zeros((nimg, hw + 1, C), dtype=_F32, device=img.device)
+        gemm(img, wc, tok, hw, C, Cin, a=(1, hw), b=(1, Cin), c=(C, 1), batch=nimg, inner=1, a_bs=(Cin * hw, 0),
+             b_bs=(0, 0), c_bs=((hw + 1) * C, 0), c_off=C, a_dtype=a_dt)
+        eltwise(6, tok, bc, ncol=C, out=tok)                     # row 0 is overwritten below
+        _ck(_abi.lib().ptx_op_tokens_finish(_p(tok), _p(pos), nimg, hw, C, _st()), "tokens_finish")
+        ctx.save_for_backward(img, wc)
+        ctx.a_dt = a_dt
+        return tok
+
+    @staticmethod
+    def backward(ctx, dtok):
+        img, wc = ctx.saved_tensors
+        nimg, Cin, hw = img.shape
+        C = wc.shape[0]
+        dtok = _c(dtok)
+        dpos = colsum(dtok.view(nimg, (hw + 1) * C)).view(hw + 1, C)
+        d2 = eltwise(1, dtok, s=1.0)                             # private copy: the mean-token gradient is folded in place
+        _ck(_abi.lib().ptx_op_tokens_finish_bwd(_p(d2), nimg, hw, C, _st()), "tokens_finish_bwd")
+        dbc = colsum(d2.view(nimg * (hw + 1), C))                # token-0 rows are zero now
+        # dWc[c][cin] = sum_img sum_p d2[img][1+p][c] img[img][cin][p]: per-image products, then a fixed-order sum over images
+        part = torch.empty((nimg, C * Cin), dtype=_F32, device=dtok.device)
+        gemm(d2, img, part, C, Cin, hw, a=(1, C), b=(1, hw), c=(Cin, 1), batch=nimg, inner=1, a_bs=((hw + 1) * C, 0),
+             b_bs=(Cin * hw, 0), c_bs=(C * Cin, 0), a_off=C, b_dtype=ctx.a_dt)
+        dwc = colsum(part).view_as(wc)
+        dimg = None
+        if ctx.needs_input_grad[0]:
+            dimg32 = torch.empty((nimg, Cin, hw), dtype=_F32, device=dtok.device)
+            gemm(wc, d2, dimg32, Cin, hw, C, a=(1, Cin), b=(1, C), c=(hw, 1), batch=nimg, inner=1, a_bs=(0, 0),
+                 b_bs=((hw + 1) * C, 0), c_bs=(Cin * hw, 0), b_off=C)
+            dimg = dimg32 if img.dtype == torch.float32 else dimg32.to(img.dtype)
+        return dimg, dwc, dbc, dpos
+
+
+class _AttnPoolCore(torch.autograd.Function):
+    """AttentionPool2d's attention for the one query row that is returned (token 0, PRE:158-177): separate q / k / v
+    projections, softmax over the hw+1 tokens, no dropout (dropout_p = 0 at PRE:169)."""
+
+    @staticmethod
+    def forward(ctx, tok, wq, bq, wk, bk, wv, bv, heads):
+        tok = _c(tok)
+        nimg, T, C = tok.shape
+        hd = C // heads
+        scale = float(hd) ** -0.5
+        dev = tok.device
+        tok2 = tok.view(nimg * T, C)
+        Kt = mm(tok2, wk, tb=True)
+        eltwise(6, Kt, bk, ncol=C, out=Kt)
+        Vt = mm(tok2, wv, tb=True)
+        eltwise(6, Vt, bv, ncol=C, out=Vt)
+        q = torch.empty((nimg, C), dtype=_F32, device=dev)
+        gemm(tok, wq, q, nimg, C, C, a=(T * C, 1), b=(1, C), c=(C, 1))
+        eltwise(6, q, bq, ncol=C, out=q)
+        Z = nimg * heads
+        S = torch.empty((nimg, heads, T), dtype=_F32, device=dev)
+        gemm(q, Kt, S, 1, T, hd, a=(0, 1), b=(1, C), c=(T, 1), batch=Z, inner=heads, a_bs=(C, hd), b_bs=(T * C, hd),
+             c_bs=(heads * T, T), alpha=scale)
+        P = torch.empty_like(S)
+        _ck(_abi.lib().ptx_op_softmax_fwd(_p(S), None, Z, T, 1, _p(P), _st()), "softmax_fwd")
+        o = torch.empty((nimg, C), dtype=_F32, device=dev)
+        gemm(P, Vt, o, 1, hd, T, a=(0, 1), b=(C, 1), c=(hd, 1), batch=Z, inner=heads, a_bs=(heads * T, T),
+             b_bs=(T * C, hd), c_bs=(C, hd))
+        ctx.save_for_backward(tok, wq, wk, wv, Kt, Vt, q, P)
+        ctx.cfg = (nimg, T, C, heads, hd, scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        tok, wq, wk, wv, Kt, Vt, q, P = ctx.saved_tensors
+        nimg, T, C, heads, hd, scale = ctx.cfg
+        do = _c(do)
+        dev = do.device
+        Z = nimg * heads
+        tok2 = tok.view(nimg * T, C)
+        # dP[img,h,t] = do[img,h,:] . Vt[img,t,h,:] ;  dVt[img,t,h,:] = P[img,h,t] do[img,h,:]
+        dP = torch.empty_like(P)
+        gemm(do, Vt, dP, 1, T, hd, a=(0, 1), b=(1, C), c=(T, 1), batch=Z, inner=heads, a_bs=(C, hd), b_bs=(T * C, hd),
+             c_bs=(heads * T, T))
+        dVt = torch.empty_like(Vt)
+        gemm(P, do, dVt, T, hd, 1, a=(1, 0), b=(0, 1), c=(C, 1), batch=Z, inner=heads, a_bs=(heads * T, T), b_bs=(C, hd),
+             c_bs=(T * C, hd))
+        dS = torch.empty_like(P)
+        _ck(_abi.lib().ptx_op_softmax_bwd(_p(P), _p(dP), None, Z, T, 1, _p(dS), _st()), "softmax_bwd")
+        dq = torch.empty_like(q)
+        gemm(dS, Kt, dq, 1, hd, T, a=(0, 1), b=(C, 1), c=(hd, 1), batch=Z, inner=heads, a_bs=(heads * T, T),
+             b_bs=(T * C, hd), c_bs=(C, hd), alpha=scale)
+        dKt = torch.empty_like(Kt)
+        gemm(dS, q, dKt, T, hd, 1, a=(1, 0), b=(0, 1), c=(C, 1), batch=Z, inner=heads, a_bs=(heads * T, T), b_bs=(C, hd),
+             c_bs=(T * C, hd), alpha=scale)
+        dtok = mm(dKt, wk)
+        mm(dVt, wv, out=dtok, accumulate=True)
+        gemm(dq, wq, dtok, nimg, C, C, a=(C, 1), b=(C, 1), c=(T * C, 1), accumulate=True)      # token-0 rows
+        dwk, dbk = mm(dKt, tok2, ta=True), colsum(dKt)
+        dwv, dbv = mm(dVt, tok2, ta=True), colsum(dVt)
+        dwq = torch.empty_like(wq)
+        gemm(dq, tok, dwq, C, C, nimg, a=(1, C), b=(T * C, 1), c=(C, 1))
+        return dtok.view(nimg, T, C), dwq, colsum(dq), dwk, dbk, dwv, dbv, None
+
+
+class _AffineApply(torch.autograd.Function):
+    """Per-cluster affine + pt_replace + remove_points_by_index (PRE:459-467) through the eval path's compaction
+    kernel; backward = ptx_op_affine_bwd."""
+
+    @staticmethod
+    def forward(ctx, kcenter, translate, transform, pts, tag, opos, kidx, kcluster, shape, ws):
+        lib = _abi.lib()
+        B, N = pts.shape[0], pts.shape[1]
+        out = torch.zeros((B, N, 3), dtype=_F32, device=pts.device)
+        counts = torch.empty((B,), dtype=torch.int32, device=pts.device)
+        kcenter, translate, transform = _c(kcenter), _c(translate), _c(transform)
+        _ck(lib.ptx_affine_compact(ctypes.byref(shape), _p(pts), _p(tag), _p(kcenter), _p(translate), _p(transform),
+                                   _p(out), _p(counts), _p(ws), ws.numel(), _st()), "ptx_affine_compact")
+        ctx.save_for_backward(opos, kidx, kcluster, kcenter, transform)
+        ctx.dims = (B, N, shape.Mk, shape.K)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        opos, kidx, kcluster, kcenter, transform = ctx.saved_tensors
+        B, N, Mk, K = ctx.dims
+        dout = _c(dout)
+        dev = dout.device
+        dt = torch.empty((B * Mk, 3), dtype=_F32, device=dev)
+        dT = torch.empty((B * Mk, 9), dtype=_F32, device=dev)
+        dc = torch.empty((B * Mk, 3), dtype=_F32, device=dev)
+        _ck(_abi.lib().ptx_op_affine_bwd(_p(dout), _p(opos), _p(kidx), _p(kcluster), _p(kcenter), _p(transform), B, N, Mk, K,
+                                         _p(dt), _p(dT), _p(dc), _st()), "ptx_op_affine_bwd")
+        return dc, dt, dT, None, None, None, None, None, None, None
+
+
+# --------------------------------------------------------------------------- the train-mode forward
+def _block(mod, blk, out_norm, head, head_bn, xa, xb, proxy2d, mask_u8, B, n, L, seeds):
+    """One ProxyBlock in train mode (PRE:273-276) + trailing LayerNorm + Linear head + BatchNorm1d (PRE:441-446)."""
+    C, heads = mod.embed_dim, mod.num_heads
+    a = blk.attn
+    s = a.pc_bias.shape[2]
+    eps = blk.norm1.eps
+    x = _LayerNorm.apply(xa, blk.norm1.weight, blk.norm1.bias, eps)
+    x = _SlotBiasAdd.apply(x, a.pb_bias, a.pc_bias, a.pr_bias, n, s)
+    qkv = _Linear.apply(x, a.qkv.weight, a.qkv.bias)
+    pt = _Linear.apply(proxy2d, a.proxy_proj.weight, a.proxy_proj.bias)
+    o = _ProxyAttnCore.apply(qkv, pt, mask_u8, B, n, L, heads, float(mod.attn_drop_rate), seeds[0])
+    o = _Linear.apply(o, a.proj.weight, a.proj.bias)
+    o = dropout(o, mod.drop_rate, seeds[1])
+    o = dropout(o, mod._dpr_last(blk), seeds[2], group=n * C)                      # DropPath: one decision per sample
+    x1 = _Add.apply(xb, o)
+    x1a, x1b = fork(x1, 2)
+    h = _LayerNorm.apply(x1a, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+    h = _Linear.apply(h, blk.mlp.fc1.weight, blk.mlp.fc1.bias)
+    h = _Gelu.apply(h)
+    h = dropout(h, mod.drop_rate, seeds[3])
+    h = _Linear.apply(h, blk.mlp.fc2.weight, blk.mlp.fc2.bias)
+    h = dropout(h, mod.drop_rate, seeds[4])
+    h = dropout(h, mod._dpr_last(blk), seeds[5], group=n * C)
+    x2 = _Add.apply(x1b, h)
+    g = _LayerNorm.apply(x2, out_norm.weight, out_norm.bias, out_norm.eps)
+    t = _Linear.apply(g, head.weight, head.bias)
+    t = _BatchNormRows.apply(t, head_bn.weight, head_bn.bias, head_bn.running_mean, head_bn.running_var, head_bn.eps,
+                             head_bn.momentum, False)
+    if head_bn.num_batches_tracked is not None:
+        head_bn.num_batches_tracked.add_(1)
+    return t
+
+
+def forward_train(mod, points: List[torch.Tensor], text_feats, text_mask, img_feat, shape, ws, order_override=None):
+    """Train-mode forward of ``mod`` (a ProxyTransformationNormReverse).  Returns (list of (N_i',3) tensors with
+    grad_fn, dict of index tensors for tests)."""
+    lib = _abi.lib()
+    dev = points[0].device
+    st = _st()
+    B, N = len(points), points[0].shape[0]
+    M, K, Mt, Mk, C = mod.num_cluster, mod.num_sub, shape.Mt, shape.Mk, mod.embed_dim
+    Kd = Mt - Mk
+    i32 = dict(dtype=torch.int32, device=dev)
+    pts = torch.stack([p.detach().to(_F32) for p in points]).contiguous()          # PRE:426-427
+    mod._train_calls += 1
+    base = (torch.initial_seed() * 1000003 + mod._train_calls * 7919) & 0x7FFFFFFFFFFF
+    seeds = [[base + 100 * b + i for i in range(6)] for b in range(2)]
+
+    # ---- index half, part 1: grid centres + ball query #1 (PRE:55-56)
+    minmax = torch.empty((B, 2, 3), dtype=_F32, device=dev)
+    c0 = torch.empty((B, M, 3), dtype=_F32, device=dev)
+    lin = mod._train_lin(dev)
+    enc_scratch = torch.empty((max(B * 6, 64),), **i32)        # NOT the lane workspace: its encoded boxes must stay zero
+    _ck(lib.ptx_grid_centers(_p(pts), B, N, _p(lin), mod.grid_size, 4.0, _p(minmax), _p(c0), _p(enc_scratch),
+                             enc_scratch.numel() * 4, st), "ptx_grid_centers")
+    idx1 = torch.empty((B, M, K), **i32)
+    cl1 = torch.empty((B, M, K, 3), dtype=_F32, device=dev)
+    _ck(lib.ptx_ball_query(_p(c0), _p(pts), B, M, N, K, 3.0, _p(idx1), _p(cl1), None, st), "ptx_ball_query")
+
+    # ---- offset network (PRE:58-62)
+    off = mod.get_deformable_cluster.get_offsets
+    bn = off.mlp[1]
+    pooled = _SlotNet.apply(c0.view(B * M, 3), cl1, off.mlp[0].weight, off.mlp[0].bias, bn.weight, bn.bias,
+                            bn.running_mean, bn.running_var, bn.eps, bn.momentum, False)
+    bn.num_batches_tracked.add_(1)
+    centers = _OffsetHead.apply(pooled, off.channel_mapper.weight, c0, minmax, M, 4.0)       # (B*M,3)
+
+    # ---- index half, part 2: ball query #2, selection, tags, output positions (PRE:65, 352-420, 478-523)
+    cdet = centers.detach()
+    if mod._centers_override is not None:
+        cdet = mod._centers_override.to(device=dev, dtype=_F32).reshape(B * M, 3).contiguous()
+    idx2 = torch.empty((B, M, K), **i32)
+    cl2 = torch.empty((B, M, K, 3), dtype=_F32, device=dev)
+    pad = torch.empty((B, M), **i32)
+    _ck(lib.ptx_ball_query(_p(cdet), _p(pts), B, M, N, K, 3.0, _p(idx2), _p(cl2), _p(pad), st), "ptx_ball_query")
+    order = torch.empty((B, Mt), **i32)
+    picks = torch.empty((B, max(Kd, 1)), **i32)
+    keep = torch.empty((B, Mk), **i32)
+    kcenter_i = torch.empty((B, Mk, 3), dtype=_F32, device=dev)
+    kcluster = torch.empty((B, Mk, K, 3), dtype=_F32, device=dev)
+    kidx = torch.empty((B, Mk, K), **i32)
+    drop_idx = torch.empty((B, max(Kd, 1) * K), **i32)
+    tag = torch.zeros((B, N), **i32)
+    oo = None if order_override is None else order_override.to(device=dev, dtype=torch.int32).contiguous()
+    _ck(lib.ptx_select_clusters(ctypes.byref(shape), _p(idx2), _p(cdet), _p(cl2), _p(pad), _p(oo), _p(order), _p(picks),
+                                _p(keep), _p(kcenter_i), _p(kcluster), _p(kidx), _p(drop_idx), _p(tag), st), "ptx_select_clusters")
+    ntiles = (N + 2047) // 2048
+    tile_counts = torch.empty((B * ntiles,), **i32)
+    opos = torch.empty((B, N), **i32)
+    counts = torch.empty((B,), **i32)
+    _ck(lib.ptx_op_out_positions(_p(tag), B, N, _p(tile_counts), _p(opos), _p(counts), st), "ptx_op_out_positions")
+    src = torch.empty((B * Mk,), **i32)
+    _ck(lib.ptx_op_keep_rows(_p(order), _p(keep), B, M, Mt, Mk, _p(src), st), "ptx_op_keep_rows")
+
+    # ---- float half: kept centres, point proxies (PRE:437)
+    kcenter = _GatherRows.apply(centers, src)                                    # (B*Mk,3), differentiable
+    kc_enc, kc_aff = fork(kcenter, 2)
+    enc = mod.simple_encoder
+    ebn = enc.mlp[1]
+    pp = _SlotNet.apply(kc_enc, kcluster, enc.mlp[0].weight, enc.mlp[0].bias, ebn.weight, ebn.bias, ebn.running_mean,
+                        ebn.running_var, ebn.eps, ebn.momentum, True)            # (B*Mk, C)
+    ebn.num_batches_tracked.add_(1)
+    pp_t1, pp_t2, pp_i1, pp_i2 = fork(pp, 4)
+
+    # ---- text branch (PRE:440-446)
+    L = text_feats.shape[1]
+    tf2 = _c(text_feats.to(_F32)).view(B * L, C)
+    translate = _block(mod, mod.textformer[-1], mod.text_norm[-1], mod.text_trans, mod.text_trans_norm, pp_t1, pp_t2,
+                       tf2, text_mask, B, Mk, L, seeds[0])
+
+    # ---- image branch (PRE:449-455)
+    V = img_feat.shape[1]
+    hw = mod.img_spacial_dim ** 2
+    ap = mod.attn_pool2d
+    img3 = _c(img_feat).view(B * V, mod.input_dim, hw)
+    tok = _ImgTokens.apply(img3, mod.channel_mapper.weight, mod.channel_mapper.bias, ap.positional_embedding)
+    o = _AttnPoolCore.apply(tok, ap.q_proj.weight, ap.q_proj.bias, ap.k_proj.weight, ap.k_proj.bias, ap.v_proj.weight,
+                            ap.v_proj.bias, mod.num_heads)
+    y = _Linear.apply(o, ap.c_proj.weight, ap.c_proj.bias)
+    img_proxy = _LayerNorm.apply(y, mod.norm_img.weight, mod.norm_img.bias, mod.norm_img.eps)       # (B*V, C)
+    transform = _block(mod, mod.imgformer[-1], mod.img_norm[-1], mod.img_trans, mod.img_trans_norm, pp_i1, pp_i2,
+                       img_proxy, None, B, Mk, V, seeds[1])
+
+    # ---- submanifold reshape + scatter + drop (PRE:459-467)
+    out = _AffineApply.apply(kc_aff, translate, transform, pts, tag, opos, kidx, kcluster, shape, ws)
+    n_keep = counts.cpu().tolist()                                              # the list lengths of PRE:467 (one sync)
+    outs = [out[b, : n_keep[b]] for b in range(B)]
+    aux = dict(idx2=idx2, order=order, picks=picks[:, :Kd], keep=keep, kidx=kidx, drop_idx=drop_idx[:, : Kd * K],
+               centers=centers, translate=translate, transform=transform, point_proxy=pp, img_proxy=img_proxy,
+               kcenter=kcenter, opos=opos)
+    return outs, aux

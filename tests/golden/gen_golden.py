@@ -304,6 +304,98 @@ def run_case(reg, cfg: PreshapeConfig):
           f"margin={margins} -> {os.path.getsize(path) / 1e6:.2f} MB")
 
 
+# ----------------------------------------------------------------------------- train mode
+TRAIN_CASE = PreshapeConfig("g4_train", B=2, N=3000, grid_size=4, dynamic_drop_radio=0.5, L=6, V=3,
+                            text_blocks=2, img_blocks=2, seed_base=7500)
+GRAD_SAMPLES = 4096
+
+
+def loss_weights(b: int, n: int) -> np.ndarray:
+    """Fixed upstream gradient of output b: d loss / d out_b[i, d] (the tests rebuild it from the same formula)."""
+    i = np.arange(n, dtype=np.float64)[:, None]
+    d = np.arange(3, dtype=np.float64)[None, :]
+    return np.sin(0.37 * i + 1.3 * d + 0.7 * b).astype(np.float32)
+
+
+def sample_idx(numel: int) -> np.ndarray:
+    step = max(1, -(-numel // GRAD_SAMPLES))
+    return np.arange(0, numel, step, dtype=np.int64)
+
+
+def run_train_case(reg, cfg: PreshapeConfig):
+    """One optimisation-free training step of the reference: model.train() (batch-statistics BatchNorm, running-stat
+    update), all drop rates 0 (deterministic), loss = sum_b <out_b, W_b>, backward.  Captures the train-mode
+    intermediates, the gradient of every parameter and input (sampled for big tensors) and which parameters get none."""
+    torch.manual_seed(0)
+    model = reg.build(dict(type="ProxyTransformationNormReverse", drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.0,
+                           **cfg.module_kwargs()))
+    sd_np = fill_state_dict(model.state_dict())
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+    model.train()
+    pts, text, mask, img = make_scene_batch(cfg)
+    tpts = [torch.from_numpy(pts[b].copy()) for b in range(cfg.B)]
+    ttext = torch.from_numpy(text).requires_grad_(True)
+    timg = torch.from_numpy(img).requires_grad_(True)
+    text_dict = {"text_feats": ttext, "text_token_mask": torch.from_numpy(mask)}
+    hooks = {}
+
+    def hook(name):
+        def fn(mod, inp, outp):
+            hooks[name] = outp.detach().clone()
+        return fn
+    hs = [model.simple_encoder.register_forward_hook(hook("point_proxy")),
+          model.norm_img.register_forward_hook(hook("img_proxy")),
+          model.text_trans_norm.register_forward_hook(hook("translate_t")),
+          model.img_trans_norm.register_forward_hook(hook("transform_t"))]
+    real_argsort = torch.argsort
+    captured = {}
+
+    def argsort(x, dim=-1, descending=False, stable=False):
+        r = real_argsort(x, dim=dim, descending=descending, stable=True)
+        captured["sorted"] = r.clone()
+        return r
+    CAPTURE.clear()
+    torch.argsort = argsort
+    try:
+        torch.set_num_threads(1)
+        outs = model(tpts, text_dict, timg)
+        loss = sum((o * torch.from_numpy(loss_weights(b, o.shape[0]))).sum() for b, o in enumerate(outs))
+        loss.backward()
+    finally:
+        torch.argsort = real_argsort
+    for h in hs:
+        h.remove()
+    save = dict(points=pts, text_feats=text, text_mask=mask, img_feat=img,
+                cfg=np.array([cfg.B, cfg.N, cfg.grid_size, cfg.L, cfg.V, cfg.embed_dim, cfg.num_heads, cfg.num_sub,
+                              cfg.text_blocks, cfg.img_blocks], np.int64),
+                dynamic_drop_radio=np.float64(cfg.dynamic_drop_radio), extent=np.asarray(cfg.extent, np.float64),
+                seed_base=np.int64(cfg.seed_base), loss=np.float64(loss.item()),
+                centers=CAPTURE["bq"][1][0].detach().numpy().copy(), idx2=CAPTURE["bq"][1][1].numpy().copy(),
+                order=captured["sorted"][:, :cfg.Mt].numpy().copy(), fps=CAPTURE["fps_idx"].numpy().copy(),
+                point_proxy=hooks["point_proxy"].numpy(), img_proxy=hooks["img_proxy"].numpy(),
+                translate=hooks["translate_t"].numpy().transpose(0, 2, 1),
+                transform=hooks["transform_t"].numpy().transpose(0, 2, 1))
+    for b, o in enumerate(outs):
+        save[f"out_{b}"] = o.detach().numpy().copy()
+    none = []
+    for name, prm in list(model.named_parameters()) + [("input.text_feats", ttext), ("input.img_feat", timg)]:
+        if prm.grad is None:
+            none.append(name)
+            continue
+        g = prm.grad.detach().numpy().reshape(-1)
+        idx = sample_idx(g.size)
+        save["grad." + name] = g[idx].copy()
+        save["gnorm." + name] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        save["gsum." + name] = np.float64(g.astype(np.float64).sum())
+    save["none_grads"] = np.array(none)
+    for name, buf in model.named_buffers():                       # running statistics after the step
+        save["buf." + name] = buf.detach().numpy().copy()
+    path = os.path.join(HERE, cfg.name + ".npz")
+    np.savez_compressed(path, **save)
+    print(f"{cfg.name}: loss={loss.item():.6f} outs={[tuple(o.shape) for o in outs]} none_grads={len(none)} "
+          f"-> {os.path.getsize(path) / 1e6:.2f} MB")
+
+
 def write_manifest(reg):
     """Key / shape / dtype manifest of the reference module's state_dict (data, not code)."""
     import json
@@ -332,6 +424,8 @@ def main():
         if only and cfg.name not in only:
             continue
         run_case(reg, cfg)
+    if not only or TRAIN_CASE.name in only:
+        run_train_case(reg, TRAIN_CASE)
 
 
 if __name__ == "__main__":

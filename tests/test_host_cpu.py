@@ -120,8 +120,8 @@ def test_no_cpu_fallback_and_error_classes():
         m([torch.from_numpy(p) for p in pts], td, torch.from_numpy(img))
     with pytest.raises(RuntimeError):                      # unequal N, like torch.cat at PRE:427
         m([torch.zeros(10, 3), torch.zeros(11, 3)], td, torch.from_numpy(img))
-    m.train()
-    with pytest.raises(NotImplementedError):
+    m.train()                                              # train mode is HIP as well: same refusal of CPU tensors
+    with pytest.raises(RuntimeError, match="no CPU path"):
         m([torch.from_numpy(p) for p in pts], td, torch.from_numpy(img))
 
 
