@@ -90,7 +90,7 @@ def colsum(x2, y2=None, mode=0, scale=1.0, out=None, accumulate=False):
     if out is None:
         out = torch.empty((N,), dtype=_F32, device=x2.device)
     # enough (column tile, row split) blocks to fill the chip; every split walks >= ~64 rows per slice
-    nsplit = int(max(1, min(1024, R // 256, 2048 // ((N + 63) // 64))))
+    nsplit = int(max(1, min(96, R // 256, 2048 // ((N + 63) // 64))))
     scratch = torch.empty((nsplit, N), dtype=torch.float64, device=x2.device)
     _ck(_abi.lib().ptx_op_colsum(_p(x2), _p(y2), R, N, mode, scale, 1 if accumulate else 0, _p(out), _p(scratch), nsplit,
                                  _st()), "ptx_op_colsum")
