@@ -251,6 +251,18 @@ int ptx_forward(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, const v
  * (the caller then falls back to a stream synchronise, which also surfaces device faults). */
 int ptx_wait_counts(const int32_t *counts_host, int B, int64_t timeout_us);
 
+/* ------------------------------------------------------------------ voxel quantisation
+ * The step right after the path in the reference's detector (detectors/sparse_featfusion_grounder_preshape.py:388-397):
+ * ME.utils.batch_sparse_collate([(p[:, :3] / voxel_size, p) ...]) + ME.SparseTensor(coordinates, features), i.e.
+ * coordinates (b, floor(p / voxel_size)) int32 and ONE row per occupied voxel.  MinkowskiEngine is not vendored: the
+ * surviving duplicate / row order are pinned to the first point of every voxel in (scene, point) order.
+ * points (B,Ncap,3) with counts[b] valid rows per scene (device int32) = exactly the `out` / `counts` of ptx_forward;
+ * coords (B*Ncap,4) int32 and feats (B*Ncap,3) capacity; inverse (B,Ncap) int32 voxel row of every point (-1 past the
+ * valid rows) or NULL; nvox_overflow: 2 device int32 = {voxel rows written, points whose voxel index left +-2^18}. */
+size_t ptx_voxel_workspace_bytes(int B, int Ncap);
+int ptx_voxelize(const float *points, const int32_t *counts, int B, int Ncap, float voxel_size, int32_t *coords,
+                 float *feats, int32_t *inverse, int32_t *nvox_overflow, void *workspace, size_t ws_bytes, void *stream);
+
 /* ------------------------------------------------------------------ train-mode operators
  * The differentiable half of the path in train mode -- batch-statistics BatchNorm2d / BatchNorm1d (PRE:74, 114,
  * 329-330), Dropout (PRE:189-191, timm Mlp), DropPath (PRE:268) and the gradients of everything between the ball

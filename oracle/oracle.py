@@ -430,3 +430,28 @@ def forward_train(sd_np: Dict[str, np.ndarray], *, grid_size: int, dynamic_drop_
         out.update(loss=float(loss.item()), grads=grads, none_grads=none)
     out["buffers"] = {k: v.detach().numpy() for k, v in sd.items() if k.endswith(("running_mean", "running_var"))}
     return out
+
+
+# --------------------------------------------------------------------------
+# voxel quantisation right after the path -- PARITY UNPINNED against MinkowskiEngine
+# --------------------------------------------------------------------------
+def voxelize(outs, voxel_size: float = 0.01):
+    """detectors/sparse_featfusion_grounder_preshape.py:388-397 restated: ``batch_sparse_collate`` floors
+    ``p / voxel_size`` (fp32 division) to int32 and prepends the scene index; ``ME.SparseTensor`` keeps one row per
+    distinct coordinate.  MinkowskiEngine is not vendored under /root/reference and its choice of the surviving
+    duplicate / row order is unspecified ("random subsample"): pinned to the first point of every voxel in (scene,
+    point) order.  Returns coords (Nv,4) int32, feats (Nv,3) f32, list of per-scene inverse maps."""
+    coords, feats = [], []
+    for b, p in enumerate(outs):
+        p = _f32(p)
+        v = np.floor(p / np.float32(voxel_size)).astype(np.int32)
+        coords.append(np.concatenate([np.full((len(p), 1), b, np.int32), v], axis=1))
+        feats.append(p)
+    coords, feats = np.concatenate(coords), np.concatenate(feats)
+    _, first, inv = np.unique(coords, axis=0, return_index=True, return_inverse=True)
+    rows = np.sort(first)                                   # representatives in (scene, point) order
+    rank = np.empty(len(first), np.int64)
+    rank[np.argsort(first)] = np.arange(len(first))
+    inverse = rank[inv.reshape(-1)].astype(np.int32)
+    sizes = np.cumsum([0] + [len(p) for p in outs])
+    return coords[rows], feats[rows], [inverse[sizes[b]:sizes[b + 1]] for b in range(len(outs))]

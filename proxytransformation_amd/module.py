@@ -566,6 +566,47 @@ class ProxyTransformationNormReverse(nn.Module):
         return train.forward_train(self, list(points), tf, mask_u8, im, shape, ws, self._order_override)
 
     @torch.no_grad()
+    def quantize(self, outs: List[torch.Tensor], voxel_size: float = 0.01, return_inverse: bool = False):
+        """What the reference's detector does with this module's output next (detectors/
+        sparse_featfusion_grounder_preshape.py:388-397, ``use_xyz_feat``): ``ME.utils.batch_sparse_collate([(p / voxel_size,
+        p) ...])`` + ``ME.SparseTensor`` -- coordinates ``(Nv,4) int32 = (scene, floor(p / voxel_size))`` and features
+        ``(Nv,3)``, one row per occupied voxel (the first point of a voxel in (scene, point) order; MinkowskiEngine's own
+        choice is unspecified).  ``outs`` = the list ``forward`` returned (views of one padded buffer are used in place,
+        anything else is packed).  Runs on the current stream; one host sync for the row count."""
+        lib = _abi.lib()
+        B = len(outs)
+        dev = outs[0].device
+        n = [int(o.shape[0]) for o in outs]
+        base = outs[0]._base if outs[0]._base is not None else None
+        packed = base is not None and base.dim() == 3 and base.shape[0] == B and base.dtype == torch.float32 and all(
+            o._base is base and o.data_ptr() == base[b].data_ptr() for b, o in enumerate(outs))
+        if packed:
+            buf, Ncap = base, base.shape[1]
+        else:
+            Ncap = max(max(n), 1)
+            buf = torch.zeros((B, Ncap, 3), dtype=torch.float32, device=dev)
+            for b, o in enumerate(outs):
+                buf[b, : n[b]].copy_(o)
+        counts = torch.tensor(n, dtype=torch.int32).to(dev)
+        coords = torch.empty((B * Ncap, 4), dtype=torch.int32, device=dev)
+        feats = torch.empty((B * Ncap, 3), dtype=torch.float32, device=dev)
+        inverse = torch.empty((B, Ncap), dtype=torch.int32, device=dev) if return_inverse else None
+        info = torch.empty((2,), dtype=torch.int32, device=dev)
+        ws = torch.empty((lib.ptx_voxel_workspace_bytes(B, Ncap),), dtype=torch.uint8, device=dev)
+        if ws.numel() == 0:
+            raise RuntimeError(f"quantize: unsupported size B={B}, N={Ncap}")
+        _abi.check(lib.ptx_voxelize(buf.data_ptr(), counts.data_ptr(), B, Ncap, float(voxel_size), coords.data_ptr(),
+                                    feats.data_ptr(), _ptr(inverse), info.data_ptr(), ws.data_ptr(), ws.numel(),
+                                    torch.cuda.current_stream(dev).cuda_stream), "ptx_voxelize")
+        nvox, overflow = info.cpu().tolist()
+        if overflow:
+            raise RuntimeError(f"quantize: {overflow} points fall outside +-2^18 voxels of size {voxel_size}")
+        res = (coords[:nvox], feats[:nvox])
+        if return_inverse:
+            res += ([inverse[b, : n[b]] for b in range(B)],)
+        return res
+
+    @torch.no_grad()
     def forward_debug(self, points, text_dict, img_feat):
         """forward + every intermediate the C ABI can export (tests / parity only)."""
         outs, dbg = self._run(points, text_dict, img_feat, debug=True)

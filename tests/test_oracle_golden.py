@@ -72,3 +72,14 @@ def test_unstable_argsort_really_differs():
     """the as-shipped permutation is not the stable one, so both modes are exercised."""
     g = load_golden("g1_cfg1")
     assert not np.array_equal(g["order_stable"], g["order_shipped"])
+
+
+def test_voxel_restatement_keeps_the_first_point_of_every_voxel():
+    """oracle.voxelize (parity unpinned against MinkowskiEngine): floor(p / size) in fp32, scene index in
+    front, first point of a voxel in (scene, point) order survives, inverse maps consistent."""
+    a = np.array([[0.004, 0.0, 0.0], [0.013, 0.0, 0.0], [0.009, 0.0, 0.0], [-0.001, 0.5, 0.0]], np.float32)
+    b = np.array([[0.004, 0.0, 0.0], [0.004, 0.0, 0.0]], np.float32)
+    c, f, inv = oracle.voxelize([a, b], 0.01)
+    assert c.tolist() == [[0, 0, 0, 0], [0, 1, 0, 0], [0, -1, 50, 0], [1, 0, 0, 0]]
+    assert np.array_equal(f, np.stack([a[0], a[1], a[3], b[0]]))
+    assert inv[0].tolist() == [0, 1, 0, 2] and inv[1].tolist() == [3, 3]
