@@ -523,7 +523,9 @@ __global__ __launch_bounds__(256) void k_select(SelectArgs a)
     // the four wave candidates exchanged through LDS with one barrier, and every wave takes the same decision.
     // First-max tie-break (PRE:613): in-lane strict '>', across lanes the lowest set ballot bit, across waves the
     // lowest wave.  (One wave with all points, no barrier: 0.37 us per pick at Mt = 359 but 1.04 us at the
-    // shipped configuration's Mt = 1210 -- VALU-bound on one SIMD, 540 us for its 519 picks.)
+    // shipped configuration's Mt = 1210 -- VALU-bound on one SIMD, 540 us for its 519 picks.  Carrying the winner's
+    // coordinates through the candidate exchange instead of re-reading sx[last]: slower, 233 vs 215 us at Mt = 1210 --
+    // the per-lane select of the candidate's registers and three more LDS words cost more than the saved read.)
     const int kn = Kd < Mt ? Kd : Mt;                                            // PRE:595
     {
         // the whole scene waits on this latency-bound loop while bandwidth-bound kernels of the image branch
