@@ -238,7 +238,7 @@ bool img_pool_supported(int dt, int in_dim, int hw, int heads);
 size_t img_pool_bytes(int nimg, int in_dim, int EW);
 void img_pool_layout(float *scratch, int nimg, int in_dim, int EW, float **Gs, float **E, float **ML);
 int launch_img_pool(const void *img, int dt, const float *we, const float *qkv0, int nimg, int in_dim, int hw, int C,
-                    int KT1, int EW, float scale, float *scratch, hipStream_t st);
+                    int KT1, int EW, float scale, float *Gs, float *E, float *ML, hipStream_t st);
 
 // ---- prep (prep.hip) ----------------------------------------------------------------------------
 int run_prepare(const PtxShape &s, const PtxWeights &w, float *prep, hipStream_t st);

@@ -370,13 +370,11 @@ void img_pool_layout(float *scratch, int nimg, int in_dim, int EW, float **Gs, f
     *ML = *E + (size_t)nimg * kPoolHeads * EW;
 }
 
-// `scratch` = img_pool_bytes() bytes (Gs | E | ML, img_pool_layout)
+// Gs / E / ML: the three result arrays of img_pool_layout(), already offset to the first image of this launch
 int launch_img_pool(const void *img, int dt, const float *we, const float *qkv0, int nimg, int in_dim, int hw, int C,
-                    int KT1, int EW, float scale, float *scratch, hipStream_t st)
+                    int KT1, int EW, float scale, float *Gs, float *E, float *ML, hipStream_t st)
 {
     PTX_REQUIRE(EW % 4 == 0 && EW >= hw + 1 && hw > 128 && hw <= 255, "img pool: hw=%d EW=%d", hw, EW);
-    float *Gs, *E, *ML;
-    img_pool_layout(scratch, nimg, in_dim, EW, &Gs, &E, &ML);
     PoolArgs pa{static_cast<const unsigned short *>(img), we, qkv0, nimg, in_dim, hw, C, KT1, EW, scale, Gs, E, ML};
     const size_t lds = sizeof(float) * 8 * kPoolHeads * 128 + sizeof(unsigned short) * 24 * (kPoolWPad + kPoolPPad);
     PTX_REQUIRE(lds <= 64 * 1024, "img pool: %zu B of LDS", lds);
