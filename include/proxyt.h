@@ -263,6 +263,21 @@ size_t ptx_voxel_workspace_bytes(int B, int Ncap);
 int ptx_voxelize(const float *points, const int32_t *counts, int B, int Ncap, float voxel_size, int32_t *coords,
                  float *feats, int32_t *inverse, int32_t *nvox_overflow, void *workspace, size_t ws_bytes, void *stream);
 
+/* ------------------------------------------------------------------ image feature -> point sampling
+ * batch_point_sample (models/layers/fusion_layers/point_fusion.py:208-313) as called at detectors/
+ * sparse_featfusion_grounder_preshape.py:428-444 (nearest, zeros padding, align_corners=True, valid_flag=True):
+ * out (N,C) = sum over ALL V views of the nearest feature pixel / max(#views in which the point is inside the padded
+ * image with depth > 0, 1), zero rows where that count is 0.  feats (V,C,H,W) fp32 / bf16 / fp16 (feat_dtype 0/1/2);
+ * proj (V,4,4) row-major = intrinsic @ extrinsic; pre: optional (3,4) affine applied to the points first (the reverse
+ * 3D augmentation of apply_3d_transformation, composed by the host) or NULL; image transform scale -> crop -> flip
+ * (flip: x = ori_w - x); pad_h / pad_w: padded image size.  workspace: ptx_point_sample_workspace_bytes() bytes (one
+ * channels-last copy of the feature maps).  valid_num (N) int32 optional. */
+size_t ptx_point_sample_workspace_bytes(int V, int C, int H, int W);
+int ptx_point_sample(const float *points, int N, const void *feats, int feat_dtype, int V, int C, int H, int W,
+                     const float *proj, const float *pre, float scale_w, float scale_h, float crop_w, float crop_h, int flip,
+                     float ori_w, float pad_h, float pad_w, float *out, int32_t *valid_num, void *workspace, size_t ws_bytes,
+                     void *stream);
+
 /* ------------------------------------------------------------------ train-mode operators
  * The differentiable half of the path in train mode -- batch-statistics BatchNorm2d / BatchNorm1d (PRE:74, 114,
  * 329-330), Dropout (PRE:189-191, timm Mlp), DropPath (PRE:268) and the gradients of everything between the ball

@@ -455,3 +455,55 @@ def voxelize(outs, voxel_size: float = 0.01):
     inverse = rank[inv.reshape(-1)].astype(np.int32)
     sizes = np.cumsum([0] + [len(p) for p in outs])
     return coords[rows], feats[rows], [inverse[sizes[b]:sizes[b + 1]] for b in range(len(outs))]
+
+
+# --------------------------------------------------------------------------
+# image feature -> point sampling after the backbone
+# --------------------------------------------------------------------------
+def _fma32(a, b, c):
+    """fp32 fused multiply-add, emulated: the product of two fp32 values is exact in double."""
+    return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
+
+
+def point_sample(points, feats, proj, *, scale=(1.0, 1.0), crop=(0.0, 0.0), flip=False, ori_w=0.0, pad_hw=(480.0, 640.0)):
+    """batch_point_sample (models/layers/fusion_layers/point_fusion.py:208-313) as the detector calls it
+    (detectors/sparse_featfusion_grounder_preshape.py:428-444: nearest sampling, zeros padding, align_corners=True,
+    valid_flag=True), for points already in the projectable frame (the reverse 3D augmentation of
+    apply_3d_transformation is host-side metadata).  feats (V,C,H,W), proj (V,4,4) = intrinsic @ extrinsic.
+    Per view: q = P [x y z 1]; (u, v) = q[:2] / max(q[2], 1e-3) (structures/bbox_3d/utils.py:324-327); image
+    transform scale -> crop -> flip; normalise by the padded size; nearest pixel (round half to even); a view is valid
+    when 0 < x < w_pad, 0 < y < h_pad and depth > 0; result = sum of ALL views' samples / max(#valid, 1), zero rows
+    where no view is valid (point_fusion.py:299-311)."""
+    p = _f32(points)
+    f = _f32(feats)
+    P = _f32(proj)
+    V, C, H, W = f.shape
+    N = p.shape[0]
+    pad_h, pad_w = np.float32(pad_hw[0]), np.float32(pad_hw[1])
+    acc = np.zeros((N, C), np.float32)
+    nvalid = np.zeros(N, np.int64)
+    one = np.float32(1.0)
+    for v in range(V):
+        q = []
+        for r in range(3):
+            t = p[:, 0] * P[v, r, 0]
+            t = _fma32(p[:, 1], np.full(N, P[v, r, 1], np.float32), t)
+            t = _fma32(p[:, 2], np.full(N, P[v, r, 2], np.float32), t)
+            q.append(t + P[v, r, 3])
+        z = np.maximum(q[2], np.float32(1e-3))
+        cx = (q[0] / z) * np.float32(scale[0]) - np.float32(crop[0])
+        cy = (q[1] / z) * np.float32(scale[1]) - np.float32(crop[1])
+        if flip:
+            cx = np.float32(ori_w) - cx
+        nx = cx / pad_w * np.float32(2) - one
+        ny = cy / pad_h * np.float32(2) - one
+        ix = np.rint(((nx + one) / np.float32(2)) * np.float32(W - 1))
+        iy = np.rint(((ny + one) / np.float32(2)) * np.float32(H - 1))
+        inb = (ix >= 0) & (ix <= W - 1) & (iy >= 0) & (iy <= H - 1)
+        ixi, iyi = np.where(inb, ix, 0).astype(np.int64), np.where(inb, iy, 0).astype(np.int64)
+        samp = f[v][:, iyi, ixi].T                         # (N,C)
+        acc = acc + np.where(inb[:, None], samp, np.float32(0))
+        nvalid += (cx < pad_w) & (cx > 0) & (cy < pad_h) & (cy > 0) & (q[2] > 0)
+    out = acc / np.maximum(nvalid, 1)[:, None].astype(np.float32)
+    out[nvalid == 0] = 0
+    return out, nvalid

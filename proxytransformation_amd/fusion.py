@@ -1,0 +1,67 @@
+"""Image feature -> point sampling on the GPU: the reference's ``batch_point_sample``
+(embodiedscan/models/layers/fusion_layers/point_fusion.py:208-313) with the argument list its detector uses
+(detectors/sparse_featfusion_grounder_preshape.py:428-444), executed by ``ptx_point_sample`` (csrc/pointsample.hip)."""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+
+from . import _abi
+
+_DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+
+
+def _pair(v, dev):
+    if isinstance(v, torch.Tensor):
+        v = v.detach().cpu().tolist()
+    if isinstance(v, (int, float)):
+        return float(v), float(v)
+    return float(v[0]), float(v[1])
+
+
+def batch_point_sample(img_meta: Optional[dict], img_features: torch.Tensor, points: torch.Tensor, proj_mat: torch.Tensor,
+                       coord_type: str = "DEPTH", img_scale_factor=1.0, img_crop_offset=0.0, img_flip: bool = False,
+                       img_pad_shape: Sequence[int] = (480, 640), img_shape: Sequence[int] = (480, 640),
+                       aligned: bool = False, padding_mode: str = "zeros", align_corners: bool = True,
+                       valid_flag: bool = True, pre_transform: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Same arguments as the reference function.  img_features (V,C,H,W) on the GPU (fp32 / bf16 / fp16), points (N,3)
+    fp32, proj_mat (V,4,4) = intrinsic @ extrinsic.  Returns (N,C) fp32.
+
+    Only the mode the detector uses is implemented in HIP (nearest sampling, zeros padding, align_corners, valid_flag).
+    The reverse 3D augmentation of ``apply_3d_transformation`` (point_fusion.py:20-107) is metadata: pass it as
+    ``pre_transform`` (3,4) if ``img_meta`` records a ``transformation_3d_flow``."""
+    if aligned or padding_mode != "zeros" or not align_corners or not valid_flag:
+        raise NotImplementedError("HIP path: aligned=False, padding_mode='zeros', align_corners=True, valid_flag=True "
+                                  "(the call at sparse_featfusion_grounder_preshape.py:428-444)")
+    if img_meta and img_meta.get("transformation_3d_flow") and pre_transform is None:
+        raise NotImplementedError("img_meta carries a 3D augmentation flow: compose its reverse into pre_transform (3,4)")
+    if not (img_features.is_cuda and points.is_cuda and proj_mat.is_cuda):
+        raise RuntimeError("batch_point_sample (HIP) needs GPU tensors: there is no CPU path")
+    if img_features.dtype not in _DT:
+        img_features = img_features.float()
+    V, C, H, W = img_features.shape
+    feats = img_features.contiguous()
+    pts = points.detach().to(torch.float32).contiguous()
+    proj = proj_mat.detach().to(torch.float32).contiguous()
+    if proj.shape != (V, 4, 4) or pts.dim() != 2 or pts.shape[1] != 3:
+        raise RuntimeError(f"expected points (N,3) and proj_mat ({V},4,4), got {tuple(pts.shape)}, {tuple(proj.shape)}")
+    N = pts.shape[0]
+    dev = pts.device
+    out = torch.empty((N, C), dtype=torch.float32, device=dev)
+    if N == 0:
+        return out
+    lib = _abi.lib()
+    nbytes = lib.ptx_point_sample_workspace_bytes(V, C, H, W)
+    if nbytes == 0:
+        raise RuntimeError(f"unsupported feature shape {tuple(img_features.shape)} (C <= 512)")
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    sw, sh = _pair(img_scale_factor, dev)
+    cw, ch = _pair(img_crop_offset, dev)
+    pre = None if pre_transform is None else pre_transform.detach().to(device=dev, dtype=torch.float32).contiguous()
+    _abi.check(lib.ptx_point_sample(pts.data_ptr(), N, feats.data_ptr(), _DT[feats.dtype], V, C, H, W, proj.data_ptr(),
+                                    None if pre is None else pre.data_ptr(), sw, sh, cw, ch, 1 if img_flip else 0,
+                                    float(img_shape[1]), float(img_pad_shape[0]), float(img_pad_shape[1]), out.data_ptr(),
+                                    None, ws.data_ptr(), ws.numel(), torch.cuda.current_stream(dev).cuda_stream),
+               "ptx_point_sample")
+    return out

@@ -396,6 +396,89 @@ def run_train_case(reg, cfg: PreshapeConfig):
           f"-> {os.path.getsize(path) / 1e6:.2f} MB")
 
 
+# ----------------------------------------------------------------------------- image -> point sampling
+def gen_point_sample():
+    """batch_point_sample (models/layers/fusion_layers/point_fusion.py:208-313) exactly as the detector calls it
+    (detectors/sparse_featfusion_grounder_preshape.py:428-444: aligned=False -> nearest, zeros padding, align_corners,
+    valid_flag), run from the reference file with stand-ins for its framework imports.  Points whose projection lands
+    within 1e-3 px of a rounding / validity boundary in any view are filtered out (fp32 bmm order is not pinned)."""
+    import types
+    ref = "/root/reference/embodiedscan"
+    mm = types.ModuleType("mmcv"); mmc = types.ModuleType("mmcv.cnn"); mmc.ConvModule = nn.Module
+    me = types.ModuleType("mmengine"); mem = types.ModuleType("mmengine.model"); mem.BaseModule = nn.Module
+    p3t = types.ModuleType("pytorch3d.transforms"); p3t.euler_angles_to_matrix = lambda *a, **k: None
+    eu = types.ModuleType("embodiedscan.utils"); eu.ConfigType = dict
+    sys.modules.update({"mmcv": mm, "mmcv.cnn": mmc, "mmengine": me, "mmengine.model": mem, "pytorch3d.transforms": p3t,
+                        "embodiedscan.utils": eu})
+
+    def load(name, path):
+        spec = importlib.util.spec_from_file_location(name, path)
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[name] = mod
+        spec.loader.exec_module(mod)
+        return mod
+    load("embodiedscan.utils.array_converter", ref + "/utils/array_converter.py")
+    b3 = load("embodiedscan.structures.bbox_3d", ref + "/structures/bbox_3d/utils.py")
+    b3.get_proj_mat_by_coord_type = lambda *a, **k: None
+    pts_mod = types.ModuleType("embodiedscan.structures.points")
+
+    class _Pts:                     # no 3D augmentation in img_meta: the flow is empty, only .coord is used
+        def __init__(self, t):
+            self.coord = t
+
+        def scale(self, *a, **k): raise AssertionError("empty flow")
+        translate = rotate = flip = scale
+    pts_mod.get_points_type = lambda coord_type: _Pts
+    sys.modules["embodiedscan.structures.points"] = pts_mod
+    pf = load("pf_ref", ref + "/models/layers/fusion_layers/point_fusion.py")
+
+    rng = np.random.default_rng(123)
+    V, C, H, W, N = 6, 32, 30, 40, 4000
+    pad_h, pad_w = 480.0, 640.0
+    feats = rng.standard_normal((V, C, H, W), dtype=np.float32)
+    proj = np.zeros((V, 4, 4), np.float32)
+    for v in range(V):                                   # pin-hole cameras on a ring looking at the scene centre
+        ang = 2 * np.pi * v / V
+        R = np.array([[np.cos(ang), 0, -np.sin(ang)], [0, 1, 0], [np.sin(ang), 0, np.cos(ang)]], np.float64)
+        t = np.array([0.3 * v - 0.5, 0.2, 4.0 + 0.3 * v])
+        ext = np.eye(4); ext[:3, :3] = R; ext[:3, 3] = t
+        K = np.eye(4); K[0, 0] = K[1, 1] = 420.0 + 10 * v; K[0, 2] = 320.0; K[1, 2] = 240.0
+        proj[v] = (K @ ext).astype(np.float32)
+    points = ((rng.random((N, 3)) - 0.5) * np.array([9.0, 6.0, 9.0])).astype(np.float32)
+    save = dict(feats=feats, proj=proj, pad=np.array([pad_h, pad_w], np.float32))
+    for name, scale, crop, flip in (("plain", (1.0, 1.0), (0.0, 0.0), False), ("aug", (0.9, 1.1), (12.0, -7.0), True)):
+        pts_t, proj_t = torch.from_numpy(points), torch.from_numpy(proj)
+        # boundary filter, in float64
+        p4 = np.concatenate([points.astype(np.float64), np.ones((N, 1))], 1)
+        q = np.einsum("vrk,nk->vnr", proj.astype(np.float64), p4)
+        z = np.maximum(q[..., 2], 1e-3)
+        cx = q[..., 0] / z * scale[0] - crop[0]
+        cy = q[..., 1] / z * scale[1] - crop[1]
+        if flip:
+            cx = 480.0 * 1.3 - cx
+        ix = ((cx / pad_w * 2 - 1) + 1) / 2 * (W - 1)
+        iy = ((cy / pad_h * 2 - 1) + 1) / 2 * (H - 1)
+        safe = np.ones(N, bool)
+        for arr, lim in ((ix, None), (iy, None)):
+            frac = np.abs(arr - np.floor(arr) - 0.5)
+            safe &= (frac > 1e-3).all(0)
+        for arr, hi in ((cx, pad_w), (cy, pad_h)):
+            safe &= (np.abs(arr) > 1e-2).all(0) & (np.abs(arr - hi) > 1e-2).all(0)
+        safe &= (np.abs(q[..., 2]) > 1e-2).all(0) & (np.abs(q[..., 2] - 1e-3) > 1e-4).all(0)
+        sel = np.nonzero(safe)[0][:1500]
+        out = pf.batch_point_sample({}, img_features=torch.from_numpy(feats), points=pts_t[sel], proj_mat=proj_t,
+                                    coord_type="DEPTH", img_scale_factor=torch.tensor(scale), img_crop_offset=torch.tensor(crop),
+                                    img_flip=flip, img_pad_shape=(int(pad_h), int(pad_w)), img_shape=(600, int(480 * 1.3)),
+                                    aligned=False)
+        save[f"{name}_points"] = points[sel]
+        save[f"{name}_out"] = out.numpy()
+        save[f"{name}_cfg"] = np.array([scale[0], scale[1], crop[0], crop[1], float(flip), 480 * 1.3], np.float32)
+        print(f"g5_point_sample/{name}: {len(sel)} points, nonzero rows {(np.abs(out.numpy()).sum(1) > 0).sum()}")
+    path = os.path.join(HERE, "g5_point_sample.npz")
+    np.savez_compressed(path, **save)
+    print(f"g5_point_sample -> {os.path.getsize(path) / 1e6:.2f} MB")
+
+
 def write_manifest(reg):
     """Key / shape / dtype manifest of the reference module's state_dict (data, not code)."""
     import json
@@ -426,6 +509,8 @@ def main():
         run_case(reg, cfg)
     if not only or TRAIN_CASE.name in only:
         run_train_case(reg, TRAIN_CASE)
+    if not only or "g5_point_sample" in only:
+        gen_point_sample()
 
 
 if __name__ == "__main__":
