@@ -200,6 +200,7 @@ class ProxyTransformationNormReverse(nn.Module):
         self._slots = None
         self._lanes: Dict[tuple, _Lane] = {}
         self._train_calls = 0
+        self._warned_eval_grad = False
         self._lin_t = None
         # stochastic-depth rate of the blocks that are live (the last of each list; PRE:298-299)
         self._text_dpr = float(torch.linspace(0, drop_path_rate, text_blocks)[-1])
@@ -526,6 +527,11 @@ class ProxyTransformationNormReverse(nn.Module):
                 return outs, {k: aux[k].view(len(points), self.real_cluster_num, -1)
                               for k in ("kcenter", "translate", "transform")}
             return self._run_train(points, text_dict, img_feat)[0]
+        if torch.is_grad_enabled() and not self._warned_eval_grad and any(p.requires_grad for p in self.parameters()):
+            import warnings
+            self._warned_eval_grad = True
+            warnings.warn("ProxyTransformationNormReverse in eval mode returns tensors without grad_fn (the eval path is "
+                          "inference-only HIP); call .train() to differentiate, or wrap the call in torch.no_grad()")
         chunks = [(0, len(points))]
         if isinstance(points, (list, tuple)) and len(points) > _MAX_SCENES_PER_CALL:
             # scenes are independent in eval mode: larger batches run as consecutive calls
