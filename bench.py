@@ -68,6 +68,9 @@ def parse():
     ap.add_argument("--no-passes", action="store_true", help="skip roofline_passes / fp32-feature extras")
     ap.add_argument("--cpu-scenes", type=int, default=None, help="scenes in the CPU baseline sample")
     ap.add_argument("--breakdown", action="store_true", help="print per-kernel event timings to stderr")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (nccl = RCCL)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="test aid for 1-GPU boxes: every rank uses cuda:0 (with --backend gloo); numbers are meaningless")
     return ap.parse_args()
 
 
@@ -268,12 +271,15 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path to measure)"
-    device = torch.device("cuda", local)
+    device = torch.device("cuda", 0 if args.share_gpu else local)
     torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     cfg = CONFIGS[args.config]
     B = args.scenes_per_gpu or cfg.B
@@ -328,7 +334,7 @@ def main():
                   file=sys.stderr)
 
     vals = [elapsed, extras.get("f32", 0.0)]
-    t = torch.tensor(vals, device=device, dtype=torch.float64)
+    t = torch.tensor(vals, device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, f32_step = (float(x) for x in t.tolist())

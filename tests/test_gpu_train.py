@@ -252,13 +252,16 @@ def test_training_step_matches_the_reference_capture():
         assert_close(buf.detach().cpu().numpy(), g["buf." + name], atol=1e-5, rtol=1e-5, what=name)
 
 
-@pytest.mark.parametrize("case", ["f32", "bf16_blocks3"])
+@pytest.mark.parametrize("case", ["f32", "bf16_blocks3", "embed512_f16"])
 def test_training_step_matches_the_oracle_on_fresh_scenes(case):
     from oracle import oracle
     from proxytransformation_amd import MODELS
     from tests.gpu_util import t
     if case == "f32":
         cfg, dt = PreshapeConfig("tr1", B=3, N=5000, grid_size=5, dynamic_drop_radio=0.6, L=9, V=4, seed_base=8100), torch.float32
+    elif case == "embed512_f16":      # the cfg5 generalisation (512-wide tokens, head_dim 64, 23 x 23 bias grid cropped)
+        cfg, dt = PreshapeConfig("tr5", B=2, N=2500, grid_size=4, dynamic_drop_radio=0.5, L=7, V=3, embed_dim=512,
+                                 seed_base=8400), torch.float16
     else:
         cfg, dt = PreshapeConfig("tr2", B=2, N=2500, grid_size=4, dynamic_drop_radio=0.5, L=5, V=2, text_blocks=3,
                                  img_blocks=3, seed_base=8200), torch.bfloat16
