@@ -52,6 +52,14 @@
 //     every case -- the second read gets nothing from the 256 MiB cache; the kernel waits on its own load / compute
 //     phases, not on DRAM.  Two independent batches in flight on two streams: no gain either (12.7-13.9k scenes/s):
 //     the resident pooling work-groups fill the register files and the other batch's small kernels stretch 3-5x
+//   * r02, two more attempts at hiding a unit's load wait: (a) every other image of the first residents started half a
+//     period late (s_sleep) so that half of the chip streams while the other half computes: purely additive, +5 us per
+//     3.4 us of delay -- the launch is not bandwidth-bound in rounds, each slot simply runs ~3 units of fixed latency;
+//     (b) a persistent work-group per CU with two register sets (242 VGPRs, no spills), the next unit's 28 loads issued
+//     before the current unit is processed, LDS-only barriers (s_waitcnt lgkmcnt(0); s_barrier): 107 us on 256
+//     work-groups, 146 us on 128 -- 11.9-17.5 us per unit, i.e. no overlap at all: across the loop's back edge hipcc's
+//     wait-count pass falls back to s_waitcnt vmcnt(0) in stage 1, so the prefetch is drained before it can help;
+//     making it work needs the loads and their waits in inline assembly
 #include <cstdlib>
 
 #include "common.h"
