@@ -30,6 +30,6 @@ for dt in bf16 f32; do
 done
 python $R/tools/profile_digest.py "$O" "$TAG"
 for dt in bf16 f32; do
-  python $R/tools/timeline.py "$(find "$O/stats_$dt" -name '*kernel_trace.csv' | head -1)" 60 > "$O/${TAG}_timeline_$dt.txt" 2>/dev/null
+  python $R/tools/timeline.py "$(find "$O/stats_$dt" -name '*kernel_trace.csv' | head -1)" > "$O/${TAG}_timeline_$dt.txt" 2>/dev/null
 done
 ls "$O"

@@ -6,11 +6,14 @@ import sys
 
 
 def main():
-    fn, step = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 60
+    fn, step = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else -1
     rows = [r for r in csv.DictReader(open(fn))]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     # a step starts at each k_img_mean* launch
     starts = [i for i, r in enumerate(rows) if "k_img_mean" in r["Kernel_Name"]]
+    # the profiler makes some steps host-bound: take the shortest step among the last ones (the GPU-bound steady state)
+    cand = range(max(1, len(starts) - 40), len(starts) - 1) if step < 0 else [step]
+    step = min(cand, key=lambda i: int(rows[starts[i + 1]]["Start_Timestamp"]) - int(rows[starts[i]]["Start_Timestamp"]))
     a, b = starts[step], starts[step + 1]
     t0 = int(rows[a]["Start_Timestamp"])
     prev_end = None
