@@ -294,6 +294,8 @@ int ptx_point_sample(const float *points, int N, const void *feats, int feat_dty
 int ptx_op_gemm(const void *A, const void *B, float *C, int M, int N, int K, long a_rs, long a_cs, long b_rs, long b_cs,
                 long c_rs, long c_cs, int batch, int inner, long a_s1, long a_s2, long b_s1, long b_s2, long c_s1, long c_s2,
                 int a_dtype, int b_dtype, float alpha, int accumulate, int ksplit, long c_sk, void *stream);
+/* out (cols,rows) = in (rows,cols)^T */
+int ptx_op_transpose(const float *in, int rows, int cols, float *out, void *stream);
 /* out[n] (+)= scale * sum_r f(x[r][n]), accumulated in double; mode 0: x, 1: x*y, 2: x*x, 3: (x - y[n])^2 with y a
  * per-column vector (bias / LayerNorm / BatchNorm parameter gradients, batch statistics) */
 int ptx_op_colsum(const float *x, const float *y, int R, int N, int mode, float scale, int accumulate, float *out,

@@ -123,6 +123,16 @@ using namespace ptx;
 
 extern "C" {
 
+/* out (cols, rows) = in (rows, cols)^T, fp32 (train mode: transposed weights for the input-gradient GEMMs) */
+int ptx_op_transpose(const float *in, int rows, int cols, float *out, void *stream)
+{
+    PTX_REQUIRE(in && out && rows >= 1 && cols >= 1, "ptx_op_transpose: bad arguments");
+    hipLaunchKernelGGL(k_feat_transpose, dim3(cdiv(cols, 32), cdiv(rows, 32), 1), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       in, 0, rows, cols, out);
+    PTX_LAUNCHED("k_feat_transpose");
+    return PTX_OK;
+}
+
 size_t ptx_point_sample_workspace_bytes(int V, int C, int H, int W)
 {
     if (V < 1 || C < 1 || C > 64 * kPsMaxQ || H < 1 || W < 1) return 0;

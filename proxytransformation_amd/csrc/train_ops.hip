@@ -40,11 +40,11 @@ __device__ __forceinline__ float load_a(const void *base, long off, int dt)
     return (float)h;
 }
 
-constexpr int TBK = 16;
+constexpr int TBK = 32;
 __global__ __launch_bounds__(256) void k_bgemm(BGemmArgs g)
 {
-    __shared__ float As[64][TBK + 1];
-    __shared__ float Bs[TBK][64 + 1];
+    __shared__ __attribute__((aligned(16))) float As[64][TBK + 4];     // 144-B rows: b128 fragment reads, conflict-free
+    __shared__ __attribute__((aligned(16))) float Bs[64][TBK + 4];     // B tile stored n-major: Bs[n][k]
     const int zz = blockIdx.z, z = zz / g.ksplit, ks = zz - z * g.ksplit, z1 = z / g.inner, z2 = z - z1 * g.inner;
     const long ao = z1 * g.a_s1 + z2 * g.a_s2, bo = z1 * g.b_s1 + z2 * g.b_s2, co = z1 * g.c_s1 + z2 * g.c_s2 + ks * g.c_sk;
     const int kper = ((g.K + g.ksplit - 1) / g.ksplit + TBK - 1) / TBK * TBK;
@@ -61,25 +61,54 @@ __global__ __launch_bounds__(256) void k_bgemm(BGemmArgs g)
     // staging maps: pick the thread -> element map whose fastest index follows the unit stride of the operand
     const bool a_k_fast = g.a_cs == 1 || g.a_rs != 1;       // A: contiguous along k (or neither)
     const bool b_n_fast = g.b_cs == 1 || g.b_rs != 1;       // B: contiguous along n
+    constexpr int E = 64 * TBK / 256;                       // elements of each tile per thread
+    int am[E], ak[E], bk[E], bn[E];
+    long aoff[E], boff[E];                                  // element offsets at k0 = kbeg (advanced by TBK * stride per step)
+    bool aok[E], bok[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int idx = tid + 256 * e;
+        if (a_k_fast) { am[e] = idx / TBK; ak[e] = idx % TBK; } else { ak[e] = idx / 64; am[e] = idx % 64; }
+        if (b_n_fast) { bk[e] = idx / 64; bn[e] = idx % 64; } else { bn[e] = idx / TBK; bk[e] = idx % TBK; }
+        aok[e] = row0 + am[e] < g.M; bok[e] = col0 + bn[e] < g.N;
+        aoff[e] = ao + (long)(row0 + am[e]) * g.a_rs + (long)(kbeg + ak[e]) * g.a_cs;
+        boff[e] = bo + (long)(kbeg + bk[e]) * g.b_rs + (long)(col0 + bn[e]) * g.b_cs;
+    }
+    const long astep = (long)TBK * g.a_cs, bstep = (long)TBK * g.b_rs;
+    const bool plain = g.a_dtype == 0 && g.b_dtype == 0;   // uniform: the fp32 x fp32 case skips the type dispatch
+    float ra[E], rb[E];
+    // the tile of step k0 is fetched into registers while the previous one is multiplied out of LDS
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const bool av = aok[e] && k0 + ak[e] < kend, bv = bok[e] && k0 + bk[e] < kend;
+            if (plain) {
+                ra[e] = av ? static_cast<const float *>(g.A)[aoff[e]] : 0.0f;
+                rb[e] = bv ? static_cast<const float *>(g.B)[boff[e]] : 0.0f;
+            } else {
+                ra[e] = av ? load_a(g.A, aoff[e], g.a_dtype) : 0.0f;
+                rb[e] = bv ? load_a(g.B, boff[e], g.b_dtype) : 0.0f;
+            }
+            aoff[e] += astep; boff[e] += bstep;
+        }
+    };
+    if (kbeg < kend) fetch(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += TBK) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int idx = tid + 256 * e;                  // 1024 elements of each tile
-            int m, k;
-            if (a_k_fast) { m = idx / TBK; k = idx % TBK; } else { k = idx / 64; m = idx % 64; }
-            const int gm = row0 + m, gk = k0 + k;
-            As[m][k] = (gm < g.M && gk < kend) ? load_a(g.A, ao + gm * g.a_rs + gk * g.a_cs, g.a_dtype) : 0.0f;
-            int kb, n;
-            if (b_n_fast) { kb = idx / 64; n = idx % 64; } else { n = idx / TBK; kb = idx % TBK; }
-            const int gn = col0 + n, gkb = k0 + kb;
-            Bs[kb][n] = (gn < g.N && gkb < kend) ? load_a(g.B, bo + gkb * g.b_rs + gn * g.b_cs, g.b_dtype) : 0.0f;
+        for (int e = 0; e < E; ++e) { As[am[e]][ak[e]] = ra[e]; Bs[bn[e]][bk[e]] = rb[e]; }
+        __syncthreads();
+        if (k0 + TBK < kend) fetch(k0 + TBK);
+#pragma unroll
+        for (int kk = 0; kk < TBK / 8; ++kk) {          // lanes hh = 0 / 1 contract k = 8 kk + j and 8 kk + 4 + j
+            const float4 a4 = *reinterpret_cast<const float4 *>(&As[wr * 32 + li][kk * 8 + hh * 4]);
+            const float4 b4 = *reinterpret_cast<const float4 *>(&Bs[wc * 32 + li][kk * 8 + hh * 4]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
         }
         __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < TBK / 2; ++kk)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[wr * 32 + li][kk * 2 + hh], Bs[kk * 2 + hh][wc * 32 + li], acc, 0, 0, 0);
-        __syncthreads();
-        if ((((k0 - kbeg) / TBK) & 15) == 15) {
+        if ((((k0 - kbeg) / TBK) & 7) == 7) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) { dacc[i] += (double)acc[i]; acc[i] = 0.0f; }
         }
@@ -123,7 +152,14 @@ __global__ __launch_bounds__(256) void k_colsum(const float *__restrict__ x, con
     double s = 0.0;
     if (c < N) {
         const float yc = mode == 3 ? y[c] : 0.0f;
-        for (int r = sp * 4 + sl; r < R; r += 4 * nsplit) s += colsum_term(x, y, (size_t)r, N, c, mode, yc);
+        const int step = 4 * nsplit;
+        int r = sp * 4 + sl;
+        for (; r + 3 * step < R; r += 4 * step) {           // four rows in flight; summed in row order
+            const double t0 = colsum_term(x, y, (size_t)r, N, c, mode, yc), t1 = colsum_term(x, y, (size_t)r + step, N, c, mode, yc);
+            const double t2 = colsum_term(x, y, (size_t)r + 2 * step, N, c, mode, yc), t3 = colsum_term(x, y, (size_t)r + 3 * step, N, c, mode, yc);
+            s += t0; s += t1; s += t2; s += t3;
+        }
+        for (; r < R; r += step) s += colsum_term(x, y, (size_t)r, N, c, mode, yc);
     }
     red[sl][threadIdx.x & 63] = s;
     __syncthreads();

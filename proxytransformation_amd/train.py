@@ -148,17 +148,41 @@ class _Add(torch.autograd.Function):
         return g, g
 
 
+def _tuned_ok(*tensors_and_k):
+    """The eval path's tuned NT GEMM (ptx_linear) takes dense fp32 operands with n_in % 4 == 0, 16-byte aligned."""
+    *ts, k = tensors_and_k
+    return k % 4 == 0 and k >= 4 and all(t.data_ptr() % 16 == 0 for t in ts)
+
+
+def linear_nt(x, w2, b=None):
+    """x (R,K) @ w2 (N,K)^T (+ b): the tuned MFMA kernel where its layout rules hold, the strided one otherwise."""
+    R, K = x.shape
+    N = w2.shape[0]
+    if _tuned_ok(x, w2, K):
+        y = torch.empty((R, N), dtype=_F32, device=x.device)
+        _ck(_abi.lib().ptx_linear(_p(x), _p(w2), _p(b), None, _p(y), R, N, K, 0, _st()), "ptx_linear")
+        return y
+    y = mm(x, w2, tb=True)
+    if b is not None:
+        eltwise(6, y, b, ncol=N, out=y)
+    return y
+
+
+def transpose2d(x2):
+    r, c = x2.shape
+    out = torch.empty((c, r), dtype=_F32, device=x2.device)
+    _ck(_abi.lib().ptx_op_transpose(_p(x2), r, c, _p(out), _st()), "ptx_op_transpose")
+    return out
+
+
 class _Linear(torch.autograd.Function):
     """y = x w^T + b (nn.Linear / 1x1 convolutions); w may be any contiguous tensor whose leading dim is n_out."""
 
     @staticmethod
     def forward(ctx, x, w, b):
         x = _c(x)
-        R, K = x.shape
         w2 = w.reshape(w.shape[0], -1)
-        y = mm(x, w2, tb=True)
-        if b is not None:
-            eltwise(6, y, b, ncol=w2.shape[0], out=y)
+        y = linear_nt(x, w2, b)
         ctx.save_for_backward(x, w)
         ctx.has_b = b is not None
         return y
@@ -168,7 +192,9 @@ class _Linear(torch.autograd.Function):
         x, w = ctx.saved_tensors
         dy = _c(dy)
         w2 = w.reshape(w.shape[0], -1)
-        dx = mm(dy, w2) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:     # dy (R,N) @ w2 (N,K) = dy @ (w2^T)^T: NT again with the transposed weight
+            dx = linear_nt(dy, transpose2d(w2)) if _tuned_ok(dy, dy.shape[1]) and w2.shape[1] % 4 == 0 else mm(dy, w2)
         dw = mm(dy, x, ta=True).view_as(w) if ctx.needs_input_grad[1] else None
         db = colsum(dy) if (ctx.has_b and ctx.needs_input_grad[2]) else None
         return dx, dw, db
