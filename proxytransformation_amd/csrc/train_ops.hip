@@ -143,38 +143,85 @@ __device__ __forceinline__ double colsum_term(const float *__restrict__ x, const
     const double d = (double)a - (double)yc;
     return d * d;
 }
-// stage 1: block (column tile, row split) -> part[split][c]; rows are dealt to the 4 * nsplit slices round-robin
+// stage 1: block (column tile, row split) -> part[split][c]; rows are dealt to the 4 * nsplit slices round-robin.
+// V = 4: a thread owns four adjacent columns (16-B loads: the big reductions run over 10^5 rows of 256 columns and are
+// pure streaming); V = 1: any N / alignment.
+template <int V>
 __global__ __launch_bounds__(256) void k_colsum(const float *__restrict__ x, const float *__restrict__ y, int R, int N,
                                                 int mode, int nsplit, double *__restrict__ part)
 {
-    __shared__ double red[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6, sp = blockIdx.y;
-    double s = 0.0;
-    if (c < N) {
-        const float yc = mode == 3 ? y[c] : 0.0f;
+    __shared__ double red[4][64 * V];
+    const int c0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * V, sl = threadIdx.x >> 6, sp = blockIdx.y;
+    double s[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) s[v] = 0.0;
+    if (c0 < N) {
+        float yc[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) yc[v] = (mode == 3 && c0 + v < N) ? y[c0 + v] : 0.0f;
         const int step = 4 * nsplit;
+        auto term = [&](size_t r, double (&t)[V]) {
+            float a[V], b[V];
+            if (V == 4) {
+                const float4 q = *reinterpret_cast<const float4 *>(x + r * N + c0);
+                a[0] = q.x; a[1 % V] = q.y; a[2 % V] = q.z; a[3 % V] = q.w;
+                if (mode == 1) { const float4 w = *reinterpret_cast<const float4 *>(y + r * N + c0); b[0] = w.x; b[1 % V] = w.y; b[2 % V] = w.z; b[3 % V] = w.w; }
+            } else {
+                a[0] = x[r * N + c0];
+                if (mode == 1) b[0] = y[r * N + c0];
+            }
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                if (mode == 0) t[v] = (double)a[v];
+                else if (mode == 1) t[v] = (double)a[v] * (double)b[v];
+                else if (mode == 2) t[v] = (double)a[v] * (double)a[v];
+                else { const double d = (double)a[v] - (double)yc[v]; t[v] = d * d; }
+            }
+        };
         int r = sp * 4 + sl;
         for (; r + 3 * step < R; r += 4 * step) {           // four rows in flight; summed in row order
-            const double t0 = colsum_term(x, y, (size_t)r, N, c, mode, yc), t1 = colsum_term(x, y, (size_t)r + step, N, c, mode, yc);
-            const double t2 = colsum_term(x, y, (size_t)r + 2 * step, N, c, mode, yc), t3 = colsum_term(x, y, (size_t)r + 3 * step, N, c, mode, yc);
-            s += t0; s += t1; s += t2; s += t3;
+            double t0[V], t1[V], t2[V], t3[V];
+            term((size_t)r, t0); term((size_t)r + step, t1); term((size_t)r + 2 * step, t2); term((size_t)r + 3 * step, t3);
+#pragma unroll
+            for (int v = 0; v < V; ++v) { s[v] += t0[v]; s[v] += t1[v]; s[v] += t2[v]; s[v] += t3[v]; }
         }
-        for (; r < R; r += step) s += colsum_term(x, y, (size_t)r, N, c, mode, yc);
+        for (; r < R; r += step) {
+            double t0[V];
+            term((size_t)r, t0);
+#pragma unroll
+            for (int v = 0; v < V; ++v) s[v] += t0[v];
+        }
     }
-    red[sl][threadIdx.x & 63] = s;
+#pragma unroll
+    for (int v = 0; v < V; ++v) red[sl][(threadIdx.x & 63) * V + v] = s[v];
     __syncthreads();
-    if (sl == 0 && c < N)
-        part[(size_t)sp * N + c] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    if (sl == 0 && c0 < N) {
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+            if (c0 + v < N) {
+                const int i = (threadIdx.x & 63) * V + v;
+                part[(size_t)sp * N + c0 + v] = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
+            }
+    }
 }
-// stage 2: the splits in order
-__global__ void k_colsum_fin(const double *__restrict__ part, int N, int nsplit, float scale, int accumulate, float *__restrict__ out)
+// stage 2: the splits, dealt to 16 lanes per column round-robin and combined in lane order (fixed order)
+__global__ __launch_bounds__(256) void k_colsum_fin(const double *__restrict__ part, int N, int nsplit, float scale, int accumulate,
+                                                    float *__restrict__ out)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= N) return;
+    __shared__ double red[16][17];
+    const int cl = threadIdx.x & 15, q = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
     double t = 0.0;
-    for (int sp = 0; sp < nsplit; ++sp) t += part[(size_t)sp * N + c];
-    t *= (double)scale;
-    out[c] = accumulate ? (float)((double)out[c] + t) : (float)t;
+    if (c < N)
+        for (int sp = q; sp < nsplit; sp += 16) t += part[(size_t)sp * N + c];
+    red[q][cl] = t;
+    __syncthreads();
+    if (q == 0 && c < N) {
+        double tot = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tot += red[i][cl];
+        tot *= (double)scale;
+        out[c] = accumulate ? (float)((double)out[c] + tot) : (float)tot;
+    }
 }
 
 // ------------------------------------------------------------------------------ element-wise family
@@ -478,24 +525,44 @@ __global__ void k_slotbias_fwd(const float *pb, const float *pc, const float *pr
     const float v = ly0 * (lx0 * p[y0 * 4 + x0] + lx1 * p[y0 * 4 + x1]) + ly1 * (lx0 * p[y1 * 4 + x0] + lx1 * p[y1 * 4 + x1]);
     out[i] = v + (pc[(size_t)j * s + y] + pr[(size_t)j * s + x]);
 }
-// one thread per kept slot j: walks its C table gradients in a fixed order
-__global__ void k_slotbias_bwd(const float *dtab, int Mk, int s, int C, float *dpb, float *dpc, float *dpr)
+// one wave per kept slot j: the C table gradients of the slot are staged in LDS, then lane o computes output o
+// (16 taps of pb, s entries of pc, s entries of pr; s <= 23) by walking them in a fixed order
+__global__ __launch_bounds__(256) void k_slotbias_bwd(const float *dtab, int Mk, int s, int C, float *dpb, float *dpc, float *dpr)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float g[4][512];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + wv;
     if (j >= Mk) return;
-    float gpb[16];
-    for (int i = 0; i < 16; ++i) gpb[i] = 0.0f;
-    for (int i = 0; i < s; ++i) { dpc[(size_t)j * s + i] = 0.0f; dpr[(size_t)j * s + i] = 0.0f; }
-    for (int yx = 0; yx < C; ++yx) {
-        const int y = yx / s, x = yx - y * s;
-        const float g = dtab[(size_t)j * C + yx];
-        int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
-        bilin_taps(y, x, s, y0, y1, x0, x1, ly0, ly1, lx0, lx1);
-        gpb[y0 * 4 + x0] += g * ly0 * lx0; gpb[y0 * 4 + x1] += g * ly0 * lx1;
-        gpb[y1 * 4 + x0] += g * ly1 * lx0; gpb[y1 * 4 + x1] += g * ly1 * lx1;
-        dpc[(size_t)j * s + y] += g; dpr[(size_t)j * s + x] += g;
+    for (int i = lane; i < C; i += 64) g[wv][i] = dtab[(size_t)j * C + i];
+    // same wave: LDS accesses complete in order
+    const float *gj = g[wv];
+    if (lane < 16) {                       // pb tap (ty, tx) = (lane / 4, lane % 4)
+        const int ty = lane >> 2, tx = lane & 3;
+        float acc = 0.0f;
+        for (int yx = 0; yx < C; ++yx) {
+            const int y = yx / s, x = yx - y * s;
+            int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
+            bilin_taps(y, x, s, y0, y1, x0, x1, ly0, ly1, lx0, lx1);
+            float wy = 0.0f, wx = 0.0f;
+            if (y0 == ty) wy += ly0;
+            if (y1 == ty) wy += ly1;
+            if (x0 == tx) wx += lx0;
+            if (x1 == tx) wx += lx1;
+            acc = fmaf(gj[yx], wy * wx, acc);
+        }
+        dpb[(size_t)j * 16 + lane] = acc;
+    } else if (lane < 16 + s) {            // pc[y]: sum over the row
+        const int y = lane - 16;
+        float acc = 0.0f;
+        for (int x = 0; x < s; ++x) { const int yx = y * s + x; if (yx < C) acc += gj[yx]; }
+        dpc[(size_t)j * s + y] = acc;
     }
-    for (int i = 0; i < 16; ++i) dpb[(size_t)j * 16 + i] = gpb[i];
+    if (lane >= 40 && lane < 40 + s) {     // pr[x]: sum over the column
+        const int x = lane - 40;
+        float acc = 0.0f;
+        for (int y = 0; y * s + x < C; ++y) acc += gj[y * s + x];
+        dpr[(size_t)j * s + x] = acc;
+    }
 }
 
 // ------------------------------------------------------------------------------ row gather / scatter (kept centres)
@@ -663,9 +730,12 @@ int ptx_op_colsum(const float *x, const float *y, int R, int N, int mode, float 
     PTX_REQUIRE(x && out && scratch && R >= 1 && N >= 1 && mode >= 0 && mode <= 3 && ((mode != 1 && mode != 3) || y) &&
                 nsplit >= 1 && nsplit <= 1024, "ptx_op_colsum: bad arguments");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(k_colsum, dim3(cdiv(N, 64), nsplit), dim3(256), 0, st, x, y, R, N, mode, nsplit, scratch);
+    const bool vec = N % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 && mode != 3 ? true
+                     : (N % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && mode == 3);
+    if (vec) hipLaunchKernelGGL(k_colsum<4>, dim3(cdiv(N, 256), nsplit), dim3(256), 0, st, x, y, R, N, mode, nsplit, scratch);
+    else     hipLaunchKernelGGL(k_colsum<1>, dim3(cdiv(N, 64), nsplit), dim3(256), 0, st, x, y, R, N, mode, nsplit, scratch);
     PTX_LAUNCHED("k_colsum");
-    hipLaunchKernelGGL(k_colsum_fin, dim3(cdiv(N, 256)), dim3(256), 0, st, scratch, N, nsplit, scale, accumulate, out);
+    hipLaunchKernelGGL(k_colsum_fin, dim3(cdiv(N, 16)), dim3(256), 0, st, scratch, N, nsplit, scale, accumulate, out);
     PTX_LAUNCHED("k_colsum_fin");
     return PTX_OK;
 }
@@ -825,7 +895,8 @@ int ptx_op_slotbias_fwd(const float *pb, const float *pc, const float *pr, int M
 int ptx_op_slotbias_bwd(const float *dtable, int Mk, int s, int C, float *dpb, float *dpc, float *dpr, void *stream)
 {
     PTX_REQUIRE(dtable && dpb && dpc && dpr && Mk >= 1, "ptx_op_slotbias_bwd: bad arguments");
-    hipLaunchKernelGGL(k_slotbias_bwd, dim3(cdiv(Mk, 64)), dim3(64), 0, static_cast<hipStream_t>(stream), dtable, Mk, s, C, dpb,
+    PTX_REQUIRE(s <= 23 && C <= 512, "ptx_op_slotbias_bwd: s=%d C=%d", s, C);
+    hipLaunchKernelGGL(k_slotbias_bwd, dim3(cdiv(Mk, 4)), dim3(256), 0, static_cast<hipStream_t>(stream), dtable, Mk, s, C, dpb,
                        dpc, dpr);
     PTX_LAUNCHED("k_slotbias_bwd");
     return PTX_OK;

@@ -90,7 +90,7 @@ def colsum(x2, y2=None, mode=0, scale=1.0, out=None, accumulate=False):
     if out is None:
         out = torch.empty((N,), dtype=_F32, device=x2.device)
     # enough (column tile, row split) blocks to fill the chip; every split walks >= ~64 rows per slice
-    nsplit = int(max(1, min(96, R // 256, 2048 // ((N + 63) // 64))))
+    nsplit = int(max(1, min(512, R // 256, 4096 // ((N + 255) // 256))))
     scratch = torch.empty((nsplit, N), dtype=torch.float64, device=x2.device)
     _ck(_abi.lib().ptx_op_colsum(_p(x2), _p(y2), R, N, mode, scale, 1 if accumulate else 0, _p(out), _p(scratch), nsplit,
                                  _st()), "ptx_op_colsum")
@@ -541,10 +541,8 @@ class _AttnPoolCore(torch.autograd.Function):
         scale = float(hd) ** -0.5
         dev = tok.device
         tok2 = tok.view(nimg * T, C)
-        Kt = mm(tok2, wk, tb=True)
-        eltwise(6, Kt, bk, ncol=C, out=Kt)
-        Vt = mm(tok2, wv, tb=True)
-        eltwise(6, Vt, bv, ncol=C, out=Vt)
+        Kt = linear_nt(tok2, wk, bk)
+        Vt = linear_nt(tok2, wv, bv)
         q = torch.empty((nimg, C), dtype=_F32, device=dev)
         gemm(tok, wq, q, nimg, C, C, a=(T * C, 1), b=(1, C), c=(C, 1))
         eltwise(6, q, bq, ncol=C, out=q)
@@ -584,8 +582,14 @@ class _AttnPoolCore(torch.autograd.Function):
         dKt = torch.empty_like(Kt)
         gemm(dS, q, dKt, T, hd, 1, a=(1, 0), b=(0, 1), c=(C, 1), batch=Z, inner=heads, a_bs=(heads * T, T), b_bs=(C, hd),
              c_bs=(T * C, hd), alpha=scale)
-        dtok = mm(dKt, wk)
-        mm(dVt, wv, out=dtok, accumulate=True)
+        dtok = linear_nt(dKt, transpose2d(wk))
+        if _tuned_ok(dVt, C):
+            wvT = transpose2d(wv)
+            d2 = torch.empty_like(dtok)
+            _ck(_abi.lib().ptx_linear(_p(dVt), _p(wvT), None, _p(dtok), _p(d2), nimg * T, C, C, 0, _st()), "ptx_linear")
+            dtok = d2
+        else:
+            mm(dVt, wv, out=dtok, accumulate=True)
         gemm(dq, wq, dtok, nimg, C, C, a=(C, 1), b=(C, 1), c=(T * C, 1), accumulate=True)      # token-0 rows
         dwk, dbk = mm(dKt, tok2, ta=True), colsum(dKt)
         dwv, dbv = mm(dVt, tok2, ta=True), colsum(dVt)
