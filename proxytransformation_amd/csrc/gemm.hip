@@ -17,6 +17,44 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 32, LDT = BK + 4;   // 144-B LDS rows: 16-B aligned, b128 fragment reads conflict-free
 
+// ---- three-way bf16 operand split (the "x3" kernels) ---------------------------------------------------------------
+// An fp32 operand is written x = x1 + x2 + x3 with each part a bf16 (round to nearest: |x - x1| <= 2^-9 |x|,
+// |x - x1 - x2| <= 2^-18 |x|, the third part carries the rest), and a product of two operands is the six bf16
+// matrix-core products x1 y1 + (x1 y2 + x2 y1) + (x1 y3 + x2 y2 + x3 y1), accumulated in fp32; the dropped terms
+// are <= 2^-25 |x y|, below the fp32 rounding of the sum.  Six v_mfma_f32_32x32x16_bf16 do the work of eight
+// v_mfma_f32_32x32x2_f32 in 3/8 of the matrix-pipe cycles.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split3_pair(float x, float y, unsigned &p1, unsigned &p2, unsigned &p3)
+{
+    const f32x2 v = {x, y};
+    p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    const f32x2 r1 = {x - __uint_as_float(p1 << 16), y - __uint_as_float(p1 & 0xffff0000u)};
+    p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2));
+    const f32x2 r2 = {r1[0] - __uint_as_float(p2 << 16), r1[1] - __uint_as_float(p2 & 0xffff0000u)};
+    p3 = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
+}
+// one float4 (four consecutive k) -> the three planes' 8-byte pieces at dst, dst + plane, dst + 2 plane (bytes)
+__device__ __forceinline__ void stash_split3(char *dst, int plane, const float4 &v)
+{
+    unsigned a1, a2, a3, b1, b2, b3;
+    split3_pair(v.x, v.y, a1, a2, a3);
+    split3_pair(v.z, v.w, b1, b2, b3);
+    *reinterpret_cast<uint2 *>(dst) = make_uint2(a1, b1);
+    *reinterpret_cast<uint2 *>(dst + plane) = make_uint2(a2, b2);
+    *reinterpret_cast<uint2 *>(dst + 2 * plane) = make_uint2(a3, b3);
+}
+// the value is "re-defined" here: arithmetic on a prefetched register cannot be hoisted above this point (hipcc moves
+// pure VALU work across s_barrier, which turns a three-steps-ahead prefetch into a wait on the loads just issued)
+__device__ __forceinline__ void pin4(float4 &v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+// LDS rows of the split tiles: 32 bf16 = 64 bytes, unpadded; the four 16-byte pieces of row r sit at piece ^ ((r >> 2) & 3),
+// which makes both the 8-byte stash writes (four rows x 64 B per half wave) and the 16-byte fragment reads (sixteen rows,
+// one piece each) bank-conflict free
+constexpr int XROW = 64;
+__device__ __forceinline__ int xswz(int row, int piece) { return (piece ^ ((row >> 2) & 3)) * 16; }
+
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 // ---- LayerNorm fold helpers (GemmProb::lnp_out / lnp_in) ----------------------------------------------------------
@@ -160,6 +198,146 @@ __global__ __launch_bounds__(256) void k_gemm64(GemmBatch gb)
 #undef PTX_G64_FETCH
 #undef PTX_G64_STASH
 #undef PTX_G64_COMPUTE
+
+// (Measured on the way, r02: 2048x1024x1024 takes 49.4 us with the fp32 instruction -- 55 % of the matrix pipe, and neither
+// four register stages, nor removing the stash or the barrier moves it much: the phases of a step do not overlap
+// across the two resident work-groups of a CU.  The split kernel: 37.8 us; its matrix part is 3/8 but the split is
+// ~110 VALU instructions per step and VALU and MFMA time mostly ADD (SQ_VALU_MFMA_COEXEC 24 % of MFMA busy).  A
+// register-direct variant -- every lane loads its own k-contiguous fragments from global memory, no LDS at all -- is
+// correct and slower (68 us): 32 rows x 16 B per load instruction touches 32 cache lines.)
+// The same tiling with the operands split three ways into bf16 on the way into LDS (see split3_pair) and the K loop
+// written out for K = 128 NKG (every problem of the batch): 3/8 of the matrix-pipe cycles of the fp32 instruction.
+// Step t is consumed from LDS[t & 1] while step t + 1 is split (VALU) and stored into the other buffer IN THE SHADOW
+// of step t's matrix instructions -- a wave's next MFMA cannot issue before the previous one leaves the pipe, the
+// stash fills those slots (one scheduling region per step, the interleave spelled out with sched_group_barrier);
+// steps t + 2 .. t + 4 are in flight in registers.  Written out, not a loop: at a back edge hipcc copies the
+// loop-carried prefetch registers and waits for the loads just issued to do it; and arithmetic on a prefetched
+// register is pinned (pin4) below its step's barrier, or hipcc hoists it and waits there.
+#define PTX_X64_FETCH(S, it_)                                                              \
+    do {                                                                                   \
+        const int kc_ = (it_) * BK + kq;                                                   \
+        a##S##0 = *reinterpret_cast<const float4 *>(pr.A + ao0 + kc_);                     \
+        a##S##1 = *reinterpret_cast<const float4 *>(pr.A + ao1 + kc_);                     \
+        w##S##0 = *reinterpret_cast<const float4 *>(pr.W + wo0 + kc_);                     \
+        w##S##1 = *reinterpret_cast<const float4 *>(pr.W + wo1 + kc_);                     \
+    } while (0)
+#define PTX_X64_STASH(S, buf_)                                                             \
+    do {                                                                                   \
+        pin4(a##S##0); pin4(a##S##1); pin4(w##S##0); pin4(w##S##1);                        \
+        char *d_ = smem + (buf_) * kXBuf + sr * XROW + xswz(sr, kq >> 3) + (kq & 4) * 2;   /* (sr + 32) swizzles alike */ \
+        stash_split3(d_, kXPlane, a##S##0);                                                \
+        stash_split3(d_ + 32 * XROW, kXPlane, a##S##1);                                    \
+        stash_split3(d_ + 3 * kXPlane, kXPlane, w##S##0);                                  \
+        stash_split3(d_ + 3 * kXPlane + 32 * XROW, kXPlane, w##S##1);                      \
+    } while (0)
+#define PTX_X64_COMPUTE(buf_)                                                              \
+    do {                                                                                   \
+        const char *A_ = smem + (buf_) * kXBuf + (wr * 32 + li) * XROW;                    \
+        const char *W_ = smem + (buf_) * kXBuf + 3 * kXPlane + (wc * 32 + li) * XROW;      \
+        _Pragma("unroll") for (int kg = 0; kg < BK / 16; ++kg) {                           \
+            const int o_ = xswz(li, kg * 2 + hh);           /* wr * 32, wc * 32 do not change the swizzle */ \
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8 *>(A_ + o_);                  \
+            const bf16x8 a2 = *reinterpret_cast<const bf16x8 *>(A_ + o_ + kXPlane);        \
+            const bf16x8 a3 = *reinterpret_cast<const bf16x8 *>(A_ + o_ + 2 * kXPlane);    \
+            const bf16x8 b1 = *reinterpret_cast<const bf16x8 *>(W_ + o_);                  \
+            const bf16x8 b2 = *reinterpret_cast<const bf16x8 *>(W_ + o_ + kXPlane);        \
+            const bf16x8 b3 = *reinterpret_cast<const bf16x8 *>(W_ + o_ + 2 * kXPlane);    \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc, 0, 0, 0);   /* small terms first */ \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc, 0, 0, 0);           \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc, 0, 0, 0);           \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc, 0, 0, 0);           \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc, 0, 0, 0);           \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc, 0, 0, 0);           \
+        }                                                                                  \
+    } while (0)
+
+template <int NKG>
+__global__ __launch_bounds__(256) void k_gemm64x(GemmBatch gb)
+{
+    constexpr int kXPlane = 64 * XROW, kXBuf = 6 * kXPlane;     // one plane of a 64 x 32 tile; [A1 A2 A3 W1 W2 W3] per buffer
+    static_assert(2 * kXBuf >= 4 * 32 * 33 * 4, "the LayerNorm-partials scratch re-uses the staging area");
+    const GemmProb pr = gb.p[blockIdx.z];          // by value: fields live in SGPRs, not re-read from kernarg
+    const int row0 = blockIdx.x * 64, col0 = blockIdx.y * 64;
+    if (row0 >= pr.R || col0 >= pr.N) return;
+    __shared__ __attribute__((aligned(16))) char smem[2 * kXBuf];
+    __shared__ float s_mu[64], s_rs[64];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (pr.lnp_in != nullptr && tid < 64) {
+        float mu, rs;
+        ln_row_stats(pr, min(row0 + tid, pr.R - 1), mu, rs);
+        s_mu[tid] = mu; s_rs[tid] = rs;                    // read after the barriers of the K loop
+    }
+    const int wr = wid >> 1, wc = wid & 1;
+    const int li = lane & 31, hh = lane >> 5;
+    const int sr = tid >> 3, kq = (tid & 7) * 4;        // staging: rows sr and sr + 32
+    const size_t ao0 = (size_t)min(row0 + sr, pr.R - 1) * pr.lda, ao1 = (size_t)min(row0 + sr + 32, pr.R - 1) * pr.lda;
+    const size_t wo0 = (size_t)min(col0 + sr, pr.N - 1) * pr.ldw, wo1 = (size_t)min(col0 + sr + 32, pr.N - 1) * pr.ldw;
+    float4 aA0, aA1, wA0, wA1, aB0, aB1, wB0, wB1, aC0, aC1, wC0, wC1, aD0, aD1, wD0, wD1;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    // epilogue operands are requested up front: a dependent ~1 us round trip after the K loop otherwise
+    const int n = col0 + wc * 32 + li;
+    const float bias = (pr.bias && n < pr.N) ? pr.bias[n] : 0.0f;
+    float resv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = row0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        resv[r] = (pr.res && row < pr.R && n < pr.N) ? pr.res[(size_t)row * pr.ldres + n] : 0.0f;
+    }
+#define PTX_X64_PIPE()                                                                     \
+    do {                                                                                   \
+        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);             /* fragment reads */ \
+        _Pragma("unroll") for (int g_ = 0; g_ < 12; ++g_) {                                \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                             \
+            __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);                   \
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                             \
+        }                                                                                  \
+    } while (0)
+#define PTX_X64_STEP(S, SN, par_)                                                          \
+    if (it + 4 < 4 * NKG) PTX_X64_FETCH(S, it + 4);                                        \
+    __builtin_amdgcn_sched_barrier(0);     /* the loads are issued first: live across the step, their own registers */ \
+    PTX_X64_COMPUTE(par_);                                                                 \
+    PTX_X64_STASH(SN, 1 - (par_));                                                         \
+    PTX_X64_PIPE();                                                                        \
+    __syncthreads();                                                                       \
+    ++it;
+    PTX_X64_FETCH(A, 0); PTX_X64_FETCH(B, 1); PTX_X64_FETCH(C, 2); PTX_X64_FETCH(D, 3);
+    PTX_X64_STASH(A, 0);
+    __syncthreads();
+    int it = 0;
+#pragma unroll
+    for (int g = 0; g < NKG; ++g) {
+        PTX_X64_STEP(A, B, 0) PTX_X64_STEP(B, C, 1) PTX_X64_STEP(C, D, 0) PTX_X64_STEP(D, A, 1)
+    }
+#undef PTX_X64_STEP
+#undef PTX_X64_PIPE
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const bool ncol = n < pr.N;
+    float lns = 0.0f, lnc = 0.0f;
+    if (pr.lnp_in != nullptr && ncol) { lns = pr.ln_s[n]; lnc = pr.ln_c[n]; }
+    float fin[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rl = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh, row = row0 + rl;
+        float v = acc[r] + bias;
+        if (pr.lnp_in != nullptr) v = fmaf(s_rs[rl], fmaf(-s_mu[rl], lns, acc[r]), lnc);
+        if (pr.epi == EPI_GELU) v = gelu_erf(v);
+        const bool ok = ncol && row < pr.R;
+        if (ok) {
+            if (pr.rs) v = fmaf(pr.rs[(size_t)row * pr.rs_stride], pr.ad[(size_t)row * pr.ldad + n], v);
+            if (pr.res) v += resv[r];
+            pr.C[(size_t)row * pr.ldc + n] = v;
+        }
+        fin[r] = ok ? v : 0.0f;
+    }
+    if (pr.lnp_out != nullptr)      // every wave is past its last LDS read (barrier after the last stash)
+        ln_tile_partials(pr, fin, reinterpret_cast<float *>(smem) + wid * (32 * 33), row0 + wr * 32, (col0 >> 5) + wc,
+                         (pr.N + 31) >> 5);
+}
+#undef PTX_X64_FETCH
+#undef PTX_X64_STASH
+#undef PTX_X64_COMPUTE
 
 // Latency-regime variant for the small GEMMs of this path (a few hundred 32x32 tiles): one wave
 // per (tile, K-slice).  SK waves of a work-group split the K range of ONE 32x32 tile, each with
@@ -390,7 +568,7 @@ int launch_gemm(const GemmBatch &gb_in, hipStream_t st)
     GemmBatch gb = gb_in;
     gb.rotate = rot_env;
     PTX_REQUIRE(gb.n >= 1 && gb.n <= kMaxGroups, "gemm: %d groups", gb.n);
-    int rmax = 0, nmax = 0, kmin = 1 << 30;
+    int rmax = 0, nmax = 0, kmin = 1 << 30, kmax = 0;
     long tiles32 = 0;
     for (int g = 0; g < gb.n; ++g) {
         const GemmProb &p = gb.p[g];
@@ -411,6 +589,7 @@ int launch_gemm(const GemmBatch &gb_in, hipStream_t st)
         rmax = p.R > rmax ? p.R : rmax;
         nmax = p.N > nmax ? p.N : nmax;
         kmin = p.K < kmin ? p.K : kmin;
+        kmax = p.K > kmax ? p.K : kmax;
         tiles32 += (long)cdiv(p.R, 32) * cdiv(p.N, 32);
     }
     if (gb.p[0].pg != nullptr) {
@@ -418,7 +597,14 @@ int launch_gemm(const GemmBatch &gb_in, hipStream_t st)
         PTX_TRY((launch_gemm32<4, 1>(gb, rmax, nmax, st)));
     } else if (tiles32 >= 1536) {
         // enough tiles to fill the chip: 64x64 tiles re-use each staged operand twice as often
-        hipLaunchKernelGGL(k_gemm64, dim3(cdiv(rmax, 64), cdiv(nmax, 64), gb.n), dim3(256), 0, st, gb);
+        static const bool fp32_env = getenv("PTX_GEMM_FP32") != nullptr;
+        const dim3 grid(cdiv(rmax, 64), cdiv(nmax, 64), gb.n);
+        const int nkg = (!fp32_env && kmin == kmax && kmin % 128 == 0) ? kmin / 128 : 0;
+        if (nkg == 1) hipLaunchKernelGGL(k_gemm64x<1>, grid, dim3(256), 0, st, gb);
+        else if (nkg == 2) hipLaunchKernelGGL(k_gemm64x<2>, grid, dim3(256), 0, st, gb);
+        else if (nkg == 4) hipLaunchKernelGGL(k_gemm64x<4>, grid, dim3(256), 0, st, gb);
+        else if (nkg == 8) hipLaunchKernelGGL(k_gemm64x<8>, grid, dim3(256), 0, st, gb);
+        else hipLaunchKernelGGL(k_gemm64, grid, dim3(256), 0, st, gb);      // fp32 matrix instruction, any K
     } else {
         // latency regime: aim for >= 4 waves per SIMD (4096 waves) by slicing K inside the work-group
         const int nk = cdiv(kmin, BK);

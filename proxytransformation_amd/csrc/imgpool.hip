@@ -356,7 +356,11 @@ __global__ __launch_bounds__(512) void k_img_pool(PoolArgs a)
         const float *G = partial;
         float *dst = a.Gs + (size_t)slab * heads * in_dim;
         for (int i = tid * 4; i < heads * in_dim; i += 512 * 4)
-            *reinterpret_cast<float4 *>(dst + i) = *reinterpret_cast<const float4 *>(G + i);
+        {   // write-through (sc1): the 25 MB of partials must not sit dirty in the L2s when the launch ends -- the
+            // kernel boundary pays ~1 us per 6 MB of dirty lines (MI355X_MICROARCH.md, "boundary")
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(G + i);
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst + i), "v"(v) : "memory");
+        }
     }
 }
 
