@@ -748,9 +748,15 @@ int ptx_forward(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, const v
         PTX_REQUIRE(dev == side->dev, "ptx_forward: context belongs to device %d, current device is %d", side->dev, dev);
     }
     std::lock_guard<std::mutex> enqueue_lock(side->mu);
-    hipStream_t cs = side->st, is = st;
+    // Which chain is the longer one depends on the shape: with many farthest-point picks (the reference's own gs = 12
+    // configuration: 519 sequential picks) it is the clustering chain, and then THAT one stays on the caller's stream
+    // and the image chain takes the side stream.  (Rough per-shape estimates in us: measured slopes.)
+    const double est_cluster = 80.0 + 0.42 * Kd, est_image = 40.0 + (S.img_dtype == 0 ? 0.45 : 0.18) * ((double)B * S.V);
+    static const int swap_env = getenv("PTX_CHAIN_SWAP") ? atoi(getenv("PTX_CHAIN_SWAP")) : -1;
+    const bool cluster_on_caller = swap_env >= 0 ? swap_env != 0 : est_cluster > est_image;
+    hipStream_t cs = cluster_on_caller ? st : side->st, is = cluster_on_caller ? side->st : st;
     PTX_HIP(hipEventRecord(side->fork, st));
-    PTX_HIP(hipStreamWaitEvent(cs, side->fork, 0));
+    PTX_HIP(hipStreamWaitEvent(side->st, side->fork, 0));
     float *img_proxy = at<float>(ws, L.img_proxy);
     // (Two staggered slices of images on two streams -- slice B streaming its means under slice A's table GEMMs, A
     // pooling under B's tables -- measured again in r02 with the fused / folded chain: 0.319 vs 0.298 ms per step.
@@ -809,8 +815,9 @@ int ptx_forward(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, const v
     // branch after the join, was measured slower: 12.6k vs 13.7k scenes/s -- eight more launches, and its
     // small kernels take CUs from the image passes that are on the critical path.)
     PTX_TRY(run_blocks(S, br, 2, point_proxy, ws, cs, 1));
-    PTX_HIP(hipEventRecord(side->join, cs));
+    if (!cluster_on_caller) PTX_HIP(hipEventRecord(side->join, cs));
     PTX_TRY(run_img_proxy(S, *w, pf, img_feat, img_proxy, ws, is, 2, want_img_proxy));      // rest of the image chain
+    if (cluster_on_caller) PTX_HIP(hipEventRecord(side->join, is));
     PTX_HIP(hipStreamWaitEvent(st, side->join, 0));
     PTX_TRY(run_blocks(S, br, 2, point_proxy, ws, st, 2));
 
