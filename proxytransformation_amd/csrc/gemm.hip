@@ -592,10 +592,11 @@ int launch_gemm(const GemmBatch &gb_in, hipStream_t st)
         kmax = p.K > kmax ? p.K : kmax;
         tiles32 += (long)cdiv(p.R, 32) * cdiv(p.N, 32);
     }
+    static const int g64_min = getenv("PTX_G64_MIN") ? atoi(getenv("PTX_G64_MIN")) : 1024;
     if (gb.p[0].pg != nullptr) {
         // A merged on the fly from the pooling tiles: always the latency-regime kernel, K split four ways
         PTX_TRY((launch_gemm32<4, 1>(gb, rmax, nmax, st)));
-    } else if (tiles32 >= 1536) {
+    } else if (tiles32 >= g64_min) {
         // enough tiles to fill the chip: 64x64 tiles re-use each staged operand twice as often
         static const bool fp32_env = getenv("PTX_GEMM_FP32") != nullptr;
         const dim3 grid(cdiv(rmax, 64), cdiv(nmax, 64), gb.n);
