@@ -135,7 +135,7 @@ WsLayout ws_layout(const PtxShape &s)
     L.offsets = take(B * M * 3 * 4);  L.centers = take(B * M * 3 * 4);
     L.idx2 = take(B * M * K * 4);     L.cluster2 = take(B * M * K * 3 * 4);
     L.pad_count = take(B * M * 4);
-    L.order = take(B * Mt * 4); L.picks = take(B * (Kd ? Kd : 1) * 4); L.keep = take(B * Mk * 4);
+    L.order = take(B * Mt * 4); L.picks = take(B * (Kd ? Kd : 1) * 4); L.keep = take(B * Mk * 4); L.ksrc = take(B * Mk * 4);
     L.kcenter = take(B * Mk * 3 * 4); L.kcluster = take(B * Mk * K * 3 * 4); L.kidx = take(B * Mk * K * 4);
     L.drop_idx = take(B * (Kd ? Kd : 1) * K * 4);
     L.tile_counts = take(B * (size_t)cdiv(s.N, kTilePts) * 4);
@@ -652,7 +652,7 @@ int ptx_pointnet(const PtxShape *s, const PtxWeights *w, const void *prep, const
     const PrepLayout P = prep_layout(*s);
     return launch_pointnet(static_cast<const float *>(prep) + P.enc_ab, w->encoder, kcenter, kcluster,
                            s->B * s->Mk, s->Mk, s->K, s->C, point_proxy, nullptr, nullptr, nullptr, nullptr, nullptr,
-                           nullptr, s->ln_eps, nullptr, nullptr, 0, 0, static_cast<hipStream_t>(stream));
+                           nullptr, s->ln_eps, nullptr, 0, static_cast<hipStream_t>(stream));
 }
 
 int ptx_img_proxy(const PtxShape *s, const PtxWeights *w, const void *prep, const void *img_feat,
@@ -785,8 +785,9 @@ int ptx_forward(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, const v
     float *kcluster = dbg && debug->kcluster ? at<float>(ws, L.kcluster) : nullptr;
     int32_t *kidx = dbg && debug->kidx ? at<int32_t>(ws, L.kidx) : nullptr;
     int32_t *drop_idx = dbg && debug->drop_idx ? at<int32_t>(ws, L.drop_idx) : nullptr;
+    int32_t *ksrc = at<int32_t>(ws, L.ksrc);
     PTX_TIMED(KID_SELECT, cs, launch_select_order(S, centers, pad_count, order_override, order, picks, keep, kcenter,
-                                                  mm_enc, cs));
+                                                  ksrc, mm_enc, cs));
     int32_t *tile_counts = at<int32_t>(ws, L.tile_counts);
     hipStream_t ts = side->lo;
     PTX_HIP(hipEventRecord(side->aux, cs));
@@ -798,9 +799,9 @@ int ptx_forward(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, const v
     // ---- point proxies (PRE:437) + norm1 / slot bias of both blocks; the kept clusters are read through the selection
     float *point_proxy = at<float>(ws, L.point_proxy);
     float *xin_t = at<float>(ws, L.x_in[0]), *xin_i = at<float>(ws, L.x_in[1]);
-    PTX_TIMED(KID_POINTNET, cs, launch_pointnet(pf + P.enc_ab, w->encoder, centers, cluster2, B * S.Mk, S.Mk, K,
+    PTX_TIMED(KID_POINTNET, cs, launch_pointnet(pf + P.enc_ab, w->encoder, kcenter, cluster2, B * S.Mk, S.Mk, K,
                                                 S.C, point_proxy, &w->text, &w->img, pf + P.posb_t, pf + P.posb_i, xin_t,
-                                                xin_i, S.ln_eps, order, keep, M, S.Mt, cs));
+                                                xin_i, S.ln_eps, ksrc, M, cs));
 
     // ---- both proxy blocks + heads in shared launches (PRE:440-455); the input projections that
     // do not need the image proxies still run on the clustering stream

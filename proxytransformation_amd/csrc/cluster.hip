@@ -203,7 +203,7 @@ struct SlotNetArgs {
     // MODE 1
     float *proxy; const float *n1w[2]; const float *n1b[2]; const float *posb[2]; float *xin[2];
     float ln_eps;
-    const int32_t *order, *keep; int Msrc, Mt;      // MODE 1: gather through the selection when keep != null
+    const int32_t *ksrc; int Msrc;                  // MODE 1: cluster rows gathered through the selection when ksrc != null
 };
 
 // pooled hidden features of one cluster: lane k (< K) holds slot k's input x[6]; returns acc[q] = channel
@@ -278,14 +278,26 @@ __global__ __launch_bounds__(256) void k_slot_net(SlotNetArgs a)
     const int lane = lane_id();
     const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (w >= a.BM) return;
-    // MODE 1 may gather its cluster through the selection (src = order[keep[j]]) instead of reading the
-    // gathered copies: the gathers are then off the chain that leads to the proxy blocks
+    // MODE 1 may read its cluster through the selection (row ksrc[w] of the un-gathered array, written by k_select next
+    // to the kept centres) instead of a gathered copy: the gathers are then off the chain that leads to the proxy blocks
     int src = w;
-    if (MODE == 1 && a.keep != nullptr) {
-        const int b = w / a.Mper, j = w - b * a.Mper;
-        src = b * a.Msrc + a.order[(size_t)b * a.Mt + a.keep[(size_t)b * a.Mper + j]];
+    if (MODE == 1 && a.ksrc != nullptr) src = (w / a.Mper) * a.Msrc + a.ksrc[w];
+    // MODE 1: everything the epilogue needs from memory is requested NOW (LayerNorm weights, the slot-bias rows): on a
+    // chip that holds one wave per SIMD for this launch nothing else hides those round trips
+    float e_w[2][Q], e_b[2][Q], e_p[2][Q];
+    if (MODE == 1) {
+        const int j = w % a.Mper;                                                  // kept-slot position (Q9)
+#pragma unroll
+        for (int br = 0; br < 2; ++br) {
+            if (a.xin[br] == nullptr) continue;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const int c = lane + 64 * q;
+                e_w[br][q] = a.n1w[br][c]; e_b[br][q] = a.n1b[br][c]; e_p[br][q] = a.posb[br][(size_t)j * W + c];
+            }
+        }
     }
-    const float cx = a.center[(size_t)src * 3], cy = a.center[(size_t)src * 3 + 1], cz = a.center[(size_t)src * 3 + 2];
+    const float cx = a.center[(size_t)w * 3], cy = a.center[(size_t)w * 3 + 1], cz = a.center[(size_t)w * 3 + 2];
     // lane k (< K) prepares slot k
     float x[6] = {0, 0, 0, 0, 0, 0};
     if (lane < a.K) {
@@ -318,15 +330,14 @@ __global__ __launch_bounds__(256) void k_slot_net(SlotNetArgs a)
         for (int q = 0; q < Q; ++q) { const float d = acc[q] - mean; var = fmaf(d, d, var); }
         var = wave_sum(var) * (1.0f / W);
         const float rstd = 1.0f / sqrtf(var + a.ln_eps);
-        const int j = w % a.Mper;                                                  // kept-slot position (Q9)
 #pragma unroll
         for (int br = 0; br < 2; ++br) {
             if (a.xin[br] == nullptr) continue;
 #pragma unroll
             for (int q = 0; q < Q; ++q) {
                 const int c = lane + 64 * q;
-                const float xn = (acc[q] - mean) * rstd * a.n1w[br][c] + a.n1b[br][c];
-                a.xin[br][(size_t)w * W + c] = xn + a.posb[br][(size_t)j * W + c];
+                const float xn = (acc[q] - mean) * rstd * e_w[br][q] + e_b[br][q];
+                a.xin[br][(size_t)w * W + c] = xn + e_p[br][q];
             }
         }
     }
@@ -419,14 +430,14 @@ int launch_pointnet(const float *ab, const PtxSlotMlp &mlp, const float *kcenter
                     const float *kcluster, int BM, int Mk, int K, int width, float *point_proxy,
                     const PtxBlock *blk_t, const PtxBlock *blk_i, const float *posb_t,
                     const float *posb_i, float *xin_t, float *xin_i, float ln_eps,
-                    const int32_t *order, const int32_t *keep, int Msrc, int Mt, hipStream_t st)
+                    const int32_t *ksrc, int Msrc, hipStream_t st)
 {
-    // order / keep given: kcenter / kcluster are the UN-gathered (B,Msrc,..) arrays and kept cluster j of scene b
-    // reads row order[b][keep[b][j]] itself
+    // ksrc given: kcluster is the UN-gathered (B,Msrc,K,3) array and kept cluster j of scene b reads row ksrc[b][j]
+    // (kcenter is always the gathered (B,Mk,3) array)
     SlotNetArgs a{};
     a.ab = ab; a.conv_w = mlp.conv_w; a.conv_b = mlp.conv_b; a.center = kcenter; a.cluster = kcluster;
     a.BM = BM; a.Mper = Mk; a.K = K; a.proxy = point_proxy; a.ln_eps = ln_eps;
-    a.order = order; a.keep = keep; a.Msrc = Msrc; a.Mt = Mt;
+    a.ksrc = ksrc; a.Msrc = Msrc;
     if (blk_t && xin_t) { a.n1w[0] = blk_t->norm1_w; a.n1b[0] = blk_t->norm1_b; a.posb[0] = posb_t; a.xin[0] = xin_t; }
     if (blk_i && xin_i) { a.n1w[1] = blk_i->norm1_w; a.n1b[1] = blk_i->norm1_b; a.posb[1] = posb_i; a.xin[1] = xin_i; }
     PTX_REQUIRE(width == 256 || width == 512, "pointnet: width=%d (supported: 256, 512)", width);
@@ -448,6 +459,7 @@ struct SelectArgs {
     const int32_t *order_override;
     int32_t *order, *picks, *keep; float *kcenter, *kcluster; int32_t *kidx, *drop_idx; uint32_t *tag;
     int M, K, Mt, Mk, Kd, N;
+    int32_t *ksrc;           // (B,Mk) row of kept cluster j in the un-gathered arrays (= order[keep[j]]), or null
     uint32_t *mm_clear;      // forward only: the encoded bounding boxes (B,6), last read before this launch, are
                              // zeroed here so that the next call finds them clean (no memset launch per call)
 };
@@ -598,6 +610,7 @@ __global__ __launch_bounds__(256) void k_select(SelectArgs a)
     for (int j = tid; j < Mk; j += T) {
         const int t = s_keep[j];
         a.keep[(size_t)b * Mk + j] = t;
+        if (a.ksrc != nullptr) a.ksrc[(size_t)b * Mk + j] = s_order[t];
         a.kcenter[((size_t)b * Mk + j) * 3] = sx[t];
         a.kcenter[((size_t)b * Mk + j) * 3 + 1] = sy[t];
         a.kcenter[((size_t)b * Mk + j) * 3 + 2] = sz[t];
@@ -656,16 +669,17 @@ static SelectArgs select_args(const PtxShape &s, const int32_t *idx, const float
 {
     return SelectArgs{idx, centers, cluster, pad_count, order_override, order, picks, keep, kcenter,
                       kcluster, kidx, drop_idx, tag, s.grid_size * s.grid_size * s.grid_size, s.K, s.Mt,
-                      s.Mk, s.Mt - s.Mk, s.N, mm_clear};
+                      s.Mk, s.Mt - s.Mk, s.N, nullptr, mm_clear};
 }
 
 // ordering + FPS + keep list + kept centres (one work-group per scene)
 int launch_select_order(const PtxShape &s, const float *centers, const int32_t *pad_count,
                         const int32_t *order_override, int32_t *order, int32_t *picks, int32_t *keep,
-                        float *kcenter, uint32_t *mm_clear, hipStream_t st)
+                        float *kcenter, int32_t *ksrc, uint32_t *mm_clear, hipStream_t st)
 {
     SelectArgs a = select_args(s, nullptr, centers, nullptr, pad_count, order_override, order, picks, keep, kcenter,
                                nullptr, nullptr, nullptr, nullptr, mm_clear);
+    a.ksrc = ksrc;
     const size_t lds = select_lds_bytes(s);
     PTX_REQUIRE(lds <= 160 * 1024, "select: Mt=%d needs %zu B of LDS (> 160 KiB)", s.Mt, lds);
     const int per = cdiv(s.Mt, 256);
@@ -710,7 +724,7 @@ int launch_select(const PtxShape &s, const int32_t *idx, const float *centers, c
                   int32_t *picks, int32_t *keep, float *kcenter, float *kcluster, int32_t *kidx,
                   int32_t *drop_idx, uint32_t *tag, hipStream_t st)
 {
-    PTX_TRY(launch_select_order(s, centers, pad_count, order_override, order, picks, keep, kcenter, nullptr, st));
+    PTX_TRY(launch_select_order(s, centers, pad_count, order_override, order, picks, keep, kcenter, nullptr, nullptr, st));
     return launch_select_slots(s, idx, cluster, order, picks, keep, kcluster, kidx, drop_idx, tag, st);
 }
 

@@ -118,7 +118,7 @@ struct WsLayout {
     size_t scene_acc;               // (B,2) int32 survivor-count accumulator + arrival ticket
     size_t tag;                     // (B,N) uint32
     size_t minmax, centers0, cluster1, offsets, centers, idx2, cluster2, pad_count;
-    size_t order, picks, keep, kcenter, kcluster, kidx, drop_idx, tile_counts;
+    size_t order, picks, keep, ksrc, kcenter, kcluster, kidx, drop_idx, tile_counts;
     size_t point_proxy, x_in[2];    // x_in: LN1(x)+slot bias per branch (B*Mk,C)
     size_t fm, qkv0, we, pool, gbuf, obuf, cbuf, img_proxy;
     size_t qkv[2], pt[2], pv[2], ao[2], x1[2], xn2[2], hbuf[2], x2[2], guide[2], head[2];
@@ -199,7 +199,7 @@ int launch_pointnet(const float *ab, const PtxSlotMlp &mlp, const float *kcenter
                     const float *kcluster, int BM, int Mk, int K, int width, float *point_proxy,
                     const PtxBlock *blk_t, const PtxBlock *blk_i, const float *posb_t,
                     const float *posb_i, float *xin_t, float *xin_i, float ln_eps,
-                    const int32_t *order, const int32_t *keep, int Msrc, int Mt, hipStream_t st);
+                    const int32_t *ksrc, int Msrc, hipStream_t st);
 int launch_cluster(const PtxShape &s, const uint32_t *mm_enc, const float *lin, const ScenePts &points,
                    const float *off_ab, const PtxSlotMlp &mlp, const float *map_w, const float *centers_override,
                    float *minmax_out, float *centers0, float *cluster1, float *offsets, float *centers,
@@ -210,7 +210,7 @@ int launch_select(const PtxShape &s, const int32_t *idx, const float *centers, c
                   int32_t *drop_idx, uint32_t *tag, hipStream_t st);
 int launch_select_order(const PtxShape &s, const float *centers, const int32_t *pad_count,
                         const int32_t *order_override, int32_t *order, int32_t *picks, int32_t *keep,
-                        float *kcenter, uint32_t *mm_clear, hipStream_t st);
+                        float *kcenter, int32_t *ksrc, uint32_t *mm_clear, hipStream_t st);
 int launch_select_slots(const PtxShape &s, const int32_t *idx, const float *cluster, const int32_t *order,
                         const int32_t *picks, const int32_t *keep, float *kcluster, int32_t *kidx,
                         int32_t *drop_idx, uint32_t *tag, hipStream_t st);
