@@ -790,11 +790,18 @@ int ptx_forward(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, const v
                                                   ksrc, mm_enc, cs));
     int32_t *tile_counts = at<int32_t>(ws, L.tile_counts);
     hipStream_t ts = side->lo;
-    PTX_HIP(hipEventRecord(side->aux, cs));
-    PTX_HIP(hipStreamWaitEvent(ts, side->aux, 0));
-    PTX_TIMED(KID_SLOTS, ts, launch_select_slots(S, idx2, cluster2, order, picks, keep, kcluster, kidx, drop_idx, tag, ts));
-    PTX_TIMED(KID_TILECOUNT, ts, launch_tile_count(tag, B, S.N, tile_counts, counts, at<int32_t>(ws, L.scene_acc), ts));   // publishes counts early
-    PTX_HIP(hipEventRecord(side->tags, ts));
+    // the slot tags / survivor counts (side stream) start before the point proxies when the image chain is the long
+    // one, after them when the clustering chain is (they share the chip with the kernel the step is waiting for)
+    const bool slots_first = !cluster_on_caller;
+    auto enqueue_tags = [&]() -> int {
+        PTX_HIP(hipEventRecord(side->aux, cs));
+        PTX_HIP(hipStreamWaitEvent(ts, side->aux, 0));
+        PTX_TIMED(KID_SLOTS, ts, launch_select_slots(S, idx2, cluster2, order, picks, keep, kcluster, kidx, drop_idx, tag, ts));
+        PTX_TIMED(KID_TILECOUNT, ts, launch_tile_count(tag, B, S.N, tile_counts, counts, at<int32_t>(ws, L.scene_acc), ts));   // publishes counts early
+        PTX_HIP(hipEventRecord(side->tags, ts));
+        return PTX_OK;
+    };
+    if (slots_first) PTX_TRY(enqueue_tags());
 
     // ---- point proxies (PRE:437) + norm1 / slot bias of both blocks; the kept clusters are read through the selection
     float *point_proxy = at<float>(ws, L.point_proxy);
@@ -802,6 +809,7 @@ int ptx_forward(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, const v
     PTX_TIMED(KID_POINTNET, cs, launch_pointnet(pf + P.enc_ab, w->encoder, kcenter, cluster2, B * S.Mk, S.Mk, K,
                                                 S.C, point_proxy, &w->text, &w->img, pf + P.posb_t, pf + P.posb_i, xin_t,
                                                 xin_i, S.ln_eps, ksrc, M, cs));
+    if (!slots_first) PTX_TRY(enqueue_tags());
 
     // ---- both proxy blocks + heads in shared launches (PRE:440-455); the input projections that
     // do not need the image proxies still run on the clustering stream
