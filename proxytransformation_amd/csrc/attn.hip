@@ -15,14 +15,19 @@
 //                    MFMA left them (key index of step s, half hh = (s&3) + 8*(s>>2) + 4*hh),
 //                    so P never moves between lanes and the running rescale is per lane.
 // fp32 in / fp32 accumulate: this is the parity configuration.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace ptx {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int HD>      // 32 or 64: HD / 2 contraction steps for the scores, HD / 32 accumulators for O^T
-__global__ __launch_bounds__(256) void k_attn32(AttnBatch ab)
+// NW waves per work-group share the key tiles of one query tile: 4 for the shapes of the benchmark (<= 8 key tiles);
+// 8 when there are many keys and few work-groups (proxies as queries over the 691 tokens of the reference's own
+// gs = 12 configuration: 22 dependent key tiles on 32 work-groups otherwise)
+template <int HD, int NW>      // HD 32 or 64: HD / 2 contraction steps for the scores, HD / 32 accumulators for O^T
+__global__ __launch_bounds__(NW * 64) void k_attn32(AttnBatch ab)
 {
     constexpr int NS = HD / 2;          // MFMA steps of S^T = K Q^T (each contracts 2 dims: halves hh = 0, 1)
     constexpr int NA = HD / 32;         // 32-row blocks of O^T
@@ -31,7 +36,7 @@ __global__ __launch_bounds__(256) void k_attn32(AttnBatch ab)
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q0 = blockIdx.x * 32;
     if (q0 >= p.nq) return;
-    const int ntile = (p.nk + 31) >> 5, tper = (ntile + 3) >> 2;
+    const int ntile = (p.nk + 31) >> 5, tper = (ntile + NW - 1) / NW;
     const int kbeg = wv * tper * 32, kend = min(p.nk, (wv + 1) * tper * 32);   // this wave's keys
     const int b = blockIdx.y / ab.heads, h = blockIdx.y - b * ab.heads;
     const int li = lane & 31, hh = lane >> 5;
@@ -133,9 +138,9 @@ __global__ __launch_bounds__(256) void k_attn32(AttnBatch ab)
             for (int i = 0; i < 16 * NA; ++i) vf[i] = vn[i];
         }
     }
-    // ---- merge the 4 key slices in fixed order: m = max m_w, O = sum_w O_w exp(m_w - m), l likewise
-    __shared__ float s_ml[3][2][64];
-    __shared__ __attribute__((aligned(16))) float s_o[3][16 * NA][64];
+    // ---- merge the NW key slices in fixed order: m = max m_w, O = sum_w O_w exp(m_w - m), l likewise
+    __shared__ float s_ml[NW - 1][2][64];
+    __shared__ __attribute__((aligned(16))) float s_o[NW - 1][16 * NA][64];
     if (wv > 0) {
         s_ml[wv - 1][0][lane] = m_run;
         s_ml[wv - 1][1][lane] = l_run;
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(256) void k_attn32(AttnBatch ab)
     if (wv > 0) return;
     float m_all = m_run;
 #pragma unroll
-    for (int w = 0; w < 3; ++w) m_all = fmaxf(m_all, s_ml[w][0][lane]);
+    for (int w = 0; w < NW - 1; ++w) m_all = fmaxf(m_all, s_ml[w][0][lane]);
     {
         const float a0 = expf(m_run - m_all);                       // wave 0 always owns >= 1 tile
         l_run *= a0;
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(256) void k_attn32(AttnBatch ab)
             for (int r = 0; r < 16; ++r) o[a][r] *= a0;
     }
 #pragma unroll
-    for (int w = 0; w < 3; ++w) {
+    for (int w = 0; w < NW - 1; ++w) {
         const float mw = s_ml[w][0][lane];
         const float aw = mw == -INFINITY ? 0.0f : expf(mw - m_all);   // slice without keys
         l_run = fmaf(s_ml[w][1][lane], aw, l_run);
@@ -184,7 +189,7 @@ __global__ __launch_bounds__(256) void k_attn32(AttnBatch ab)
 
 int launch_attn32(const AttnBatch &ab, hipStream_t st)
 {
-    int nqmax = 0;
+    int nqmax = 0, nkmax = 0;
     for (int g = 0; g < ab.n; ++g) {
         const AttnProb &p = ab.p[g];
         PTX_REQUIRE(p.Q && p.K && p.V && p.O, "attention: null operand in group %d", g);
@@ -192,12 +197,26 @@ int launch_attn32(const AttnBatch &ab, hipStream_t st)
         PTX_REQUIRE(p.ldq % 4 == 0 && p.ldk % 4 == 0 && p.ldo % 4 == 0 && p.sQ % 4 == 0 &&
                     p.sK % 4 == 0 && p.sO % 4 == 0, "attention: strides must be multiples of 4 floats");
         nqmax = p.nq > nqmax ? p.nq : nqmax;
+        nkmax = p.nk > nkmax ? p.nk : nkmax;
     }
     if (nqmax == 0) return PTX_OK;
     PTX_REQUIRE(ab.hd == 32 || ab.hd == 64, "attention: head_dim=%d (supported: 32, 64)", ab.hd);
     const dim3 grid(cdiv(nqmax, 32), ab.B * ab.heads, ab.n);
-    if (ab.hd == 32) hipLaunchKernelGGL(k_attn32<32>, grid, dim3(256), 0, st, ab);
-    else             hipLaunchKernelGGL(k_attn32<64>, grid, dim3(256), 0, st, ab);
+    // waves per work-group: enough that a wave walks at most two key tiles, while the launch is small enough to be
+    // waiting on that walk (with thousands of work-groups the chip is full anyway and more waves only add merge work)
+    const int ntile = cdiv(nkmax, 32);
+    const long wgs = (long)grid.x * grid.y * grid.z;
+    static const int nw_env = getenv("PTX_ATTN_NW") ? atoi(getenv("PTX_ATTN_NW")) : 0;
+    int nw = 4;
+    if (wgs <= 512 && ntile > 8) nw = 8;        // (16 waves: 128 VGPRs with spills and 68 KB of merge space -- not built)
+    if (nw_env == 4 || nw_env == 8) nw = nw_env;
+    if (ab.hd == 32) {
+        if (nw == 8) hipLaunchKernelGGL((k_attn32<32, 8>), grid, dim3(512), 0, st, ab);
+        else hipLaunchKernelGGL((k_attn32<32, 4>), grid, dim3(256), 0, st, ab);
+    } else {
+        if (nw == 8) hipLaunchKernelGGL((k_attn32<64, 8>), grid, dim3(512), 0, st, ab);
+        else hipLaunchKernelGGL((k_attn32<64, 4>), grid, dim3(256), 0, st, ab);
+    }
     PTX_LAUNCHED("k_attn32");
     return PTX_OK;
 }
