@@ -537,7 +537,9 @@ __global__ __launch_bounds__(256) void k_select(SelectArgs a)
     // lowest wave.  (One wave with all points, no barrier: 0.37 us per pick at Mt = 359 but 1.04 us at the
     // shipped configuration's Mt = 1210 -- VALU-bound on one SIMD, 540 us for its 519 picks.  Carrying the winner's
     // coordinates through the candidate exchange instead of re-reading sx[last]: slower, 233 vs 215 us at Mt = 1210 --
-    // the per-lane select of the candidate's registers and three more LDS words cost more than the saved read.)
+    // the per-lane select of the candidate's registers and three more LDS words cost more than the saved read.
+    // Eight waves with P = 3: slower as well, 273 vs 211 us -- two waves per SIMD at the barrier; the pick is bound by
+    // its synchronisation chain, not by the distance updates.)
     const int kn = Kd < Mt ? Kd : Mt;                                            // PRE:595
     {
         // the whole scene waits on this latency-bound loop while bandwidth-bound kernels of the image branch
