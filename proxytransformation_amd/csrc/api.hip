@@ -796,8 +796,17 @@ int ptx_forward(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, const v
     auto enqueue_tags = [&]() -> int {
         PTX_HIP(hipEventRecord(side->aux, cs));
         PTX_HIP(hipStreamWaitEvent(ts, side->aux, 0));
-        PTX_TIMED(KID_SLOTS, ts, launch_select_slots(S, idx2, cluster2, order, picks, keep, kcluster, kidx, drop_idx, tag, ts));
-        PTX_TIMED(KID_TILECOUNT, ts, launch_tile_count(tag, B, S.N, tile_counts, counts, at<int32_t>(ws, L.scene_acc), ts));   // publishes counts early
+        // gathered copies of the kept clusters / the drop list: debug outputs only
+        if (kcluster || kidx || drop_idx)
+            PTX_TRY(launch_select_slots(S, idx2, cluster2, order, picks, keep, kcluster, kidx, drop_idx, nullptr, ts));
+        static const bool old_tags = getenv("PTX_TAGS_ATOMIC") != nullptr;
+        if (old_tags) {
+            PTX_TIMED(KID_SLOTS, ts, launch_select_slots(S, idx2, cluster2, order, picks, keep, nullptr, nullptr, nullptr, tag, ts));
+            PTX_TIMED(KID_TILECOUNT, ts, launch_tile_count(tag, B, S.N, tile_counts, counts, at<int32_t>(ws, L.scene_acc), ts));
+        } else {
+            // ownership / drop tags + survivor counts (published early) in one launch, LDS atomics only
+            PTX_TIMED(KID_SLOTS, ts, launch_tags(S, idx2, order, picks, ksrc, tag, tile_counts, counts, at<int32_t>(ws, L.scene_acc), ts));
+        }
         PTX_HIP(hipEventRecord(side->tags, ts));
         return PTX_OK;
     };

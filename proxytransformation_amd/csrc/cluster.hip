@@ -768,6 +768,104 @@ __global__ __launch_bounds__(256) void k_tile_count(const uint32_t *__restrict__
     }
 }
 
+// Ownership / drop tags AND the per-tile survivor counts of one range of points in one work-group, without a single
+// global atomic (forward path; k_select_slots + k_tile_count are the stage-API form).  The work-group owns the tag words of
+// kTagRange consecutive points in LDS, scans every slot of its scene -- kept clusters: LDS max of 1 + flat slot (last
+// writer in flat order), then, after a barrier, dropped clusters: LDS or of bit 31 -- and writes the range
+// out with plain stores together with its tiles' counts.  (The ~50k device-scope atomics of k_select_slots ran next to
+// the kernels the step waits for and stretched them: 23 us of the 401 us step at the reference's gs = 12 shape.)
+constexpr int kTagRange = 16 * kTilePts;        // 32768 points = 128 KB of LDS
+struct TagArgs {
+    const int32_t *idx, *order, *picks, *ksrc;  // ksrc (B,Mk): source row of kept cluster j (= order[keep[j]])
+    uint32_t *tag; int32_t *tile_counts, *scene_acc, *counts;
+    int M, K, Mt, Mk, Kd, N, ntiles;
+};
+
+__global__ __launch_bounds__(1024) void k_tags(TagArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_tag[];      // kTagRange words + 16 tile counters
+    int *s_cnt = reinterpret_cast<int *>(s_tag + kTagRange);
+    const int b = blockIdx.y, base = blockIdx.x * kTagRange, tid = threadIdx.x;
+    const int M = a.M, K = a.K, Mt = a.Mt, Mk = a.Mk, Kd = a.Kd;
+    const int kn = Kd < Mt ? Kd : Mt;
+    for (int i = tid * 4; i < kTagRange; i += 1024 * 4) *reinterpret_cast<uint4 *>(s_tag + i) = make_uint4(0u, 0u, 0u, 0u);
+    if (tid < 16) s_cnt[tid] = 0;
+    __syncthreads();
+    const int32_t *idx = a.idx + (size_t)b * M * K;
+    for (int e = tid; e < Mk * K; e += 1024) {                  // owners
+        const int j = e / K, k = e - j * K;
+        const int id = idx[(size_t)a.ksrc[(size_t)b * Mk + j] * K + k];
+        const unsigned r = (unsigned)(id - base);               // id = -1 (padding) is out of range too
+        if (r < (unsigned)kTagRange) atomicMax(&s_tag[r], (uint32_t)(e + 1));
+    }
+    __syncthreads();
+    const int32_t *order = a.order + (size_t)b * Mt;
+    for (int ed = tid; ed < Kd * K; ed += 1024) {               // drops
+        const int kk = ed / K, k = ed - kk * K;
+        const int pk = kk < kn ? a.picks[(size_t)b * Kd + kk] : -1;
+        if (pk < 0) continue;
+        const int id = idx[(size_t)order[pk] * K + k];
+        const unsigned r = (unsigned)(id - base);
+        if (r < (unsigned)kTagRange) atomicOr(&s_tag[r], 0x80000000u);
+    }
+    __syncthreads();
+    // write-out (16-B stores when the scene's tag row allows it) + survivors per tile
+    uint32_t *tg = a.tag + (size_t)b * a.N;
+    const int lim = min(kTagRange, a.N - base);                 // valid words of this range
+    const bool vec = ((a.N & 3) == 0);
+    for (int i0 = 0; i0 < lim; i0 += 1024 * 4) {               // wave-uniform trip count: the wave reduction needs all lanes
+        const int i = i0 + tid * 4;
+        int c = 0;
+        if (i < lim) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(s_tag + i);
+            if (vec) {                                          // then lim is a multiple of 4 as well
+                *reinterpret_cast<uint4 *>(tg + base + i) = v;
+                c = (int)((v.x >> 31) == 0) + (int)((v.y >> 31) == 0) + (int)((v.z >> 31) == 0) + (int)((v.w >> 31) == 0);
+            } else {
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (i + q < lim) { tg[base + i + q] = w[q]; c += (int)((w[q] >> 31) == 0); }
+            }
+        }
+        // the 64 lanes of a wave cover 256 consecutive points: one tile (2048 points) per 8 waves and pass
+        c = wave_sum(c);
+        if (lane_id() == 0 && i < kTagRange) atomicAdd(&s_cnt[i / kTilePts], c);
+    }
+    __syncthreads();
+    const int t0 = blockIdx.x * 16;
+    if (tid < 16 && t0 + tid < a.ntiles) a.tile_counts[b * a.ntiles + t0 + tid] = s_cnt[tid];
+    if (tid == 0 && a.scene_acc != nullptr) {
+        int total = 0;
+        for (int t = 0; t < 16; ++t) total += s_cnt[t];
+        // the last range of a scene to arrive publishes the scene's count (see k_tile_count)
+        __hip_atomic_fetch_add(a.scene_acc + 2 * b, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int ticket = __hip_atomic_fetch_add(a.scene_acc + 2 * b + 1, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (ticket == (int)gridDim.x - 1) {
+            const int sum = __hip_atomic_exchange(a.scene_acc + 2 * b, 0, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.scene_acc + 2 * b + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.counts + b, sum, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+int launch_tags(const PtxShape &s, const int32_t *idx, const int32_t *order, const int32_t *picks, const int32_t *ksrc,
+                uint32_t *tag, int32_t *tile_counts, int32_t *counts, int32_t *scene_acc, hipStream_t st)
+{
+    const int M = s.grid_size * s.grid_size * s.grid_size;
+    TagArgs a{idx, order, picks, ksrc, tag, tile_counts, scene_acc, counts, M, s.K, s.Mt, s.Mk, s.Mt - s.Mk, s.N,
+              cdiv(s.N, kTilePts)};
+    const size_t lds = sizeof(uint32_t) * kTagRange + 16 * sizeof(int);
+    static bool attr_set = false;
+    if (!attr_set) {
+        PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tags), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_tags, dim3(cdiv(s.N, kTagRange), s.B), dim3(1024), lds, st, a);
+    PTX_LAUNCHED("k_tags");
+    return PTX_OK;
+}
+
 // stand-alone form of the per-scene sum (stage API without accumulators)
 __global__ __launch_bounds__(64) void k_scene_counts(const int32_t *tile_counts, int ntiles, int32_t *counts)
 {
