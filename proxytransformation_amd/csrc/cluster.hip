@@ -856,11 +856,8 @@ int launch_tags(const PtxShape &s, const int32_t *idx, const int32_t *order, con
     TagArgs a{idx, order, picks, ksrc, tag, tile_counts, scene_acc, counts, M, s.K, s.Mt, s.Mk, s.Mt - s.Mk, s.N,
               cdiv(s.N, kTilePts)};
     const size_t lds = sizeof(uint32_t) * kTagRange + 16 * sizeof(int);
-    static bool attr_set = false;
-    if (!attr_set) {
-        PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tags), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    // (per launch, like k_select: the attribute is per device, a process may drive several)
+    PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tags), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_tags, dim3(cdiv(s.N, kTagRange), s.B), dim3(1024), lds, st, a);
     PTX_LAUNCHED("k_tags");
     return PTX_OK;
