@@ -117,10 +117,12 @@ __global__ __launch_bounds__(NW * 64) void k_attn32(AttnBatch ab)
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float m_new = fmaxf(m_run, tmax);                       // finite: every tile has a valid key
+        // (the numerators use the hardware exponential, exp2(x log2 e): ~1e-7 relative, against the 5e-5 bar of the
+        //  float stages; 16 of them per lane and key tile were a third of a tile's instruction time)
         const float alpha = expf(m_run - m_new);
         float psum = 0.0f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { const float e = expf(sc[r] - m_new); sc[r] = e; psum += e; }
+        for (int r = 0; r < 16; ++r) { const float e = __expf(sc[r] - m_new); sc[r] = e; psum += e; }
         psum += __shfl_xor(psum, 32, 64);
         l_run = fmaf(l_run, alpha, psum);
 #pragma unroll
