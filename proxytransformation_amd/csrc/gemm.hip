@@ -402,7 +402,7 @@ __global__ __launch_bounds__(SK * 64) void k_gemm32(GemmBatch gb)
             const float *ml = pr.pml + (size_t)row * pr.ldml;
             const float m0 = ml[0], l0 = ml[1], m1 = ml[2], l1 = ml[3], s0 = ml[4];
             const float m = fmaxf(fmaxf(m0, m1), s0);
-            const float x0 = expf(m0 - m), x1 = expf(m1 - m), xt = expf(s0 - m);
+            const float x0 = __expf(m0 - m), x1 = __expf(m1 - m), xt = __expf(s0 - m);
             const float inv = 1.0f / ((l0 * x0 + l1 * x1) + xt);
             fc0[i] = x0 * inv; fc1[i] = x1 * inv; fct[i] = xt * inv;
             if (wv == 0 && (lane & 7) == 0) cts[r0 + 8 * i] = fct[i];
