@@ -367,7 +367,7 @@ def main():
                                          f"L={cfg.L} text + V={cfg.V} image proxies, d={cfg.embed_dim}, eval forward",
                                 scenes_per_gpu=B, global_scenes_per_step=world * B, sharding="by scene, no collective",
                                 img_feat_dtype=img_dtype, input_sets_rotated=len(inputs.sets), streams=args.streams,
-                                arithmetic="fp32 (exact-fp32 MFMA / VALU; 16-bit matrix pipe only through exact 3-way operand splits, fp32 accumulate)",
+                                arithmetic="fp32 (fp32 MFMA / VALU; the 16-bit matrix pipe only through 3-way operand splits with fp32 accumulate: exact in the pooling pass, dropped terms <= 2^-25 |xy| in the 64x64-tile GEMMs)",
                                 surviving_points_per_step=n_out),
                     roofline=roof)
         if f32_step > 0:
