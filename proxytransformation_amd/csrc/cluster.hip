@@ -774,22 +774,25 @@ __global__ __launch_bounds__(256) void k_tile_count(const uint32_t *__restrict__
 // writer in flat order), then, after a barrier, dropped clusters: LDS or of bit 31 -- and writes the range
 // out with plain stores together with its tiles' counts.  (The ~50k device-scope atomics of k_select_slots ran next to
 // the kernels the step waits for and stretched them: 23 us of the 401 us step at the reference's gs = 12 shape.)
-constexpr int kTagRange = 16 * kTilePts;        // 32768 points = 128 KB of LDS
+// TILES 2048-point tiles per work-group: 16 (32768 points, 128 KB of LDS) when there are many scenes, 4 when a single
+// scene would otherwise sit on four work-groups (each of them scans every slot of the scene)
 struct TagArgs {
     const int32_t *idx, *order, *picks, *ksrc;  // ksrc (B,Mk): source row of kept cluster j (= order[keep[j]])
     uint32_t *tag; int32_t *tile_counts, *scene_acc, *counts;
     int M, K, Mt, Mk, Kd, N, ntiles;
 };
 
+template <int TILES>
 __global__ __launch_bounds__(1024) void k_tags(TagArgs a)
 {
+    constexpr int kTagRange = TILES * kTilePts;
     extern __shared__ __attribute__((aligned(16))) uint32_t s_tag[];      // kTagRange words + 16 tile counters
     int *s_cnt = reinterpret_cast<int *>(s_tag + kTagRange);
     const int b = blockIdx.y, base = blockIdx.x * kTagRange, tid = threadIdx.x;
     const int M = a.M, K = a.K, Mt = a.Mt, Mk = a.Mk, Kd = a.Kd;
     const int kn = Kd < Mt ? Kd : Mt;
     for (int i = tid * 4; i < kTagRange; i += 1024 * 4) *reinterpret_cast<uint4 *>(s_tag + i) = make_uint4(0u, 0u, 0u, 0u);
-    if (tid < 16) s_cnt[tid] = 0;
+    if (tid < TILES) s_cnt[tid] = 0;
     __syncthreads();
     const int32_t *idx = a.idx + (size_t)b * M * K;
     for (int e = tid; e < Mk * K; e += 1024) {                  // owners
@@ -833,11 +836,11 @@ __global__ __launch_bounds__(1024) void k_tags(TagArgs a)
         if (lane_id() == 0 && i < kTagRange) atomicAdd(&s_cnt[i / kTilePts], c);
     }
     __syncthreads();
-    const int t0 = blockIdx.x * 16;
-    if (tid < 16 && t0 + tid < a.ntiles) a.tile_counts[b * a.ntiles + t0 + tid] = s_cnt[tid];
+    const int t0 = blockIdx.x * TILES;
+    if (tid < TILES && t0 + tid < a.ntiles) a.tile_counts[b * a.ntiles + t0 + tid] = s_cnt[tid];
     if (tid == 0 && a.scene_acc != nullptr) {
         int total = 0;
-        for (int t = 0; t < 16; ++t) total += s_cnt[t];
+        for (int t = 0; t < TILES; ++t) total += s_cnt[t];
         // the last range of a scene to arrive publishes the scene's count (see k_tile_count)
         __hip_atomic_fetch_add(a.scene_acc + 2 * b, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int ticket = __hip_atomic_fetch_add(a.scene_acc + 2 * b + 1, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
@@ -855,10 +858,17 @@ int launch_tags(const PtxShape &s, const int32_t *idx, const int32_t *order, con
     const int M = s.grid_size * s.grid_size * s.grid_size;
     TagArgs a{idx, order, picks, ksrc, tag, tile_counts, scene_acc, counts, M, s.K, s.Mt, s.Mk, s.Mt - s.Mk, s.N,
               cdiv(s.N, kTilePts)};
-    const size_t lds = sizeof(uint32_t) * kTagRange + 16 * sizeof(int);
-    // (per launch, like k_select: the attribute is per device, a process may drive several)
-    PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tags), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_tags, dim3(cdiv(s.N, kTagRange), s.B), dim3(1024), lds, st, a);
+    static const int tiles_env = getenv("PTX_TAG_TILES") ? atoi(getenv("PTX_TAG_TILES")) : 0;
+    const bool small = tiles_env ? tiles_env == 4 : (long)s.B * cdiv(s.N, 16 * kTilePts) < 16;
+    if (small) {
+        const size_t lds = sizeof(uint32_t) * 4 * kTilePts + 16 * sizeof(int);
+        hipLaunchKernelGGL(k_tags<4>, dim3(cdiv(s.N, 4 * kTilePts), s.B), dim3(1024), lds, st, a);
+    } else {
+        const size_t lds = sizeof(uint32_t) * 16 * kTilePts + 16 * sizeof(int);
+        // (per launch, like k_select: the attribute is per device, a process may drive several)
+        PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tags<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_tags<16>, dim3(cdiv(s.N, 16 * kTilePts), s.B), dim3(1024), lds, st, a);
+    }
     PTX_LAUNCHED("k_tags");
     return PTX_OK;
 }
