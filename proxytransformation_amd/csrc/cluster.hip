@@ -479,8 +479,8 @@ __global__ __launch_bounds__(256) void k_select(SelectArgs a)
     int *s_keep = s_flag + Mt;                                    // Mk
     int *s_picks = s_keep + Mk;                                   // Kd
     int *s_hist = s_picks + (Kd > 0 ? Kd : 1);                    // 64
-    float *s_candv = reinterpret_cast<float *>(s_hist + 64);      // [2][4] FPS candidates of the four waves
-    int *s_candi = reinterpret_cast<int *>(s_candv + 8);          // [2][4]
+    // [2][4] FPS candidates of the four waves, (~index, distance bits), 16-byte aligned (select_lds_bytes leaves the room)
+    uint2 *s_cand = reinterpret_cast<uint2 *>(smem + ((reinterpret_cast<unsigned char *>(s_hist + 64) - smem + 15) & ~(size_t)15));
 
     const int32_t *pc = a.pad_count + (size_t)b * M;
     // ---- 1. ordering
@@ -545,39 +545,48 @@ __global__ __launch_bounds__(256) void k_select(SelectArgs a)
         // the whole scene waits on this latency-bound loop while bandwidth-bound kernels of the image branch
         // share the CU: give it issue priority
         __builtin_amdgcn_s_setprio(3);
+        // Minimum distances are >= +0: their bit patterns order like the floats, so the argmax runs on unsigned
+        // integers (v_max_u32 takes the DPP operand directly; a float max needs two more canonicalising ops per step).
+        // Padding lanes hold distance 0: they tie with picked points only and lose by index (first max, PRE:613).
         float px[P], py[P], pz[P], mind[P];
 #pragma unroll
         for (int i = 0; i < P; ++i) {
             const int t = tid * P + i;
             if (t < Mt) { px[i] = sx[t]; py[i] = sy[t]; pz[i] = sz[t]; mind[i] = INFINITY; }
-            else        { px[i] = py[i] = pz[i] = 0.0f; mind[i] = -1.0f; }      // never the maximum
+            else        { px[i] = py[i] = pz[i] = 0.0f; mind[i] = 0.0f; }          // never the FIRST maximum
         }
         int last = 0;
         if (tid == 0 && Kd > 0) s_picks[0] = 0;
         for (int k = 1; k < kn; ++k) {
             const float lx = sx[last], ly = sy[last], lz = sz[last];
-            float bv = -1.0f; int bi = 0;
+            uint32_t bv = 0u; int bi = 0;
 #pragma unroll
             for (int i = 0; i < P; ++i) {
                 const float d2 = dist2_nofma(lx, ly, lz, px[i], py[i], pz[i]);
                 const float mnv = fminf(mind[i], d2);                            // PRE:609
                 mind[i] = mnv;
-                if (mnv > bv) { bv = mnv; bi = i; }
+                const uint32_t u = __float_as_uint(mnv);
+                if (u > bv) { bv = u; bi = i; }
             }
-            const float gmax = wave_max_dpp(bv);
+            uint32_t g = bv;
+            g = max(g, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)g, 0x128, 0xf, 0xf, false));    // row_ror 8
+            g = max(g, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)g, 0x124, 0xf, 0xf, false));    // 4
+            g = max(g, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)g, 0x122, 0xf, 0xf, false));    // 2
+            g = max(g, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)g, 0x121, 0xf, 0xf, false));    // 1
+            const uint32_t gmax = max(max((uint32_t)__builtin_amdgcn_readlane((int)g, 0), (uint32_t)__builtin_amdgcn_readlane((int)g, 16)),
+                                      max((uint32_t)__builtin_amdgcn_readlane((int)g, 32), (uint32_t)__builtin_amdgcn_readlane((int)g, 48)));
             const unsigned long long who = __ballot(bv == gmax);
             const int leader = __ffsll((long long)who) - 1;
             const int cand = (wid * 64 + leader) * P + __builtin_amdgcn_readlane(bi, leader);
             const int par = (k & 1) * 4;                         // double-buffered: one barrier per pick
-            if (lane == 0) { s_candv[par + wid] = gmax; s_candi[par + wid] = cand; }
+            // one 64-bit word per wave: distance bits above the complemented index, so that a plain unsigned maximum
+            // is "largest distance, lowest index" -- and both halves of every word are wanted by the comparison itself
+            // (with separate compares hipcc reads the distances first and fetches the winner's index afterwards)
+            if (lane == 0) s_cand[par + wid] = make_uint2(~(uint32_t)cand, gmax);
             __syncthreads();
-            float best = s_candv[par];
-            last = s_candi[par];
-#pragma unroll
-            for (int w = 1; w < 4; ++w) {
-                const float v = s_candv[par + w];
-                if (v > best) { best = v; last = s_candi[par + w]; }
-            }
+            const unsigned long long *cw = reinterpret_cast<const unsigned long long *>(s_cand + par);
+            const unsigned long long bw = max(max(cw[0], cw[1]), max(cw[2], cw[3]));
+            last = (int)~(uint32_t)bw;
             if (tid == 0) s_picks[k] = last;
         }
         __builtin_amdgcn_s_setprio(0);
