@@ -548,25 +548,50 @@ __global__ __launch_bounds__(256) void k_select(SelectArgs a)
         // Minimum distances are >= +0: their bit patterns order like the floats, so the argmax runs on unsigned
         // integers (v_max_u32 takes the DPP operand directly; a float max needs two more canonicalising ops per step).
         // Padding lanes hold distance 0: they tie with picked points only and lose by index (first max, PRE:613).
-        float px[P], py[P], pz[P], mind[P];
+        // From six points per lane on (Mt > 1280) the points sit in PAIRS: the packed fp32 instructions (v_pk_add / v_pk_mul,
+        // IEEE round-to-nearest like the scalar ones, never fused) update two distances at once -- 1.38 -> 1.18 ms per step
+        // at the 2 868 centres of cfg5; with five points per lane the sixth, empty slot costs more than packing saves.
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        constexpr bool PK = P >= 6;
+        constexpr int PP = PK ? (P + 1) / 2 : P;               // register slots per coordinate
+        constexpr int NE = PK ? 2 * PP : P;                    // distance slots
+        f32x2 px[PP], py[PP], pz[PP]; uint32_t mind[NE];
 #pragma unroll
-        for (int i = 0; i < P; ++i) {
+        for (int i = 0; i < NE; ++i) {
             const int t = tid * P + i;
-            if (t < Mt) { px[i] = sx[t]; py[i] = sy[t]; pz[i] = sz[t]; mind[i] = INFINITY; }
-            else        { px[i] = py[i] = pz[i] = 0.0f; mind[i] = 0.0f; }          // never the FIRST maximum
+            const bool real = i < P && t < Mt;
+            const int j = PK ? i >> 1 : i, e = PK ? i & 1 : 0;
+            px[j][e] = real ? sx[t] : 0.0f; py[j][e] = real ? sy[t] : 0.0f; pz[j][e] = real ? sz[t] : 0.0f;
+            mind[i] = real ? 0x7f800000u : 0u;          // +inf; padding: 0, never the FIRST maximum
         }
         int last = 0;
         if (tid == 0 && Kd > 0) s_picks[0] = 0;
         for (int k = 1; k < kn; ++k) {
             const float lx = sx[last], ly = sy[last], lz = sz[last];
             uint32_t bv = 0u; int bi = 0;
+            if (PK) {
+                const f32x2 lx2 = {lx, lx}, ly2 = {ly, ly}, lz2 = {lz, lz};
 #pragma unroll
-            for (int i = 0; i < P; ++i) {
-                const float d2 = dist2_nofma(lx, ly, lz, px[i], py[i], pz[i]);
-                const float mnv = fminf(mind[i], d2);                            // PRE:609
-                mind[i] = mnv;
-                const uint32_t u = __float_as_uint(mnv);
-                if (u > bv) { bv = u; bi = i; }
+                for (int j = 0; j < PP; ++j) {
+                    // ((dx*dx)+dy*dy)+dz*dz per element, one rounding per operation (built with -ffp-contract=off)
+                    const f32x2 dx = lx2 - px[j], dy = ly2 - py[j], dz = lz2 - pz[j];
+                    const f32x2 d2 = (dx * dx + dy * dy) + dz * dz;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int i = 2 * j + e;
+                        const uint32_t u = min(mind[i], __float_as_uint(d2[e]));     // PRE:609 (non-negative floats: bit order)
+                        mind[i] = u;
+                        if (u > bv) { bv = u; bi = i; }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < P; ++i) {
+                    const float d2 = dist2_nofma(lx, ly, lz, px[i][0], py[i][0], pz[i][0]);
+                    const uint32_t u = min(mind[i], __float_as_uint(d2));            // PRE:609
+                    mind[i] = u;
+                    if (u > bv) { bv = u; bi = i; }
+                }
             }
             uint32_t g = bv;
             g = max(g, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)g, 0x128, 0xf, 0xf, false));    // row_ror 8
