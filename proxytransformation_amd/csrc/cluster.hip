@@ -464,7 +464,9 @@ struct SelectArgs {
                              // zeroed here so that the next call finds them clean (no memset launch per call)
 };
 
-template <int P>   // points per thread of the FPS (256 * P >= Mt)
+// P points per lane of the FPS; ONE: a single wave holds all points (64 P >= Mt) and picks without any exchange or barrier
+// (small Mt: the benchmark shape's 359 centres), otherwise the four waves share them (256 P >= Mt)
+template <int P, bool ONE>
 __global__ __launch_bounds__(256) void k_select(SelectArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -556,9 +558,10 @@ __global__ __launch_bounds__(256) void k_select(SelectArgs a)
         constexpr int PP = PK ? (P + 1) / 2 : P;               // register slots per coordinate
         constexpr int NE = PK ? 2 * PP : P;                    // distance slots
         f32x2 px[PP], py[PP], pz[PP]; uint32_t mind[NE];
+        const int fid = ONE ? lane : tid;                      // position of this lane among the lanes that hold points
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
-            const int t = tid * P + i;
+            const int t = fid * P + i;
             const bool real = i < P && t < Mt;
             const int j = PK ? i >> 1 : i, e = PK ? i & 1 : 0;
             px[j][e] = real ? sx[t] : 0.0f; py[j][e] = real ? sy[t] : 0.0f; pz[j][e] = real ? sz[t] : 0.0f;
@@ -566,7 +569,7 @@ __global__ __launch_bounds__(256) void k_select(SelectArgs a)
         }
         int last = 0;
         if (tid == 0 && Kd > 0) s_picks[0] = 0;
-        for (int k = 1; k < kn; ++k) {
+        for (int k = 1; k < (ONE && wid != 0 ? 0 : kn); ++k) {
             const float lx = sx[last], ly = sy[last], lz = sz[last];
             uint32_t bv = 0u; int bi = 0;
             if (PK) {
@@ -602,7 +605,12 @@ __global__ __launch_bounds__(256) void k_select(SelectArgs a)
                                       max((uint32_t)__builtin_amdgcn_readlane((int)g, 32), (uint32_t)__builtin_amdgcn_readlane((int)g, 48)));
             const unsigned long long who = __ballot(bv == gmax);
             const int leader = __ffsll((long long)who) - 1;
-            const int cand = (wid * 64 + leader) * P + __builtin_amdgcn_readlane(bi, leader);
+            const int cand = ((ONE ? 0 : wid * 64) + leader) * P + __builtin_amdgcn_readlane(bi, leader);
+            if (ONE) {
+                last = cand;
+                if (lane == 0) s_picks[k] = last;
+                continue;
+            }
             const int par = (k & 1) * 4;                         // double-buffered: one barrier per pick
             // one 64-bit word per wave: distance bits above the complemented index, so that a plain unsigned maximum
             // is "largest distance, lowest index" -- and both halves of every word are wanted by the comparison itself
@@ -718,14 +726,17 @@ int launch_select_order(const PtxShape &s, const float *centers, const int32_t *
     a.ksrc = ksrc;
     const size_t lds = select_lds_bytes(s);
     PTX_REQUIRE(lds <= 160 * 1024, "select: Mt=%d needs %zu B of LDS (> 160 KiB)", s.Mt, lds);
-    const int per = cdiv(s.Mt, 256);
+    static const int one_env = getenv("PTX_FPS_ONE") ? atoi(getenv("PTX_FPS_ONE")) : -1;
+    const bool one = one_env >= 0 ? (one_env != 0 && s.Mt <= 384) : s.Mt <= 384;
+    const int per = cdiv(s.Mt, one ? 64 : 256);
     const dim3 grid(s.B), block(256);
 #define PTX_SEL(P_)                                                                          \
     do {                                                                                     \
         if (lds > 64 * 1024)                                                                 \
-            PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_select<P_>),       \
+            PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_select<P_, false>), \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(k_select<P_>, grid, block, lds, st, a);                           \
+        if (one && P_ <= 6) hipLaunchKernelGGL((k_select<(P_ <= 6 ? P_ : 1), true>), grid, block, lds, st, a); \
+        else hipLaunchKernelGGL((k_select<P_, false>), grid, block, lds, st, a);             \
     } while (0)
     if (per <= 1) PTX_SEL(1);
     else if (per <= 2) PTX_SEL(2);
