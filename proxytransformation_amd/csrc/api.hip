@@ -787,7 +787,7 @@ int ptx_forward(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, const v
     int32_t *drop_idx = dbg && debug->drop_idx ? at<int32_t>(ws, L.drop_idx) : nullptr;
     int32_t *ksrc = at<int32_t>(ws, L.ksrc);
     PTX_TIMED(KID_SELECT, cs, launch_select_order(S, centers, pad_count, order_override, order, picks, keep, kcenter,
-                                                  ksrc, mm_enc, cs));
+                                                  ksrc, mm_enc, cs, cluster_on_caller));
     int32_t *tile_counts = at<int32_t>(ws, L.tile_counts);
     hipStream_t ts = side->lo;
     // the slot tags / survivor counts (side stream) start before the point proxies when the image chain is the long

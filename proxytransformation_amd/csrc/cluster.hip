@@ -719,7 +719,7 @@ static SelectArgs select_args(const PtxShape &s, const int32_t *idx, const float
 // ordering + FPS + keep list + kept centres (one work-group per scene)
 int launch_select_order(const PtxShape &s, const float *centers, const int32_t *pad_count,
                         const int32_t *order_override, int32_t *order, int32_t *picks, int32_t *keep,
-                        float *kcenter, int32_t *ksrc, uint32_t *mm_clear, hipStream_t st)
+                        float *kcenter, int32_t *ksrc, uint32_t *mm_clear, hipStream_t st, bool critical)
 {
     SelectArgs a = select_args(s, nullptr, centers, nullptr, pad_count, order_override, order, picks, keep, kcenter,
                                nullptr, nullptr, nullptr, nullptr, mm_clear);
@@ -727,7 +727,9 @@ int launch_select_order(const PtxShape &s, const float *centers, const int32_t *
     const size_t lds = select_lds_bytes(s);
     PTX_REQUIRE(lds <= 160 * 1024, "select: Mt=%d needs %zu B of LDS (> 160 KiB)", s.Mt, lds);
     static const int one_env = getenv("PTX_FPS_ONE") ? atoi(getenv("PTX_FPS_ONE")) : -1;
-    const bool one = one_env >= 0 ? (one_env != 0 && s.Mt <= 384) : s.Mt <= 384;
+    // one wave only when the step waits for this kernel: beside a longer image chain the four-wave form finishes early
+    // enough and leaves the point-proxy / qkv kernels later, i.e. less of them under the pooling pass
+    const bool one = one_env >= 0 ? (one_env != 0 && s.Mt <= 384) : (critical && s.Mt <= 384);
     const int per = cdiv(s.Mt, one ? 64 : 256);
     const dim3 grid(s.B), block(256);
 #define PTX_SEL(P_)                                                                          \
@@ -771,7 +773,7 @@ int launch_select(const PtxShape &s, const int32_t *idx, const float *centers, c
                   int32_t *picks, int32_t *keep, float *kcenter, float *kcluster, int32_t *kidx,
                   int32_t *drop_idx, uint32_t *tag, hipStream_t st)
 {
-    PTX_TRY(launch_select_order(s, centers, pad_count, order_override, order, picks, keep, kcenter, nullptr, nullptr, st));
+    PTX_TRY(launch_select_order(s, centers, pad_count, order_override, order, picks, keep, kcenter, nullptr, nullptr, st, true));
     return launch_select_slots(s, idx, cluster, order, picks, keep, kcluster, kidx, drop_idx, tag, st);
 }
 
