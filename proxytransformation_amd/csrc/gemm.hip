@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void k_gemm64(GemmBatch gb)
         }                                                                                  \
     } while (0)
 
-template <int NKG>
+template <int NKG, int REP>      // K = 128 NKG REP: the written-out body runs REP times (one drain of the prefetch per repetition)
 __global__ __launch_bounds__(256) void k_gemm64x(GemmBatch gb)
 {
     constexpr int kXPlane = 64 * XROW, kXBuf = 6 * kXPlane;     // one plane of a 64 x 32 tile; [A1 A2 A3 W1 W2 W3] per buffer
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void k_gemm64x(GemmBatch gb)
         }                                                                                  \
     } while (0)
 #define PTX_X64_STEP(S, SN, par_)                                                          \
-    if (it + 4 < 4 * NKG) PTX_X64_FETCH(S, it + 4);                                        \
+    if (it + 4 < 4 * NKG || rep + 1 < REP) PTX_X64_FETCH(S, kbase + it + 4);               \
     __builtin_amdgcn_sched_barrier(0);     /* the loads are issued first: live across the step, their own registers */ \
     PTX_X64_COMPUTE(par_);                                                                 \
     PTX_X64_STASH(SN, 1 - (par_));                                                         \
@@ -318,10 +318,14 @@ __global__ __launch_bounds__(256) void k_gemm64x(GemmBatch gb)
     PTX_X64_FETCH(A, 0); PTX_X64_FETCH(B, 1); PTX_X64_FETCH(C, 2); PTX_X64_FETCH(D, 3);
     PTX_X64_STASH(A, 0);
     __syncthreads();
-    int it = 0;
+    int kbase = 0;
+    for (int rep = 0; rep < REP; ++rep) {
+        int it = 0;
 #pragma unroll
-    for (int g = 0; g < NKG; ++g) {
-        PTX_X64_STEP(A, B, 0) PTX_X64_STEP(B, C, 1) PTX_X64_STEP(C, D, 0) PTX_X64_STEP(D, A, 1)
+        for (int g = 0; g < NKG; ++g) {
+            PTX_X64_STEP(A, B, 0) PTX_X64_STEP(B, C, 1) PTX_X64_STEP(C, D, 0) PTX_X64_STEP(D, A, 1)
+        }
+        kbase += 4 * NKG;
     }
 #undef PTX_X64_STEP
 #undef PTX_X64_PIPE
@@ -614,10 +618,12 @@ int launch_gemm(const GemmBatch &gb_in, hipStream_t st)
         static const bool fp32_env = getenv("PTX_GEMM_FP32") != nullptr;
         const dim3 grid(cdiv(rmax, 64), cdiv(nmax, 64), gb.n);
         const int nkg = (!fp32_env && kmin == kmax && kmin % 128 == 0) ? kmin / 128 : 0;
-        if (nkg == 1) hipLaunchKernelGGL(k_gemm64x<1>, grid, dim3(256), 0, st, gb);
-        else if (nkg == 2) hipLaunchKernelGGL(k_gemm64x<2>, grid, dim3(256), 0, st, gb);
-        else if (nkg == 4) hipLaunchKernelGGL(k_gemm64x<4>, grid, dim3(256), 0, st, gb);
-        else if (nkg == 8) hipLaunchKernelGGL(k_gemm64x<8>, grid, dim3(256), 0, st, gb);
+        if (nkg == 1) hipLaunchKernelGGL((k_gemm64x<1, 1>), grid, dim3(256), 0, st, gb);
+        else if (nkg == 2) hipLaunchKernelGGL((k_gemm64x<2, 1>), grid, dim3(256), 0, st, gb);
+        else if (nkg == 4) hipLaunchKernelGGL((k_gemm64x<4, 1>), grid, dim3(256), 0, st, gb);
+        else if (nkg == 8) hipLaunchKernelGGL((k_gemm64x<8, 1>), grid, dim3(256), 0, st, gb);
+        else if (nkg == 16) hipLaunchKernelGGL((k_gemm64x<8, 2>), grid, dim3(256), 0, st, gb);       // embed_dim 512: hidden = 2048
+        else if (nkg == 32) hipLaunchKernelGGL((k_gemm64x<8, 4>), grid, dim3(256), 0, st, gb);
         else hipLaunchKernelGGL(k_gemm64, grid, dim3(256), 0, st, gb);      // fp32 matrix instruction, any K
     } else {
         // latency regime: aim for >= 4 waves per SIMD (4096 waves) by slicing K inside the work-group

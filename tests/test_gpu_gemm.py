@@ -32,7 +32,7 @@ def _operands(R, N, K, seed, wide):
     return x.cuda(), w.cuda()
 
 
-@pytest.mark.parametrize("R,N,K", [(2048, 768, 128), (2048, 768, 256), (2048, 768, 512), (2048, 1024, 1024),   # split, 64x64
+@pytest.mark.parametrize("R,N,K", [(2048, 768, 128), (2048, 768, 256), (2048, 768, 512), (2048, 1024, 1024), (2048, 512, 2048),   # split, 64x64
                                    (2048, 768, 160), (2000, 700, 256),                                        # fp32 64x64 / ragged
                                    (784, 256, 256), (300, 96, 1024), (64, 64, 64)])                            # latency regime
 @pytest.mark.parametrize("wide", [False, True])
