@@ -842,21 +842,37 @@ __global__ __launch_bounds__(1024) void k_tags(TagArgs a)
     if (tid < TILES) s_cnt[tid] = 0;
     __syncthreads();
     const int32_t *idx = a.idx + (size_t)b * M * K;
-    for (int e = tid; e < Mk * K; e += 1024) {                  // owners
-        const int j = e / K, k = e - j * K;
-        const int id = idx[(size_t)a.ksrc[(size_t)b * Mk + j] * K + k];
-        const unsigned r = (unsigned)(id - base);               // id = -1 (padding) is out of range too
-        if (r < (unsigned)kTagRange) atomicMax(&s_tag[r], (uint32_t)(e + 1));
+    // (four slots per thread and trip: the two dependent loads of a slot are the cost of this scan, not its arithmetic)
+    for (int e0 = tid; e0 < Mk * K; e0 += 4 * 1024) {           // owners
+        int id[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * 1024;
+            const int ec = min(e, Mk * K - 1), j = ec / K, k = ec - j * K;
+            id[u] = e < Mk * K ? idx[(size_t)a.ksrc[(size_t)b * Mk + j] * K + k] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned r = (unsigned)(id[u] - base);        // id = -1 (padding) is out of range too
+            if (r < (unsigned)kTagRange) atomicMax(&s_tag[r], (uint32_t)(e0 + u * 1024 + 1));
+        }
     }
     __syncthreads();
     const int32_t *order = a.order + (size_t)b * Mt;
-    for (int ed = tid; ed < Kd * K; ed += 1024) {               // drops
-        const int kk = ed / K, k = ed - kk * K;
-        const int pk = kk < kn ? a.picks[(size_t)b * Kd + kk] : -1;
-        if (pk < 0) continue;
-        const int id = idx[(size_t)order[pk] * K + k];
-        const unsigned r = (unsigned)(id - base);
-        if (r < (unsigned)kTagRange) atomicOr(&s_tag[r], 0x80000000u);
+    for (int e0 = tid; e0 < Kd * K; e0 += 4 * 1024) {           // drops
+        int id[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int ed = e0 + u * 1024;
+            const int ec = min(ed, Kd * K - 1), kk = ec / K, k = ec - kk * K;
+            const int pk = (ed < Kd * K && kk < kn) ? a.picks[(size_t)b * Kd + kk] : -1;
+            id[u] = pk >= 0 ? idx[(size_t)order[pk] * K + k] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned r = (unsigned)(id[u] - base);
+            if (r < (unsigned)kTagRange) atomicOr(&s_tag[r], 0x80000000u);
+        }
     }
     __syncthreads();
     // write-out (16-B stores when the scene's tag row allows it) + survivors per tile
