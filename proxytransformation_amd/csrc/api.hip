@@ -786,15 +786,16 @@ int ptx_forward(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, const v
     int32_t *kidx = dbg && debug->kidx ? at<int32_t>(ws, L.kidx) : nullptr;
     int32_t *drop_idx = dbg && debug->drop_idx ? at<int32_t>(ws, L.drop_idx) : nullptr;
     int32_t *ksrc = at<int32_t>(ws, L.ksrc);
+    static const bool ext_event = getenv("PTX_NO_EXT_EVENT") == nullptr;
     PTX_TIMED(KID_SELECT, cs, launch_select_order(S, centers, pad_count, order_override, order, picks, keep, kcenter,
-                                                  ksrc, mm_enc, cs, cluster_on_caller));
+                                                  ksrc, mm_enc, cs, cluster_on_caller, ext_event ? side->aux : nullptr));
     int32_t *tile_counts = at<int32_t>(ws, L.tile_counts);
     hipStream_t ts = side->lo;
     // the slot tags / survivor counts (side stream) start before the point proxies when the image chain is the long
     // one, after them when the clustering chain is (they share the chip with the kernel the step is waiting for)
     const bool slots_first = !cluster_on_caller;
     auto enqueue_tags = [&]() -> int {
-        PTX_HIP(hipEventRecord(side->aux, cs));
+        if (!ext_event) PTX_HIP(hipEventRecord(side->aux, cs));     // else: recorded by k_select's own completion
         PTX_HIP(hipStreamWaitEvent(ts, side->aux, 0));
         // gathered copies of the kept clusters / the drop list: debug outputs only
         if (kcluster || kidx || drop_idx)

@@ -9,6 +9,8 @@
 //
 // Build with -ffp-contract=off: squared distances decide integer results and must be
 // ((dx*dx)+dy*dy)+dz*dz exactly; they additionally use __f*_rn intrinsics.
+#include <hip/hip_ext.h>
+
 #include "common.h"
 
 namespace ptx {
@@ -719,7 +721,8 @@ static SelectArgs select_args(const PtxShape &s, const int32_t *idx, const float
 // ordering + FPS + keep list + kept centres (one work-group per scene)
 int launch_select_order(const PtxShape &s, const float *centers, const int32_t *pad_count,
                         const int32_t *order_override, int32_t *order, int32_t *picks, int32_t *keep,
-                        float *kcenter, int32_t *ksrc, uint32_t *mm_clear, hipStream_t st, bool critical)
+                        float *kcenter, int32_t *ksrc, uint32_t *mm_clear, hipStream_t st, bool critical,
+                        hipEvent_t done)
 {
     SelectArgs a = select_args(s, nullptr, centers, nullptr, pad_count, order_override, order, picks, keep, kcenter,
                                nullptr, nullptr, nullptr, nullptr, mm_clear);
@@ -737,8 +740,9 @@ int launch_select_order(const PtxShape &s, const float *centers, const int32_t *
         if (lds > 64 * 1024)                                                                 \
             PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_select<P_, false>), \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        if (one && P_ <= 6) hipLaunchKernelGGL((k_select<(P_ <= 6 ? P_ : 1), true>), grid, block, lds, st, a); \
-        else hipLaunchKernelGGL((k_select<P_, false>), grid, block, lds, st, a);             \
+        /* `done` rides on the kernel's own completion signal: a separate event record is one more packet (~6 us) */ \
+        if (one && P_ <= 6) hipExtLaunchKernelGGL((k_select<(P_ <= 6 ? P_ : 1), true>), grid, block, lds, st, nullptr, done, 0, a); \
+        else hipExtLaunchKernelGGL((k_select<P_, false>), grid, block, lds, st, nullptr, done, 0, a); \
     } while (0)
     if (per <= 1) PTX_SEL(1);
     else if (per <= 2) PTX_SEL(2);
@@ -773,7 +777,7 @@ int launch_select(const PtxShape &s, const int32_t *idx, const float *centers, c
                   int32_t *picks, int32_t *keep, float *kcenter, float *kcluster, int32_t *kidx,
                   int32_t *drop_idx, uint32_t *tag, hipStream_t st)
 {
-    PTX_TRY(launch_select_order(s, centers, pad_count, order_override, order, picks, keep, kcenter, nullptr, nullptr, st, true));
+    PTX_TRY(launch_select_order(s, centers, pad_count, order_override, order, picks, keep, kcenter, nullptr, nullptr, st, true, nullptr));
     return launch_select_slots(s, idx, cluster, order, picks, keep, kcluster, kidx, drop_idx, tag, st);
 }
 
