@@ -15,6 +15,9 @@
 //                    MFMA left them (key index of step s, half hh = (s&3) + 8*(s>>2) + 4*hh),
 //                    so P never moves between lanes and the running rescale is per lane.
 // fp32 in / fp32 accumulate: this is the parity configuration.
+// (r02, 32 scenes per GPU, 113 us for both launches = 24 % of the fp32 matrix peak: neither K rows fetched coalesced and
+// turned into the row-per-lane fragment through wave-private LDS (115 us), nor four waves per SIMD (128 VGPRs, 24 B of
+// spill: 110 us) move it; the hardware exponential for the numerators did, 122 -> 113 us.)
 #include <cstdlib>
 
 #include "common.h"
