@@ -265,13 +265,21 @@ static int run_img_proxy(const PtxShape &s, const PtxWeights &w, const float *pr
         else PTX_TIMED(KID_IMG_MEAN, st, launch_img_mean16(img_any, dt, nimg, s.in_dim, s.hw, fm, st));
     }
     if (phase == 1) return PTX_OK;
+    // head_dim 32: a 32-column tile of the qkv0 GEMM IS one head's q, and the work-group that finishes it goes on to that
+    // head's [w_h | e_h] = q_h T1_h^T (GemmProb::w2): one launch (and one boundary) less on the image chain
+    static const bool no_chain = getenv("PTX_NO_CHAIN") != nullptr;
+    const bool chained = hd == 32 && !no_chain;
     {   // [q | k0 | v0] of token 0 = W3 mean(f) + b3
         GemmBatch g{}; g.n = 1;
         g.p[0] = GemmProb{fm, prep + P.w3, qkv0, prep + P.b3, nullptr, nullptr, nullptr,
                           nimg, 3 * C, s.in_dim, s.in_dim, s.in_dim, 3 * C, 0, 0, 0, EPI_NONE};
+        if (chained) {
+            g.p[0].w2 = prep + P.t1; g.p[0].c2 = we; g.p[0].n2 = P.KT1; g.p[0].ldc2 = s.heads * P.KT1;
+            g.p[0].chain_tiles = s.heads; g.p[0].w2_stride = (long)P.KT1 * hd; g.p[0].c2_stride = P.KT1;
+        }
         PTX_TIMED(KID_IMG_QKV0, st, launch_gemm(g, st));
     }
-    {   // per head: [w_h | e_h] = q_h T1_h^T
+    if (!chained) {   // per head: [w_h | e_h] = q_h T1_h^T
         GemmBatch g{}; g.n = s.heads;
         for (int h = 0; h < s.heads; ++h)
             g.p[h] = GemmProb{qkv0 + h * hd, prep + P.t1 + (size_t)h * P.KT1 * hd, we + (size_t)h * P.KT1,

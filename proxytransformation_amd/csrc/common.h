@@ -151,6 +151,11 @@ struct GemmProb {
     //     (mean_r, rstd_r from the ln_parts partials of row r; `bias` must be null) -- LN(x) W'^T + b, reassociated.
     float *lnp_out;
     const float *lnp_in, *ln_s, *ln_c; int ln_parts, ln_C; float ln_eps;
+    // Chained product (latency-regime kernel, 32-column tiles): the work-group of column tile t < chain_tiles multiplies
+    // its finished 32 x 32 tile Y (rows x 32 columns) by a second weight table,  C2_t[r][m] = sum_k Y[r][k] W2_t[m][k]
+    // (m < n2, K = 32), W2_t = w2 + t * w2_stride (row-major (n2,32)), C2_t = c2 + t * c2_stride -- the attention pool's
+    // per-head [w_h | e_h] = q_h T1_h^T straight out of the q columns of the qkv0 GEMM, without a launch of its own.
+    const float *w2; float *c2; int n2, ldc2, chain_tiles; long w2_stride, c2_stride;
 };
 constexpr int kMaxGroups = 8;
 struct GemmBatch { GemmProb p[kMaxGroups]; int n; int rotate; };

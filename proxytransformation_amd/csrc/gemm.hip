@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void k_gemm64x(GemmBatch gb)
 // basic block and hipcc interleaves the next tile's global loads with the MFMAs.
 // blockIdx.x = row tile: work-groups that share an A row-panel land on the same XCD (b % 8)
 // whenever the row-tile count is a multiple of 8.
-template <int SK, int AMODE>   // AMODE 1: A merged on the fly from the k_img_pool tiles (see GemmProb)
+template <int SK, int AMODE, bool CHAIN = false>   // AMODE 1: A merged on the fly from the k_img_pool tiles; CHAIN: see GemmProb::w2
 __global__ __launch_bounds__(SK * 64) void k_gemm32(GemmBatch gb)
 {
     const GemmProb pr = gb.p[blockIdx.z];
@@ -529,6 +529,7 @@ __global__ __launch_bounds__(SK * 64) void k_gemm32(GemmBatch gb)
 #undef PTX_FETCH
 #undef PTX_STASH
 #undef PTX_COMPUTE
+    const bool chain = CHAIN && pr.w2 != nullptr && (int)blockIdx.y < pr.chain_tiles;      // work-group uniform
     if (SK > 1) {
         // fixed-order reduction of the K slices: slice w parks its accumulator in its own LDS
         __syncthreads();
@@ -537,45 +538,89 @@ __global__ __launch_bounds__(SK * 64) void k_gemm32(GemmBatch gb)
             for (int r = 0; r < 16; ++r) base[r * 64 + lane] = acc[r];
         }
         __syncthreads();
-        if (wv > 0) return;
+        if (wv > 0 && !chain) return;
+        if (wv == 0) {
 #pragma unroll
-        for (int w = 1; w < SK; ++w) {
-            const float *o = lds + (size_t)w * (4 * 32 * LDT);
+            for (int w = 1; w < SK; ++w) {
+                const float *o = lds + (size_t)w * (4 * 32 * LDT);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] += o[r * 64 + lane];
+                for (int r = 0; r < 16; ++r) acc[r] += o[r * 64 + lane];
+            }
         }
     }
-    const bool ncol = n < pr.N;
-    float lns = 0.0f, lnc = 0.0f;
-    if (pr.lnp_in != nullptr && ncol) { lns = pr.ln_s[n]; lnc = pr.ln_c[n]; }
-    float fin[16];
+    if (wv == 0) {
+        const bool ncol = n < pr.N;
+        float lns = 0.0f, lnc = 0.0f;
+        if (pr.lnp_in != nullptr && ncol) { lns = pr.ln_s[n]; lnc = pr.ln_c[n]; }
+        float fin[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int rl = (r & 3) + 8 * (r >> 2) + 4 * hh, row = row0 + rl;
-        float v = acc[r] + bias;
-        if (pr.lnp_in != nullptr) v = fmaf(lnst[2 * rl + 1], fmaf(-lnst[2 * rl], lns, acc[r]), lnc);
-        if (pr.epi == EPI_GELU) v = gelu_erf(v);
-        const bool ok = ncol && row < pr.R;
-        if (ok) {
-            if (AMODE == 1) v = fmaf(cts[rl], pr.ad[(size_t)row * pr.ldad + n], v);
-            else if (pr.rs) v = fmaf(pr.rs[(size_t)row * pr.rs_stride], pr.ad[(size_t)row * pr.ldad + n], v);
-            if (pr.res) v += resv[r];
-            pr.C[(size_t)row * pr.ldc + n] = v;
+        for (int r = 0; r < 16; ++r) {
+            const int rl = (r & 3) + 8 * (r >> 2) + 4 * hh, row = row0 + rl;
+            float v = acc[r] + bias;
+            if (pr.lnp_in != nullptr) v = fmaf(lnst[2 * rl + 1], fmaf(-lnst[2 * rl], lns, acc[r]), lnc);
+            if (pr.epi == EPI_GELU) v = gelu_erf(v);
+            const bool ok = ncol && row < pr.R;
+            if (ok) {
+                if (AMODE == 1) v = fmaf(cts[rl], pr.ad[(size_t)row * pr.ldad + n], v);
+                else if (pr.rs) v = fmaf(pr.rs[(size_t)row * pr.rs_stride], pr.ad[(size_t)row * pr.ldad + n], v);
+                if (pr.res) v += resv[r];
+                pr.C[(size_t)row * pr.ldc + n] = v;
+            }
+            fin[r] = ok ? v : 0.0f;
         }
-        fin[r] = ok ? v : 0.0f;
+        if (pr.lnp_out != nullptr)      // wave 0's staging area is free: its K loop is over, the other slices parked elsewhere
+            ln_tile_partials(pr, fin, lds, row0, col0 >> 5, (pr.N + 31) >> 5);
+        if (chain) {                    // the finished tile, [row][column], for the chained product (wave 0's staging area)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lds[((r & 3) + 8 * (r >> 2) + 4 * hh) * LDT + li] = fin[r];
+        }
     }
-    if (pr.lnp_out != nullptr)      // wave 0's staging area is free: its K loop is over, the other slices parked elsewhere
-        ln_tile_partials(pr, fin, lds, row0, col0 >> 5, (pr.N + 31) >> 5);
+    if (!chain) return;
+    if (CHAIN) {
+        __syncthreads();
+        // C2[r][m] = sum_k Y[r][k] W2[m][k]: the SK waves take the 32-column tiles of C2 round-robin; A fragments from LDS,
+        // W2 rows (32 floats = one 128-byte line each) straight from memory, 16 fp32 MFMAs per tile
+        const float *W2 = pr.w2 + (size_t)blockIdx.y * pr.w2_stride;
+        float *C2 = pr.c2 + (size_t)blockIdx.y * pr.c2_stride;
+        float4 ya[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) ya[kk] = *reinterpret_cast<const float4 *>(lds + li * LDT + kk * 8 + hh * 4);
+        const int nt2 = (pr.n2 + 31) >> 5;
+        for (int t = wv; t < nt2; t += SK) {
+            const int m = t * 32 + li;
+            const float *wr = W2 + (size_t)min(m, pr.n2 - 1) * 32 + hh * 4;
+            float4 wb[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) wb[kk] = *reinterpret_cast<const float4 *>(wr + kk * 8);
+            f32x16 c2;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) c2[i] = 0.0f;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ya[kk].x, wb[kk].x, c2, 0, 0, 0);
+                c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ya[kk].y, wb[kk].y, c2, 0, 0, 0);
+                c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ya[kk].z, wb[kk].z, c2, 0, 0, 0);
+                c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ya[kk].w, wb[kk].w, c2, 0, 0, 0);
+            }
+            if (m < pr.n2) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    if (row < pr.R) C2[(size_t)row * pr.ldc2 + m] = c2[r];
+                }
+            }
+        }
+    }
 }
 
-template <int SK, int AMODE>
+template <int SK, int AMODE, bool CHAIN = false>
 static int launch_gemm32(const GemmBatch &gb, int rmax, int nmax, hipStream_t st)
 {
     const size_t lds = sizeof(float) * (SK * 4 * 32 * LDT + 32 + 64);
     if (lds > 64 * 1024)
-        PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm32<SK, AMODE>),
+        PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm32<SK, AMODE, CHAIN>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_gemm32<SK, AMODE>), dim3(cdiv(rmax, 32), cdiv(nmax, 32), gb.n), dim3(SK * 64), lds, st, gb);
+    hipLaunchKernelGGL((k_gemm32<SK, AMODE, CHAIN>), dim3(cdiv(rmax, 32), cdiv(nmax, 32), gb.n), dim3(SK * 64), lds, st, gb);
     return PTX_OK;
 }
 
@@ -608,6 +653,14 @@ int launch_gemm(const GemmBatch &gb_in, hipStream_t st)
         kmin = p.K < kmin ? p.K : kmin;
         kmax = p.K > kmax ? p.K : kmax;
         tiles32 += (long)cdiv(p.R, 32) * cdiv(p.N, 32);
+    }
+    if (gb.p[0].w2 != nullptr) {
+        PTX_REQUIRE(gb.n == 1 && gb.p[0].pg == nullptr && gb.p[0].c2 && gb.p[0].n2 >= 1 && gb.p[0].chain_tiles >= 1 &&
+                    gb.p[0].chain_tiles * 32 <= gb.p[0].N && gb.p[0].K >= 4 * BK,
+                    "gemm: bad chained-product description");
+        PTX_TRY((launch_gemm32<4, 0, true>(gb, rmax, nmax, st)));
+        PTX_LAUNCHED("k_gemm");
+        return PTX_OK;
     }
     static const int g64_min = getenv("PTX_G64_MIN") ? atoi(getenv("PTX_G64_MIN")) : 1024;
     if (gb.p[0].pg != nullptr) {
