@@ -164,3 +164,36 @@ def test_real_module_sharded_over_two_ranks_matches_unsharded(tmp_path):
             seen.add(sid)
         assert torch.equal(res["allt"], want_t), "gathered transforms differ"
     assert seen == set(range(cfg.B))
+
+
+def test_launch_count_of_the_benchmark_shape():
+    """an eval forward at the benchmark's shape (bf16-stored features, head_dim 32) is 19 kernel launches --
+    counted through the library's own launch-site bracketing (every launch of the forward sits in exactly one site)."""
+    import ctypes
+    from proxytransformation_amd import _abi
+    from proxytransformation_amd.synth import PreshapeConfig, make_scene_batch
+    from tests.util import build_module
+    cfg = PreshapeConfig("launches", B=2, N=20000, grid_size=8, dynamic_drop_radio=0.5, L=16, V=20, seed_base=77)
+    m, _ = build_module(cfg)
+    m = m.cuda()
+    pts, text, mask, img = make_scene_batch(cfg)
+    dev = torch.device("cuda:0")
+    args = ([torch.from_numpy(p).to(dev) for p in pts],
+            {"text_feats": torch.from_numpy(text).to(dev), "text_token_mask": torch.from_numpy(mask).to(dev)},
+            torch.from_numpy(img).to(dev).to(torch.bfloat16))
+    lib = _abi.lib()
+    nk = lib.ptx_kernel_count()
+    with torch.no_grad():
+        m(*args)                                    # tables, workspace
+        torch.cuda.synchronize()
+        lib.ptx_timing_select_mask((1 << nk) - 1)
+        try:
+            m(*args)
+            torch.cuda.synchronize()
+            n = (ctypes.c_int * nk)()
+            ms = (ctypes.c_float * nk)()
+            lib.ptx_timing_read_sites(n, ms, nk)
+        finally:
+            lib.ptx_timing_select(-1)
+    per_site = {lib.ptx_kernel_name(i).decode(): n[i] for i in range(nk) if n[i]}
+    assert sum(per_site.values()) == 19, per_site
