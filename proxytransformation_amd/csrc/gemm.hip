@@ -656,7 +656,7 @@ int launch_gemm(const GemmBatch &gb_in, hipStream_t st)
     }
     if (gb.p[0].w2 != nullptr) {
         PTX_REQUIRE(gb.n == 1 && gb.p[0].pg == nullptr && gb.p[0].c2 && gb.p[0].n2 >= 1 && gb.p[0].chain_tiles >= 1 &&
-                    gb.p[0].chain_tiles * 32 <= gb.p[0].N && gb.p[0].K >= 4 * BK,
+                    gb.p[0].chain_tiles * 32 <= gb.p[0].N && gb.p[0].K >= 4 * BK && gb.p[0].lnp_out == nullptr,
                     "gemm: bad chained-product description");
         PTX_TRY((launch_gemm32<4, 0, true>(gb, rmax, nmax, st)));
         PTX_LAUNCHED("k_gemm");
