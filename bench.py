@@ -48,7 +48,16 @@ from proxytransformation_amd.synth import CONFIGS, fill_state_dict, make_scene_b
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix (v_mfma_f32_32x32x2_f32), 256 CUs
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+
+
+def so_sha16():
+    """sha256 (first 16 hex digits) of the HIP library this process loaded: ties PMC digests to the binary they measured."""
+    import hashlib
+    try:
+        return hashlib.sha256(open(_abi.LIB_PATH, "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
 
 
 def parse():
@@ -94,17 +103,19 @@ def site_kernel(site, dt):
 
 
 def pmc_traffic(kernel, dt, cfg, B):
-    """HBM bytes per launch of `kernel` from the committed PMC digest (tools/profile_round.sh)."""
+    """(HBM bytes per launch of `kernel` from the committed PMC digest of tools/profile_round.sh, stale flag): stale =
+    the digest was taken with another build of libproxyt_hip.so than the one loaded now."""
     try:
         d = json.load(open(PMC_FILE))
         if d.get("config") != cfg.name or d.get("scenes_per_gpu") != B:
-            return None
+            return None, None
+        stale = d.get("so_sha16") != so_sha16()
         for name, v in d[dt].items():
             if kernel in name:
-                return int(v["fetch_bytes"] + v["write_bytes"])
+                return int(v["fetch_bytes"] + v["write_bytes"]), stale
     except (OSError, KeyError, ValueError):
         pass
-    return None
+    return None, None
 
 
 def work_model(cfg, B, dt_bytes):
@@ -336,6 +347,14 @@ def main():
             print("per-kernel us/launch:", json.dumps({k: round(v, 2) for k, v in site_times(lib, names, mod, inputs, 12).items()}),
                   file=sys.stderr)
 
+    ranks_seen = None
+    if dist is not None:
+        # every rank reports (rank, device it ran on): the line shows that the process group really had N members
+        props = torch.cuda.get_device_properties(device)
+        me = (rank, str(getattr(props, "uuid", "")) or f"{props.name}#{device.index}", os.getpid())
+        ranks_seen = [None] * world
+        dist.all_gather_object(ranks_seen, me)
+        ranks_seen = sorted([list(x) for x in ranks_seen])
     vals = [elapsed, extras.get("f32", 0.0)]
     t = torch.tensor(vals, device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
     if dist is not None:
@@ -354,11 +373,13 @@ def main():
             if abytes:
                 ach = abytes / avg_s / 1e9
                 kern = site_kernel(args.time_kernel, img_dtype)
+                traffic, stale = pmc_traffic(kern, img_dtype, cfg, B)
                 roof = dict(bound="hbm", kernel=kern, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                            frac=round(ach / HBM_PEAK_GBS, 4), traffic=pmc_traffic(kern, img_dtype, cfg, B),
-                            traffic_source="profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)",
+                            frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic, traffic_stale=stale,
+                            traffic_source=os.path.relpath(PMC_FILE, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                           "this command; traffic_stale = taken with another build of the library)",
                             avg_launch_us=round(avg_s * 1e6, 2), launches=launches.value,
-                            algorithmic_bytes_per_launch=abytes)
+                            algorithmic_bytes_per_launch=abytes, so_sha16=so_sha16())
         line = dict(metric="scenes/sec (100k pts, 256 clusters, 64 proxies)", value=round(total_scenes / elapsed, 2),
                     unit="scenes/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                     ms_per_step=round(1e3 * elapsed / args.steps, 4), higher_is_better=True, scaling="weak",
@@ -370,6 +391,9 @@ def main():
                                 arithmetic="fp32 (fp32 MFMA / VALU; the 16-bit matrix pipe only through 3-way operand splits with fp32 accumulate: exact in the pooling pass, dropped terms <= 2^-25 |xy| in the 64x64-tile GEMMs)",
                                 surviving_points_per_step=n_out),
                     roofline=roof)
+        if ranks_seen is not None:
+            line["ranks_seen"] = ranks_seen
+            line["backend"] = args.backend + (" (RCCL)" if args.backend == "nccl" else "")
         if f32_step > 0:
             line["value_f32_features"] = round(world * B / f32_step, 2)
             line["ms_per_step_f32_features"] = round(1e3 * f32_step, 4)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PTX_ABI_VERSION 4
+#define PTX_ABI_VERSION 5
 
 #define PTX_OK          0
 #define PTX_EINVAL     -1   /* bad shape / null pointer / unsupported size */
@@ -246,10 +246,54 @@ int ptx_forward(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, const v
                 float *out, int32_t *counts, void *workspace, size_t ws_bytes,
                 const PtxDebug *debug, void *stream);
 
+/* ptx_forward with options (ABI 5).  opts = NULL is ptx_forward.
+ *   bbox_enc       (B,6) uint32: the scenes' bounding boxes as ptx_ingest_gather publishes them (words 0..2 =
+ *                  ~ord(min_xyz), 3..5 = ord(max_xyz), ord = the order-preserving float -> uint32 map); the forward then
+ *                  skips its own min / max pass over the points (PRE:37-38).  Read-only here.
+ *   compute_dtype  arithmetic of the ProxyBlock GEMMs and attention: 0 = fp32-equivalent (the parity path, default),
+ *                  1 = plain bf16 operands with fp32 accumulation (throughput mode; the reference under --amp,
+ *                  tools/train.py:93-105).  Index tensors are unaffected (the clustering half stays fp32). */
+typedef struct PtxForwardOpts {
+    const uint32_t *bbox_enc;
+    int32_t compute_dtype;
+    int32_t reserved[5];
+} PtxForwardOpts;
+int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, const void *prep, const float *lin,
+                   const float *points, const float *const *points_list, const float *text_feats,
+                   const uint8_t *text_mask, const void *img_feat, const int32_t *order_override,
+                   const float *centers_override,
+                   float *out, int32_t *counts, void *workspace, size_t ws_bytes,
+                   const PtxDebug *debug, const PtxForwardOpts *opts, void *stream);
+
 /* Host-side spin until counts_host[0..B) (pinned host memory, preset to -1 by the caller) are all
  * >= 0, or timeout_us elapses.  Returns 0 when the counts are there, PTX_ETIMEOUT otherwise
  * (the caller then falls back to a stream synchronise, which also surfaces device faults). */
 int ptx_wait_counts(const int32_t *counts_host, int B, int64_t timeout_us);
+
+/* ------------------------------------------------------------------ multi-view depth ingest
+ * What the reference's data pipeline computes on the host between the decoded depth maps and the (N,3) cloud handed to
+ * the path (configs/grounding/proxy-tiblock33-gs12-wbias-ddr0.6-clip.py:105-142):
+ *   ConvertRGBDToPoints       datasets/transforms/points.py:20-98  (points_img2cam, structures/bbox_3d/utils.py:336-368)
+ *   PointSample per view      datasets/transforms/points.py:290-420          [np.random.choice stays on the host]
+ *   AggregateMultiViewPoints  datasets/transforms/multiview.py:195-253       (torch.linalg.solve(global2ego, [p;1]))
+ *   PointSample of the scene  datasets/transforms/points.py:290-420          [np.random.choice stays on the host]
+ *   GlobalRotScaleTrans       datasets/transforms/augmentation.py:253-       (points only; parameters from the host)
+ * depth (V,H,W): float32 metres (depth_dtype 0) or the decoded uint16 image (1; value / depth_shift as LoadDepthFromFile
+ * does).  ptx_ingest_index builds a rank / select index over the pixels with depth != 0 (one streaming pass) and
+ * publishes view_counts[v] = their number per view with system scope (device or pinned host int32: the host needs them
+ * for `replace` of np.random.choice).  ptx_ingest_gather computes ONLY the N selected points: sel[j] (int64) = rank of
+ * output point j in the concatenation over the views of each view's depth != 0 pixels in row-major order (the
+ * reference's grid3d[nonzero_indices]; the host composes its two np.random.choice draws into it).
+ * inv_intrinsic (V,4,4) = inverse of the 4x4-padded depth_cam2img; lu (V,4,4) + piv (V,4) int32 = LU factors of
+ * global2ego with rows permuted by piv (P A = L U, unit lower); aug = NULL or 13 floats rot_mat_T (3,3) | scale | trans;
+ * points (N,3); bbox_enc (6) uint32 or NULL = the cloud's bounding box in ptx_forward_ex's encoding (cleared here);
+ * status (1) int32 device: bit 0 set if any sel[j] was out of range (that point is written as 0). */
+size_t ptx_ingest_workspace_bytes(int V, int H, int W);
+int ptx_ingest_index(const void *depth, int depth_dtype, int V, int H, int W, void *workspace, size_t ws_bytes,
+                     int32_t *view_counts, void *stream);
+int ptx_ingest_gather(const void *depth, int depth_dtype, float depth_shift, int V, int H, int W, const float *inv_intrinsic,
+                      const float *lu, const int32_t *piv, const int64_t *sel, int N, const float *aug, float *points,
+                      uint32_t *bbox_enc, int32_t *status, const void *workspace, size_t ws_bytes, void *stream);
 
 /* ------------------------------------------------------------------ voxel quantisation
  * The step right after the path in the reference's detector (detectors/sparse_featfusion_grounder_preshape.py:388-397):

@@ -507,3 +507,65 @@ def point_sample(points, feats, proj, *, scale=(1.0, 1.0), crop=(0.0, 0.0), flip
     out = acc / np.maximum(nvalid, 1)[:, None].astype(np.float32)
     out[nvalid == 0] = 0
     return out, nvalid
+
+
+# ------------------------------------------------------------------------------ multi-view depth ingest
+def points_img2cam(grid: np.ndarray, cam2img: np.ndarray) -> torch.Tensor:
+    """structures/bbox_3d/utils.py:336-368 on fp32 tensors (the array converter turns the numpy inputs into tensors of
+    their own dtype; ``pad_cam2img`` takes the dtype of the points: fp32)."""
+    pts = torch.from_numpy(np.ascontiguousarray(grid, dtype=np.float32))
+    cam = torch.from_numpy(np.ascontiguousarray(cam2img))
+    xys = pts[:, :2]
+    depths = pts[:, 2].view(-1, 1)
+    unnormed = torch.cat([xys * depths, depths], dim=1)
+    pad = torch.eye(4, dtype=xys.dtype)
+    pad[:cam.shape[0], :cam.shape[1]] = cam
+    inv_t = torch.inverse(pad).transpose(0, 1)
+    homo = torch.cat([unnormed, xys.new_ones((unnormed.shape[0], 1))], dim=1)
+    return torch.mm(homo, inv_t)[:, :3]
+
+
+def ingest(depth_imgs: np.ndarray, depth_cam2img, extrinsic: np.ndarray, n_points: int, per_view: Optional[int] = None,
+           rng=np.random, aug: Optional[dict] = None, num_threads: int = 1):
+    """The reference pipeline between the decoded depth maps and the path's input cloud
+    (configs/grounding/proxy-tiblock33-gs12-wbias-ddr0.6-clip.py:105-142), restated step by step:
+
+      ConvertRGBDToPoints       datasets/transforms/points.py:57-69   meshgrid, float32 grid, nonzero filter, points_img2cam
+      PointSample per view      points.py:335-336 (empty view: untouched), 395-411 (np.random.choice, replace iff too few)
+      AggregateMultiViewPoints  multiview.py:224-239                  torch.linalg.solve(global2ego, [p;1]^T), concat
+      PointSample of the scene  points.py:395-411
+      GlobalRotScaleTrans       augmentation.py:327-352 on the points: p @ rot_mat_T, * scale, + trans (given parameters)
+
+    depth_imgs (V,H,W) float32; depth_cam2img one matrix or (V,r,c); extrinsic (V,4,4) float32 global2ego.
+    Returns dict(points (n_points,3) float32, view_counts, sel = the composed index per output point)."""
+    torch.set_num_threads(num_threads)
+    per_view = n_points // 10 if per_view is None else per_view
+    V, H, W = depth_imgs.shape
+    k = np.asarray(depth_cam2img)
+    views, sels, counts = [], [], []
+    off = 0
+    for v in range(V):
+        depth = np.ascontiguousarray(depth_imgs[v], dtype=np.float32)
+        us, vs = np.meshgrid(np.arange(W), np.arange(H))
+        grid = np.stack([us.astype(np.float32), vs.astype(np.float32), depth], axis=-1).reshape(-1, 3)
+        nonzero = depth.reshape(-1).nonzero()[0]
+        pts = points_img2cam(grid, k if k.ndim == 2 else k[v])[nonzero]
+        counts.append(len(nonzero))
+        if len(pts) > 0:                                         # PointSample returns an empty view untouched
+            ch = rng.choice(np.arange(len(pts)), per_view, replace=len(pts) < per_view)
+            pts = pts[ch]
+            hom = torch.cat([pts, pts.new_ones(pts.shape[0], 1)], dim=1)
+            g2e = torch.from_numpy(np.ascontiguousarray(extrinsic[v], dtype=np.float32))
+            glob = torch.linalg.solve(g2e, hom.transpose(0, 1)).transpose(0, 1)
+            views.append(glob[:, :3])
+            sels.append(ch.astype(np.int64) + off)
+        off += len(nonzero)
+    cat = torch.cat(views)
+    sel = np.concatenate(sels)
+    ch2 = rng.choice(np.arange(len(cat)), n_points, replace=len(cat) < n_points)
+    pts = cat[ch2].clone()
+    if aug is not None:
+        pts = pts @ torch.from_numpy(np.asarray(aug["rot_mat_T"], np.float32))
+        pts *= float(aug["scale"])
+        pts += torch.from_numpy(np.asarray(aug["trans"], np.float32))
+    return dict(points=pts.numpy(), view_counts=np.asarray(counts, np.int64), sel=sel[ch2])

@@ -13,7 +13,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libproxyt_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_float_p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 
@@ -60,6 +60,10 @@ class PtxDebug(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in DEBUG_FIELDS]
 
 
+class PtxForwardOpts(C.Structure):
+    _fields_ = [("bbox_enc", C.c_void_p), ("compute_dtype", C.c_int32), ("reserved", C.c_int32 * 5)]
+
+
 # name -> (restype, argtypes); must list every symbol declared in include/proxyt.h
 _P, _I, _F, _Z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 _SH, _W = C.POINTER(PtxShape), C.POINTER(PtxWeights)
@@ -95,6 +99,11 @@ SIGNATURES = {
 
 _L, _U64 = C.c_long, C.c_uint64
 SIGNATURES.update({
+    "ptx_forward_ex": (_I, [_P, _SH, _W, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z,
+                            C.POINTER(PtxDebug), C.POINTER(PtxForwardOpts), _P]),
+    "ptx_ingest_workspace_bytes": (_Z, [_I, _I, _I]),
+    "ptx_ingest_index": (_I, [_P, _I, _I, _I, _I, _P, _Z, _P, _P]),
+    "ptx_ingest_gather": (_I, [_P, _I, _F, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _Z, _P]),
     "ptx_voxel_workspace_bytes": (_Z, [_I, _I]),
     "ptx_voxelize": (_I, [_P, _P, _I, _I, _F, _P, _P, _P, _P, _P, _Z, _P]),
     "ptx_point_sample_workspace_bytes": (_Z, [_I, _I, _I, _I]),

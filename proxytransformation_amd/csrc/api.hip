@@ -728,8 +728,22 @@ int ptx_forward(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, const v
                 float *out, int32_t *counts, void *workspace, size_t ws_bytes, const PtxDebug *debug,
                 void *stream)
 {
+    return ptx_forward_ex(ctx, s, w, prep, lin, points, points_list, text_feats, text_mask, img_feat, order_override,
+                          centers_override, out, counts, workspace, ws_bytes, debug, nullptr, stream);
+}
+
+int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, const void *prep, const float *lin,
+                   const float *points, const float *const *points_list, const float *text_feats,
+                   const uint8_t *text_mask, const void *img_feat, const int32_t *order_override,
+                   const float *centers_override,
+                   float *out, int32_t *counts, void *workspace, size_t ws_bytes, const PtxDebug *debug,
+                   const PtxForwardOpts *opts, void *stream)
+{
     PTX_REQUIRE(w && prep && lin && (points || points_list) && text_feats && img_feat && out && counts,
                 "ptx_forward: null argument");
+    const uint32_t *bbox_in = opts ? opts->bbox_enc : nullptr;
+    const int compute_dtype = opts ? opts->compute_dtype : 0;
+    PTX_REQUIRE(compute_dtype == 0 || compute_dtype == 1, "ptx_forward: compute_dtype=%d (0 fp32-equivalent, 1 bf16)", compute_dtype);
     PTX_TRY(check_bufs(s, workspace, ws_bytes));
     ScenePts sp;
     PTX_TRY(make_scene_pts(points, points_list, s->B, s->N, &sp));
@@ -774,14 +788,17 @@ int ptx_forward(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, const v
     // ---- clustering (PRE:430): bounding boxes, then everything per centre in one launch
     // The words of the workspace's zero region (encoded boxes, tags, count accumulators) are clean on entry and are
     // re-zeroed by their last readers (k_select, k_affine, k_tile_count): no memset launch per call.
-    uint32_t *mm_enc = at<uint32_t>(ws, L.mm_enc), *tag = at<uint32_t>(ws, L.tag);
+    // bounding boxes: computed here (k_minmax into the workspace's clean words, re-zeroed by k_select), or handed over
+    // by the ingest (ptx_ingest_gather reduced them while it wrote the points: no pass over the cloud here)
+    uint32_t *mm_ws = at<uint32_t>(ws, L.mm_enc), *tag = at<uint32_t>(ws, L.tag);
+    const uint32_t *mm_enc = bbox_in ? bbox_in : mm_ws;
     const bool dbg = debug != nullptr;
     float *centers0 = dbg && debug->centers0 ? at<float>(ws, L.centers0) : nullptr;
     float *cluster1 = dbg && debug->cluster1 ? at<float>(ws, L.cluster1) : nullptr;
     float *offsets = dbg && debug->offsets ? at<float>(ws, L.offsets) : nullptr;
     float *centers = at<float>(ws, L.centers), *cluster2 = at<float>(ws, L.cluster2);
     int32_t *idx2 = at<int32_t>(ws, L.idx2), *pad_count = at<int32_t>(ws, L.pad_count);
-    PTX_TIMED(KID_MINMAX, cs, launch_minmax(sp, B, S.N, mm_enc, cs));
+    if (!bbox_in) PTX_TIMED(KID_MINMAX, cs, launch_minmax(sp, B, S.N, mm_ws, cs));
     PTX_TIMED(KID_CLUSTER, cs, launch_cluster(S, mm_enc, lin, sp, pf + P.off_ab, w->offset, w->offset_map_w,
                                               centers_override, nullptr, centers0, cluster1, offsets, centers, idx2,
                                               cluster2, pad_count, cs));
@@ -796,7 +813,7 @@ int ptx_forward(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, const v
     int32_t *ksrc = at<int32_t>(ws, L.ksrc);
     static const bool ext_event = getenv("PTX_NO_EXT_EVENT") == nullptr;
     PTX_TIMED(KID_SELECT, cs, launch_select_order(S, centers, pad_count, order_override, order, picks, keep, kcenter,
-                                                  ksrc, mm_enc, cs, cluster_on_caller, ext_event ? side->aux : nullptr));
+                                                  ksrc, bbox_in ? nullptr : mm_ws, cs, cluster_on_caller, ext_event ? side->aux : nullptr));
     int32_t *tile_counts = at<int32_t>(ws, L.tile_counts);
     hipStream_t ts = side->lo;
     // the slot tags / survivor counts (side stream) start before the point proxies when the image chain is the long

@@ -1,0 +1,174 @@
+"""Multi-view depth ingest on the device: the part of the reference's data pipeline
+between the decoded depth maps and the ``(N,3)`` cloud that ``ProxyTransformationNormReverse.forward`` consumes
+(configs/grounding/proxy-tiblock33-gs12-wbias-ddr0.6-clip.py:105-142):
+
+    ConvertRGBDToPoints(coord_type='CAMERA')        datasets/transforms/points.py:20-98
+    PointSample(num_points=n_points // 10)          datasets/transforms/points.py:290-420      per view
+    AggregateMultiViewPoints(coord_type='DEPTH')    datasets/transforms/multiview.py:195-253
+    PointSample(num_points=n_points)                datasets/transforms/points.py:290-420      the scene
+    GlobalRotScaleTrans (points only, optional)     datasets/transforms/augmentation.py:253-   train pipeline
+
+The random draws stay where the reference has them -- ``np.random.choice`` on the host, consumed in the reference's order
+(one draw per non-empty view in view order, then one for the scene) so that a seeded run picks the same pixels -- and
+are composed into ONE index per output point.  Everything else runs in HIP behind the C ABI (``ptx_ingest_index`` /
+``ptx_ingest_gather``, csrc/ingest.hip): a streaming pass over the depth maps builds a rank / select index of the pixels
+with depth != 0, then only the N selected points are un-projected, moved to the global frame and written, together with
+the cloud's bounding box in the encoding the forward's clustering kernel reads (``forward(..., bbox=batch.bbox)`` skips
+its min / max pass, PRE:37-38).  There is no CPU path: tensors must be on the GPU and the library must be built.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _abi
+
+__all__ = ["MultiViewIngest", "IngestedBatch", "compose_choices", "lu_factor_4x4"]
+
+_DEPTH_DTYPES = {torch.float32: 0, torch.uint16: 1, torch.int16: 1}       # int16: a reinterpreted uint16 image
+
+
+@dataclass
+class IngestedBatch:
+    points: List[torch.Tensor]          # B views (N,3) of one (B,N,3) buffer: the ``points`` argument of the forward
+    bbox: torch.Tensor                  # (B,6) int32 = encoded min / max per scene (``forward(..., bbox=...)``)
+    view_counts: List[np.ndarray]       # per scene: pixels with depth != 0 per view (the reference's len(points))
+    sel: List[np.ndarray]               # per scene: the composed index per output point (tests / debugging)
+
+
+def lu_factor_4x4(a: np.ndarray):
+    """LU factors of a 4x4 float32 matrix with partial pivoting (what ``torch.linalg.solve`` factors internally,
+    multiview.py:232): returns (lu, rows) with ``a[rows] = L @ U``, L unit lower and U upper packed into ``lu``."""
+    a = np.array(a, dtype=np.float32).reshape(4, 4).copy()
+    rows = [0, 1, 2, 3]
+    for k in range(4):
+        p = k + int(np.argmax(np.abs(a[k:, k])))
+        if a[p, k] == 0.0:
+            raise ValueError("singular global2ego matrix")
+        if p != k:
+            a[[k, p]] = a[[p, k]]
+            rows[k], rows[p] = rows[p], rows[k]
+        for i in range(k + 1, 4):
+            a[i, k] = np.float32(a[i, k] / a[k, k])
+            a[i, k + 1:] = a[i, k + 1:] - a[i, k] * a[k, k + 1:]
+    return a, np.asarray(rows, dtype=np.int32)
+
+
+def compose_choices(view_counts: Sequence[int], per_view: int, n_points: int, rng=np.random):
+    """The two ``PointSample`` stages of the reference pipeline (points.py:411: ``np.random.choice(np.arange(len(points)),
+    num_samples, replace=len(points) < num_samples)``), drawn from ``rng`` in the reference's order, composed into one index per
+    output point: position in the concatenation, over the views, of each view's depth != 0 pixels in row-major order.
+    A view whose depth map is all zero contributes nothing and draws nothing (points.py:335-336)."""
+    firsts, kept = [], []
+    off = 0
+    for cnt in view_counts:
+        cnt = int(cnt)
+        if cnt > 0:
+            ch = rng.choice(np.arange(cnt), per_view, replace=cnt < per_view)
+            kept.append(ch.astype(np.int64) + off)
+        off += cnt
+    if not kept:
+        raise ValueError("every depth map of the scene is empty")
+    cat = np.concatenate(kept)                                   # AggregateMultiViewPoints: views in order
+    ch2 = rng.choice(np.arange(len(cat)), n_points, replace=len(cat) < n_points)
+    return cat[ch2]
+
+
+class MultiViewIngest:
+    """``MultiViewIngest(n_points)(scenes)``: scenes = list of dicts with the reference pipeline's keys
+
+        depth_img      (V,H,W) GPU tensor, float32 metres (LoadDepthFromFile's output) or the decoded uint16 image
+        depth_shift    divisor of a uint16 image (results['depth_shift']); ignored for float32
+        depth_cam2img  (3,3) / (3,4) / (4,4) intrinsic, one for the scene or (V,...) per view
+        extrinsic      (V,4,4) float32 global2ego (results['depth2img']['extrinsic'])
+        aug            optional dict(rot_mat_T (3,3), scale, trans (3)): GlobalRotScaleTrans's effect on the points
+        choices        optional precomputed (N,) index (see ``compose_choices``); otherwise drawn from ``rng``
+    """
+
+    def __init__(self, n_points: int = 100000, per_view_points: Optional[int] = None, depth_map_size=None,
+                 use_color: bool = False):
+        if depth_map_size is not None or use_color:
+            raise NotImplementedError("ConvertRGBDToPoints(depth_map_size=..., use_color=True) is not part of the shipped "
+                                      "pipeline (CFG:112, 134) and is not implemented on the device")
+        self.n_points = int(n_points)
+        self.per_view_points = int(per_view_points) if per_view_points is not None else self.n_points // 10   # CFG:113, 135
+
+    @staticmethod
+    def _intrinsics(k, V: int) -> np.ndarray:
+        k = np.asarray(k.cpu() if isinstance(k, torch.Tensor) else k)
+        if k.ndim == 2:
+            k = np.broadcast_to(k, (V,) + k.shape)
+        if k.shape[0] != V or k.shape[1] > 4 or k.shape[2] > 4:
+            raise ValueError(f"depth_cam2img must be (r,c) or ({V},r,c) with r, c <= 4, got {k.shape}")
+        out = np.empty((V, 4, 4), np.float32)
+        for v in range(V):                                      # points_img2cam: pad to 4x4, invert (fp32)
+            pad = np.eye(4, dtype=np.float32)
+            pad[:k.shape[1], :k.shape[2]] = k[v].astype(np.float32)
+            out[v] = np.linalg.inv(pad)
+        return out
+
+    @torch.no_grad()
+    def __call__(self, scenes: Sequence[Dict], rng=np.random) -> IngestedBatch:
+        lib = _abi.lib()
+        B, N = len(scenes), self.n_points
+        if B == 0:
+            raise ValueError("no scenes")
+        dev = scenes[0]["depth_img"].device
+        if dev.type != "cuda":
+            raise RuntimeError("MultiViewIngest (HIP) needs GPU tensors: there is no CPU path")
+        st = torch.cuda.current_stream(dev)
+        out = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
+        bbox = torch.empty((B, 6), dtype=torch.int32, device=dev)
+        status = torch.zeros((B,), dtype=torch.int32, device=dev)
+        work = []
+        for b, sc in enumerate(scenes):                          # 1. index every scene's depth maps (one pass each)
+            depth = sc["depth_img"]
+            if depth.device != dev or depth.dim() != 3 or depth.dtype not in _DEPTH_DTYPES or not depth.is_contiguous():
+                raise RuntimeError(f"depth_img must be a contiguous (V,H,W) float32 / uint16 tensor on {dev}, got "
+                                   f"{tuple(depth.shape)} {depth.dtype} on {depth.device}")
+            V, H, W = depth.shape
+            nbytes = lib.ptx_ingest_workspace_bytes(V, H, W)
+            ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+            counts = torch.empty((V,), dtype=torch.int32).pin_memory()
+            _abi.check(lib.ptx_ingest_index(depth.data_ptr(), _DEPTH_DTYPES[depth.dtype], V, H, W, ws.data_ptr(), nbytes,
+                                            counts.data_ptr(), st.cuda_stream), "ptx_ingest_index")
+            work.append((depth, ws, counts))
+        st.synchronize()                                         # the per-view counts decide `replace` on the host
+        keep, sels, vcs = [], [], []
+        for b, (sc, (depth, ws, counts)) in enumerate(zip(scenes, work)):   # 2. host RNG, 3. gather
+            V, H, W = depth.shape
+            vc = counts.numpy().copy()
+            sel = sc.get("choices")
+            if sel is None:
+                sel = compose_choices(vc, self.per_view_points, N, rng)
+            sel = np.ascontiguousarray(sel, dtype=np.int64)
+            if sel.shape != (N,):
+                raise ValueError(f"choices must be ({N},), got {sel.shape}")
+            inv_k = self._intrinsics(sc["depth_cam2img"], V)
+            ext = np.asarray(sc["extrinsic"], dtype=np.float32).reshape(V, 4, 4)
+            lus, pivs = zip(*(lu_factor_4x4(ext[v]) for v in range(V)))
+            small = np.concatenate([inv_k.reshape(-1), np.stack(lus).reshape(-1)]).astype(np.float32)
+            aug = sc.get("aug")
+            if aug is not None:
+                small = np.concatenate([small, np.asarray(aug["rot_mat_T"], np.float32).reshape(9),
+                                        np.asarray([aug["scale"]], np.float32), np.asarray(aug["trans"], np.float32).reshape(3)])
+            small_d = torch.from_numpy(small).to(dev, non_blocking=False)
+            piv_d = torch.from_numpy(np.stack(pivs).astype(np.int32)).to(dev)
+            sel_d = torch.from_numpy(sel).to(dev)
+            shift = float(sc.get("depth_shift", 1.0))
+            fp = small_d.data_ptr()
+            _abi.check(lib.ptx_ingest_gather(
+                depth.data_ptr(), _DEPTH_DTYPES[depth.dtype], shift, V, H, W, fp, fp + 4 * V * 16, piv_d.data_ptr(),
+                sel_d.data_ptr(), N, (fp + 4 * V * 32) if aug is not None else None, out[b].data_ptr(), bbox[b].data_ptr(),
+                status[b:].data_ptr(), ws.data_ptr(), ws.numel(), st.cuda_stream), "ptx_ingest_gather")
+            keep.append((small_d, piv_d, sel_d, ws))
+            sels.append(sel)
+            vcs.append(vc)
+        bad = status.cpu().numpy()                               # also keeps the temporaries alive until the kernels ran
+        if bad.any():
+            raise IndexError(f"choices beyond the scene's depth != 0 pixels in scenes {np.nonzero(bad)[0].tolist()}")
+        return IngestedBatch(points=[out[b] for b in range(B)], bbox=bbox, view_counts=vcs, sel=sels)

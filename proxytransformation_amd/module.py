@@ -42,6 +42,7 @@ def _bias_grid(dim: int) -> int:
     return s if s * s == dim else s + 1
 
 _IMG_DTYPES = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}   # PtxShape.img_dtype
+_COMPUTE_DTYPES = {"fp32": 0, "bf16": 1}                                # PtxForwardOpts.compute_dtype
 _COUNTS_TIMEOUT_US = 20_000_000         # then fall back to a stream synchronise
 _MAX_SCENES_PER_CALL = 32            # kMaxScenes of the C ABI (per-scene pointer table passed by value)
 
@@ -146,16 +147,27 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+def _invalidate_after_load(mod, _incompatible_keys):
+    mod.invalidate_weights()
+
+
 # --------------------------------------------------------------------------- the module
 @MODELS.register_module()
 class ProxyTransformationNormReverse(nn.Module):
     """Drop-in for the reference neck of the same name (see module docstring)."""
+    _instances = 0
 
     def __init__(self, embed_dim=256, num_heads=8, n_points=100000, grid_size=4, text_blocks=1,
                  img_blocks=1, dynamic_drop_radio=0.8, mlp_radio=4, qkv_bias=False, drop_rate=0.2,
                  attn_drop_rate=0.2, drop_path_rate=0.2, act_layer=nn.GELU, norm_layer=nn.LayerNorm,
-                 num_sub=30, drop_radio=0.2, input_dim=512, img_spacial_dim=15):
+                 num_sub=30, drop_radio=0.2, input_dim=512, img_spacial_dim=15, *, compute_dtype="fp32"):
         super().__init__()
+        if compute_dtype not in _COMPUTE_DTYPES:
+            raise ValueError(f"compute_dtype must be one of {sorted(_COMPUTE_DTYPES)} (got {compute_dtype!r})")
+        #: arithmetic of the ProxyBlock GEMMs / attention in EVAL mode (extra, keyword-only; not in the reference):
+        #: "fp32" = fp32-equivalent (the parity path), "bf16" = plain bf16 operands with fp32 accumulation -- what the
+        #: reference's linears run in under ``--amp`` (tools/train.py:93-105); outputs then differ by ~1e-2 m (SURVEY H5)
+        self.compute_dtype = compute_dtype
         if act_layer is not nn.GELU or norm_layer is not nn.LayerNorm:
             raise NotImplementedError("the HIP path implements act_layer=nn.GELU, norm_layer=nn.LayerNorm")
         if embed_dim not in _EMBED_DIMS or num_heads != 8:
@@ -200,12 +212,14 @@ class ProxyTransformationNormReverse(nn.Module):
         self._slots = None
         self._lanes: Dict[tuple, _Lane] = {}
         self._train_calls = 0
+        ProxyTransformationNormReverse._instances += 1
+        self._instance_salt = ProxyTransformationNormReverse._instances      # dropout masks differ between instances
         self._warned_eval_grad = False
         self._lin_t = None
         # stochastic-depth rate of the blocks that are live (the last of each list; PRE:298-299)
         self._text_dpr = float(torch.linspace(0, drop_path_rate, text_blocks)[-1])
         self._img_dpr = float(torch.linspace(0, drop_path_rate, img_blocks)[-1])
-        self.register_load_state_dict_post_hook(lambda mod, _keys: mod.invalidate_weights())
+        self.register_load_state_dict_post_hook(_invalidate_after_load)
         #: True = block until the whole forward has drained (the pre-ABI-3 behaviour); default is
         #: to return once the output lengths are known, like any asynchronous torch op
         self.sync_outputs = os.environ.get("PTX_SYNC_OUTPUTS", "0") == "1"
@@ -217,6 +231,29 @@ class ProxyTransformationNormReverse(nn.Module):
         # test-only hooks: replay a captured argsort / inject clamped centres
         self._order_override: Optional[torch.Tensor] = None
         self._centers_override: Optional[torch.Tensor] = None
+
+    # host caches that hold ctypes pointers / device scratch: never copied or pickled (copy.deepcopy(model),
+    # torch.save(model), EMA / SWA copies made after the first forward); a copy rebuilds them on its first call
+    _HOST_CACHES = dict(_tensors=None, _slots=None, _lanes=None, _lin_t=None, _wkey=None, _wstruct=None, _prep=None,
+                        _lin=None, _shapes=None)
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        for k in self._HOST_CACHES:
+            state[k] = {} if k in ("_lanes", "_shapes") else None
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        ProxyTransformationNormReverse._instances += 1
+        self._instance_salt = ProxyTransformationNormReverse._instances
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        new.__setstate__(copy.deepcopy(self.__getstate__(), memo))
+        return new
 
     def _dpr_last(self, blk) -> float:
         return self._text_dpr if blk is self.textformer[-1] else self._img_dpr
@@ -333,9 +370,11 @@ class ProxyTransformationNormReverse(nn.Module):
         nbytes = lib.ptx_prep_bytes(ctypes.byref(shape))
         if nbytes == 0:
             raise RuntimeError("unsupported configuration: " + lib.ptx_last_error().decode())
-        multi = len(self._lanes) > 1
-        if multi:                       # other streams may still be reading the old tables
-            torch.cuda.synchronize(device)
+        # forwards already enqueued on OTHER streams may still be reading the old tables (the lane of the calling
+        # stream may not exist yet, so the test is per lane, not a count)
+        for lane in list(self._lanes.values()):
+            if lane.stream.cuda_stream != stream:
+                lane.stream.synchronize()
         prep = torch.empty(nbytes, dtype=torch.uint8, device=device)
         # torch.linspace is part of the reference's arithmetic (PRE:41)
         lin = torch.linspace(0, 1, self.grid_size, device="cpu").to(device)
@@ -442,7 +481,7 @@ class ProxyTransformationNormReverse(nn.Module):
             img_feat = img_feat.contiguous()
         return (B, shp[0], p0.device), pts, plist, text_feats, mask_u8, img_feat
 
-    def _run(self, points, text_dict, img_feat, debug: bool, transforms: bool = False):
+    def _run(self, points, text_dict, img_feat, debug: bool, transforms: bool = False, bbox=None):
         (B, N, dev), pts, plist, text_feats, mask_u8, img = self._check_inputs(points, text_dict, img_feat)
         skey = (B, N, text_feats.shape[1], img.shape[1], _IMG_DTYPES[img.dtype])
         shape = self._shapes.get(skey)
@@ -479,12 +518,19 @@ class ProxyTransformationNormReverse(nn.Module):
             oo = oo.to(device=dev, dtype=torch.int32).contiguous()
         if co is not None:
             co = co.to(device=dev, dtype=torch.float32).contiguous()
+        opts = None
+        if bbox is not None or self.compute_dtype != "fp32":
+            if bbox is not None and (not isinstance(bbox, torch.Tensor) or bbox.device != dev or bbox.shape != (B, 6)
+                                     or bbox.dtype != torch.int32 or not bbox.is_contiguous()):
+                raise RuntimeError(f"bbox must be a contiguous ({B},6) int32 tensor on {dev} (IngestedBatch.bbox)")
+            opts = _abi.PtxForwardOpts(bbox_enc=_ptr(bbox), compute_dtype=_COMPUTE_DTYPES[self.compute_dtype])
         lane.ws_dirty = True              # until the call has been enqueued completely
-        _abi.check(lib.ptx_forward(
+        _abi.check(lib.ptx_forward_ex(
             lane.ctx, ctypes.byref(shape), ctypes.byref(self._wstruct), self._prep.data_ptr(),
             self._lin.data_ptr(), _ptr(pts), plist, text_feats.data_ptr(), mask_u8.data_ptr(),
             img.data_ptr(), _ptr(oo), _ptr(co), out.data_ptr(), counts.data_ptr(),
-            ws.data_ptr(), ws.numel(), ctypes.byref(dbg_struct) if dbg_struct else None, stream),
+            ws.data_ptr(), ws.numel(), ctypes.byref(dbg_struct) if dbg_struct else None,
+            ctypes.byref(opts) if opts is not None else None, stream),
             "ptx_forward")
         lane.ws_dirty = False
         if debug or self.sync_outputs or lib.ptx_wait_counts(counts.data_ptr(), B, _COUNTS_TIMEOUT_US) != 0:
@@ -512,7 +558,7 @@ class ProxyTransformationNormReverse(nn.Module):
                 if only is None or k in only}
 
     def forward(self, points: List[torch.Tensor], text_dict: dict, img_feat: torch.Tensor,
-                return_transforms: bool = False):
+                return_transforms: bool = False, bbox: Optional[torch.Tensor] = None):
         """points: list of B (N,3) fp32 GPU tensors; text_dict.values() -> (text_feats (B,L,C),
         text_token_mask (B,L) bool, True = valid); img_feat (B,V,input_dim,H,W).
         Returns a list of B tensors (N_i',3): transformed points, dropped points removed,
@@ -520,7 +566,11 @@ class ProxyTransformationNormReverse(nn.Module):
 
         ``return_transforms=True`` (not in the reference) additionally returns the per-cluster affine
         parameters ``dict(kcenter (B,M',3), translate (B,M',3), transform (B,M',9))`` -- what
-        ``shard.gather_cluster_transforms`` exchanges between ranks -- as stream-ordered tensors."""
+        ``shard.gather_cluster_transforms`` exchanges between ranks -- as stream-ordered tensors.
+
+        ``bbox`` (not in the reference): ``IngestedBatch.bbox`` of ``ingest.MultiViewIngest`` -- the clouds' encoded
+        bounding boxes, reduced while the points were written; the eval forward then skips its own min / max pass over
+        the points (PRE:37-38).  Train mode computes its boxes itself."""
         if self.training:
             if return_transforms:
                 outs, aux = self._run_train(points, text_dict, img_feat)
@@ -538,14 +588,15 @@ class ProxyTransformationNormReverse(nn.Module):
             chunks = [(i, min(i + _MAX_SCENES_PER_CALL, len(points)))
                       for i in range(0, len(points), _MAX_SCENES_PER_CALL)]
         if len(chunks) == 1:
-            outs, extra = self._run(points, text_dict, img_feat, debug=False, transforms=return_transforms)
+            outs, extra = self._run(points, text_dict, img_feat, debug=False, transforms=return_transforms, bbox=bbox)
             return (outs, extra) if return_transforms else outs
         feats, mask = self.get_text_proxy(text_dict)
         outs: List[torch.Tensor] = []
         extras = []
         for i, j in chunks:
             o, e = self._run(points[i:j], {"text_feats": feats[i:j], "text_token_mask": mask[i:j]},
-                             img_feat[i:j], debug=False, transforms=return_transforms)
+                             img_feat[i:j], debug=False, transforms=return_transforms,
+                             bbox=None if bbox is None else bbox[i:j])
             outs += o
             extras.append(e)
         if return_transforms:
@@ -562,6 +613,14 @@ class ProxyTransformationNormReverse(nn.Module):
         for name, t in self.state_dict(keep_vars=True).items():
             if t.device != dev or (t.is_floating_point() and (t.dtype != torch.float32 or not t.is_contiguous())):
                 raise RuntimeError(f"parameter {name} must be contiguous float32 on {dev}")
+        if dev.index is not None and dev.index != torch.cuda.current_device():
+            raise RuntimeError(f"inputs are on {dev} but the current device is cuda:{torch.cuda.current_device()}")
+        for name, bn in self._batch_norms():
+            if type(bn) not in (nn.BatchNorm1d, nn.BatchNorm2d):
+                raise NotImplementedError(f"{name} is a {type(bn).__name__}: the HIP train path computes local batch "
+                                          "statistics (the reference trains with plain DDP, no SyncBatchNorm)")
+            if bn.momentum is None:
+                raise NotImplementedError(f"{name}.momentum=None (cumulative moving average) is not implemented")
         shape = self._shape(B, N, text_feats.shape[1], img.shape[1], _IMG_DTYPES[img.dtype])
         tstream = torch.cuda.current_stream(dev)
         lane = self._lane(dev, tstream)
@@ -569,7 +628,17 @@ class ProxyTransformationNormReverse(nn.Module):
         # _check_inputs hands back the caller's own tensors when their layout is already right, so gradients w.r.t.
         # text_feats / img_feat reach them directly
         tf, im = text_feats, img
-        return train.forward_train(self, list(points), tf, mask_u8, im, shape, ws, self._order_override)
+        res = train.forward_train(self, list(points), tf, mask_u8, im, shape, ws, self._order_override)
+        # the running statistics were updated through raw pointers: tell torch (and _weights_key) that they changed
+        for _, bn in self._batch_norms():
+            bn.running_mean.add_(0)
+            bn.running_var.add_(0)
+        return res
+
+    def _batch_norms(self):
+        return (("get_deformable_cluster.get_offsets.mlp.1", self.get_deformable_cluster.get_offsets.mlp[1]),
+                ("simple_encoder.mlp.1", self.simple_encoder.mlp[1]),
+                ("text_trans_norm", self.text_trans_norm), ("img_trans_norm", self.img_trans_norm))
 
     @torch.no_grad()
     def quantize(self, outs: List[torch.Tensor], voxel_size: float = 0.01, return_inverse: bool = False):
@@ -613,8 +682,8 @@ class ProxyTransformationNormReverse(nn.Module):
         return res
 
     @torch.no_grad()
-    def forward_debug(self, points, text_dict, img_feat):
+    def forward_debug(self, points, text_dict, img_feat, bbox=None):
         """forward + every intermediate the C ABI can export (tests / parity only)."""
-        outs, dbg = self._run(points, text_dict, img_feat, debug=True)
+        outs, dbg = self._run(points, text_dict, img_feat, debug=True, bbox=bbox)
         dbg["outputs"] = outs
         return dbg

@@ -630,6 +630,18 @@ class _AffineApply(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------- the train-mode forward
+_SITES_PER_BLOCK = 8         # seed slots of one ProxyBlock: 0, 1 attention (query_attn, proxy-as-key attn), 2..6 the rest
+
+
+def site_seeds(torch_seed: int, call: int, salt: int = 0):
+    """Dropout seeds of one training call: ``seeds[branch][i]`` for the six dropout / DropPath sites of ``_block``.
+    ``k_dropout`` is a pure function of (seed, element), so every site needs a seed of its own: the attention node
+    draws its two masks with ``seeds[b][0]`` and ``seeds[b][0] + 1``, hence the other five sites start at +2
+    (``_SITES_PER_BLOCK`` slots per branch; ``salt`` separates module instances that share torch's seed)."""
+    base = (torch_seed * 1000003 + call * 7919 + salt * 104729) & 0x7FFFFFFFFFFF
+    return [[base + _SITES_PER_BLOCK * b + (0 if i == 0 else i + 1) for i in range(6)] for b in range(2)]
+
+
 def _block(mod, blk, out_norm, head, head_bn, xa, xb, proxy2d, mask_u8, B, n, L, seeds):
     """One ProxyBlock in train mode (PRE:273-276) + trailing LayerNorm + Linear head + BatchNorm1d (PRE:441-446)."""
     C, heads = mod.embed_dim, mod.num_heads
@@ -675,8 +687,7 @@ def forward_train(mod, points: List[torch.Tensor], text_feats, text_mask, img_fe
     i32 = dict(dtype=torch.int32, device=dev)
     pts = torch.stack([p.detach().to(_F32) for p in points]).contiguous()          # PRE:426-427
     mod._train_calls += 1
-    base = (torch.initial_seed() * 1000003 + mod._train_calls * 7919) & 0x7FFFFFFFFFFF
-    seeds = [[base + 100 * b + i for i in range(6)] for b in range(2)]
+    seeds = site_seeds(torch.initial_seed(), mod._train_calls, mod._instance_salt)
 
     # ---- index half, part 1: grid centres + ball query #1 (PRE:55-56)
     minmax = torch.empty((B, 2, 3), dtype=_F32, device=dev)

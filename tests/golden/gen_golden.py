@@ -479,6 +479,113 @@ def gen_point_sample():
     print(f"g5_point_sample -> {os.path.getsize(path) / 1e6:.2f} MB")
 
 
+# ----------------------------------------------------------------------------- multi-view depth ingest
+def gen_ingest():
+    """The reference's own transform classes -- MultiViewPipeline(ConvertRGBDToPoints, PointSample) ->
+    AggregateMultiViewPoints -> PointSample (-> GlobalRotScaleTrans), as configured at CFG:105-142 -- run from the
+    reference files on small synthetic depth maps with ``np.random.seed`` fixed.  Stand-ins only for the framework
+    imports (mmcv BaseTransform / Compose / imresize, the TRANSFORMS registry, mmdet's RandomFlip base class) and for
+    the file loader (the depth maps are handed over in memory)."""
+    import types
+    ref = "/root/reference/embodiedscan"
+
+    class BaseTransform:
+        def __call__(self, results):
+            return self.transform(results)
+
+    class Compose:
+        def __init__(self, transforms):
+            self.transforms = list(transforms)
+
+        def __call__(self, data):
+            for t in self.transforms:
+                data = t(data)
+            return data
+
+    class _Reg:
+        def register_module(self, *a, **k):
+            return lambda cls: cls
+    mm = types.ModuleType("mmcv"); mm.imresize = None; mm.__path__ = []
+    mmt = types.ModuleType("mmcv.transforms"); mmt.BaseTransform = BaseTransform; mmt.Compose = Compose
+    md = types.ModuleType("mmdet"); md.__path__ = []
+    mdd = types.ModuleType("mmdet.datasets"); mdd.__path__ = []
+    mddt = types.ModuleType("mmdet.datasets.transforms"); mddt.RandomFlip = BaseTransform
+    es = types.ModuleType("embodiedscan"); es.__path__ = []
+    esr = types.ModuleType("embodiedscan.registry"); esr.TRANSFORMS = _Reg()
+    est = types.ModuleType("embodiedscan.structures"); est.__path__ = []
+    eu = types.ModuleType("embodiedscan.utils"); eu.__path__ = []
+    p3 = types.ModuleType("pytorch3d"); p3.__path__ = []
+    p3t = types.ModuleType("pytorch3d.transforms"); p3t.euler_angles_to_matrix = lambda *a, **k: None
+    sys.modules.update({"pytorch3d": p3, "pytorch3d.transforms": p3t, "mmcv": mm, "mmcv.transforms": mmt, "mmdet": md, "mmdet.datasets": mdd,
+                        "mmdet.datasets.transforms": mddt, "embodiedscan": es, "embodiedscan.registry": esr,
+                        "embodiedscan.structures": est, "embodiedscan.utils": eu})
+
+    def load(name, path, package=False):
+        spec = importlib.util.spec_from_file_location(
+            name, path, submodule_search_locations=[os.path.dirname(path)] if package else None)
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[name] = mod
+        spec.loader.exec_module(mod)
+        return mod
+    load("embodiedscan.utils.array_converter", ref + "/utils/array_converter.py")
+    b3 = types.ModuleType("embodiedscan.structures.bbox_3d"); b3.__path__ = []
+    sys.modules["embodiedscan.structures.bbox_3d"] = b3
+    b3u = load("embodiedscan.structures.bbox_3d.utils", ref + "/structures/bbox_3d/utils.py")
+    b3.points_cam2img, b3.points_img2cam = b3u.points_cam2img, b3u.points_img2cam
+    load("embodiedscan.structures.points", ref + "/structures/points/__init__.py", package=True)
+    tp = load("ref_points_tf", ref + "/datasets/transforms/points.py")
+    tm = load("ref_multiview_tf", ref + "/datasets/transforms/multiview.py")
+    ta = load("ref_augmentation_tf", ref + "/datasets/transforms/augmentation.py")
+
+    rng = np.random.default_rng(606)
+    V, H, W, n_points = 5, 36, 48, 3000
+    depth = (1.0 + 3.5 * rng.random((V, H, W))).astype(np.float32)
+    depth[rng.random((V, H, W)) < 0.25] = 0.0                    # holes, like a real sensor
+    depth[2, :, : W // 2] = 0.0
+    depth[3, 5:, :] = 0.0                                         # few points: sampled WITH replacement (points.py:396)
+    raw = np.round(depth * 1000.0).astype(np.uint16)              # the decoded 16-bit image; depth_shift = 1000
+    depth = raw.astype(np.float32) / 1000.0                       # LoadDepthFromFile (loading.py:135-136)
+    K = np.array([[40.0, 0.0, 23.5, 0.0], [0.0, 41.0, 17.5, 0.0], [0.0, 0.0, 1.0, 0.0], [0.0, 0.0, 0.0, 1.0]])
+    ext = []
+    for v in range(V):                                           # global2ego of cameras on a ring (mv_3dvg_dataset.py:547: float32)
+        ang = 2 * np.pi * v / V
+        R = np.array([[np.cos(ang), -np.sin(ang), 0.0], [np.sin(ang), np.cos(ang), 0.0], [0.0, 0.0, 1.0]]) @ \
+            np.array([[1.0, 0.0, 0.0], [0.0, 0.0, -1.0], [0.0, 1.0, 0.0]])
+        cam2global = np.eye(4); cam2global[:3, :3] = R; cam2global[:3, 3] = [1.5 * np.cos(ang), 1.5 * np.sin(ang), 1.2 + 0.1 * v]
+        ext.append(np.linalg.inv(cam2global).astype(np.float32))
+
+    def load_depth(results):                                     # in-memory LoadDepthFromFile
+        results["depth_img"] = depth[results["depth_img_path"]]
+        return results
+    save = dict(depth_u16=raw, depth_shift=np.float32(1000.0), depth_cam2img=K, extrinsic=np.stack(ext),
+                n_points=np.int64(n_points))
+    for name, with_aug, seed in (("plain", False, 11), ("aug", True, 12)):
+        np.random.seed(seed)
+        results = dict(img_path=list(range(V)), depth_img_path=list(range(V)), depth_cam2img=K.copy(), cam2img=K.copy(),
+                       depth_shift=1000.0, depth2img=dict(intrinsic=K.copy(), extrinsic=[e.copy() for e in ext]))
+        pipe = [tm.MultiViewPipeline(n_images=V, ordered=True,
+                                     transforms=[load_depth, tp.ConvertRGBDToPoints(coord_type="CAMERA"),
+                                                 tp.PointSample(num_points=n_points // 10)]),
+                tm.AggregateMultiViewPoints(coord_type="DEPTH"), tp.PointSample(num_points=n_points)]
+        if with_aug:
+            pipe.append(ta.GlobalRotScaleTrans(rot_range=[-0.087266, 0.087266], scale_ratio_range=[.9, 1.1],
+                                               translation_std=[.1, .1, .1], shift_height=False))
+        for t in pipe:
+            results = t(results)
+        pts = results["points"].tensor.numpy()
+        assert pts.shape == (n_points, 3) and pts.dtype == np.float32
+        save[f"{name}_points"] = pts
+        save[f"{name}_seed"] = np.int64(seed)
+        if with_aug:
+            save["aug_rot_mat_T"] = np.asarray(results["pcd_rotation"], np.float32)
+            save["aug_scale"] = np.float32(results["pcd_scale_factor"])
+            save["aug_trans"] = np.asarray(results["pcd_trans"], np.float32)
+        print(f"g6_ingest/{name}: {pts.shape}, bbox {pts.min(0)} .. {pts.max(0)}")
+    path = os.path.join(HERE, "g6_ingest.npz")
+    np.savez_compressed(path, **save)
+    print(f"g6_ingest -> {os.path.getsize(path) / 1e6:.2f} MB")
+
+
 def write_manifest(reg):
     """Key / shape / dtype manifest of the reference module's state_dict (data, not code)."""
     import json
@@ -511,6 +618,8 @@ def main():
         run_train_case(reg, TRAIN_CASE)
     if not only or "g5_point_sample" in only:
         gen_point_sample()
+    if not only or "g6_ingest" in only:
+        gen_ingest()
 
 
 if __name__ == "__main__":

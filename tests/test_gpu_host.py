@@ -166,6 +166,27 @@ def test_real_module_sharded_over_two_ranks_matches_unsharded(tmp_path):
     assert seen == set(range(cfg.B))
 
 
+def test_bench_multi_rank_path_on_one_gpu():
+    """bench.py's own N > 1 path -- self-launch under torch.distributed.run, process-group init, barrier-bracketed timing,
+    MAX all-reduce, the rank census -- exercised on the 1-GPU box: two ranks share cuda:0 over gloo (the numbers mean
+    nothing; with --backend nccl the same code runs over RCCL on an 8-GPU node)."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu",
+                        "--steps", "2", "--warmup", "1", "--no-passes", "--no-cpu-baseline"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                        # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_scenes_per_step"] == 8 and d["config"]["scenes_per_gpu"] == 4
+    assert d["cpu_baseline"] is None and d["value"] > 0 and d["scaling"] == "weak"
+    assert [x[0] for x in d["ranks_seen"]] == [0, 1] and len({x[2] for x in d["ranks_seen"]}) == 2     # two processes
+    assert d["roofline"]["launches"] == 2 and 0 < d["roofline"]["frac"] < 1
+
+
 def test_launch_count_of_the_benchmark_shape():
     """an eval forward at the benchmark's shape (bf16-stored features, head_dim 32) is 19 kernel launches --
     counted through the library's own launch-site bracketing (every launch of the forward sits in exactly one site)."""

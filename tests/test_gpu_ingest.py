@@ -1,0 +1,137 @@
+"""Multi-view depth ingest on the device through the C ABI (ptx_ingest_index / ptx_ingest_gather) against
+the fixture captured from the reference's own transform classes (tests/golden/g6_ingest.npz), against the CPU oracle on
+larger random scenes, and end to end: the ingested cloud + its bounding box drive the forward without a min / max pass."""
+import numpy as np
+import pytest
+import torch
+
+from proxytransformation_amd.ingest import MultiViewIngest, compose_choices, lu_factor_4x4
+from proxytransformation_amd.synth import PreshapeConfig, make_scene_batch
+from tests.util import assert_close, build_module, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _scene(g, as_u16):
+    raw = g["depth_u16"]
+    if as_u16:
+        depth = torch.from_numpy(raw.view(np.int16)).to(_dev()).view(torch.uint16)
+    else:
+        depth = torch.from_numpy(raw.astype(np.float32) / float(g["depth_shift"])).to(_dev())
+    return dict(depth_img=depth, depth_shift=float(g["depth_shift"]), depth_cam2img=g["depth_cam2img"],
+                extrinsic=g["extrinsic"])
+
+
+@pytest.mark.parametrize("as_u16", [False, True], ids=["f32", "u16"])
+@pytest.mark.parametrize("case", ["plain", "aug"])
+def test_ingest_matches_the_reference_pipeline(case, as_u16):
+    """Same np.random seed as the capture -> same pixels; coordinates within 1e-5 of the reference transforms' output."""
+    g = load_golden("g6_ingest")
+    sc = _scene(g, as_u16)
+    if case == "aug":
+        sc["aug"] = dict(rot_mat_T=g["aug_rot_mat_T"], scale=float(g["aug_scale"]), trans=g["aug_trans"])
+    np.random.seed(int(g[f"{case}_seed"]))
+    batch = MultiViewIngest(int(g["n_points"]))([sc], rng=np.random)
+    got = batch.points[0].cpu().numpy()
+    assert_close(got, g[f"{case}_points"], atol=1e-5, what=f"g6_ingest/{case}")
+    # the published bounding box is exactly the min / max of what was written
+    enc = batch.bbox[0].cpu().numpy().view(np.uint32)
+
+    def ord2f(u):
+        u = np.uint32(u)
+        return np.array([u & np.uint32(0x7fffffff)] if u & np.uint32(0x80000000) else [~u], np.uint32).view(np.float32)[0]
+    lo = np.array([ord2f(~np.uint32(enc[d])) for d in range(3)])
+    hi = np.array([ord2f(enc[3 + d]) for d in range(3)])
+    assert np.array_equal(lo, got.min(0)) and np.array_equal(hi, got.max(0))
+
+
+def test_ingest_random_scenes_vs_oracle_and_precomputed_choices():
+    """Larger scenes (several chunks of the rank / select index per view, one empty view, ragged tail) against the CPU
+    restatement with the same seed; then the same scene through a precomputed `choices` vector."""
+    from oracle import oracle
+    rng = np.random.default_rng(42)
+    V, H, W, N = 4, 150, 221, 20000                             # 33150 pixels per view: 3 chunks, ragged last group
+    depth = (0.5 + 5.0 * rng.random((V, H, W))).astype(np.float32)
+    depth[rng.random((V, H, W)) < 0.4] = 0.0
+    depth[1] = 0.0                                               # an empty view draws nothing and contributes nothing
+    K = np.array([[200.0, 0.0, 110.0], [0.0, 205.0, 75.0], [0.0, 0.0, 1.0]])
+    ext = np.stack([np.eye(4, dtype=np.float32) for _ in range(V)])
+    for v in range(V):
+        a = 0.7 * v
+        ext[v, :3, :3] = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], np.float32)
+        ext[v, :3, 3] = [0.3 * v, -0.2 * v, 1.0]
+    ref = oracle.ingest(depth, K, ext, N, rng=np.random.RandomState(9))
+    sc = dict(depth_img=torch.from_numpy(depth).to(_dev()), depth_cam2img=K, extrinsic=ext)
+    ing = MultiViewIngest(N)
+    b1 = ing([sc], rng=np.random.RandomState(9))
+    assert np.array_equal(b1.view_counts[0], ref["view_counts"]) and np.array_equal(b1.sel[0], ref["sel"])
+    assert_close(b1.points[0].cpu().numpy(), ref["points"], atol=1e-5, what="ingest vs oracle")
+    sc2 = dict(sc, choices=ref["sel"])
+    b2 = ing([sc2, sc2])                                         # two scenes per call, no RNG involved
+    assert torch.equal(b2.points[0], b1.points[0]) and torch.equal(b2.points[1], b1.points[0])
+    assert torch.equal(b2.bbox[0], b1.bbox[0]) and torch.equal(b2.bbox[1], b1.bbox[0])
+    with pytest.raises(IndexError):
+        ing([dict(sc, choices=np.full((N,), int(ref["view_counts"].sum()), np.int64))])
+
+
+def test_host_helpers():
+    a = np.array([[0.0, 2, 1, 3], [4, 1, 0, 2], [1, 1, 5, 0], [0, 0, 0, 1]], np.float32)
+    lu, rows = lu_factor_4x4(a)
+    L = np.tril(lu, -1) + np.eye(4, dtype=np.float32)
+    U = np.triu(lu)
+    assert np.allclose(L @ U, a[rows], atol=1e-6)
+    sel = compose_choices([5, 0, 7], 3, 10, np.random.RandomState(0))
+    assert sel.shape == (10,) and sel.min() >= 0 and sel.max() < 12
+
+
+def test_forward_takes_the_ingested_bounding_box():
+    """forward(points, ..., bbox=batch.bbox) == forward(points, ...): every index tensor and the outputs, with the min / max
+    launch gone from the chain."""
+    import ctypes
+    from proxytransformation_amd import _abi
+    from tests.gpu_util import t
+    cfg = PreshapeConfig("ing", B=2, N=6000, grid_size=4, dynamic_drop_radio=0.5, L=6, V=3, seed_base=660)
+    m, _ = build_module(cfg)
+    m = m.cuda()
+    _, text, mask, img = make_scene_batch(cfg)
+    rng = np.random.default_rng(7)
+    scenes = []
+    for b in range(cfg.B):
+        V, H, W = 3, 96, 128
+        depth = (2.0 + 6.0 * rng.random((V, H, W))).astype(np.float32)
+        depth[rng.random((V, H, W)) < 0.2] = 0.0
+        K = np.array([[60.0, 0, 64], [0, 60.0, 48], [0, 0, 1]])
+        ext = np.stack([np.eye(4, dtype=np.float32) for _ in range(V)])
+        for v in range(V):
+            a = 2.1 * v + b
+            ext[v, :3, :3] = np.array([[np.cos(a), 0, -np.sin(a)], [0, 1, 0], [np.sin(a), 0, np.cos(a)]], np.float32)
+        scenes.append(dict(depth_img=torch.from_numpy(depth).to(_dev()), depth_cam2img=K, extrinsic=ext))
+    batch = MultiViewIngest(cfg.N)(scenes, rng=np.random.RandomState(3))
+    ext_span = (batch.points[0].max(0).values - batch.points[0].min(0).values).cpu().numpy()
+    assert (ext_span > 8.0).all(), ext_span                      # the grid needs > 2 * margin per side (PRE:48)
+    td = {"text_feats": t(text), "text_token_mask": t(mask)}
+    d0 = m.forward_debug(batch.points, td, t(img))
+    lib = _abi.lib()
+    nk = lib.ptx_kernel_count()
+    lib.ptx_timing_select_mask((1 << nk) - 1)
+    try:
+        d1 = m.forward_debug(batch.points, td, t(img), bbox=batch.bbox)
+        n = (ctypes.c_int * nk)()
+        ms = (ctypes.c_float * nk)()
+        lib.ptx_timing_read_sites(n, ms, nk)
+    finally:
+        lib.ptx_timing_select(-1)
+    sites = {lib.ptx_kernel_name(i).decode(): n[i] for i in range(nk)}
+    assert sites["k_minmax"] == 0 and sites["k_cluster"] == 1
+    for k in ("centers0", "idx2", "order", "picks", "keep", "kidx", "drop_idx", "translate", "transform"):
+        assert torch.equal(d0[k], d1[k]), k
+    for a, b in zip(d0["outputs"], d1["outputs"]):
+        assert torch.equal(a, b)
+    outs = m(batch.points, td, t(img), bbox=batch.bbox)          # the product call, twice (workspace invariant intact)
+    outs2 = m(batch.points, td, t(img))
+    for a, b, c in zip(outs, outs2, d0["outputs"]):
+        assert torch.equal(a, c) and torch.equal(b, c)

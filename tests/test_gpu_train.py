@@ -128,6 +128,22 @@ def test_dropout_nodes_statistics_and_mask_consistency():
     assert T.dropout(x, 0.0, seed=1) is x
 
 
+def test_every_dropout_site_of_a_block_draws_its_own_mask():
+    """k_dropout is a pure function of (seed, element): the attention node uses seeds[b][0] and seeds[b][0] + 1, so the
+    projection dropout (seeds[b][1]) must not land on either of them (r02 advisory: it did, D2 == proj mask)."""
+    from proxytransformation_amd import train as T
+    x = torch.ones(4096, 64, device=_dev())
+    seeds = T.site_seeds(1234, 1, 1)
+    flat = [s for br in seeds for s in br] + [br[0] + 1 for br in seeds]
+    assert len(set(flat)) == len(flat)
+    masks = [T.dropout_k(x, 0.2, s) for s in flat]
+    for i in range(len(masks)):
+        for j in range(i):
+            assert not torch.equal(masks[i], masks[j]), (i, j)
+    # another call / another module instance with the same torch seed: other masks
+    assert T.site_seeds(1234, 2, 1) != seeds and T.site_seeds(1234, 1, 2) != seeds
+
+
 def test_slot_networks_and_image_pool_nodes_against_the_oracle():
     """_SlotNet (batch-statistics BatchNorm over all slots, mean / max pooling), _ImgTokens + _AttnPoolCore against the
     oracle's torch-CPU functions with autograd."""
@@ -276,24 +292,28 @@ def test_training_step_matches_the_oracle_on_fresh_scenes(case):
                                img_feat=img_t.float().numpy(), float64=True)     # double: the gradients' ground truth
     m._centers_override = torch.from_numpy(ref["centers"].astype(np.float32))
     tx = t(text).requires_grad_(True)
-    outs = m([t(p) for p in pts], {"text_feats": tx, "text_token_mask": t(mask)}, img_t.cuda())
+    ix = img_t.cuda().requires_grad_(True)
+    outs = m([t(p) for p in pts], {"text_feats": tx, "text_token_mask": t(mask)}, ix)
     for b in range(cfg.B):
         assert_close(outs[b].detach().cpu().numpy(), ref["outputs"][b], atol=1e-4, what=f"output {b}")
     _loss(outs).backward()
     assert sorted(n for n, p in m.named_parameters() if p.grad is None) == sorted(ref["none_grads"])
     named = dict(m.named_parameters())
     named["input.text_feats"] = tx
+    named["input.img_feat"] = ix
     worst = {}
     for name, gref in ref["grads"].items():
-        if name == "input.img_feat":
-            continue
-        got = named[name].grad.detach().cpu().numpy().astype(np.float64)
+        got = named[name].grad.detach().float().cpu().numpy().astype(np.float64).reshape(gref.shape)
         rms = np.sqrt((gref.astype(np.float64) ** 2).mean())
         if rms * np.sqrt(gref.size) < 2e-3:
             continue
         err = np.abs(got - gref).max() / rms
         worst[name] = err
-        assert err < 1e-4, f"grad {name}: max err / rms = {err:.3e}"        # north-star bar for the gradients
+        bar = 1e-4                                                           # north-star bar for the gradients
+        if name == "input.img_feat" and dt is not torch.float32:
+            # the gradient of a 16-bit leaf is delivered in that type: one rounding of the fp32 value on top
+            bar += (2.0 ** -8 if dt is torch.bfloat16 else 2.0 ** -11) * np.abs(gref).max() / rms
+        assert err < bar, f"grad {name}: max err / rms = {err:.3e} (bar {bar:.1e})"
     print("worst gradient errors (max err / rms vs the float64 oracle):",
           sorted(((round(v, 6), k) for k, v in worst.items()), reverse=True)[:5])
     for k, v in ref["buffers"].items():

@@ -37,15 +37,15 @@ def test_struct_layout_matches_header():
     prog = r'''
 #include <stdio.h>
 #include "proxyt.h"
-int main(void){printf("%zu %zu %zu %zu %zu %zu\n", sizeof(PtxShape), sizeof(PtxSlotMlp), sizeof(PtxBlock),
- sizeof(PtxBn1d), sizeof(PtxWeights), sizeof(PtxDebug));return 0;}'''
+int main(void){printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(PtxShape), sizeof(PtxSlotMlp), sizeof(PtxBlock),
+ sizeof(PtxBn1d), sizeof(PtxWeights), sizeof(PtxDebug), sizeof(PtxForwardOpts));return 0;}'''
     import tempfile
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "s.c"), "w").write(prog)
         subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")], check=True)
         out = subprocess.run([os.path.join(d, "s")], capture_output=True, text=True, check=True).stdout.split()
     got = [ctypes.sizeof(c) for c in (_abi.PtxShape, _abi.PtxSlotMlp, _abi.PtxBlock, _abi.PtxBn1d,
-                                      _abi.PtxWeights, _abi.PtxDebug)]
+                                      _abi.PtxWeights, _abi.PtxDebug, _abi.PtxForwardOpts)]
     assert got == [int(x) for x in out]
 
 
@@ -220,3 +220,36 @@ def test_sharding_two_ranks_gloo(tmp_path):
         out, _ = p.communicate(timeout=240)
         assert p.returncode == 0, out
         assert "ok" in out
+
+
+def test_dropout_site_seeds_are_distinct():
+    """Every dropout / DropPath site of the two live ProxyBlocks, and the second mask of each attention node, has its
+    own seed (train.site_seeds); calls and module instances are separated too."""
+    from proxytransformation_amd import train
+    seen = set()
+    for call in (1, 2, 3):
+        for salt in (1, 2):
+            seeds = train.site_seeds(42, call, salt)
+            flat = [s for br in seeds for s in br] + [br[0] + 1 for br in seeds]
+            assert len(set(flat)) == 14
+            assert not (seen & set(flat))
+            seen |= set(flat)
+
+
+def test_module_copies_drop_the_host_caches():
+    """copy.deepcopy / torch.save of a module that has run (ctypes pointers in its caches) must work and must not share
+    library contexts (r02 advisory)."""
+    import copy
+    import ctypes
+    import io
+    from proxytransformation_amd import MODELS
+    m = MODELS.build(dict(type="ProxyTransformationNormReverse", grid_size=4))
+    m._wstruct = ctypes.c_void_p(5)             # what a forward leaves behind
+    m._shapes[(1, 2)] = ctypes.c_void_p(7)
+    m2 = copy.deepcopy(m)
+    assert m2._wstruct is None and m2._lanes == {} and m2._shapes == {} and m2._instance_salt != m._instance_salt
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    m3 = torch.load(buf, weights_only=False)
+    assert list(m3.state_dict()) == list(m.state_dict()) and m3._wstruct is None

@@ -95,3 +95,21 @@ def test_point_sample_restatement_matches_the_reference(case):
                                       flip=bool(flip), ori_w=ori_w, pad_hw=tuple(float(x) for x in g["pad"]))
     assert_close(out, g[f"{case}_out"], atol=1e-5, rtol=1e-5, what="sampled features")
     assert (nvalid > 0).sum() == (np.abs(g[f"{case}_out"]).sum(1) > 0).sum()
+
+
+# ------------------------------------------------------------------ multi-view depth ingest
+@pytest.mark.parametrize("case", ["plain", "aug"])
+def test_ingest_restatement_matches_the_reference_transforms(case):
+    """oracle.ingest against tests/golden/g6_ingest.npz, which gen_golden.py captured by running the reference's own
+    MultiViewPipeline(ConvertRGBDToPoints, PointSample) -> AggregateMultiViewPoints -> PointSample (-> GlobalRotScaleTrans)
+    with np.random.seed fixed: the same seed must pick the same pixels (the restatement consumes the RNG in the
+    reference's order) and give the same coordinates."""
+    g = load_golden("g6_ingest")
+    depth = g["depth_u16"].astype(np.float32) / float(g["depth_shift"])
+    aug = None
+    np.random.seed(int(g[f"{case}_seed"]))
+    if case == "aug":
+        aug = dict(rot_mat_T=g["aug_rot_mat_T"], scale=g["aug_scale"], trans=g["aug_trans"])
+    out = oracle.ingest(depth, g["depth_cam2img"], g["extrinsic"], int(g["n_points"]), rng=np.random, aug=aug)
+    assert out["view_counts"][3] < int(g["n_points"]) // 10          # one view is sampled with replacement
+    assert_close(out["points"], g[f"{case}_points"], atol=2e-6, what=f"g6_ingest/{case}")

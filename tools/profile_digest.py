@@ -51,7 +51,12 @@ def pmc(odir, counter, dt):
 
 def main():
     odir, tag = sys.argv[1], sys.argv[2]
-    traffic = {"config": "cfg2", "scenes_per_gpu": 4, "units": "bytes per launch", "correction": "FETCH_SIZE*1024*2 (gfx950 half-count), WRITE_SIZE*1024"}
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "proxytransformation_amd", "libproxyt_hip.so")
+    traffic = {"config": "cfg2", "scenes_per_gpu": 4, "units": "bytes per launch", "correction": "FETCH_SIZE*1024*2 (gfx950 half-count), WRITE_SIZE*1024",
+               # the binary these counters were taken with (bench.py reports traffic_stale when it runs another one)
+               "so_sha16": hashlib.sha256(open(so, "rb").read()).hexdigest()[:16]}
     for dt in ("bf16", "f32"):
         stats(odir, tag, dt)
         fetch, write = pmc(odir, "FETCH_SIZE", dt), pmc(odir, "WRITE_SIZE", dt)
