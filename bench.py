@@ -133,6 +133,7 @@ def work_model(cfg, B, dt_bytes):
     }
     flops = {
         "k_attn32[proxy_as_query]": 4.0 * R * (L + V) * C, "k_attn32[proxy_as_key]": 4.0 * R * (L + V) * C,
+        "k_proxy_attn[fused]": 8.0 * R * (L + V) * C,            # both contractions in one launch (csrc/fattn.hip)
         "k_gemm_nt[qkv+proxy_proj]": 2.0 * 2 * R * 3 * C * C + 2.0 * B * L * C * C,
         "k_gemm_nt[pp_img]": 2.0 * B * V * C * C,
         "k_gemm_nt[proj]": 2.0 * 2 * R * C * C, "k_gemm_nt[fc1]": 2.0 * 2 * R * H * C, "k_gemm_nt[fc2]": 2.0 * 2 * R * H * C,
@@ -257,7 +258,7 @@ def passes_report(cfg, B, us, dt_bytes):
     rep["k_affine"] = hbm(["k_affine<compact>"])
     rep["img_mean_pass_hbm"] = hbm(["k_img_mean"])
     rep["img_pool_pass_hbm"] = hbm(["img_pass2"])
-    rep["proxy_attention_mfma"] = mfma(["k_attn32[proxy_as_query]", "k_attn32[proxy_as_key]"])
+    rep["proxy_attention_mfma"] = mfma(["k_attn32[proxy_as_query]", "k_attn32[proxy_as_key]", "k_proxy_attn[fused]"])
     rep["block_gemms_mfma"] = mfma(["k_gemm_nt[qkv+proxy_proj]", "k_gemm_nt[pp_img]", "k_gemm_nt[proj]",
                                     "k_gemm_nt[fc1]", "k_gemm_nt[fc2]"])
     rep["site_us"] = {k: round(v, 2) for k, v in us.items()}

@@ -221,6 +221,15 @@ int ptx_affine_compact(const PtxShape *s, const float *points, const uint32_t *t
                        const float *kcenter, const float *translate, const float *transform,
                        float *out, int32_t *counts, void *workspace, size_t ws_bytes, void *stream);
 
+/* The two attention products of ProxyAttention (PRE:230-250) on projected inputs: qkv (B*n, 3C) rows [q | k | v] of the
+ * cluster tokens (PRE:221), pt (B*Lp, C) = proxy_proj(proxy) (PRE:223), mask (B,Lp) uint8 (1 = valid; NULL: none),
+ *   pv  = softmax_n((P scale) K^T) V                      (proxy as query, unmasked, PRE:232-238)
+ *   out = softmax_L(masked_fill((Q scale) P^T, -1e9)) pv  (proxy as key, PRE:241-250), heads merged: out (B*n, C).
+ * impl 0: the library's choice for the shape; 1: one fused launch (csrc/fattn.hip; head_dim 32 only); 2: two launches of
+ * the fp32 matrix-instruction kernel (csrc/attn.hip), which need scratch (B*Lp*C floats) for pv. */
+int ptx_proxy_attention(const float *qkv, const float *pt, const uint8_t *mask, float *out, float *scratch, int B, int n,
+                        int Lp, int heads, int C, int impl, void *stream);
+
 /* Whole forward, PRE:424-469, enqueued on `stream` (the side streams of `ctx` fork the
  * clustering chain).  Points: either `points` (B,N,3) stacked, or `points_list` = HOST array of B
  * device pointers to (N,3) clouds (the reference's list input, used in place; B <= 32), the other

@@ -33,12 +33,12 @@ static const char *const kKernelNames[] = {
     "k_gemm_nt[we]", "img_pass2", "img_pass3", "k_gemm_nt[o]", "k_gemm_nt[c_proj]",
     "k_ln_rows[norm_img]", "k_gemm_nt[qkv+proxy_proj]", "k_gemm_nt[pp_img]", "k_attn32[proxy_as_query]",
     "k_attn32[proxy_as_key]", "k_gemm_nt[proj]", "k_gemm_nt[fc1]", "k_gemm_nt[fc2]",
-    "k_heads", "k_affine<compact>"};
+    "k_heads", "k_affine<compact>", "k_proxy_attn[fused]"};
 enum Kid : int {
     KID_MINMAX = 0, KID_CLUSTER, KID_SELECT, KID_SLOTS, KID_TILECOUNT, KID_POINTNET,
     KID_IMG_MEAN, KID_IMG_QKV0, KID_IMG_WE, KID_IMG_SCORES, KID_IMG_GATHER, KID_IMG_O, KID_IMG_C,
     KID_IMG_LN, KID_BLK_QKV, KID_BLK_PP, KID_BLK_ATTN_A, KID_BLK_ATTN_B, KID_BLK_PROJ, KID_BLK_FC1,
-    KID_BLK_FC2, KID_BLK_HEADS, KID_AFFINE, KID_COUNT};
+    KID_BLK_FC2, KID_BLK_HEADS, KID_AFFINE, KID_BLK_ATTN_F, KID_COUNT};
 static_assert(sizeof(kKernelNames) / sizeof(kKernelNames[0]) == KID_COUNT, "kernel name table");
 
 struct TimingRec { int kid; hipEvent_t a, b; };
@@ -341,6 +341,18 @@ struct Branch {
     const float *fc1_gw, *fc1_gs, *fc1_gc;      // norm2 folded into fc1
 };
 
+// One work-group per (scene, head, branch) must be enough parallelism: the two-launch form spreads the query tiles of the
+// second contraction over the chip, which wins when a call has few scenes and many tokens (measured; PTX_ATTN_FUSED=1 / 0
+// forces either form).
+static bool fused_attn_pays(const PtxShape &s, const Branch *br, int nb)
+{
+    static const int env = getenv("PTX_ATTN_FUSED") ? atoi(getenv("PTX_ATTN_FUSED")) : -1;
+    if (env >= 0) return env != 0;
+    (void)br;
+    const long wgs = (long)s.B * s.heads * nb;
+    return s.Mk <= 256 || wgs >= 96;
+}
+
 // phase 0: everything; phase 1: only the projections that do not wait for late proxies
 // (qkv of every branch + proxy_proj of the early ones); phase 2: the rest.
 static int run_blocks(const PtxShape &s, const Branch *br, int nb, const float *point_proxy, void *ws,
@@ -370,23 +382,32 @@ static int run_blocks(const PtxShape &s, const Branch *br, int nb, const float *
         if (g.n > 0) PTX_TIMED(phase == 2 ? KID_BLK_PP : KID_BLK_QKV, st, launch_gemm(g, st));
         if (phase == 1) return PTX_OK;
     }
+    FAttnBatch fa{}; fa.nb = nb; fa.B = s.B; fa.heads = s.heads; fa.hd = C / s.heads; fa.n = s.Mk; fa.C = C;
+    fa.scale = attn_scale(C / s.heads);
+    for (int i = 0; i < nb; ++i) {
+        const int sl = br[i].slot;
+        fa.p[i] = FAttnProb{at<float>(ws, L.qkv[sl]), at<float>(ws, L.pt[sl]), br[i].mask, at<float>(ws, L.ao[sl]), br[i].Lp};
+    }
+    // head_dim 32: both contractions of a (scene, head, branch) in one work-group, PV never leaves the CU (fattn.hip)
+    const bool fused = fused_attn_supported(fa) && fused_attn_pays(s, br, nb);
+    if (fused) PTX_TIMED(KID_BLK_ATTN_F, st, launch_proxy_attn(fa, st));
     AttnBatch a{}; a.n = nb; a.B = s.B; a.heads = s.heads; a.hd = C / s.heads; a.scale = attn_scale(C / s.heads);
-    for (int i = 0; i < nb; ++i) {   // proxy as query (PRE:232-238): no mask
+    for (int i = 0; i < nb && !fused; ++i) {   // proxy as query (PRE:232-238): no mask
         const int sl = br[i].slot;
         float *qkv = at<float>(ws, L.qkv[sl]);
         a.p[i] = AttnProb{at<float>(ws, L.pt[sl]), qkv + C, qkv + 2 * C, at<float>(ws, L.pv[sl]), nullptr,
                           br[i].Lp, s.Mk, C, 3 * C, 3 * C, C,
                           (long)br[i].Lp * C, (long)s.Mk * 3 * C, (long)s.Mk * 3 * C, (long)br[i].Lp * C};
     }
-    PTX_TIMED(KID_BLK_ATTN_A, st, launch_attn32(a, st));
-    for (int i = 0; i < nb; ++i) {   // proxy as key (PRE:241-250): padded text tokens masked
+    if (!fused) PTX_TIMED(KID_BLK_ATTN_A, st, launch_attn32(a, st));
+    for (int i = 0; i < nb && !fused; ++i) {   // proxy as key (PRE:241-250): padded text tokens masked
         const int sl = br[i].slot;
         float *qkv = at<float>(ws, L.qkv[sl]);
         a.p[i] = AttnProb{qkv, at<float>(ws, L.pt[sl]), at<float>(ws, L.pv[sl]), at<float>(ws, L.ao[sl]),
                           br[i].mask, s.Mk, br[i].Lp, 3 * C, C, C, C,
                           (long)s.Mk * 3 * C, (long)br[i].Lp * C, (long)br[i].Lp * C, (long)s.Mk * C};
     }
-    PTX_TIMED(KID_BLK_ATTN_B, st, launch_attn32(a, st));
+    if (!fused) PTX_TIMED(KID_BLK_ATTN_B, st, launch_attn32(a, st));
     {   // x1 = x + proj(attn) (PRE:255, 274); every tile also leaves the LayerNorm partials of its rows for fc1
         GemmBatch g{}; g.n = nb;
         for (int i = 0; i < nb; ++i) {
@@ -692,6 +713,28 @@ int ptx_proxy_block(const PtxShape *s, const PtxWeights *w, const void *prep, in
     PTX_TRY(launch_ln_rows(lb, st));
     Branch br = make_branch(*s, *w, pf, which, x_in, proxy, Lp, mask, head_out, guide);
     return run_blocks(*s, &br, 1, point_proxy, workspace, st);
+}
+
+int ptx_proxy_attention(const float *qkv, const float *pt, const uint8_t *mask, float *out, float *scratch, int B, int n,
+                        int Lp, int heads, int C, int impl, void *stream)
+{
+    PTX_REQUIRE(qkv && pt && out, "ptx_proxy_attention: null argument");
+    PTX_REQUIRE(B >= 1 && n >= 1 && Lp >= 1 && heads >= 1 && C >= heads && C % heads == 0, "ptx_proxy_attention: B=%d n=%d Lp=%d heads=%d C=%d", B, n, Lp, heads, C);
+    PTX_REQUIRE(impl >= 0 && impl <= 2, "ptx_proxy_attention: impl=%d", impl);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int hd = C / heads;
+    FAttnBatch fa{}; fa.nb = 1; fa.B = B; fa.heads = heads; fa.hd = hd; fa.n = n; fa.C = C; fa.scale = attn_scale(hd);
+    fa.p[0] = FAttnProb{qkv, pt, mask, out, Lp};
+    const bool can = fused_attn_supported(fa);
+    PTX_REQUIRE(impl != 1 || can, "ptx_proxy_attention: the fused kernel does not support head_dim=%d, Lp=%d", hd, Lp);
+    if (impl == 1 || (impl == 0 && can && (n <= 256 || (long)B * heads >= 96))) return launch_proxy_attn(fa, st);
+    PTX_REQUIRE(scratch != nullptr, "ptx_proxy_attention: the two-launch form needs scratch for pv");
+    AttnBatch a{}; a.n = 1; a.B = B; a.heads = heads; a.hd = hd; a.scale = attn_scale(hd);
+    a.p[0] = AttnProb{pt, qkv + C, qkv + 2 * C, scratch, nullptr, Lp, n, C, 3 * C, 3 * C, C,
+                      (long)Lp * C, (long)n * 3 * C, (long)n * 3 * C, (long)Lp * C};
+    PTX_TRY(launch_attn32(a, st));
+    a.p[0] = AttnProb{qkv, pt, scratch, out, mask, n, Lp, 3 * C, C, C, C, (long)n * 3 * C, (long)Lp * C, (long)Lp * C, (long)n * C};
+    return launch_attn32(a, st);
 }
 
 int ptx_affine_scatter(const PtxShape *s, const float *points, const uint32_t *tag, const float *kcenter,

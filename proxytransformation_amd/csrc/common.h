@@ -183,6 +183,13 @@ struct AttnProb {
 struct AttnBatch { AttnProb p[2]; int n; int B, heads, hd; float scale; };
 int launch_attn32(const AttnBatch &ab, hipStream_t st);
 
+// fused ProxyAttention of one (scene, head, branch) per work-group (fattn.hip): qkv (B*n, 3C) rows [q | k | v], pt (B*Lp, C)
+// projected proxies, mask (B,Lp) uint8 (1 = valid) or null, out (B*n, C)
+struct FAttnProb { const float *qkv, *pt; const uint8_t *mask; float *out; int Lp; };
+struct FAttnBatch { FAttnProb p[2]; int nb, B, heads, hd, n, C; float scale; };
+bool fused_attn_supported(const FAttnBatch &ab);
+int launch_proxy_attn(const FAttnBatch &ab, hipStream_t st);
+
 // Per-scene base pointers of the point clouds, passed by value as a kernel argument: the caller's
 // list of (N,3) tensors is used in place (the reference stacks them into a copy, PRE:426-427; the
 // path never writes to its input, so no copy is needed).

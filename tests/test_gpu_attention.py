@@ -1,0 +1,71 @@
+"""The two attention products of ProxyAttention (PRE:230-250) through the C ABI (ptx_proxy_attention): the fused
+single-launch kernel (csrc/fattn.hip, split-operand bf16 matrix pipe) and the two-launch fp32 kernel (csrc/attn.hip)
+against a float64 evaluation of the reference's formulas -- ragged proxy / token counts, padded text tokens, both the
+register-resident (n <= 256) and the streaming key-tile paths."""
+import numpy as np
+import pytest
+import torch
+
+from proxytransformation_amd import _abi
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(qkv, pt, mask, B, n, Lp, heads, C):
+    """PRE:225-252 in float64."""
+    hd = C // heads
+    scale = hd ** -0.5
+    x = qkv.double().view(B, n, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    q, k, v = x[0], x[1], x[2]                                              # (B,h,n,hd)
+    p = pt.double().view(B, Lp, heads, hd).permute(0, 2, 1, 3)              # (B,h,Lp,hd)
+    a1 = ((p * scale) @ k.transpose(-2, -1)).softmax(-1)                    # PRE:232-236 (no mask)
+    pv = a1 @ v                                                             # (B,h,Lp,hd)
+    a2 = (q * scale) @ p.transpose(-2, -1)                                  # (B,h,n,Lp)
+    if mask is not None:
+        a2 = a2.masked_fill(mask.view(B, 1, 1, Lp) == 0, -1e9)              # PRE:245-247
+    out = a2.softmax(-1) @ pv
+    return out.transpose(1, 2).reshape(B * n, C)                            # PRE:252
+
+
+@pytest.mark.parametrize("impl", [1, 2], ids=["fused", "two-launch"])
+@pytest.mark.parametrize("B,n,Lp,masked", [(2, 256, 196, False), (3, 256, 64, True), (1, 64, 16, True), (2, 100, 37, True),
+                                           (1, 691, 50, False), (2, 691, 77, True), (1, 300, 256, False), (1, 1024, 5, True)])
+def test_proxy_attention_matches_float64(impl, B, n, Lp, masked):
+    heads, C = 8, 256
+    g = torch.Generator().manual_seed(1000 * n + Lp)
+    qkv = torch.randn(B * n, 3 * C, generator=g).cuda()
+    pt = (torch.randn(B * Lp, C, generator=g) * 1.5).cuda()
+    mask = None
+    if masked:
+        mask = (torch.rand(B, Lp, generator=g) > 0.3).to(torch.uint8)
+        mask[:, 0] = 1
+        if B > 1:
+            mask[1, :] = 0                                                   # a scene with every token padded: uniform weights
+        mask = mask.cuda()
+    out = torch.full((B * n, C), float("nan"), device="cuda")
+    scratch = torch.empty(B * Lp * C, device="cuda")
+    _abi.check(_abi.lib().ptx_proxy_attention(qkv.data_ptr(), pt.data_ptr(), None if mask is None else mask.data_ptr(),
+                                              out.data_ptr(), scratch.data_ptr(), B, n, Lp, heads, C, impl,
+                                              torch.cuda.current_stream().cuda_stream), "ptx_proxy_attention")
+    ref = _ref(qkv, pt, mask, B, n, Lp, heads, C)
+    err = (out.double() - ref).abs().max().item()
+    assert torch.isfinite(out).all()
+    assert err < 2e-5, f"max abs error {err:.3e} against the float64 reference (outputs are O(1))"
+
+
+def test_fused_and_two_launch_forms_agree_on_large_scores():
+    """Scores of a few hundred (sharp soft-max): both forms must still agree to fp32 level."""
+    B, n, Lp, heads, C = 1, 256, 96, 8, 256
+    g = torch.Generator().manual_seed(5)
+    qkv = (torch.randn(B * n, 3 * C, generator=g) * 6).cuda()
+    pt = (torch.randn(B * Lp, C, generator=g) * 6).cuda()
+    outs = []
+    for impl in (1, 2):
+        out = torch.empty((B * n, C), device="cuda")
+        scratch = torch.empty(B * Lp * C, device="cuda")
+        _abi.check(_abi.lib().ptx_proxy_attention(qkv.data_ptr(), pt.data_ptr(), None, out.data_ptr(), scratch.data_ptr(),
+                                                  B, n, Lp, heads, C, impl, torch.cuda.current_stream().cuda_stream), "attn")
+        outs.append(out)
+    ref = _ref(qkv, pt, None, B, n, Lp, heads, C)
+    for o in outs:
+        assert (o.double() - ref).abs().max().item() < 2e-4 * ref.abs().max().item()
