@@ -318,8 +318,9 @@ int ptx_voxelize(const float *points, const int32_t *counts, int B, int Ncap, fl
 
 /* ------------------------------------------------------------------ image feature -> point sampling
  * batch_point_sample (models/layers/fusion_layers/point_fusion.py:208-313) as called at detectors/
- * sparse_featfusion_grounder_preshape.py:428-444 (nearest, zeros padding, align_corners=True, valid_flag=True):
- * out (N,C) = sum over ALL V views of the nearest feature pixel / max(#views in which the point is inside the padded
+ * sparse_featfusion_grounder_preshape.py:428-444 (nearest, zeros padding, align_corners=True, valid_flag=True; bilinear != 0:
+ * the function's own default aligned=True, F.grid_sample(mode='bilinear'), neighbours outside the map count as 0):
+ * out (N,C) = sum over ALL V views of the sampled feature pixel / max(#views in which the point is inside the padded
  * image with depth > 0, 1), zero rows where that count is 0.  feats (V,C,H,W) fp32 / bf16 / fp16 (feat_dtype 0/1/2);
  * proj (V,4,4) row-major = intrinsic @ extrinsic; pre: optional (3,4) affine applied to the points first (the reverse
  * 3D augmentation of apply_3d_transformation, composed by the host) or NULL; image transform scale -> crop -> flip
@@ -328,8 +329,8 @@ int ptx_voxelize(const float *points, const int32_t *counts, int B, int Ncap, fl
 size_t ptx_point_sample_workspace_bytes(int V, int C, int H, int W);
 int ptx_point_sample(const float *points, int N, const void *feats, int feat_dtype, int V, int C, int H, int W,
                      const float *proj, const float *pre, float scale_w, float scale_h, float crop_w, float crop_h, int flip,
-                     float ori_w, float pad_h, float pad_w, float *out, int32_t *valid_num, void *workspace, size_t ws_bytes,
-                     void *stream);
+                     float ori_w, float pad_h, float pad_w, int bilinear, float *out, int32_t *valid_num, void *workspace,
+                     size_t ws_bytes, void *stream);
 
 /* ------------------------------------------------------------------ train-mode operators
  * The differentiable half of the path in train mode -- batch-statistics BatchNorm2d / BatchNorm1d (PRE:74, 114,

@@ -465,7 +465,36 @@ def _fma32(a, b, c):
     return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
 
 
-def point_sample(points, feats, proj, *, scale=(1.0, 1.0), crop=(0.0, 0.0), flip=False, ori_w=0.0, pad_hw=(480.0, 640.0)):
+def reverse_3d_points(points, img_meta, coord_type="DEPTH"):
+    """apply_3d_transformation(..., reverse=True) (point_fusion.py:20-107) step by step in fp32, as the reference applies
+    it: the recorded flow back to front -- 'T': += -pcd_trans, 'S': *= 1 / pcd_scale_factor, 'R': @ inverse(pcd_rotation),
+    'HF' / 'VF': the BEV flips of DEPTH / LIDAR coordinates (x / y negated; depth_points.py:47-50)."""
+    p = torch.from_numpy(_f32(points)).clone()
+    flow = list(img_meta.get("transformation_3d_flow", []))
+    rot = torch.from_numpy(_f32(img_meta["pcd_rotation"])) if "pcd_rotation" in img_meta else torch.eye(3)
+    scale = img_meta.get("pcd_scale_factor", 1.0)
+    trans = torch.from_numpy(_f32(img_meta["pcd_trans"])) if "pcd_trans" in img_meta else torch.zeros(3)
+    assert coord_type.upper() in ("DEPTH", "LIDAR")
+    for op in flow[::-1]:
+        if op == "T":
+            p += -trans
+        elif op == "S":
+            p *= 1.0 / scale
+        elif op == "R":
+            p = p @ rot.inverse()
+        elif op == "HF":
+            if img_meta.get("pcd_horizontal_flip", False):
+                p[:, 0] = -p[:, 0]
+        elif op == "VF":
+            if img_meta.get("pcd_vertical_flip", False):
+                p[:, 1] = -p[:, 1]
+        else:
+            raise AssertionError(op)
+    return p.numpy()
+
+
+def point_sample(points, feats, proj, *, scale=(1.0, 1.0), crop=(0.0, 0.0), flip=False, ori_w=0.0, pad_hw=(480.0, 640.0),
+                 bilinear=False):
     """batch_point_sample (models/layers/fusion_layers/point_fusion.py:208-313) as the detector calls it
     (detectors/sparse_featfusion_grounder_preshape.py:428-444: nearest sampling, zeros padding, align_corners=True,
     valid_flag=True), for points already in the projectable frame (the reverse 3D augmentation of
@@ -497,12 +526,27 @@ def point_sample(points, feats, proj, *, scale=(1.0, 1.0), crop=(0.0, 0.0), flip
             cx = np.float32(ori_w) - cx
         nx = cx / pad_w * np.float32(2) - one
         ny = cy / pad_h * np.float32(2) - one
-        ix = np.rint(((nx + one) / np.float32(2)) * np.float32(W - 1))
-        iy = np.rint(((ny + one) / np.float32(2)) * np.float32(H - 1))
-        inb = (ix >= 0) & (ix <= W - 1) & (iy >= 0) & (iy <= H - 1)
-        ixi, iyi = np.where(inb, ix, 0).astype(np.int64), np.where(inb, iy, 0).astype(np.int64)
-        samp = f[v][:, iyi, ixi].T                         # (N,C)
-        acc = acc + np.where(inb[:, None], samp, np.float32(0))
+        fx = ((nx + one) / np.float32(2)) * np.float32(W - 1)
+        fy = ((ny + one) / np.float32(2)) * np.float32(H - 1)
+        if not bilinear:
+            ix, iy = np.rint(fx), np.rint(fy)
+            inb = (ix >= 0) & (ix <= W - 1) & (iy >= 0) & (iy <= H - 1)
+            ixi, iyi = np.where(inb, ix, 0).astype(np.int64), np.where(inb, iy, 0).astype(np.int64)
+            samp = f[v][:, iyi, ixi].T                         # (N,C)
+            acc = acc + np.where(inb[:, None], samp, np.float32(0))
+        else:
+            # F.grid_sample(mode='bilinear', padding_mode='zeros', align_corners=True): four neighbours weighted by the
+            # opposite areas, neighbours outside the map contribute 0 (aligned=True, point_fusion.py:287-293)
+            x0, y0 = np.floor(fx), np.floor(fy)
+            wx1, wy1 = fx - x0, fy - y0
+            wx0, wy0 = one - wx1, one - wy1
+            s = np.zeros((N, C), np.float32)
+            for dx, dy, w in ((0, 0, wx0 * wy0), (1, 0, wx1 * wy0), (0, 1, wx0 * wy1), (1, 1, wx1 * wy1)):
+                xx, yy = x0 + dx, y0 + dy
+                ok = (xx >= 0) & (xx <= W - 1) & (yy >= 0) & (yy <= H - 1)
+                xi, yi = np.where(ok, xx, 0).astype(np.int64), np.where(ok, yy, 0).astype(np.int64)
+                s = s + np.where(ok[:, None], f[v][:, yi, xi].T * w[:, None].astype(np.float32), np.float32(0))
+            acc = acc + s
         nvalid += (cx < pad_w) & (cx > 0) & (cy < pad_h) & (cy > 0) & (q[2] > 0)
     out = acc / np.maximum(nvalid, 1)[:, None].astype(np.float32)
     out[nvalid == 0] = 0

@@ -48,6 +48,7 @@ struct PsArgs {
     const float *proj; const float *pre;
     float sx, sy, cx, cy; int flip; float ori_w, pad_h, pad_w;
     float *out; int32_t *valid_num;
+    int bilinear;       // aligned=True: F.grid_sample(mode='bilinear'); 0: 'nearest' (what the detector asks for)
 };
 
 constexpr int kPsMaxQ = 8;      // C <= 512
@@ -74,6 +75,8 @@ __global__ __launch_bounds__(256) void k_point_sample(PsArgs a)
         const int v = v0 + lane;
         bool inb = false, valid = false;
         int pix = 0;
+        float wx1 = 0.0f, wy1 = 0.0f;          // bilinear: weights of the +1 neighbours; pix = (y0 * W + x0), possibly outside
+        int cx0 = 0, cy0 = 0;
         if (v < a.V) {
             const float *P = a.proj + (size_t)v * 16;
             // q = [x y z 1] P^T (structures/bbox_3d/utils.py:322-327), one rounding per step, in this order
@@ -87,11 +90,20 @@ __global__ __launch_bounds__(256) void k_point_sample(PsArgs a)
             if (a.flip) cx = __fsub_rn(a.ori_w, cx);                                  // horizontal flip (:276)
             const float nx = __fsub_rn(__fmul_rn(__fdiv_rn(cx, a.pad_w), 2.0f), 1.0f);
             const float ny = __fsub_rn(__fmul_rn(__fdiv_rn(cy, a.pad_h), 2.0f), 1.0f);
-            // grid_sample, nearest, align_corners=True, zeros padding
-            const float fx = rintf(__fmul_rn(__fdiv_rn(__fadd_rn(nx, 1.0f), 2.0f), (float)(a.W - 1)));
-            const float fy = rintf(__fmul_rn(__fdiv_rn(__fadd_rn(ny, 1.0f), 2.0f), (float)(a.H - 1)));
-            inb = fx >= 0.0f && fx <= (float)(a.W - 1) && fy >= 0.0f && fy <= (float)(a.H - 1);
-            if (inb) pix = (int)fy * a.W + (int)fx;
+            // grid_sample, align_corners=True (unnormalise: ((g + 1) / 2) * (size - 1)), zeros padding
+            const float ix = __fmul_rn(__fdiv_rn(__fadd_rn(nx, 1.0f), 2.0f), (float)(a.W - 1));
+            const float iy = __fmul_rn(__fdiv_rn(__fadd_rn(ny, 1.0f), 2.0f), (float)(a.H - 1));
+            if (!a.bilinear) {                                  // nearest: round half to even
+                const float fx = rintf(ix), fy = rintf(iy);
+                inb = fx >= 0.0f && fx <= (float)(a.W - 1) && fy >= 0.0f && fy <= (float)(a.H - 1);
+                if (inb) pix = (int)fy * a.W + (int)fx;
+            } else {                                            // the four neighbours, those outside the map count as 0
+                const float x0 = floorf(ix), y0 = floorf(iy);
+                wx1 = __fsub_rn(ix, x0); wy1 = __fsub_rn(iy, y0);
+                // a point whose four neighbours are all outside contributes nothing (also covers inf / nan coordinates)
+                inb = x0 >= -1.0f && x0 <= (float)(a.W - 1) && y0 >= -1.0f && y0 <= (float)(a.H - 1);
+                if (inb) { cx0 = (int)x0; cy0 = (int)y0; }
+            }
             valid = cx < a.pad_w && cx > 0.0f && cy < a.pad_h && cy > 0.0f && q[2] > 0.0f;     // :300-301
         }
         nvalid += __popcll(__ballot(valid));
@@ -99,12 +111,37 @@ __global__ __launch_bounds__(256) void k_point_sample(PsArgs a)
         while (hit) {                                           // views in ascending order (the reference sums dim 0)
             const int l = __ffsll((long long)hit) - 1;
             hit &= hit - 1;
-            const int px = __builtin_amdgcn_readlane(pix, l);
-            const float *f = a.featT + ((size_t)(v0 + l) * HW + px) * a.C;
+            if (!a.bilinear) {
+                const int px = __builtin_amdgcn_readlane(pix, l);
+                const float *f = a.featT + ((size_t)(v0 + l) * HW + px) * a.C;
 #pragma unroll
-            for (int q = 0; q < kPsMaxQ; ++q) {
-                const int c = lane + 64 * q;
-                if (c < a.C) acc[q] += f[c];
+                for (int q = 0; q < kPsMaxQ; ++q) {
+                    const int c = lane + 64 * q;
+                    if (c < a.C) acc[q] += f[c];
+                }
+            } else {
+                const int x0 = __builtin_amdgcn_readlane(cx0, l), y0 = __builtin_amdgcn_readlane(cy0, l);
+                const float fx = PTX_LANE_F(wx1, l), fy = PTX_LANE_F(wy1, l);
+                const float gx = __fsub_rn(1.0f, fx), gy = __fsub_rn(1.0f, fy);
+                // weights as torch's grid sampler forms them: nw = (x1 - ix)(y1 - iy), ne = (ix - x0)(y1 - iy), ...
+                const float w[4] = {__fmul_rn(gx, gy), __fmul_rn(fx, gy), __fmul_rn(gx, fy), __fmul_rn(fx, fy)};
+                const float *fv = a.featT + (size_t)(v0 + l) * HW * a.C;
+                float s[kPsMaxQ];
+#pragma unroll
+                for (int q = 0; q < kPsMaxQ; ++q) s[q] = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {                   // nw, ne, sw, se
+                    const int xx = x0 + (k & 1), yy = y0 + (k >> 1);
+                    if (xx < 0 || xx >= a.W || yy < 0 || yy >= a.H) continue;      // wave-uniform
+                    const float *f = fv + ((size_t)yy * a.W + xx) * a.C;
+#pragma unroll
+                    for (int q = 0; q < kPsMaxQ; ++q) {
+                        const int c = lane + 64 * q;
+                        if (c < a.C) s[q] = __fadd_rn(s[q], __fmul_rn(f[c], w[k]));
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < kPsMaxQ; ++q) acc[q] += s[q];
             }
         }
     }
@@ -141,8 +178,8 @@ size_t ptx_point_sample_workspace_bytes(int V, int C, int H, int W)
 
 int ptx_point_sample(const float *points, int N, const void *feats, int feat_dtype, int V, int C, int H, int W,
                      const float *proj, const float *pre, float scale_w, float scale_h, float crop_w, float crop_h, int flip,
-                     float ori_w, float pad_h, float pad_w, float *out, int32_t *valid_num, void *workspace, size_t ws_bytes,
-                     void *stream)
+                     float ori_w, float pad_h, float pad_w, int bilinear, float *out, int32_t *valid_num, void *workspace,
+                     size_t ws_bytes, void *stream)
 {
     PTX_REQUIRE(points && feats && proj && out && workspace, "ptx_point_sample: null argument");
     PTX_REQUIRE(N >= 1 && V >= 1 && C >= 1 && C <= 64 * kPsMaxQ && H >= 1 && W >= 1 && feat_dtype >= 0 && feat_dtype <= 2 &&
@@ -154,7 +191,7 @@ int ptx_point_sample(const float *points, int N, const void *feats, int feat_dty
     float *featT = static_cast<float *>(workspace);
     hipLaunchKernelGGL(k_feat_transpose, dim3(cdiv(H * W, 32), cdiv(C, 32), V), dim3(256), 0, st, feats, feat_dtype, C, H * W, featT);
     PTX_LAUNCHED("k_feat_transpose");
-    PsArgs a{points, N, featT, V, C, H, W, proj, pre, scale_w, scale_h, crop_w, crop_h, flip, ori_w, pad_h, pad_w, out, valid_num};
+    PsArgs a{points, N, featT, V, C, H, W, proj, pre, scale_w, scale_h, crop_w, crop_h, flip, ori_w, pad_h, pad_w, out, valid_num, bilinear ? 1 : 0};
     hipLaunchKernelGGL(k_point_sample, dim3(cdiv(N, 4)), dim3(256), 0, st, a);
     PTX_LAUNCHED("k_point_sample");
     return PTX_OK;

@@ -20,6 +20,46 @@ def _pair(v, dev):
     return float(v[0]), float(v[1])
 
 
+def reverse_3d_flow(img_meta: Optional[dict], coord_type: str = "DEPTH") -> Optional[torch.Tensor]:
+    """``apply_3d_transformation(points, coord_type, img_meta, reverse=True)`` (point_fusion.py:20-107) as ONE (3,4) affine
+    ``[A | t]`` (p' = A p + t), composed on the host in float64: the recorded ``transformation_3d_flow`` is undone back to
+    front -- 'T': p - pcd_trans, 'S': p / pcd_scale_factor, 'R': p @ inverse(pcd_rotation), 'HF' / 'VF': the BEV flips of
+    the coordinate type (DEPTH / LIDAR: x -> -x / y -> -y, depth_points.py:47-50; CAMERA: x -> -x / z -> -z).  Returns
+    ``None`` when nothing was recorded."""
+    flow = list(img_meta.get("transformation_3d_flow", [])) if img_meta else []
+    if not flow:
+        return None
+    import numpy as np
+    A, t = np.eye(3), np.zeros(3)
+
+    def host(x):
+        return np.asarray(x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else x, np.float64)
+    rot = host(img_meta["pcd_rotation"]).reshape(3, 3) if "pcd_rotation" in img_meta else np.eye(3)
+    scale = float(img_meta.get("pcd_scale_factor", 1.0))
+    trans = host(img_meta["pcd_trans"]).reshape(3) if "pcd_trans" in img_meta else np.zeros(3)
+    ct = coord_type.upper()
+    if ct not in ("DEPTH", "LIDAR", "CAMERA"):
+        raise ValueError(f"coord_type {coord_type!r}")
+    for op in flow[::-1]:
+        if op == "T":
+            t = t - trans
+        elif op == "S":
+            A, t = A / scale, t / scale
+        elif op == "R":                                  # row vectors: p @ inv(rot)  <=>  column vectors: inv(rot)^T p
+            M = np.linalg.inv(rot).T
+            A, t = M @ A, M @ t
+        elif op in ("HF", "VF"):
+            flipped = bool(img_meta.get("pcd_horizontal_flip" if op == "HF" else "pcd_vertical_flip", False))
+            if flipped:
+                axis = 0 if op == "HF" else (2 if ct == "CAMERA" else 1)
+                F = np.eye(3)
+                F[axis, axis] = -1.0
+                A, t = F @ A, F @ t
+        else:
+            raise AssertionError(f"This 3D data transformation op ({op}) is not supported")     # point_fusion.py:101-102
+    return torch.from_numpy(np.concatenate([A, t[:, None]], 1).astype(np.float32))
+
+
 def batch_point_sample(img_meta: Optional[dict], img_features: torch.Tensor, points: torch.Tensor, proj_mat: torch.Tensor,
                        coord_type: str = "DEPTH", img_scale_factor=1.0, img_crop_offset=0.0, img_flip: bool = False,
                        img_pad_shape: Sequence[int] = (480, 640), img_shape: Sequence[int] = (480, 640),
@@ -28,14 +68,16 @@ def batch_point_sample(img_meta: Optional[dict], img_features: torch.Tensor, poi
     """Same arguments as the reference function.  img_features (V,C,H,W) on the GPU (fp32 / bf16 / fp16), points (N,3)
     fp32, proj_mat (V,4,4) = intrinsic @ extrinsic.  Returns (N,C) fp32.
 
-    Only the mode the detector uses is implemented in HIP (nearest sampling, zeros padding, align_corners, valid_flag).
-    The reverse 3D augmentation of ``apply_3d_transformation`` (point_fusion.py:20-107) is metadata: pass it as
-    ``pre_transform`` (3,4) if ``img_meta`` records a ``transformation_3d_flow``."""
-    if aligned or padding_mode != "zeros" or not align_corners or not valid_flag:
-        raise NotImplementedError("HIP path: aligned=False, padding_mode='zeros', align_corners=True, valid_flag=True "
+    ``aligned=False`` (the detector's call: nearest) and ``aligned=True`` (bilinear) are both HIP; zeros padding,
+    align_corners and valid_flag as the detector passes them.  The reverse 3D augmentation of
+    ``apply_3d_transformation`` (point_fusion.py:20-107) is composed from ``img_meta['transformation_3d_flow']``
+    (``reverse_3d_flow``; the training pipeline's GlobalRotScaleTrans records 'R', 'S', 'T') unless an explicit
+    ``pre_transform`` (3,4) is given."""
+    if padding_mode != "zeros" or not align_corners or not valid_flag:
+        raise NotImplementedError("HIP path: padding_mode='zeros', align_corners=True, valid_flag=True "
                                   "(the call at sparse_featfusion_grounder_preshape.py:428-444)")
-    if img_meta and img_meta.get("transformation_3d_flow") and pre_transform is None:
-        raise NotImplementedError("img_meta carries a 3D augmentation flow: compose its reverse into pre_transform (3,4)")
+    if pre_transform is None:
+        pre_transform = reverse_3d_flow(img_meta, coord_type)
     if not (img_features.is_cuda and points.is_cuda and proj_mat.is_cuda):
         raise RuntimeError("batch_point_sample (HIP) needs GPU tensors: there is no CPU path")
     if img_features.dtype not in _DT:
@@ -61,7 +103,8 @@ def batch_point_sample(img_meta: Optional[dict], img_features: torch.Tensor, poi
     pre = None if pre_transform is None else pre_transform.detach().to(device=dev, dtype=torch.float32).contiguous()
     _abi.check(lib.ptx_point_sample(pts.data_ptr(), N, feats.data_ptr(), _DT[feats.dtype], V, C, H, W, proj.data_ptr(),
                                     None if pre is None else pre.data_ptr(), sw, sh, cw, ch, 1 if img_flip else 0,
-                                    float(img_shape[1]), float(img_pad_shape[0]), float(img_pad_shape[1]), out.data_ptr(),
+                                    float(img_shape[1]), float(img_pad_shape[0]), float(img_pad_shape[1]), 1 if aligned else 0,
+                                    out.data_ptr(),
                                     None, ws.data_ptr(), ws.numel(), torch.cuda.current_stream(dev).cuda_stream),
                "ptx_point_sample")
     return out

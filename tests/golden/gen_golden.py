@@ -420,16 +420,15 @@ def gen_point_sample():
     load("embodiedscan.utils.array_converter", ref + "/utils/array_converter.py")
     b3 = load("embodiedscan.structures.bbox_3d", ref + "/structures/bbox_3d/utils.py")
     b3.get_proj_mat_by_coord_type = lambda *a, **k: None
-    pts_mod = types.ModuleType("embodiedscan.structures.points")
-
-    class _Pts:                     # no 3D augmentation in img_meta: the flow is empty, only .coord is used
-        def __init__(self, t):
-            self.coord = t
-
-        def scale(self, *a, **k): raise AssertionError("empty flow")
-        translate = rotate = flip = scale
-    pts_mod.get_points_type = lambda coord_type: _Pts
+    # the reference's own point containers (DepthPoints.flip / rotate / scale / translate run the reverse 3D flow)
+    es_st = types.ModuleType("embodiedscan.structures"); es_st.__path__ = []
+    sys.modules.setdefault("embodiedscan.structures", es_st)
+    sys.modules["embodiedscan.structures.bbox_3d.utils"] = b3
+    spec = importlib.util.spec_from_file_location("embodiedscan.structures.points", ref + "/structures/points/__init__.py",
+                                                  submodule_search_locations=[ref + "/structures/points"])
+    pts_mod = importlib.util.module_from_spec(spec)
     sys.modules["embodiedscan.structures.points"] = pts_mod
+    spec.loader.exec_module(pts_mod)
     pf = load("pf_ref", ref + "/models/layers/fusion_layers/point_fusion.py")
 
     rng = np.random.default_rng(123)
@@ -446,9 +445,24 @@ def gen_point_sample():
         proj[v] = (K @ ext).astype(np.float32)
     points = ((rng.random((N, 3)) - 0.5) * np.array([9.0, 6.0, 9.0])).astype(np.float32)
     save = dict(feats=feats, proj=proj, pad=np.array([pad_h, pad_w], np.float32))
-    for name, scale, crop, flip in (("plain", (1.0, 1.0), (0.0, 0.0), False), ("aug", (0.9, 1.1), (12.0, -7.0), True)):
-        pts_t, proj_t = torch.from_numpy(points), torch.from_numpy(proj)
-        # boundary filter, in float64
+    # 3D augmentation as the training pipeline records it (GlobalRotScaleTrans: 'R', 'S', 'T'; RandomFlip3D: 'HF'):
+    # the sampled points live in the AUGMENTED frame and are taken back by apply_3d_transformation(reverse=True)
+    ang = 0.07
+    rot_T = np.array([[np.cos(ang), -np.sin(ang), 0.0], [np.sin(ang), np.cos(ang), 0.0], [0.0, 0.0, 1.0]], np.float32)
+    meta3d = dict(transformation_3d_flow=["HF", "R", "S", "T"], pcd_horizontal_flip=True, pcd_vertical_flip=False,
+                  pcd_rotation=rot_T, pcd_scale_factor=1.07, pcd_trans=np.array([0.11, -0.06, 0.04], np.float32))
+    fwd = points.astype(np.float64).copy()
+    fwd[:, 0] = -fwd[:, 0]
+    fwd = (fwd @ rot_T.astype(np.float64)) * 1.07 + meta3d["pcd_trans"].astype(np.float64)
+    points_aug3d = fwd.astype(np.float32)
+    save.update(flow3d_rot_T=rot_T, flow3d_scale=np.float32(1.07), flow3d_trans=meta3d["pcd_trans"])
+    for name, scale, crop, flip, meta, aligned in (("plain", (1.0, 1.0), (0.0, 0.0), False, {}, False),
+                                                   ("aug", (0.9, 1.1), (12.0, -7.0), True, {}, False),
+                                                   ("flow3d", (0.9, 1.1), (12.0, -7.0), False, meta3d, False),
+                                                   ("bilinear", (1.0, 1.0), (3.0, 2.0), False, {}, True)):
+        src_points = points_aug3d if meta else points
+        pts_t, proj_t = torch.from_numpy(src_points), torch.from_numpy(proj)
+        # boundary filter, in float64 (on the un-augmented positions the projection sees)
         p4 = np.concatenate([points.astype(np.float64), np.ones((N, 1))], 1)
         q = np.einsum("vrk,nk->vnr", proj.astype(np.float64), p4)
         z = np.maximum(q[..., 2], 1e-3)
@@ -460,17 +474,17 @@ def gen_point_sample():
         iy = ((cy / pad_h * 2 - 1) + 1) / 2 * (H - 1)
         safe = np.ones(N, bool)
         for arr, lim in ((ix, None), (iy, None)):
-            frac = np.abs(arr - np.floor(arr) - 0.5)
-            safe &= (frac > 1e-3).all(0)
+            frac = np.abs(arr - np.floor(arr) - 0.5) if not aligned else np.minimum(arr - np.floor(arr), np.ceil(arr) - arr)
+            safe &= (frac > (2e-3 if meta or aligned else 1e-3)).all(0)      # nearest: away from x.5; bilinear: from integers
         for arr, hi in ((cx, pad_w), (cy, pad_h)):
             safe &= (np.abs(arr) > 1e-2).all(0) & (np.abs(arr - hi) > 1e-2).all(0)
         safe &= (np.abs(q[..., 2]) > 1e-2).all(0) & (np.abs(q[..., 2] - 1e-3) > 1e-4).all(0)
         sel = np.nonzero(safe)[0][:1500]
-        out = pf.batch_point_sample({}, img_features=torch.from_numpy(feats), points=pts_t[sel], proj_mat=proj_t,
+        out = pf.batch_point_sample(dict(meta), img_features=torch.from_numpy(feats), points=pts_t[sel], proj_mat=proj_t,
                                     coord_type="DEPTH", img_scale_factor=torch.tensor(scale), img_crop_offset=torch.tensor(crop),
                                     img_flip=flip, img_pad_shape=(int(pad_h), int(pad_w)), img_shape=(600, int(480 * 1.3)),
-                                    aligned=False)
-        save[f"{name}_points"] = points[sel]
+                                    aligned=aligned)
+        save[f"{name}_points"] = src_points[sel]
         save[f"{name}_out"] = out.numpy()
         save[f"{name}_cfg"] = np.array([scale[0], scale[1], crop[0], crop[1], float(flip), 480 * 1.3], np.float32)
         print(f"g5_point_sample/{name}: {len(sel)} points, nonzero rows {(np.abs(out.numpy()).sum(1) > 0).sum()}")

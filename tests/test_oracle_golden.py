@@ -85,14 +85,23 @@ def test_voxel_restatement_keeps_the_first_point_of_every_voxel():
     assert inv[0].tolist() == [0, 1, 0, 2] and inv[1].tolist() == [3, 3]
 
 
-@pytest.mark.parametrize("case", ["plain", "aug"])
+def _meta3d(g):
+    return dict(transformation_3d_flow=["HF", "R", "S", "T"], pcd_horizontal_flip=True, pcd_vertical_flip=False,
+                pcd_rotation=g["flow3d_rot_T"], pcd_scale_factor=float(g["flow3d_scale"]), pcd_trans=g["flow3d_trans"])
+
+
+@pytest.mark.parametrize("case", ["plain", "aug", "flow3d", "bilinear"])
 def test_point_sample_restatement_matches_the_reference(case):
     """oracle.point_sample against batch_point_sample run from the reference file (tests/golden/g5_point_sample.npz;
     SURVEY 8f N3): same pixels, same valid-view counts -> identical up to the fp32 order of the view sum."""
     g = load_golden("g5_point_sample")
     sx, sy, cw, ch, flip, ori_w = [float(x) for x in g[f"{case}_cfg"]]
-    out, nvalid = oracle.point_sample(g[f"{case}_points"], g["feats"], g["proj"], scale=(sx, sy), crop=(cw, ch),
-                                      flip=bool(flip), ori_w=ori_w, pad_hw=tuple(float(x) for x in g["pad"]))
+    pts = g[f"{case}_points"]
+    if case == "flow3d":            # the training pipeline's 3D augmentation, undone as apply_3d_transformation(reverse=True) does
+        pts = oracle.reverse_3d_points(pts, _meta3d(g))
+    out, nvalid = oracle.point_sample(pts, g["feats"], g["proj"], scale=(sx, sy), crop=(cw, ch),
+                                      flip=bool(flip), ori_w=ori_w, pad_hw=tuple(float(x) for x in g["pad"]),
+                                      bilinear=case == "bilinear")
     assert_close(out, g[f"{case}_out"], atol=1e-5, rtol=1e-5, what="sampled features")
     assert (nvalid > 0).sum() == (np.abs(g[f"{case}_out"]).sum(1) > 0).sum()
 
