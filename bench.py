@@ -335,6 +335,18 @@ def main():
                 for i in range(4):
                     mod(*inputs.args(i, True))
                 extras["f32"] = timed_steps(mod, inputs, steps2, barrier, None, True)[0] / steps2
+            # opt-in reduced-precision compute (proxy-block GEMMs + attention on plain bf16 operands, fp32 accumulate): never the
+            # headline; reported beside it with its error against the fp32 path on the same inputs
+            ref_out = [o.clone() for o in mod(*inputs.args(0))]
+            mod.compute_dtype = "bf16"
+            for i in range(4):
+                mod(*inputs.args(i))
+            extras["bf16c"] = timed_steps(mod, inputs, steps2, barrier, None)[0] / steps2
+            got = mod(*inputs.args(0))
+            torch.cuda.synchronize()
+            extras["bf16c_err"] = max(float((a - b).abs().max()) if a.shape == b.shape else float("inf")
+                                      for a, b in zip(got, ref_out))
+            mod.compute_dtype = "fp32"
             if rank == 0:
                 extras["passes"] = [passes_report(cfg, B, site_times(lib, names, mod, inputs, 20), inputs.sets[0]["img"].element_size())]
                 if cfg.name == "cfg2" and B * 8 <= 32:
@@ -343,6 +355,16 @@ def main():
                         mod(*wide.args(i))
                     extras["passes"].append(passes_report(cfg, wide.B, site_times(lib, names, mod, wide, 9),
                                                           wide.sets[0]["img"].element_size()))
+                    # the same two compute modes at 32 scenes per GPU (whole step, cold inputs)
+                    t32 = {}
+                    for cdt in ("fp32", "bf16"):
+                        mod.compute_dtype = cdt
+                        for i in range(3):
+                            mod(*wide.args(i))
+                        t32[cdt] = timed_steps(mod, wide, 9, barrier, None)[0] / 9
+                    mod.compute_dtype = "fp32"
+                    extras["wide"] = dict(scenes_per_gpu=wide.B, value_fp32_compute=round(wide.B / t32["fp32"], 2),
+                                          value_bf16_compute=round(wide.B / t32["bf16"], 2))
                     del wide
         if args.breakdown and rank == 0:
             print("per-kernel us/launch:", json.dumps({k: round(v, 2) for k, v in site_times(lib, names, mod, inputs, 12).items()}),
@@ -356,11 +378,11 @@ def main():
         ranks_seen = [None] * world
         dist.all_gather_object(ranks_seen, me)
         ranks_seen = sorted([list(x) for x in ranks_seen])
-    vals = [elapsed, extras.get("f32", 0.0)]
+    vals = [elapsed, extras.get("f32", 0.0), extras.get("bf16c", 0.0)]
     t = torch.tensor(vals, device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed, f32_step = (float(x) for x in t.tolist())
+    elapsed, f32_step, bf16c_step = (float(x) for x in t.tolist())
 
     if rank == 0:
         total_scenes = world * B * args.steps
@@ -398,6 +420,13 @@ def main():
         if f32_step > 0:
             line["value_f32_features"] = round(world * B / f32_step, 2)
             line["ms_per_step_f32_features"] = round(1e3 * f32_step, 4)
+        if bf16c_step > 0:
+            line["value_bf16_compute"] = round(world * B / bf16c_step, 2)
+            line["bf16_compute"] = dict(ms_per_step=round(1e3 * bf16c_step, 4), max_abs_dxyz_vs_fp32=extras.get("bf16c_err"),
+                                        what="compute_dtype='bf16': proxy-block GEMMs and attention on plain bf16 operands, fp32 "
+                                             "accumulation; clustering / index tensors unchanged; not the headline value")
+            if "wide" in extras:
+                line["bf16_compute"]["at_32_scenes_per_gpu"] = extras["wide"]
         if "passes" in extras:
             line["roofline_passes"] = extras["passes"]
         if world == 1 and not args.no_cpu_baseline:

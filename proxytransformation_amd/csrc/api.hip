@@ -356,7 +356,7 @@ static bool fused_attn_pays(const PtxShape &s, const Branch *br, int nb)
 // phase 0: everything; phase 1: only the projections that do not wait for late proxies
 // (qkv of every branch + proxy_proj of the early ones); phase 2: the rest.
 static int run_blocks(const PtxShape &s, const Branch *br, int nb, const float *point_proxy, void *ws,
-                      hipStream_t st, int phase = 0)
+                      hipStream_t st, int phase = 0, int cd = 0)
 {
     const WsLayout L = ws_layout(s);
     const int C = s.C, R = s.B * s.Mk;
@@ -379,17 +379,18 @@ static int run_blocks(const PtxShape &s, const Branch *br, int nb, const float *
                 }
             }
         }
-        if (g.n > 0) PTX_TIMED(phase == 2 ? KID_BLK_PP : KID_BLK_QKV, st, launch_gemm(g, st));
+        if (g.n > 0) PTX_TIMED(phase == 2 ? KID_BLK_PP : KID_BLK_QKV, st, launch_gemm(g, st, cd));
         if (phase == 1) return PTX_OK;
     }
     FAttnBatch fa{}; fa.nb = nb; fa.B = s.B; fa.heads = s.heads; fa.hd = C / s.heads; fa.n = s.Mk; fa.C = C;
-    fa.scale = attn_scale(C / s.heads);
+    fa.scale = attn_scale(C / s.heads); fa.compute_dtype = cd;
     for (int i = 0; i < nb; ++i) {
         const int sl = br[i].slot;
         fa.p[i] = FAttnProb{at<float>(ws, L.qkv[sl]), at<float>(ws, L.pt[sl]), br[i].mask, at<float>(ws, L.ao[sl]), br[i].Lp};
     }
     // head_dim 32: both contractions of a (scene, head, branch) in one work-group, PV never leaves the CU (fattn.hip)
-    const bool fused = fused_attn_supported(fa) && fused_attn_pays(s, br, nb);
+    // (reduced-precision mode: always the fused kernel where it exists -- the two-launch form is fp32 only)
+    const bool fused = fused_attn_supported(fa) && (cd == 1 || fused_attn_pays(s, br, nb));
     if (fused) PTX_TIMED(KID_BLK_ATTN_F, st, launch_proxy_attn(fa, st));
     AttnBatch a{}; a.n = nb; a.B = s.B; a.heads = s.heads; a.hd = C / s.heads; a.scale = attn_scale(C / s.heads);
     for (int i = 0; i < nb && !fused; ++i) {   // proxy as query (PRE:232-238): no mask
@@ -416,7 +417,7 @@ static int run_blocks(const PtxShape &s, const Branch *br, int nb, const float *
                               br[i].blk->proj_b, point_proxy, nullptr, nullptr, R, C, C, C, C, C, C, 0, 0, EPI_NONE};
             g.p[i].lnp_out = at<float>(ws, L.lnp_x1[sl]);
         }
-        PTX_TIMED(KID_BLK_PROJ, st, launch_gemm(g, st));
+        PTX_TIMED(KID_BLK_PROJ, st, launch_gemm(g, st, cd));
     }
     {   // h = GELU(fc1(norm2(x1))) (PRE:275): norm2 folded into the GEMM (W1 diag(gamma), row statistics in the epilogue)
         GemmBatch g{}; g.n = nb;
@@ -428,7 +429,7 @@ static int run_blocks(const PtxShape &s, const Branch *br, int nb, const float *
             g.p[i].lnp_in = at<float>(ws, L.lnp_x1[sl]); g.p[i].ln_s = br[i].fc1_gs; g.p[i].ln_c = br[i].fc1_gc;
             g.p[i].ln_parts = C / 32; g.p[i].ln_C = C; g.p[i].ln_eps = s.ln_eps;
         }
-        PTX_TIMED(KID_BLK_FC1, st, launch_gemm(g, st));
+        PTX_TIMED(KID_BLK_FC1, st, launch_gemm(g, st, cd));
     }
     {   // x2 = x1 + fc2(h)
         GemmBatch g{}; g.n = nb;
@@ -438,7 +439,7 @@ static int run_blocks(const PtxShape &s, const Branch *br, int nb, const float *
                               br[i].blk->fc2_b, at<float>(ws, L.x1[sl]), nullptr, nullptr, R, C, s.hidden,
                               s.hidden, s.hidden, C, C, 0, 0, EPI_NONE};
         }
-        PTX_TIMED(KID_BLK_FC2, st, launch_gemm(g, st));
+        PTX_TIMED(KID_BLK_FC2, st, launch_gemm(g, st, cd));
     }
     HeadBatch hb{}; hb.n = nb; hb.C = C; hb.eps = s.ln_eps;
     for (int i = 0; i < nb; ++i) {
@@ -901,12 +902,12 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     // (The whole text branch on a third stream while the image chain finishes, leaving only the image
     // branch after the join, was measured slower: 12.6k vs 13.7k scenes/s -- eight more launches, and its
     // small kernels take CUs from the image passes that are on the critical path.)
-    PTX_TRY(run_blocks(S, br, 2, point_proxy, ws, cs, 1));
+    PTX_TRY(run_blocks(S, br, 2, point_proxy, ws, cs, 1, compute_dtype));
     if (!cluster_on_caller) PTX_HIP(hipEventRecord(side->join, cs));
     PTX_TRY(run_img_proxy(S, *w, pf, img_feat, img_proxy, ws, is, 2, want_img_proxy));      // rest of the image chain
     if (cluster_on_caller) PTX_HIP(hipEventRecord(side->join, is));
     PTX_HIP(hipStreamWaitEvent(st, side->join, 0));
-    PTX_TRY(run_blocks(S, br, 2, point_proxy, ws, st, 2));
+    PTX_TRY(run_blocks(S, br, 2, point_proxy, ws, st, 2, compute_dtype));
 
     // ---- submanifold reshape + scatter + drop (PRE:459-467); k_affine is the last reader of the tags and clears them
     PTX_HIP(hipStreamWaitEvent(st, side->tags, 0));

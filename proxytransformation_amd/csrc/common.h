@@ -159,7 +159,7 @@ struct GemmProb {
 };
 constexpr int kMaxGroups = 8;
 struct GemmBatch { GemmProb p[kMaxGroups]; int n; int rotate; };
-int launch_gemm(const GemmBatch &gb, hipStream_t st);
+int launch_gemm(const GemmBatch &gb, hipStream_t st, int compute_dtype = 0);     // 1: plain bf16 operands where supported
 
 struct LnProb { const float *x; float *y; const float *w; const float *b; const float *add; int R, add_rows; };
 struct LnBatch { LnProb p[2]; int n; int C; float eps; };
@@ -186,7 +186,7 @@ int launch_attn32(const AttnBatch &ab, hipStream_t st);
 // fused ProxyAttention of one (scene, head, branch) per work-group (fattn.hip): qkv (B*n, 3C) rows [q | k | v], pt (B*Lp, C)
 // projected proxies, mask (B,Lp) uint8 (1 = valid) or null, out (B*n, C)
 struct FAttnProb { const float *qkv, *pt; const uint8_t *mask; float *out; int Lp; };
-struct FAttnBatch { FAttnProb p[2]; int nb, B, heads, hd, n, C; float scale; };
+struct FAttnBatch { FAttnProb p[2]; int nb, B, heads, hd, n, C; float scale; int compute_dtype; };
 bool fused_attn_supported(const FAttnBatch &ab);
 int launch_proxy_attn(const FAttnBatch &ab, hipStream_t st);
 

@@ -67,14 +67,16 @@ constexpr int kFaSlotOff = kFaRegOff + 3 * kFaTPlane;
 constexpr int kFaLds = kFaRegOff + 3 * kFaRowPlane + 3 * kFaTPlane;
 static_assert(kFaSlotOff + kFaWaves * 18 * 64 * 4 <= kFaLds && kFaLds <= 160 * 1024, "LDS carve of k_proxy_attn");
 
+template <int NP>
 __device__ __forceinline__ void mfma_one_chain(const bf16x8 (&a)[2][3], const bf16x8 (&b)[2][3], f32x16 &c)
 {
-    c = mfma_split6(a[0], b[0], c);
-    c = mfma_split6(a[1], b[1], c);
+    c = mfma_parts<NP>(a[0], b[0], c);
+    c = mfma_parts<NP>(a[1], b[1], c);
 }
 
 // One soft-max step of a 32 x 32 score tile held as sc[r] (this lane's query, 16 of the 32 keys; -inf = no key): running
 // maximum mb (already times c1) and sum l, rescale factor of the running output, probabilities split for the MFMA
+template <int NP>
 __device__ __forceinline__ float softmax_tile(f32x16 &sc, float c1, float &mb, float &l, bf16x8 (&pb)[2][3])
 {
     float tmax = fmaxf(sc[0], sc[1]);
@@ -93,7 +95,7 @@ __device__ __forceinline__ float softmax_tile(f32x16 &sc, float c1, float &mb, f
         float x[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) x[j] = e[8 * s + j];
-        split3_frag(x, pb[s]);
+        frag_parts<NP>(x, pb[s]);
     }
     return alpha;
 }
@@ -113,6 +115,7 @@ __device__ __forceinline__ float softmax_tile(f32x16 &sc, float c1, float &mb, f
 // segment a wave is in); the first version's per-query-tile merges behind barriers (32 us).  What would help is an
 // in-wave software pipeline with the soft-max instructions placed BETWEEN the matrix instructions of the neighbouring
 // tiles in program order (<= 5 per MFMA slot) -- not done.
+template <int NP>       // 3: split operands (fp32-equivalent); 1: plain bf16 operands (compute_dtype = 1)
 __global__ __launch_bounds__(kFaWaves * 64) void k_proxy_attn(FAttnBatch ab)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(kFaWaves * 64) void k_proxy_attn(FAttnBatch ab)
     const int trow = li * kFaTStride + 16 * hh;                                         // + tile * 64 + 32 s + plane * kFaTPlane
     auto read_rows = [&](const char *base, int tile, bf16x8 (&f)[2][3]) {
 #pragma unroll
-        for (int pt3 = 0; pt3 < 3; ++pt3) {
+        for (int pt3 = 0; pt3 < NP; ++pt3) {
             f[0][pt3] = *reinterpret_cast<const bf16x8 *>(base + rowA + tile * (32 * XROW) + pt3 * kFaRowPlane);
             f[1][pt3] = *reinterpret_cast<const bf16x8 *>(base + rowB + tile * (32 * XROW) + pt3 * kFaRowPlane);
         }
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(kFaWaves * 64) void k_proxy_attn(FAttnBatch ab)
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int pt3 = 0; pt3 < 3; ++pt3)
+            for (int pt3 = 0; pt3 < NP; ++pt3)
                 f[s][pt3] = *reinterpret_cast<const bf16x8 *>(base + trow + tile * 64 + 32 * s + pt3 * kFaTPlane);
     };
 
@@ -171,10 +174,10 @@ __global__ __launch_bounds__(kFaWaves * 64) void k_proxy_attn(FAttnBatch ab)
 #pragma unroll
             for (int i = 0; i < 8; ++i) { x[i] = kf[8 * s + i]; y[i] = vf[8 * s + i]; }
             bf16x8 fk[3], fv[3];
-            split3_frag(x, fk);
-            split3_frag(y, fv);
+            frag_parts<NP>(x, fk);
+            frag_parts<NP>(y, fv);
 #pragma unroll
-            for (int pt3 = 0; pt3 < 3; ++pt3) {
+            for (int pt3 = 0; pt3 < NP; ++pt3) {
                 *reinterpret_cast<bf16x8 *>(Kp + (s ? rowB : rowA) + lt * (32 * XROW) + pt3 * kFaRowPlane) = fk[pt3];
                 *reinterpret_cast<bf16x8 *>(Vt + trow + lt * 64 + 32 * s + pt3 * kFaTPlane) = fv[pt3];
             }
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(kFaWaves * 64) void k_proxy_attn(FAttnBatch ab)
             const int row = e >> 3, kq = (e & 7) * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row < Lp) v = *reinterpret_cast<const float4 *>(pt + (size_t)row * C + kq);
-            stash_split3(Pk + row * XROW + xswz(row, kq >> 3) + (kq & 4) * 2, kFaRowPlane, v);
+            stash_parts<NP>(Pk + row * XROW + xswz(row, kq >> 3) + (kq & 4) * 2, kFaRowPlane, v);
         }
         const float masked = -1e9f / ab.scale;              // masked_fill(-1e9) of the SCALED scores (PRE:247), in raw units
         for (int k = tid; k < LpPad; k += kFaWaves * 64) {
@@ -235,17 +238,17 @@ __global__ __launch_bounds__(kFaWaves * 64) void k_proxy_attn(FAttnBatch ab)
             read_trans(Vt, lt, va);
 #pragma unroll
             for (int i = 0; i < 16; ++i) sc[i] = 0.0f;
-            mfma_one_chain(ka, qb, sc);
+            mfma_one_chain<NP>(ka, qb, sc);
             if (lt + 1 < lt1) read_rows(Kp, lt + 1, ka);
             if (32 * (c0 + lt) + 32 > n) {                  // the scene's last, partial key tile (wave-uniform)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     if (32 * (c0 + lt) + acc_row(r, hh) >= n) sc[r] = -INFINITY;
             }
-            const float alpha = softmax_tile(sc, c1, mb_run, l_run, pb);
+            const float alpha = softmax_tile<NP>(sc, c1, mb_run, l_run, pb);
 #pragma unroll
             for (int i = 0; i < 16; ++i) oA[i] *= alpha;
-            mfma_one_chain(va, pb, oA);
+            mfma_one_chain<NP>(va, pb, oA);
         }
     }
     float4 qraw[4];
@@ -283,10 +286,12 @@ __global__ __launch_bounds__(kFaWaves * 64) void k_proxy_attn(FAttnBatch ab)
             char *d0 = PVt + acc_row(r, hh) * kFaTStride + pos * 2, *d1 = PVt + acc_row(r + 1, hh) * kFaTStride + pos * 2;
             *reinterpret_cast<unsigned short *>(d0) = (unsigned short)(q1 & 0xffffu);
             *reinterpret_cast<unsigned short *>(d1) = (unsigned short)(q1 >> 16);
-            *reinterpret_cast<unsigned short *>(d0 + kFaTPlane) = (unsigned short)(q2 & 0xffffu);
-            *reinterpret_cast<unsigned short *>(d1 + kFaTPlane) = (unsigned short)(q2 >> 16);
-            *reinterpret_cast<unsigned short *>(d0 + 2 * kFaTPlane) = (unsigned short)(q3 & 0xffffu);
-            *reinterpret_cast<unsigned short *>(d1 + 2 * kFaTPlane) = (unsigned short)(q3 >> 16);
+            if (NP == 3) {
+                *reinterpret_cast<unsigned short *>(d0 + kFaTPlane) = (unsigned short)(q2 & 0xffffu);
+                *reinterpret_cast<unsigned short *>(d1 + kFaTPlane) = (unsigned short)(q2 >> 16);
+                *reinterpret_cast<unsigned short *>(d0 + 2 * kFaTPlane) = (unsigned short)(q3 & 0xffffu);
+                *reinterpret_cast<unsigned short *>(d1 + 2 * kFaTPlane) = (unsigned short)(q3 >> 16);
+            }
         }
     }
     __syncthreads();
@@ -300,8 +305,8 @@ __global__ __launch_bounds__(kFaWaves * 64) void k_proxy_attn(FAttnBatch ab)
         if (has) {
             const float x0[8] = {qraw[0].x, qraw[0].y, qraw[0].z, qraw[0].w, qraw[1].x, qraw[1].y, qraw[1].z, qraw[1].w};
             const float x1[8] = {qraw[2].x, qraw[2].y, qraw[2].z, qraw[2].w, qraw[3].x, qraw[3].y, qraw[3].z, qraw[3].w};
-            split3_frag(x0, qb[0]);
-            split3_frag(x1, qb[1]);
+            frag_parts<NP>(x0, qb[0]);
+            frag_parts<NP>(x1, qb[1]);
         }
         if (qt + kFaWaves < NKT) load_q(rnd + 1, qraw);
         float mb = -INFINITY, l = 0.0f;
@@ -323,13 +328,13 @@ __global__ __launch_bounds__(kFaWaves * 64) void k_proxy_attn(FAttnBatch ab)
             read_trans(PVt, j, va);
 #pragma unroll
             for (int i = 0; i < 16; ++i) sc[i] = 0.0f;
-            mfma_one_chain(ka, qb, sc);
+            mfma_one_chain<NP>(ka, qb, sc);
             if (j + 1 < NQ) read_rows(Pk, j + 1, ka);
             bias_tile(j);
-            const float alpha = softmax_tile(sc, c1, mb, l, pb);
+            const float alpha = softmax_tile<NP>(sc, c1, mb, l, pb);
 #pragma unroll
             for (int i = 0; i < 16; ++i) o[i] *= alpha;
-            mfma_one_chain(va, pb, o);
+            mfma_one_chain<NP>(va, pb, o);
         }
         if (has && tok < n) {
             const float inv = 1.0f / l;
@@ -363,9 +368,13 @@ int launch_proxy_attn(const FAttnBatch &ab_in, hipStream_t st)
     PTX_REQUIRE(lpmax <= 32 * kFaWaves, "fused attention: at most %d proxies (got %d)", 32 * kFaWaves, lpmax);
     const int lds = kFaLds;
     const dim3 grid(ab.B * ab.heads, ab.nb), block(kFaWaves * 64);
-    if (lds > 64 * 1024)
-        PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_proxy_attn), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL(k_proxy_attn, grid, block, lds, st, ab);
+    if (ab.compute_dtype == 1) {
+        PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_proxy_attn<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL(k_proxy_attn<1>, grid, block, lds, st, ab);
+    } else {
+        PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_proxy_attn<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL(k_proxy_attn<3>, grid, block, lds, st, ab);
+    }
     PTX_LAUNCHED("k_proxy_attn");
     return PTX_OK;
 }

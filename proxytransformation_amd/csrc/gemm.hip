@@ -203,10 +203,10 @@ __global__ __launch_bounds__(256) void k_gemm64(GemmBatch gb)
     do {                                                                                   \
         pin4(a##S##0); pin4(a##S##1); pin4(w##S##0); pin4(w##S##1);                        \
         char *d_ = smem + (buf_) * kXBuf + sr * XROW + xswz(sr, kq >> 3) + (kq & 4) * 2;   /* (sr + 32) swizzles alike */ \
-        stash_split3(d_, kXPlane, a##S##0);                                                \
-        stash_split3(d_ + 32 * XROW, kXPlane, a##S##1);                                    \
-        stash_split3(d_ + 3 * kXPlane, kXPlane, w##S##0);                                  \
-        stash_split3(d_ + 3 * kXPlane + 32 * XROW, kXPlane, w##S##1);                      \
+        stash_parts<NP>(d_, kXPlane, a##S##0);                                             \
+        stash_parts<NP>(d_ + 32 * XROW, kXPlane, a##S##1);                                 \
+        stash_parts<NP>(d_ + 3 * kXPlane, kXPlane, w##S##0);                               \
+        stash_parts<NP>(d_ + 3 * kXPlane + 32 * XROW, kXPlane, w##S##1);                   \
     } while (0)
 #define PTX_X64_COMPUTE(buf_)                                                              \
     do {                                                                                   \
@@ -215,9 +215,13 @@ __global__ __launch_bounds__(256) void k_gemm64(GemmBatch gb)
         _Pragma("unroll") for (int kg = 0; kg < BK / 16; ++kg) {                           \
             const int o_ = xswz(li, kg * 2 + hh);           /* wr * 32, wc * 32 do not change the swizzle */ \
             const bf16x8 a1 = *reinterpret_cast<const bf16x8 *>(A_ + o_);                  \
+            const bf16x8 b1 = *reinterpret_cast<const bf16x8 *>(W_ + o_);                  \
+            if (NP == 1) {          /* plain bf16 operands */                              \
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc, 0, 0, 0);       \
+                continue;                                                                  \
+            }                                                                              \
             const bf16x8 a2 = *reinterpret_cast<const bf16x8 *>(A_ + o_ + kXPlane);        \
             const bf16x8 a3 = *reinterpret_cast<const bf16x8 *>(A_ + o_ + 2 * kXPlane);    \
-            const bf16x8 b1 = *reinterpret_cast<const bf16x8 *>(W_ + o_);                  \
             const bf16x8 b2 = *reinterpret_cast<const bf16x8 *>(W_ + o_ + kXPlane);        \
             const bf16x8 b3 = *reinterpret_cast<const bf16x8 *>(W_ + o_ + 2 * kXPlane);    \
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc, 0, 0, 0);   /* small terms first */ \
@@ -229,7 +233,8 @@ __global__ __launch_bounds__(256) void k_gemm64(GemmBatch gb)
         }                                                                                  \
     } while (0)
 
-template <int NKG, int REP>      // K = 128 NKG REP: the written-out body runs REP times (one drain of the prefetch per repetition)
+template <int NKG, int REP, int NP = 3>   // K = 128 NKG REP: the written-out body runs REP times (one drain of the prefetch per
+                                         // repetition); NP = 3: split operands (fp32-equivalent), 1: plain bf16 operands
 __global__ __launch_bounds__(256) void k_gemm64x(GemmBatch gb)
 {
     constexpr int kXPlane = 64 * XROW, kXBuf = 6 * kXPlane;     // one plane of a 64 x 32 tile; [A1 A2 A3 W1 W2 W3] per buffer
@@ -265,6 +270,7 @@ __global__ __launch_bounds__(256) void k_gemm64x(GemmBatch gb)
     }
 #define PTX_X64_PIPE()                                                                     \
     do {                                                                                   \
+        if (NP != 3) break;         /* the interleave below is written for the 12 MFMAs of the split product */ \
         __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);             /* fragment reads */ \
         _Pragma("unroll") for (int g_ = 0; g_ < 12; ++g_) {                                \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                             \
@@ -589,7 +595,7 @@ static int launch_gemm32(const GemmBatch &gb, int rmax, int nmax, hipStream_t st
     return PTX_OK;
 }
 
-int launch_gemm(const GemmBatch &gb_in, hipStream_t st)
+int launch_gemm(const GemmBatch &gb_in, hipStream_t st, int compute_dtype)
 {
     static const int rot_env = getenv("PTX_GEMM_ROTATE") ? atoi(getenv("PTX_GEMM_ROTATE")) : 0;   // measured neutral (r01)
     GemmBatch gb = gb_in;
@@ -628,6 +634,18 @@ int launch_gemm(const GemmBatch &gb_in, hipStream_t st)
         return PTX_OK;
     }
     static const int g64_min = getenv("PTX_G64_MIN") ? atoi(getenv("PTX_G64_MIN")) : 1024;
+    if (compute_dtype == 1 && gb.p[0].pg == nullptr && kmin == kmax && kmin % 128 == 0 && kmin / 128 <= 8) {
+        // reduced-precision mode: plain bf16 operands, fp32 accumulation, the 64 x 64-tile kernel at every size
+        const dim3 grid(cdiv(rmax, 64), cdiv(nmax, 64), gb.n);
+        const int nkg = kmin / 128;
+        if (nkg == 1) hipLaunchKernelGGL((k_gemm64x<1, 1, 1>), grid, dim3(256), 0, st, gb);
+        else if (nkg == 2) hipLaunchKernelGGL((k_gemm64x<2, 1, 1>), grid, dim3(256), 0, st, gb);
+        else if (nkg == 4) hipLaunchKernelGGL((k_gemm64x<4, 1, 1>), grid, dim3(256), 0, st, gb);
+        else if (nkg == 8) hipLaunchKernelGGL((k_gemm64x<8, 1, 1>), grid, dim3(256), 0, st, gb);
+        else { set_error("gemm: K=%d in bf16 mode", kmin); return PTX_EINVAL; }
+        PTX_LAUNCHED("k_gemm64x<bf16>");
+        return PTX_OK;
+    }
     if (gb.p[0].pg != nullptr) {
         // A merged on the fly from the pooling tiles: always the latency-regime kernel, K split four ways
         PTX_TRY((launch_gemm32<4, 1>(gb, rmax, nmax, st)));

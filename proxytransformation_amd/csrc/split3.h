@@ -57,6 +57,37 @@ __device__ __forceinline__ f32x16 mfma_split6(const bf16x8 (&a)[3], const bf16x8
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
     return acc;
 }
+// NP = 3: the exact split above; NP = 1: plain bf16 operands (round to nearest), one product per 16 k -- the opt-in
+// reduced-precision mode of the proxy blocks (PtxForwardOpts::compute_dtype = 1, what autocast gives the reference's
+// linears under --amp)
+template <int NP>
+__device__ __forceinline__ void stash_parts(char *dst, int plane, const float4 &v)
+{
+    if (NP == 3) { stash_split3(dst, plane, v); return; }
+    const f32x2 a = {v.x, v.y}, b = {v.z, v.w};
+    *reinterpret_cast<uint2 *>(dst) = make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(a, bf16x2)),
+                                                 __builtin_bit_cast(unsigned, __builtin_convertvector(b, bf16x2)));
+}
+template <int NP>
+__device__ __forceinline__ void frag_parts(const float (&x)[8], bf16x8 (&f)[3])
+{
+    if (NP == 3) { split3_frag(x, f); return; }
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 q;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x2 v = {x[2 * i], x[2 * i + 1]};
+        q[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    }
+    f[0] = __builtin_bit_cast(bf16x8, q);
+}
+template <int NP>
+__device__ __forceinline__ f32x16 mfma_parts(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 acc)
+{
+    if (NP == 3) return mfma_split6(a, b, acc);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+}
+
 // LDS rows of the split tiles: 32 bf16 = 64 bytes, unpadded; the four 16-byte pieces of row r sit at piece ^ ((r >> 2) & 3),
 // which makes both the 8-byte stash writes (four rows x 64 B per half wave) and the 16-byte fragment reads (sixteen rows,
 // one piece each) bank-conflict free
