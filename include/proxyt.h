@@ -311,7 +311,9 @@ int ptx_ingest_gather(const void *depth, int depth_dtype, float depth_shift, int
  * surviving duplicate / row order are pinned to the first point of every voxel in (scene, point) order.
  * points (B,Ncap,3) with counts[b] valid rows per scene (device int32) = exactly the `out` / `counts` of ptx_forward;
  * coords (B*Ncap,4) int32 and feats (B*Ncap,3) capacity; inverse (B,Ncap) int32 voxel row of every point (-1 past the
- * valid rows) or NULL; nvox_overflow: 2 device int32 = {voxel rows written, points whose voxel index left +-2^18}. */
+ * valid rows) or NULL; nvox_overflow: 2 int32 = {voxel rows written, points whose voxel index left +-2^18}, device memory or
+ * device-mapped pinned host memory: published with system scope as soon as the rows are written (preset to -1 and poll
+ * with ptx_wait_counts instead of draining the stream). */
 size_t ptx_voxel_workspace_bytes(int B, int Ncap);
 int ptx_voxelize(const float *points, const int32_t *counts, int B, int Ncap, float voxel_size, int32_t *coords,
                  float *feats, int32_t *inverse, int32_t *nvox_overflow, void *workspace, size_t ws_bytes, void *stream);

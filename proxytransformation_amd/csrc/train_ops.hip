@@ -76,9 +76,11 @@ __global__ __launch_bounds__(256) void k_bgemm(BGemmArgs g)
     }
     const long astep = (long)TBK * g.a_cs, bstep = (long)TBK * g.b_rs;
     const bool plain = g.a_dtype == 0 && g.b_dtype == 0;   // uniform: the fp32 x fp32 case skips the type dispatch
-    float ra[E], rb[E];
-    // the tile of step k0 is fetched into registers while the previous one is multiplied out of LDS
-    auto fetch = [&](int k0) {
+    // Two tiles are in flight in registers while a third is multiplied out of LDS: every product of the training path is
+    // latency-bound here (a few dozen work-groups walking K = 700 .. 300 000 with one dependent round trip per step --
+    // r02: 61 launches, 4.7 of the step's 11 ms), so the depth of the prefetch is what sets the step time
+    float ra0[E], rb0[E], ra1[E], rb1[E];
+    auto fetch = [&](int k0, float (&ra)[E], float (&rb)[E]) {
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const bool av = aok[e] && k0 + ak[e] < kend, bv = bok[e] && k0 + bk[e] < kend;
@@ -92,12 +94,11 @@ __global__ __launch_bounds__(256) void k_bgemm(BGemmArgs g)
             aoff[e] += astep; boff[e] += bstep;
         }
     };
-    if (kbeg < kend) fetch(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += TBK) {
+    auto step = [&](int k0, float (&ra)[E], float (&rb)[E]) {
 #pragma unroll
         for (int e = 0; e < E; ++e) { As[am[e]][ak[e]] = ra[e]; Bs[bn[e]][bk[e]] = rb[e]; }
         __syncthreads();
-        if (k0 + TBK < kend) fetch(k0 + TBK);
+        if (k0 + 2 * TBK < kend) fetch(k0 + 2 * TBK, ra, rb);       // this set is free again: two steps ahead
 #pragma unroll
         for (int kk = 0; kk < TBK / 8; ++kk) {          // lanes hh = 0 / 1 contract k = 8 kk + j and 8 kk + 4 + j
             const float4 a4 = *reinterpret_cast<const float4 *>(&As[wr * 32 + li][kk * 8 + hh * 4]);
@@ -112,6 +113,12 @@ __global__ __launch_bounds__(256) void k_bgemm(BGemmArgs g)
 #pragma unroll
             for (int i = 0; i < 16; ++i) { dacc[i] += (double)acc[i]; acc[i] = 0.0f; }
         }
+    };
+    if (kbeg < kend) fetch(kbeg, ra0, rb0);
+    if (kbeg + TBK < kend) fetch(kbeg + TBK, ra1, rb1);
+    for (int k0 = kbeg; k0 < kend; k0 += 2 * TBK) {
+        step(k0, ra0, rb0);
+        if (k0 + TBK < kend) step(k0 + TBK, ra1, rb1);
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = (float)(dacc[i] + (double)acc[i]);

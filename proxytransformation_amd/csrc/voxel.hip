@@ -142,6 +142,14 @@ __global__ __launch_bounds__(256) void k_vox_inverse(VoxArgs a)
     a.inverse[gi] = i < a.counts[b] ? a.row_of_slot[a.slot_of[gi]] : -1;
 }
 
+// last launch: the row count and the overflow count with system scope (nvox_overflow may be device-mapped pinned host
+// memory preset to -1: the host spins on it with ptx_wait_counts instead of draining the stream and copying)
+__global__ void k_vox_publish(const int32_t *acc, int32_t *nvox_overflow)
+{
+    __hip_atomic_store(nvox_overflow + 1, acc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(nvox_overflow, acc[0], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 struct VoxLayout { size_t keys, minidx, slot_of, row_of_slot, tile_counts, overflow, total; unsigned int slots; };
 static VoxLayout vox_layout(int B, int Ncap)
 {
@@ -154,7 +162,7 @@ static VoxLayout vox_layout(int B, int Ncap)
     auto take = [&](size_t bytes) { size_t r = o; o += align_up(bytes, 256); return r; };
     L.keys = take((size_t)slots * 8); L.minidx = take((size_t)slots * 4);
     L.slot_of = take(total * 4); L.row_of_slot = take((size_t)slots * 4);
-    L.tile_counts = take((size_t)B * cdiv(Ncap, kTilePts) * 4); L.overflow = take(4);
+    L.tile_counts = take((size_t)B * cdiv(Ncap, kTilePts) * 4); L.overflow = take(8);
     L.total = o;
     return L;
 }
@@ -185,11 +193,11 @@ int ptx_voxelize(const float *points, const int32_t *counts, int B, int Ncap, fl
     VoxArgs a{points, counts, B, Ncap, voxel_size,
               reinterpret_cast<unsigned long long *>(ws + L.keys), reinterpret_cast<int32_t *>(ws + L.minidx),
               reinterpret_cast<int32_t *>(ws + L.slot_of), reinterpret_cast<int32_t *>(ws + L.row_of_slot),
-              reinterpret_cast<int32_t *>(ws + L.tile_counts), L.slots - 1, coords, feats, inverse, nvox_overflow,
-              nvox_overflow + 1};
+              reinterpret_cast<int32_t *>(ws + L.tile_counts), L.slots - 1, coords, feats, inverse,
+              reinterpret_cast<int32_t *>(ws + L.overflow), reinterpret_cast<int32_t *>(ws + L.overflow) + 1};
     PTX_HIP(hipMemsetAsync(ws + L.keys, 0xFF, (size_t)L.slots * 8, st));
     PTX_HIP(hipMemsetAsync(ws + L.minidx, 0x7F, (size_t)L.slots * 4, st));
-    PTX_HIP(hipMemsetAsync(nvox_overflow, 0, 8, st));
+    PTX_HIP(hipMemsetAsync(ws + L.overflow, 0, 8, st));
     const dim3 per_point(cdiv(Ncap, 256), B), per_tile(cdiv(Ncap, kTilePts), B);
     hipLaunchKernelGGL(k_vox_insert, per_point, dim3(256), 0, st, a);
     PTX_LAUNCHED("k_vox_insert");
@@ -197,6 +205,8 @@ int ptx_voxelize(const float *points, const int32_t *counts, int B, int Ncap, fl
     PTX_LAUNCHED("k_vox_count");
     hipLaunchKernelGGL(k_vox_emit, per_tile, dim3(256), 0, st, a);
     PTX_LAUNCHED("k_vox_emit");
+    hipLaunchKernelGGL(k_vox_publish, dim3(1), dim3(1), 0, st, reinterpret_cast<const int32_t *>(ws + L.overflow), nvox_overflow);
+    PTX_LAUNCHED("k_vox_publish");
     if (inverse) {
         hipLaunchKernelGGL(k_vox_inverse, per_point, dim3(256), 0, st, a);
         PTX_LAUNCHED("k_vox_inverse");

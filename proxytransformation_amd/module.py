@@ -124,7 +124,7 @@ class _Lane:
     count buffer.  Calls on different torch streams use different lanes, so independent batches can be in flight
     on the GPU at the same time (a serving loop alternating between two streams overlaps the bandwidth-bound
     image passes of one batch with the latency-bound proxy blocks of the other)."""
-    __slots__ = ("ctx", "ws", "ws_key", "ws_dirty", "counts", "counts_np", "stream")
+    __slots__ = ("ctx", "ws", "ws_key", "ws_dirty", "counts", "counts_np", "stream", "quant")
 
     def __init__(self, stream):
         self.stream = stream
@@ -132,6 +132,7 @@ class _Lane:
         _abi.check(_abi.lib().ptx_context_create(ctypes.byref(self.ctx)), "ptx_context_create")
         self.ws, self.ws_key, self.ws_dirty = None, None, True
         self.counts = self.counts_np = None
+        self.quant = None                   # scratch of module.quantize (voxel hash, pinned count buffers)
 
     def release(self):
         ctx, self.ctx = self.ctx, None
@@ -647,7 +648,8 @@ class ProxyTransformationNormReverse(nn.Module):
         p) ...])`` + ``ME.SparseTensor`` -- coordinates ``(Nv,4) int32 = (scene, floor(p / voxel_size))`` and features
         ``(Nv,3)``, one row per occupied voxel (the first point of a voxel in (scene, point) order; MinkowskiEngine's own
         choice is unspecified).  ``outs`` = the list ``forward`` returned (views of one padded buffer are used in place,
-        anything else is packed).  Runs on the current stream; one host sync for the row count."""
+        anything else is packed).  Runs on the current stream; the host waits only for the row count, which the last kernel
+        publishes through pinned memory (the tensors' contents are stream-ordered like any torch result)."""
         lib = _abi.lib()
         B = len(outs)
         dev = outs[0].device
@@ -662,18 +664,35 @@ class ProxyTransformationNormReverse(nn.Module):
             buf = torch.zeros((B, Ncap, 3), dtype=torch.float32, device=dev)
             for b, o in enumerate(outs):
                 buf[b, : n[b]].copy_(o)
-        counts = torch.tensor(n, dtype=torch.int32).to(dev)
+        tstream = torch.cuda.current_stream(dev)
+        lane = self._lane(dev, tstream)
+        # the scratch of this step lives with the lane (one allocation per shape, not five per call); the row count comes
+        # back through pinned memory as soon as the rows are written -- no stream drain, no device-to-host copy
+        qkey = (B, Ncap, str(dev))
+        q = lane.quant if lane.quant is not None and lane.quant["key"] == qkey else None
+        if q is None:
+            nbytes = lib.ptx_voxel_workspace_bytes(B, Ncap)
+            if nbytes == 0:
+                raise RuntimeError(f"quantize: unsupported size B={B}, N={Ncap}")
+            q = lane.quant = dict(key=qkey, ws=torch.empty((nbytes,), dtype=torch.uint8, device=dev),
+                                  counts_h=torch.empty((max(B, 1),), dtype=torch.int32).pin_memory(),
+                                  info=torch.empty((2,), dtype=torch.int32).pin_memory())
+            q["info_np"] = q["info"].numpy()
+        q["counts_h"][:B] = torch.tensor(n, dtype=torch.int32)
+        counts = torch.empty((B,), dtype=torch.int32, device=dev)
+        counts.copy_(q["counts_h"][:B], non_blocking=True)       # the staging buffer is free again once `info` is published
         coords = torch.empty((B * Ncap, 4), dtype=torch.int32, device=dev)
         feats = torch.empty((B * Ncap, 3), dtype=torch.float32, device=dev)
         inverse = torch.empty((B, Ncap), dtype=torch.int32, device=dev) if return_inverse else None
-        info = torch.empty((2,), dtype=torch.int32, device=dev)
-        ws = torch.empty((lib.ptx_voxel_workspace_bytes(B, Ncap),), dtype=torch.uint8, device=dev)
-        if ws.numel() == 0:
-            raise RuntimeError(f"quantize: unsupported size B={B}, N={Ncap}")
+        q["info_np"][:] = -1
         _abi.check(lib.ptx_voxelize(buf.data_ptr(), counts.data_ptr(), B, Ncap, float(voxel_size), coords.data_ptr(),
-                                    feats.data_ptr(), _ptr(inverse), info.data_ptr(), ws.data_ptr(), ws.numel(),
-                                    torch.cuda.current_stream(dev).cuda_stream), "ptx_voxelize")
-        nvox, overflow = info.cpu().tolist()
+                                    feats.data_ptr(), _ptr(inverse), q["info"].data_ptr(), q["ws"].data_ptr(), q["ws"].numel(),
+                                    tstream.cuda_stream), "ptx_voxelize")
+        if lib.ptx_wait_counts(q["info"].data_ptr(), 2, _COUNTS_TIMEOUT_US) != 0:
+            tstream.synchronize()
+        nvox, overflow = (int(x) for x in q["info_np"])
+        if nvox < 0:
+            raise RuntimeError("ptx_voxelize finished without publishing its row count")
         if overflow:
             raise RuntimeError(f"quantize: {overflow} points fall outside +-2^18 voxels of size {voxel_size}")
         res = (coords[:nvox], feats[:nvox])

@@ -74,9 +74,10 @@ def mm(a2, b2, ta=False, tb=False, out=None, alpha=1.0, accumulate=False):
         out = torch.empty((M, N), dtype=_F32, device=a2.device)
     kw = dict(a=(1, ac) if ta else (ac, 1), b=(1, bc) if tb else (bc, 1), c=(N, 1), alpha=alpha)
     tiles = ((M + 63) // 64) * ((N + 63) // 64)
-    if K >= 4096 and tiles < 512 and not accumulate:
-        # a long contraction into a small result (weight gradients): slices of K across the chip, summed in order
-        ks = int(min(256, max(2, 1024 // tiles), K // 1024))
+    if K >= 1024 and tiles < 512 and not accumulate:
+        # a long contraction into a small result (weight gradients): slices of K across the chip, summed in order.  A
+        # work-group's walk over K is a chain of dependent round trips, so the slices are short (>= 256 k = 8 steps) and many
+        ks = int(min(256, max(2, 2048 // tiles), max(2, K // 256)))
         part = torch.empty((ks, M * N), dtype=_F32, device=a2.device)
         gemm(a2, b2, part, M, N, K, ksplit=ks, c_sk=M * N, **kw)
         colsum(part, out=out.view(-1))
@@ -90,7 +91,7 @@ def colsum(x2, y2=None, mode=0, scale=1.0, out=None, accumulate=False):
     if out is None:
         out = torch.empty((N,), dtype=_F32, device=x2.device)
     # enough (column tile, row split) blocks to fill the chip; every split walks >= ~64 rows per slice
-    nsplit = int(max(1, min(512, R // 256, 4096 // ((N + 255) // 256))))
+    nsplit = int(max(1, min(512, R // 32, 4096 // ((N + 255) // 256))))
     scratch = torch.empty((nsplit, N), dtype=torch.float64, device=x2.device)
     _ck(_abi.lib().ptx_op_colsum(_p(x2), _p(y2), R, N, mode, scale, 1 if accumulate else 0, _p(out), _p(scratch), nsplit,
                                  _st()), "ptx_op_colsum")

@@ -1,0 +1,25 @@
+"""cProfile of the host side of the training step: python scratch/train_hostprof.py"""
+import cProfile, pstats, os, sys, io
+sys.argv = [sys.argv[0]]
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from proxytransformation_amd import MODELS
+from proxytransformation_amd.synth import PreshapeConfig, fill_state_dict, make_scene_batch
+cfg = PreshapeConfig("cfg4train", B=6, N=100000, grid_size=12, dynamic_drop_radio=0.6, L=20, V=20, text_blocks=3, img_blocks=3, seed_base=4500)
+m = MODELS.build(dict(type="ProxyTransformationNormReverse", **cfg.module_kwargs()))
+m.load_state_dict({k: torch.from_numpy(v) for k, v in fill_state_dict(m.state_dict()).items()})
+m = m.cuda().train()
+pts, text, mask, img = make_scene_batch(cfg)
+dev = torch.device("cuda:0")
+args = ([torch.from_numpy(p).to(dev) for p in pts], {"text_feats": torch.from_numpy(text).to(dev).requires_grad_(True),
+        "text_token_mask": torch.from_numpy(mask).to(dev)}, torch.from_numpy(img).to(dev).requires_grad_(True))
+def step():
+    outs = m(*args)
+    sum(o.sum() for o in outs).backward()
+for _ in range(3): step()
+torch.cuda.synchronize()
+pr = cProfile.Profile(); pr.enable()
+for _ in range(5): step()
+torch.cuda.synchronize()
+pr.disable()
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28); print(s.getvalue()[:6000])

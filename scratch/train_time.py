@@ -29,3 +29,13 @@ with torch.no_grad():
     for _ in range(n): m(*args)
     torch.cuda.synchronize()
 print(f"eval forward same shape: {1e3*(time.perf_counter()-t0)/n:.2f} ms")
+# host-side enqueue time of a step (no synchronise inside) vs GPU time (events)
+m.train()
+for _ in range(2): step()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+t0 = time.perf_counter(); e0.record()
+for _ in range(n): step()
+e1.record(); t_host = time.perf_counter() - t0
+torch.cuda.synchronize()
+print(f"host enqueue per step {1e3*t_host/n:.2f} ms; GPU span per step {e0.elapsed_time(e1)/n:.2f} ms")
