@@ -30,6 +30,16 @@ struct BGemmArgs {
                             // sums the slices with ptx_op_colsum: fixed order, and the chip is busy when M x N is small)
 };
 
+template <int DT>
+__device__ __forceinline__ float load_t(const void *base, long off)
+{
+    if (DT == 0) return static_cast<const float *>(base)[off];
+    const unsigned short u = static_cast<const unsigned short *>(base)[off];
+    if (DT == 1) return __uint_as_float((unsigned int)u << 16);
+    _Float16 h;
+    __builtin_memcpy(&h, &u, 2);
+    return (float)h;
+}
 __device__ __forceinline__ float load_a(const void *base, long off, int dt)
 {
     if (dt == 0) return static_cast<const float *>(base)[off];
@@ -41,6 +51,9 @@ __device__ __forceinline__ float load_a(const void *base, long off, int dt)
 }
 
 constexpr int TBK = 32;
+// ADT / BDT: storage types of the operands, compile-time: a run-time type test inside the fetch makes every load its own
+// basic block with its own s_waitcnt vmcnt(0) (r03: that, not the arithmetic, was the 3.6 us per K step of this kernel)
+template <int ADT, int BDT>
 __global__ __launch_bounds__(256) void k_bgemm(BGemmArgs g)
 {
     __shared__ __attribute__((aligned(16))) float As[64][TBK + 4];     // 144-B rows: b128 fragment reads, conflict-free
@@ -63,7 +76,7 @@ __global__ __launch_bounds__(256) void k_bgemm(BGemmArgs g)
     const bool b_n_fast = g.b_cs == 1 || g.b_rs != 1;       // B: contiguous along n
     constexpr int E = 64 * TBK / 256;                       // elements of each tile per thread
     int am[E], ak[E], bk[E], bn[E];
-    long aoff[E], boff[E];                                  // element offsets at k0 = kbeg (advanced by TBK * stride per step)
+    long arow[E], bcol[E];                                  // element offsets of (row, k = 0) / (k = 0, column), rows / columns clamped
     bool aok[E], bok[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -71,34 +84,34 @@ __global__ __launch_bounds__(256) void k_bgemm(BGemmArgs g)
         if (a_k_fast) { am[e] = idx / TBK; ak[e] = idx % TBK; } else { ak[e] = idx / 64; am[e] = idx % 64; }
         if (b_n_fast) { bk[e] = idx / 64; bn[e] = idx % 64; } else { bn[e] = idx / TBK; bk[e] = idx % TBK; }
         aok[e] = row0 + am[e] < g.M; bok[e] = col0 + bn[e] < g.N;
-        aoff[e] = ao + (long)(row0 + am[e]) * g.a_rs + (long)(kbeg + ak[e]) * g.a_cs;
-        boff[e] = bo + (long)(kbeg + bk[e]) * g.b_rs + (long)(col0 + bn[e]) * g.b_cs;
+        arow[e] = ao + (long)min(row0 + am[e], g.M - 1) * g.a_rs;
+        bcol[e] = bo + (long)min(col0 + bn[e], g.N - 1) * g.b_cs;
     }
-    const long astep = (long)TBK * g.a_cs, bstep = (long)TBK * g.b_rs;
-    const bool plain = g.a_dtype == 0 && g.b_dtype == 0;   // uniform: the fp32 x fp32 case skips the type dispatch
     // Two tiles are in flight in registers while a third is multiplied out of LDS: every product of the training path is
     // latency-bound here (a few dozen work-groups walking K = 700 .. 300 000 with one dependent round trip per step --
-    // r02: 61 launches, 4.7 of the step's 11 ms), so the depth of the prefetch is what sets the step time
+    // r02: 61 launches, 4.7 of the step's 11 ms).  The fetches are BRANCH-FREE (clamped addresses, out-of-range elements
+    // zeroed after the load): with predicated loads hipcc cannot count the outstanding ones and drains them all
+    // (s_waitcnt vmcnt(0)) before every stash -- the prefetch then hides nothing (3.6 us per K step)
     float ra0[E], rb0[E], ra1[E], rb1[E];
     auto fetch = [&](int k0, float (&ra)[E], float (&rb)[E]) {
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            const bool av = aok[e] && k0 + ak[e] < kend, bv = bok[e] && k0 + bk[e] < kend;
-            if (plain) {
-                ra[e] = av ? static_cast<const float *>(g.A)[aoff[e]] : 0.0f;
-                rb[e] = bv ? static_cast<const float *>(g.B)[boff[e]] : 0.0f;
-            } else {
-                ra[e] = av ? load_a(g.A, aoff[e], g.a_dtype) : 0.0f;
-                rb[e] = bv ? load_a(g.B, boff[e], g.b_dtype) : 0.0f;
-            }
-            aoff[e] += astep; boff[e] += bstep;
+            const long ai = arow[e] + (long)min(k0 + ak[e], kend - 1) * g.a_cs;
+            const long bi = bcol[e] + (long)min(k0 + bk[e], kend - 1) * g.b_rs;
+            // raw values only: the out-of-range elements are zeroed when the tile is stashed, two steps later -- a select
+            // right here would make the wave wait for each load as it is issued
+            ra[e] = load_t<ADT>(g.A, ai); rb[e] = load_t<BDT>(g.B, bi);
         }
     };
     auto step = [&](int k0, float (&ra)[E], float (&rb)[E]) {
 #pragma unroll
-        for (int e = 0; e < E; ++e) { As[am[e]][ak[e]] = ra[e]; Bs[bn[e]][bk[e]] = rb[e]; }
+        for (int e = 0; e < E; ++e) {
+            As[am[e]][ak[e]] = (aok[e] && k0 + ak[e] < kend) ? ra[e] : 0.0f;
+            Bs[bn[e]][bk[e]] = (bok[e] && k0 + bk[e] < kend) ? rb[e] : 0.0f;
+        }
         __syncthreads();
-        if (k0 + 2 * TBK < kend) fetch(k0 + 2 * TBK, ra, rb);       // this set is free again: two steps ahead
+        fetch(k0 + 2 * TBK, ra, rb);    // this set is free again: two steps ahead.  Unconditional (beyond the end the clamped
+                                        // addresses re-read the last column): a branch here hides the number of loads in flight
 #pragma unroll
         for (int kk = 0; kk < TBK / 8; ++kk) {          // lanes hh = 0 / 1 contract k = 8 kk + j and 8 kk + 4 + j
             const float4 a4 = *reinterpret_cast<const float4 *>(&As[wr * 32 + li][kk * 8 + hh * 4]);
@@ -114,11 +127,13 @@ __global__ __launch_bounds__(256) void k_bgemm(BGemmArgs g)
             for (int i = 0; i < 16; ++i) { dacc[i] += (double)acc[i]; acc[i] = 0.0f; }
         }
     };
-    if (kbeg < kend) fetch(kbeg, ra0, rb0);
-    if (kbeg + TBK < kend) fetch(kbeg + TBK, ra1, rb1);
-    for (int k0 = kbeg; k0 < kend; k0 += 2 * TBK) {
-        step(k0, ra0, rb0);
-        if (k0 + TBK < kend) step(k0 + TBK, ra1, rb1);
+    if (kbeg < kend) {
+        fetch(kbeg, ra0, rb0);
+        fetch(kbeg + TBK, ra1, rb1);
+        for (int k0 = kbeg; k0 < kend; k0 += 2 * TBK) {     // an odd number of steps runs one step on zeros
+            step(k0, ra0, rb0);
+            step(k0 + TBK, ra1, rb1);
+        }
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = (float)(dacc[i] + (double)acc[i]);
@@ -726,7 +741,14 @@ int ptx_op_gemm(const void *A, const void *B, float *C, int M, int N, int K, lon
     PTX_REQUIRE(ksplit >= 1 && (long)batch * ksplit <= 65535 && (ksplit == 1 || !accumulate), "ptx_op_gemm: ksplit=%d", ksplit);
     BGemmArgs g{A, B, C, M, N, K, a_rs, a_cs, b_rs, b_cs, c_rs, c_cs, batch, inner, a_s1, a_s2, b_s1, b_s2, c_s1, c_s2,
                 a_dtype, b_dtype, alpha, accumulate, ksplit, c_sk};
-    hipLaunchKernelGGL(k_bgemm, dim3(cdiv(M, 64), cdiv(N, 64), batch * ksplit), dim3(256), 0, static_cast<hipStream_t>(stream), g);
+    const dim3 grid(cdiv(M, 64), cdiv(N, 64), batch * ksplit);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    PTX_REQUIRE(a_dtype == 0 || b_dtype == 0, "ptx_op_gemm: at most one 16-bit operand (a_dtype=%d, b_dtype=%d)", a_dtype, b_dtype);
+    if (a_dtype == 0 && b_dtype == 0) hipLaunchKernelGGL((k_bgemm<0, 0>), grid, dim3(256), 0, st, g);
+    else if (a_dtype == 1) hipLaunchKernelGGL((k_bgemm<1, 0>), grid, dim3(256), 0, st, g);
+    else if (a_dtype == 2) hipLaunchKernelGGL((k_bgemm<2, 0>), grid, dim3(256), 0, st, g);
+    else if (b_dtype == 1) hipLaunchKernelGGL((k_bgemm<0, 1>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((k_bgemm<0, 2>), grid, dim3(256), 0, st, g);
     PTX_LAUNCHED("k_bgemm");
     return PTX_OK;
 }
