@@ -390,6 +390,21 @@ int ptx_op_slot_pool(const float *h, long nclus, int K, int C, int mode, float *
 int ptx_op_slot_pool_bwd(const float *dout, const int32_t *arg, long nclus, int K, int C, int mode, float *dh, void *stream);
 int ptx_op_offset_apply(const float *c0, const float *raw, const float *minmax, long nclus, int M, float margin, float *cout,
                         float *dcoef, void *stream);
+/* The same networks fused (csrc/slotnet_train.hip): slot inputs -> Conv2d(6,C,1) -> BatchNorm2d (batch statistics over all
+ * nclus*K slots, running statistics updated) -> ReLU -> mean (maxpool 0) / max (1, first arg-max in arg) over the K slots,
+ * recomputing the C channels of a slot from its six inputs in every pass instead of storing (nclus*K, C) activations.
+ * center (nclus,3), cluster (nclus,K,3); out (nclus,C); mean_rstd (2,C) is saved for the backward; stat_tmp (2,C) scratch;
+ * scratch: ptx_op_slotnet_scratch_bytes(C).  Backward: dout (nclus,C) -> dconv_w (C,6), dconv_b (C), dbeta_dgamma (2,C),
+ * dcenter (nclus,3) or NULL. */
+size_t ptx_op_slotnet_scratch_bytes(int C);
+int ptx_op_slotnet_fwd(const float *center, const float *cluster, long nclus, int K, int C, const float *conv_w,
+                       const float *conv_b, const float *bn_w, const float *bn_b, float eps, float momentum, float *run_mean,
+                       float *run_var, int maxpool, float *out, int32_t *arg, float *mean_rstd, float *stat_tmp, void *scratch,
+                       size_t scratch_bytes, void *stream);
+int ptx_op_slotnet_bwd(const float *center, const float *cluster, long nclus, int K, int C, const float *conv_w,
+                       const float *conv_b, const float *bn_w, const float *bn_b, const float *mean_rstd, int maxpool,
+                       const int32_t *arg, const float *dout, float *dconv_w, float *dconv_b, float *dbeta_dgamma,
+                       float *dcenter, void *scratch, size_t scratch_bytes, void *stream);
 /* per-slot bias table of ProxyAttention (PRE:212-215) and its parameter gradients */
 int ptx_op_slotbias_fwd(const float *pb, const float *pc, const float *pr, int Mk, int s, int C, float *table, void *stream);
 int ptx_op_slotbias_bwd(const float *dtable, int Mk, int s, int C, float *dpb, float *dpc, float *dpr, void *stream);

@@ -126,6 +126,9 @@ SIGNATURES.update({
     "ptx_op_slot_inputs_bwd": (_I, [_P, _P, _L, _I, _P, _P]),
     "ptx_op_slot_pool": (_I, [_P, _L, _I, _I, _I, _P, _P, _P]),
     "ptx_op_slot_pool_bwd": (_I, [_P, _P, _L, _I, _I, _I, _P, _P]),
+    "ptx_op_slotnet_scratch_bytes": (_Z, [_I]),
+    "ptx_op_slotnet_fwd": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _P, _F, _F, _P, _P, _I, _P, _P, _P, _P, _P, _Z, _P]),
+    "ptx_op_slotnet_bwd": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "ptx_op_offset_apply": (_I, [_P, _P, _P, _L, _I, _F, _P, _P, _P]),
     "ptx_op_slotbias_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
     "ptx_op_slotbias_bwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _P]),

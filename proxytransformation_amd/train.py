@@ -317,52 +317,41 @@ class _SlotNet(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, center, cluster, conv_w, conv_b, bn_w, bn_b, run_mean, run_var, eps, momentum, maxpool):
+        # fused (csrc/slotnet_train.hip): the (B*M*K, W) activations are recomputed from the six slot inputs in every pass
+        # instead of being written and re-read (r02: GEMM + bias + two column sums + normalise + pool over 318 MB)
         lib = _abi.lib()
-        center = _c(center)
+        center, cluster = _c(center), _c(cluster)
         n, K = center.shape[0], cluster.shape[-2]
         W = conv_w.shape[0]
         dev = center.device
-        x6 = torch.empty((n * K, 6), dtype=_F32, device=dev)
-        pad = torch.empty((n * K,), dtype=torch.uint8, device=dev)
-        _ck(lib.ptx_op_slot_inputs(_p(center), _p(cluster), None, n, K, _p(x6), _p(pad), _st()), "slot_inputs")
-        w2 = conv_w.reshape(W, 6)
-        h = mm(x6, w2, tb=True)
-        eltwise(6, h, conv_b, ncol=W, out=h)
-        s1 = colsum(h, scale=1.0 / (n * K))
-        s2 = colsum(h, s1, mode=3)
-        mr = torch.empty((2, W), dtype=_F32, device=dev)
-        _ck(lib.ptx_op_bn_stats(_p(s1), _p(s2), W, n * K, eps, momentum, _p(mr), _p(run_mean), _p(run_var), _st()), "bn_stats")
-        act = torch.empty_like(h)
-        _ck(lib.ptx_op_bn_apply(_p(h), _p(mr), _p(bn_w), _p(bn_b), n * K, W, 1, _p(act), _st()), "bn_apply")
         out = torch.empty((n, W), dtype=_F32, device=dev)
         arg = torch.empty((n, W), dtype=torch.int32, device=dev) if maxpool else None
-        _ck(lib.ptx_op_slot_pool(_p(act), n, K, W, 1 if maxpool else 0, _p(out), _p(arg), _st()), "slot_pool")
-        ctx.save_for_backward(x6, pad, h, act, mr, bn_w, conv_w, arg if maxpool else pad)
+        mr = torch.empty((2, W), dtype=_F32, device=dev)
+        tmp = torch.empty((2, W), dtype=_F32, device=dev)
+        scratch = torch.empty((lib.ptx_op_slotnet_scratch_bytes(W),), dtype=torch.uint8, device=dev)
+        _ck(lib.ptx_op_slotnet_fwd(_p(center), _p(cluster), n, K, W, _p(conv_w), _p(conv_b), _p(bn_w), _p(bn_b), eps, momentum,
+                                   _p(run_mean), _p(run_var), 1 if maxpool else 0, _p(out), _p(arg), _p(mr), _p(tmp),
+                                   _p(scratch), scratch.numel(), _st()), "slotnet_fwd")
+        ctx.save_for_backward(center, cluster, conv_w, conv_b, bn_w, bn_b, mr, arg if maxpool else mr)
         ctx.cfg = (n, K, W, maxpool)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x6, pad, h, act, mr, bn_w, conv_w, arg = ctx.saved_tensors
+        center, cluster, conv_w, conv_b, bn_w, bn_b, mr, arg = ctx.saved_tensors
         n, K, W, maxpool = ctx.cfg
         lib = _abi.lib()
         dout = _c(dout)
-        dact = torch.empty_like(h)
-        _ck(lib.ptx_op_slot_pool_bwd(_p(dout), _p(arg) if maxpool else None, n, K, W, 1 if maxpool else 0, _p(dact), _st()), "slot_pool_bwd")
-        g, gx = torch.empty_like(h), torch.empty_like(h)
-        _ck(lib.ptx_op_bn_bwd_prep(_p(h), _p(act), _p(dact), _p(mr), n * K, W, 1, _p(g), _p(gx), _st()), "bn_bwd_prep")
-        dbeta, dgamma = colsum(g), colsum(gx)
-        dh = dact                                               # reuse
-        _ck(lib.ptx_op_bn_bwd_dx(_p(h), _p(g), _p(mr), _p(bn_w), _p(dbeta), _p(dgamma), n * K, W, _p(dh), _st()), "bn_bwd_dx")
-        w2 = conv_w.reshape(W, 6)
-        dconv_w = mm(dh, x6, ta=True).view_as(conv_w)
-        dconv_b = colsum(dh)
-        dcenter = None
-        if ctx.needs_input_grad[0]:
-            dx6 = mm(dh, w2)
-            dcenter = torch.empty((n, 3), dtype=_F32, device=dout.device)
-            _ck(lib.ptx_op_slot_inputs_bwd(_p(dx6), _p(pad), n, K, _p(dcenter), _st()), "slot_inputs_bwd")
-        return dcenter, None, dconv_w, dconv_b, dgamma, dbeta, None, None, None, None, None
+        dev = dout.device
+        dconv_w = torch.empty_like(conv_w)
+        dconv_b = torch.empty((W,), dtype=_F32, device=dev)
+        dbg = torch.empty((2, W), dtype=_F32, device=dev)
+        dcenter = torch.empty((n, 3), dtype=_F32, device=dev) if ctx.needs_input_grad[0] else None
+        scratch = torch.empty((lib.ptx_op_slotnet_scratch_bytes(W),), dtype=torch.uint8, device=dev)
+        _ck(lib.ptx_op_slotnet_bwd(_p(center), _p(cluster), n, K, W, _p(conv_w), _p(conv_b), _p(bn_w), _p(bn_b), _p(mr),
+                                   1 if maxpool else 0, _p(arg) if maxpool else None, _p(dout), _p(dconv_w), _p(dconv_b),
+                                   _p(dbg), _p(dcenter), _p(scratch), scratch.numel(), _st()), "slotnet_bwd")
+        return dcenter, None, dconv_w, dconv_b, dbg[1], dbg[0], None, None, None, None, None
 
 
 class _OffsetHead(torch.autograd.Function):
