@@ -123,15 +123,30 @@ __global__ __launch_bounds__(256) void k_sn_stats(SnArgs a)
     sn_store_partials<Q, 1>(a, acc, sn_lds);
 }
 
-// out[i] = scale * sum over the work-group partials, in block order
+// sum over the work-group partials of output i: 16 lanes take the blocks round-robin (16 loads in flight per output instead
+// of one dependent chain of 256), combined in lane order -- fixed order
+__device__ __forceinline__ double sn_finish_sum(const double *__restrict__ part, int nblocks, int width, int i)
+{
+    __shared__ double red[16][17];
+    const int il = threadIdx.x & 15, sub = threadIdx.x >> 4;
+    double t = 0.0;
+    if (i < width)
+        for (int b = sub; b < nblocks; b += 16) t += part[(size_t)b * width + i];
+    red[sub][il] = t;
+    __syncthreads();
+    double s = 0.0;
+    if (sub == 0)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s += red[q][il];
+    return s;
+}
+// out[i] = scale * sum over the work-group partials
 __global__ __launch_bounds__(256) void k_sn_finish(const double *__restrict__ part, int nblocks, int width, float scale,
                                                    float *__restrict__ out)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= width) return;
-    double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * width + i];
-    out[i] = (float)(s * (double)scale);
+    const int i = blockIdx.x * 16 + (threadIdx.x & 15);
+    const double s = sn_finish_sum(part, nblocks, width, i);
+    if ((threadIdx.x >> 4) == 0 && i < width) out[i] = (float)(s * (double)scale);
 }
 
 // y = relu(bn(h)); pooled over the K slots (mean, or max with the FIRST arg-max like torch.max)
@@ -296,10 +311,9 @@ __global__ __launch_bounds__(256) void k_sn_bwd_dx(SnArgs a)
 __global__ __launch_bounds__(256) void k_sn_finish_w(const double *__restrict__ part, int nblocks, int C, float *__restrict__ dw,
                                                      float *__restrict__ db)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= 7 * C) return;
-    double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * 7 * C + i];
+    const int i = blockIdx.x * 16 + (threadIdx.x & 15);
+    const double s = sn_finish_sum(part, nblocks, 7 * C, i);
+    if ((threadIdx.x >> 4) != 0 || i >= 7 * C) return;
     const int j = i / C, c = i - j * C;
     if (j == 0) db[c] = (float)s;
     else dw[c * 6 + (j - 1)] = (float)s;
@@ -331,11 +345,11 @@ int ptx_op_slotnet_fwd(const float *center, const float *cluster, long nclus, in
     float *mean = stat_tmp, *sq = stat_tmp + C;             // (2,C): batch mean, centred sum of squares
     if (C == 256) hipLaunchKernelGGL((k_sn_stats<4, 0>), dim3(kSnBlocks), dim3(256), lds1, st, a);
     else          hipLaunchKernelGGL((k_sn_stats<8, 0>), dim3(kSnBlocks), dim3(256), lds1, st, a);
-    hipLaunchKernelGGL(k_sn_finish, dim3(cdiv(C, 256)), dim3(256), 0, st, a.part, kSnBlocks, C, a.inv_total, mean);
+    hipLaunchKernelGGL(k_sn_finish, dim3(cdiv(C, 16)), dim3(256), 0, st, a.part, kSnBlocks, C, a.inv_total, mean);
     a.mean_in = mean;
     if (C == 256) hipLaunchKernelGGL((k_sn_stats<4, 1>), dim3(kSnBlocks), dim3(256), lds1, st, a);
     else          hipLaunchKernelGGL((k_sn_stats<8, 1>), dim3(kSnBlocks), dim3(256), lds1, st, a);
-    hipLaunchKernelGGL(k_sn_finish, dim3(cdiv(C, 256)), dim3(256), 0, st, a.part, kSnBlocks, C, 1.0f, sq);
+    hipLaunchKernelGGL(k_sn_finish, dim3(cdiv(C, 16)), dim3(256), 0, st, a.part, kSnBlocks, C, 1.0f, sq);
     PTX_LAUNCHED("k_sn_stats");
     PTX_TRY(ptx_op_bn_stats(mean, sq, C, nclus * K, eps, momentum, mean_rstd, run_mean, run_var, stream));
     if (C == 256) hipLaunchKernelGGL(k_sn_apply<4>, dim3((unsigned)((nclus + 3) / 4)), dim3(256), 0, st, a);
@@ -363,7 +377,7 @@ int ptx_op_slotnet_bwd(const float *center, const float *cluster, long nclus, in
     if (C == 256) hipLaunchKernelGGL(k_sn_bwd_stats<4>, dim3(kSnBlocks), dim3(256), lds2, st, a);
     else          hipLaunchKernelGGL(k_sn_bwd_stats<8>, dim3(kSnBlocks), dim3(256), lds2, st, a);
     // partial layout [block][j * C + c]: j = 0 -> dbeta, j = 1 -> dgamma
-    hipLaunchKernelGGL(k_sn_finish, dim3(cdiv(2 * C, 256)), dim3(256), 0, st, a.part, kSnBlocks, 2 * C, 1.0f, dbeta);
+    hipLaunchKernelGGL(k_sn_finish, dim3(cdiv(2 * C, 16)), dim3(256), 0, st, a.part, kSnBlocks, 2 * C, 1.0f, dbeta);
     PTX_LAUNCHED("k_sn_bwd_stats");
     a.dbeta = dbeta; a.dgamma = dgamma;
     if (lds7 > 64 * 1024) {
@@ -372,7 +386,7 @@ int ptx_op_slotnet_bwd(const float *center, const float *cluster, long nclus, in
     }
     if (C == 256) hipLaunchKernelGGL(k_sn_bwd_dx<4>, dim3(kSnBlocks), dim3(256), lds7, st, a);
     else          hipLaunchKernelGGL(k_sn_bwd_dx<8>, dim3(kSnBlocks), dim3(256), lds7, st, a);
-    hipLaunchKernelGGL(k_sn_finish_w, dim3(cdiv(7 * C, 256)), dim3(256), 0, st, a.part, kSnBlocks, C, dconv_w, dconv_b);
+    hipLaunchKernelGGL(k_sn_finish_w, dim3(cdiv(7 * C, 16)), dim3(256), 0, st, a.part, kSnBlocks, C, dconv_w, dconv_b);
     PTX_LAUNCHED("k_sn_bwd_dx");
     return PTX_OK;
 }
