@@ -141,6 +141,35 @@ def work_model(cfg, B, dt_bytes):
     return byts, flops
 
 
+def train_step_ms(device, steps=8):
+    """One training step (train-mode forward + backward through every live parameter, text_feats and img_feat) at the
+    reference's training shape -- CFG:41, 108, 145: 6 scenes per GPU, 100k points, gs = 12, 3 + 3 blocks, 20 views."""
+    from proxytransformation_amd.synth import PreshapeConfig
+    cfg = PreshapeConfig("cfg4train", B=6, N=100000, grid_size=12, dynamic_drop_radio=0.6, L=20, V=20, text_blocks=3,
+                         img_blocks=3, seed_base=4500)
+    mod = MODELS.build(dict(type="ProxyTransformationNormReverse", **cfg.module_kwargs()))
+    mod.load_state_dict({k: torch.from_numpy(v) for k, v in fill_state_dict(mod.state_dict()).items()})
+    mod = mod.to(device).train()
+    pts, text, mask, img = make_scene_batch(cfg)
+    args = ([torch.from_numpy(p).to(device) for p in pts],
+            {"text_feats": torch.from_numpy(text).to(device).requires_grad_(True), "text_token_mask": torch.from_numpy(mask).to(device)},
+            torch.from_numpy(img).to(device).requires_grad_(True))
+
+    def step():
+        outs = mod(*args)
+        sum(o.sum() for o in outs).backward()
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    return dict(ms=round(1e3 * (time.perf_counter() - t0) / steps, 3), steps=steps,
+                shape="6 scenes x 100k points, gs=12 -> 691 kept clusters, L=20, V=20 fp32 features, 3+3 blocks (CFG:41,108,145); "
+                      "drop rates 0.2; forward + backward")
+
+
 def cpu_baseline(cfg, sd, n_scenes):
     """Time the CPU oracle (the checker, here only as the reported baseline) on a bounded sample.
 
@@ -366,6 +395,12 @@ def main():
                     extras["wide"] = dict(scenes_per_gpu=wide.B, value_fp32_compute=round(wide.B / t32["fp32"], 2),
                                           value_bf16_compute=round(wide.B / t32["bf16"], 2))
                     del wide
+        if not args.no_passes and rank == 0 and world == 1:
+            with torch.enable_grad():
+                try:
+                    extras["train"] = train_step_ms(device)
+                except Exception as e:                          # never sinks the eval number
+                    extras["train"] = dict(ms=None, error=repr(e))
         if args.breakdown and rank == 0:
             print("per-kernel us/launch:", json.dumps({k: round(v, 2) for k, v in site_times(lib, names, mod, inputs, 12).items()}),
                   file=sys.stderr)
@@ -427,6 +462,9 @@ def main():
                                              "accumulation; clustering / index tensors unchanged; not the headline value")
             if "wide" in extras:
                 line["bf16_compute"]["at_32_scenes_per_gpu"] = extras["wide"]
+        if "train" in extras:
+            line["train_step_ms"] = extras["train"]["ms"]
+            line["train_step"] = extras["train"]
         if "passes" in extras:
             line["roofline_passes"] = extras["passes"]
         if world == 1 and not args.no_cpu_baseline:

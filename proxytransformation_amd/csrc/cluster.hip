@@ -9,6 +9,7 @@
 //
 // Build with -ffp-contract=off: squared distances decide integer results and must be
 // ((dx*dx)+dy*dy)+dz*dz exactly; they additionally use __f*_rn intrinsics.
+#include <cstdlib>
 #include <hip/hip_ext.h>
 
 #include "common.h"
@@ -214,31 +215,43 @@ template <bool MAXPOOL, int Q>     // Q = hidden width / 64 channels per lane (4
 __device__ __forceinline__ void slot_pool(const float *__restrict__ conv_w, const float *__restrict__ conv_b,
                                           const float *__restrict__ ab, int K, const float (&x)[6], float (&acc)[Q])
 {
-    constexpr int W = 64 * Q;
+    // Two channels per instruction (v_pk_fma_f32 / v_pk_max_f32 / v_pk_add_f32: per element the same IEEE operations in
+    // the same order as the scalar form, so every result is bit-identical): this loop is 2/3 of k_cluster's instructions and
+    // the launch is VALU-issue-bound
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    constexpr int W = 64 * Q, P = Q / 2;
+    static_assert(Q % 2 == 0, "channels per lane come in pairs");
     const int lane = lane_id();
-    float wt[Q][6], bs[Q], al[Q], be[Q];
+    f32x2 wt[P][6], bs[P], al[P], be[P], ac[P];
 #pragma unroll
-    for (int q = 0; q < Q; ++q) {
-        const int c = lane + 64 * q;
+    for (int pq = 0; pq < P; ++pq)
 #pragma unroll
-        for (int i = 0; i < 6; ++i) wt[q][i] = conv_w[c * 6 + i];
-        bs[q] = conv_b[c]; al[q] = ab[c]; be[q] = ab[W + c];
-    }
+        for (int e = 0; e < 2; ++e) {
+            const int c = lane + 64 * (2 * pq + e);
 #pragma unroll
-    for (int q = 0; q < Q; ++q) acc[q] = MAXPOOL ? -INFINITY : 0.0f;
+            for (int i = 0; i < 6; ++i) wt[pq][i][e] = conv_w[c * 6 + i];
+            bs[pq][e] = conv_b[c]; al[pq][e] = ab[c]; be[pq][e] = ab[W + c];
+            ac[pq][e] = MAXPOOL ? -INFINITY : 0.0f;
+        }
+    const f32x2 zero = {0.0f, 0.0f};
     for (int k = 0; k < K; ++k) {
-        float s[6];
+        f32x2 s[6];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) s[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x[i]), k));
+        for (int i = 0; i < 6; ++i) {
+            const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x[i]), k));
+            s[i] = f32x2{v, v};
+        }
 #pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            float h = bs[q];
+        for (int pq = 0; pq < P; ++pq) {
+            f32x2 h = bs[pq];
 #pragma unroll
-            for (int i = 0; i < 6; ++i) h = fmaf(wt[q][i], s[i], h);
-            h = fmaxf(fmaf(h, al[q], be[q]), 0.0f);
-            acc[q] = MAXPOOL ? fmaxf(acc[q], h) : acc[q] + h;
+            for (int i = 0; i < 6; ++i) h = __builtin_elementwise_fma(wt[pq][i], s[i], h);
+            h = __builtin_elementwise_max(__builtin_elementwise_fma(h, al[pq], be[pq]), zero);
+            ac[pq] = MAXPOOL ? __builtin_elementwise_max(ac[pq], h) : ac[pq] + h;
         }
     }
+#pragma unroll
+    for (int pq = 0; pq < P; ++pq) { acc[2 * pq] = ac[pq][0]; acc[2 * pq + 1] = ac[pq][1]; }
 }
 
 // slot k's input from its xyz and the centre: [rel (zeroed on padded slots), p]   PRE:93-99 / 131-137
@@ -400,6 +413,11 @@ __global__ __launch_bounds__(256) void k_cluster(ClusterArgs a)
     if (lane == 0) a.pad_count[w] = a.K - count;
 }
 
+// (r03, measured and removed: two neighbouring centres per wave sharing the wave's point loads -- half the load instructions
+//  and dependent round trips per centre, bit-identical results -- is SLOWER at every shape: 128 -> 145 us at 32 scenes,
+//  79 -> 98 us for the reference's gs = 12 batch of six, 42 -> 56 us at 4 scenes.  The launch is bound by the VALU work of
+//  the offset network (1 950 instructions per wave, SQ_ACTIVE_INST_VALU 43 % of the kernel at 2.6 resident waves per SIMD
+//  beside the pooling pass), which two centres in one wave only serialise.)
 int launch_cluster(const PtxShape &s, const uint32_t *mm_enc, const float *lin, const ScenePts &points,
                    const float *off_ab, const PtxSlotMlp &mlp, const float *map_w, const float *centers_override,
                    float *minmax_out, float *centers0, float *cluster1, float *offsets, float *centers,
