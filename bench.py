@@ -155,7 +155,11 @@ def train_step_ms(device, steps=8):
             {"text_feats": torch.from_numpy(text).to(device).requires_grad_(True), "text_token_mask": torch.from_numpy(mask).to(device)},
             torch.from_numpy(img).to(device).requires_grad_(True))
 
+    leaves = list(mod.parameters()) + [args[1]["text_feats"], args[2]]
+
     def step():
+        for t in leaves:                # optimizer.zero_grad(set_to_none=True): gradients are written, not accumulated
+            t.grad = None
         outs = mod(*args)
         sum(o.sum() for o in outs).backward()
     for _ in range(3):

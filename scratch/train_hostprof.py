@@ -13,7 +13,9 @@ pts, text, mask, img = make_scene_batch(cfg)
 dev = torch.device("cuda:0")
 args = ([torch.from_numpy(p).to(dev) for p in pts], {"text_feats": torch.from_numpy(text).to(dev).requires_grad_(True),
         "text_token_mask": torch.from_numpy(mask).to(dev)}, torch.from_numpy(img).to(dev).requires_grad_(True))
+leaves = list(m.parameters()) + [args[1]["text_feats"], args[2]]
 def step():
+    for t in leaves: t.grad = None          # optimizer.zero_grad(set_to_none=True)
     outs = m(*args)
     sum(o.sum() for o in outs).backward()
 for _ in range(3): step()

@@ -13,7 +13,9 @@ pts, text, mask, img = make_scene_batch(cfg)
 dev = torch.device("cuda:0")
 args = ([torch.from_numpy(p).to(dev) for p in pts], {"text_feats": torch.from_numpy(text).to(dev).requires_grad_(True),
         "text_token_mask": torch.from_numpy(mask).to(dev)}, torch.from_numpy(img).to(dev).requires_grad_(True))
+leaves = list(m.parameters()) + [args[1]["text_feats"], args[2]]
 def step():
+    for t in leaves: t.grad = None          # optimizer.zero_grad(set_to_none=True)
     outs = m(*args)
     sum(o.sum() for o in outs).backward()
 for _ in range(3): step()
@@ -39,3 +41,16 @@ for _ in range(n): step()
 e1.record(); t_host = time.perf_counter() - t0
 torch.cuda.synchronize()
 print(f"host enqueue per step {1e3*t_host/n:.2f} ms; GPU span per step {e0.elapsed_time(e1)/n:.2f} ms")
+# split: forward (host returns after the count read-back = GPU forward done) vs backward enqueue vs backward GPU tail
+m.train()
+fw_h = bw_h = tail = 0.0
+for _ in range(n):
+    for t in leaves: t.grad = None
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    outs = m(*args); loss = sum(o.sum() for o in outs)
+    t1 = time.perf_counter()
+    loss.backward()
+    t2 = time.perf_counter()
+    torch.cuda.synchronize(); t3 = time.perf_counter()
+    fw_h += t1 - t0; bw_h += t2 - t1; tail += t3 - t2
+print(f"forward host (incl. wait for the counts) {1e3*fw_h/n:.2f} ms; backward enqueue {1e3*bw_h/n:.2f} ms; GPU tail after enqueue {1e3*tail/n:.2f} ms")
