@@ -268,7 +268,9 @@ static int run_img_proxy(const PtxShape &s, const PtxWeights &w, const float *pr
     // head_dim 32: a 32-column tile of the qkv0 GEMM IS one head's q, and the work-group that finishes it goes on to that
     // head's [w_h | e_h] = q_h T1_h^T (GemmProb::w2): one launch (and one boundary) less on the image chain
     static const bool no_chain = getenv("PTX_NO_CHAIN") != nullptr;
-    const bool chained = hd == 32 && !no_chain;
+    // (from ~4000 images per call on -- 32 scenes of 196 views -- the two products as launches of their own, the first on the
+    //  64 x 64 split-operand kernel, are faster than the latency-regime chained form: 80 + 72 vs 185 us)
+    const bool chained = hd == 32 && !no_chain && nimg < 4096;
     {   // [q | k0 | v0] of token 0 = W3 mean(f) + b3
         GemmBatch g{}; g.n = 1;
         g.p[0] = GemmProb{fm, prep + P.w3, qkv0, prep + P.b3, nullptr, nullptr, nullptr,
