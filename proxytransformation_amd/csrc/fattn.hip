@@ -62,13 +62,14 @@ constexpr int kFaRowPlane = kFaChunk * XROW;                // 16384
 constexpr int kFaTStride = kFaChunk * 2 + 16;               // 528
 constexpr int kFaTPlane = 32 * kFaTStride;                  // 16896
 constexpr int kFaBiasOff = 3 * kFaRowPlane;                 // key bias of stage B (256 floats)
-constexpr int kFaRegOff = kFaBiasOff + kFaChunk * 4;        // {K, V^T} during stage A, {PV^T, merge slots} afterwards
+constexpr int kFaFlagOff = kFaBiasOff + kFaChunk * 4;       // per key tile of stage B: does any key carry a bias (8 ints)
+constexpr int kFaRegOff = kFaFlagOff + 32;                  // {K, V^T} during stage A, {PV^T, merge slots} afterwards
 constexpr int kFaSlotOff = kFaRegOff + 3 * kFaTPlane;
 constexpr int kFaLds = kFaRegOff + 3 * kFaRowPlane + 3 * kFaTPlane;
 static_assert(kFaSlotOff + kFaWaves * 18 * 64 * 4 <= kFaLds && kFaLds <= 160 * 1024, "LDS carve of k_proxy_attn");
 
 template <int NP>
-__device__ __forceinline__ void mfma_one_chain(const bf16x8 (&a)[2][3], const bf16x8 (&b)[2][3], f32x16 &c)
+__device__ __forceinline__ void mfma_one_chain(const u32x4 (&a)[2][3], const u32x4 (&b)[2][3], f32x16 &c)
 {
     c = mfma_parts<NP>(a[0], b[0], c);
     c = mfma_parts<NP>(a[1], b[1], c);
@@ -77,7 +78,7 @@ __device__ __forceinline__ void mfma_one_chain(const bf16x8 (&a)[2][3], const bf
 // One soft-max step of a 32 x 32 score tile held as sc[r] (this lane's query, 16 of the 32 keys; -inf = no key): running
 // maximum mb (already times c1) and sum l, rescale factor of the running output, probabilities split for the MFMA
 template <int NP>
-__device__ __forceinline__ float softmax_tile(f32x16 &sc, float c1, float &mb, float &l, bf16x8 (&pb)[2][3])
+__device__ __forceinline__ float softmax_tile(f32x16 &sc, float c1, float &mb, float &l, u32x4 (&pb)[2][3])
 {
     float tmax = fmaxf(sc[0], sc[1]);
 #pragma unroll
@@ -104,17 +105,26 @@ __device__ __forceinline__ float softmax_tile(f32x16 &sc, float c1, float &mb, f
 // [sl * TPS, (sl + 1) * TPS) of every staged chunk, sl = w % NS.  NS = 8 / NQ: all eight waves are busy for 1, 2, 4 or 8
 // query tiles, seven for 7 (the benchmark's 196 image proxies), six for 3.
 //
-// Where the time goes (r03, s_memtime stamps per phase + PMC, 4 scenes x 196 proxies: 27 us per launch, 60 k cycles per
-// wave): a (score, soft-max, second contraction) step of one wave takes ~2900 cycles while its SIMD partner runs the same
-// program -- matrix time (24 MFMAs x 32 cycles) and VALU time (~200 instructions x 4.3 cycles) of the two waves of a SIMD
-// ADD (VALU busy 62 % + matrix busy 36 % of the cycles): an in-order wave stalls on the soft-max until its score MFMAs
-// have drained, and the partner's VALU work does not slip under another wave's matrix instructions.  Tried and
-// measured, all SLOWER or equal: two interleaved accumulator chains per contraction (27.5 us: the chain was not the
-// stall); a barrier-paced ping-pong in which one wave group runs its matrix segment (second contraction of tile t +
-// scores of tile t + 1) while the other runs its VALU segment (34 us: every phase takes ~1900 cycles whichever
-// segment a wave is in); the first version's per-query-tile merges behind barriers (32 us).  What would help is an
-// in-wave software pipeline with the soft-max instructions placed BETWEEN the matrix instructions of the neighbouring
-// tiles in program order (<= 5 per MFMA slot) -- not done.
+// Where the time goes (r03, s_memtime stamps of one work-group, 4 scenes x 196 proxies, 57 k cycles = 24 us per launch):
+// start-up 7.6 k (requests 1.5-3 k, proxies split 3.1-5 k, K / V split 5.4-7.5 k, barrier), stage A 21 k (eight steps per
+// wave, two waves per SIMD: 1330 cycles per step and wave), merge + PV^T 2.5 k, stage B 19.5 k (seven steps, 1390 each).
+// A step's matrix time is 24 MFMAs x 32 cycles = 768; with the MFMAs removed the launch takes 20.2 us, with the soft-max
+// arithmetic removed 18.8 us, with both in 24.2 us: the two waves of a SIMD hide a little more than half of the matrix time
+// under each other's VALU work, the VALU instruction stream is what a step waits for.  What that stream cost, and what
+// did NOT help (all measured on one box against the same build, scratch/lab_ab.sh):
+//   * fragments carried as bf16x8 values were taken apart and re-packed around every conditional reload (24 v_lshrrev +
+//     24 v_perm per step): raw u32x4 registers (split3.h); the masked_fill selects (16 v_cmp + 16 v_cndmask + 14 hazard
+//     nops per step) run only for key tiles that have a bias (per-tile flags); the start-up's loads are all requested up
+//     front, branch-free, with 32-bit offsets (the proxy staging loop waited with vmcnt(0) per trip; sixteen conditional V
+//     loads were sixteen basic blocks with a 64-bit multiply each): 26.1 -> 23.0 us, 31.1 -> 28.6 us at 32 scenes
+//   * hand-packed soft-max arithmetic (v_pk_fma / v_pk_mul / v_pk_add: 189 -> 154 VALU instructions per step): 24.0 us;
+//     v_pk_add_f32 for the split residuals: 24.9; v_max3_f32 by inline assembly (no canonicalising v_max x, x): 23.7 --
+//     fewer instructions, all slower; the compiler's own SLP pairing costs 2 % (-fno-slp-vectorize in the Makefile)
+//   * two interleaved accumulator chains per contraction: 27.5 vs 27 us; a barrier-paced ping-pong of matrix and VALU
+//     segments between the two wave groups: 34 us; per-query-tile merges behind barriers (first version): 32 us
+//   * an in-wave software pipeline of stage B (block j issues the MFMAs of PV(j - 1) and S(j + 1) as two chains in one
+//     basic block with the VALU work of soft-max(j), sched_group_barrier places 9 VALU behind every MFMA; 249 VGPRs, no
+//     spills, parity green): 25.35 vs 25.39 us -- the extra register traffic costs what the overlap gains.
 template <int NP>       // 3: split operands (fp32-equivalent); 1: plain bf16 operands (compute_dtype = 1)
 __global__ __launch_bounds__(kFaWaves * 64) void k_proxy_attn(FAttnBatch ab)
 {
@@ -128,84 +138,108 @@ __global__ __launch_bounds__(kFaWaves * 64) void k_proxy_attn(FAttnBatch ab)
     const int NQ = (Lp + 31) >> 5, LpPad = NQ * 32, NKT = (n + 31) >> 5;
     char *Pk = smem;
     float *kbias = reinterpret_cast<float *>(smem + kFaBiasOff);
+    int *tflag = reinterpret_cast<int *>(smem + kFaFlagOff);
     char *Kp = smem + kFaRegOff, *Vt = Kp + 3 * kFaRowPlane;        // stage A
     char *PVt = smem + kFaRegOff;                                   // after stage A (same bytes)
     float *slots = reinterpret_cast<float *>(smem + kFaSlotOff);
-    const float *qkv = p.qkv + (size_t)b * n * 3 * C + h * 32;
+    const int C3 = 3 * C;
+    const float *qkv = p.qkv + (size_t)b * n * C3 + h * 32;
     const float c1 = ab.scale * kLog2e;         // soft-max exponents in base 2: exp(scale (s - m)) = exp2(c1 s - c1 m)
     // per-lane bases of the fragment reads: rows of a row-major plane (two 16-byte pieces, swizzled), rows of a transposed one
     const int rowA = li * XROW + xswz(li, hh), rowB = li * XROW + xswz(li, 2 + hh);     // + tile * 2048 + plane * kFaRowPlane
     const int trow = li * kFaTStride + 16 * hh;                                         // + tile * 64 + 32 s + plane * kFaTPlane
-    auto read_rows = [&](const char *base, int tile, bf16x8 (&f)[2][3]) {
+    auto read_rows = [&](const char *base, int tile, u32x4 (&f)[2][3]) {
 #pragma unroll
         for (int pt3 = 0; pt3 < NP; ++pt3) {
-            f[0][pt3] = *reinterpret_cast<const bf16x8 *>(base + rowA + tile * (32 * XROW) + pt3 * kFaRowPlane);
-            f[1][pt3] = *reinterpret_cast<const bf16x8 *>(base + rowB + tile * (32 * XROW) + pt3 * kFaRowPlane);
+            f[0][pt3] = *reinterpret_cast<const u32x4 *>(base + rowA + tile * (32 * XROW) + pt3 * kFaRowPlane);
+            f[1][pt3] = *reinterpret_cast<const u32x4 *>(base + rowB + tile * (32 * XROW) + pt3 * kFaRowPlane);
         }
     };
-    auto read_trans = [&](const char *base, int tile, bf16x8 (&f)[2][3]) {
+    auto read_trans = [&](const char *base, int tile, u32x4 (&f)[2][3]) {
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int pt3 = 0; pt3 < NP; ++pt3)
-                f[s][pt3] = *reinterpret_cast<const bf16x8 *>(base + trow + tile * 64 + 32 * s + pt3 * kFaTPlane);
+                f[s][pt3] = *reinterpret_cast<const u32x4 *>(base + trow + tile * 64 + 32 * s + pt3 * kFaTPlane);
     };
 
     // K / V fragments of key tile kt as the MFMAs take them: kf = K[key li][dims 16 s + 8 hh ..], vf = V[key(t, hh, j)][dim li]
     auto load_kv = [&](int kt, float (&kf)[16], float (&vf)[16]) {
+        // (offsets are 32-bit and formed by additions from one product per lane: a 64-bit multiply per load is a dozen
+        //  quarter-rate instructions, 2 to 3 thousand cycles before the last of these loads was even issued)
         const int key = min(32 * kt + li, n - 1);
-        const float4 *kr = reinterpret_cast<const float4 *>(qkv + (size_t)key * 3 * C + C + 8 * hh);
+        const float4 *kr = reinterpret_cast<const float4 *>(qkv + (key * C3 + C + 8 * hh));
         const float4 k0 = kr[0], k1 = kr[1], k2 = kr[4], k3 = kr[5];
         kf[0] = k0.x; kf[1] = k0.y; kf[2] = k0.z; kf[3] = k0.w; kf[4] = k1.x; kf[5] = k1.y; kf[6] = k1.z; kf[7] = k1.w;
         kf[8] = k2.x; kf[9] = k2.y; kf[10] = k2.z; kf[11] = k2.w; kf[12] = k3.x; kf[13] = k3.y; kf[14] = k3.z; kf[15] = k3.w;
+        const int v0 = (32 * kt + 4 * hh) * C3 + 2 * C + li, vmax = (n - 1) * C3 + 2 * C + li;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int kk = 32 * kt + (j & 3) + 8 * (2 * t + (j >> 2)) + 4 * hh;
-                vf[8 * t + j] = kk < n ? qkv[(size_t)kk * 3 * C + 2 * C + li] : 0.0f;
+                vf[8 * t + j] = qkv[min(v0 + ((j & 3) + 8 * (2 * t + (j >> 2))) * C3, vmax)];   // clamped: no branch per load
             }
     };
     // ... split and stored as local tile `lt` of the staged chunk
-    auto stash_kv = [&](int lt, const float (&kf)[16], const float (&vf)[16]) {
+    auto stash_kv = [&](int lt, int kt, const float (&kf)[16], const float (&vf)[16]) {
+        const int kv0 = 32 * kt + 4 * hh;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             float x[8], y[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { x[i] = kf[8 * s + i]; y[i] = vf[8 * s + i]; }
-            bf16x8 fk[3], fv[3];
+            for (int i = 0; i < 8; ++i) {
+                x[i] = kf[8 * s + i];
+                y[i] = kv0 + (i & 3) + 8 * (2 * s + (i >> 2)) < n ? vf[8 * s + i] : 0.0f;       // rows beyond the scene: zero
+            }
+            u32x4 fk[3], fv[3];
             frag_parts<NP>(x, fk);
             frag_parts<NP>(y, fv);
 #pragma unroll
             for (int pt3 = 0; pt3 < NP; ++pt3) {
-                *reinterpret_cast<bf16x8 *>(Kp + (s ? rowB : rowA) + lt * (32 * XROW) + pt3 * kFaRowPlane) = fk[pt3];
-                *reinterpret_cast<bf16x8 *>(Vt + trow + lt * 64 + 32 * s + pt3 * kFaTPlane) = fv[pt3];
+                *reinterpret_cast<u32x4 *>(Kp + (s ? rowB : rowA) + lt * (32 * XROW) + pt3 * kFaRowPlane) = fk[pt3];
+                *reinterpret_cast<u32x4 *>(Vt + trow + lt * 64 + 32 * s + pt3 * kFaTPlane) = fv[pt3];
             }
         }
     };
     // the query rows of stage B's round `rnd` of this wave (tokens 32 (wv + 8 rnd) + li), requested long before they are split
     auto load_q = [&](int rnd, float4 (&q)[4]) {
         const int tok = min(32 * (wv + kFaWaves * rnd) + li, n - 1);
-        const float4 *qr = reinterpret_cast<const float4 *>(qkv + (size_t)tok * 3 * C + 8 * hh);
+        const float4 *qr = reinterpret_cast<const float4 *>(qkv + (tok * C3 + 8 * hh));
         q[0] = qr[0]; q[1] = qr[1]; q[2] = qr[4]; q[3] = qr[5];
     };
+    // ---- prologue: every global load of the start-up is requested up front, branch-free (clamped rows, masked when they
+    // are split): the projected proxies of this (scene, head), this wave's K / V tile, the key mask
+    const float *pt = p.pt + (size_t)b * Lp * C + h * 32;
+    constexpr int kTrips = kFaChunk * 8 / (kFaWaves * 64);
+    float4 pv[kTrips];
+#pragma unroll
+    for (int i = 0; i < kTrips; ++i) {
+        const int e = tid + i * kFaWaves * 64;
+        pv[i] = *reinterpret_cast<const float4 *>(pt + (min(e >> 3, Lp - 1) * C + (e & 7) * 4));
+    }
     float kf[16], vf[16];
-    if (wv < NKT) load_kv(wv, kf, vf);                      // requested first: in flight under the proxy staging
+    load_kv(min(wv, NKT - 1), kf, vf);
+    int mk = 1;
+    if (p.mask != nullptr && tid < kFaChunk) mk = p.mask[(size_t)b * Lp + min(tid, Lp - 1)];     // (wave-uniform branch)
 
-    // ---- the projected proxies of this (scene, head) -> three bf16 planes in LDS; key bias of stage B
-    {
-        const float *pt = p.pt + (size_t)b * Lp * C + h * 32;
-        for (int e = tid; e < LpPad * 8; e += kFaWaves * 64) {
-            const int row = e >> 3, kq = (e & 7) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < Lp) v = *reinterpret_cast<const float4 *>(pt + (size_t)row * C + kq);
-            stash_parts<NP>(Pk + row * XROW + xswz(row, kq >> 3) + (kq & 4) * 2, kFaRowPlane, v);
-        }
-        const float masked = -1e9f / ab.scale;              // masked_fill(-1e9) of the SCALED scores (PRE:247), in raw units
-        for (int k = tid; k < LpPad; k += kFaWaves * 64) {
-            float kb = k >= Lp ? -INFINITY : 0.0f;          // 0: valid key; -inf: beyond the proxies
-            if (k < Lp && p.mask != nullptr && p.mask[(size_t)b * Lp + k] == 0) kb = masked;
-            kbias[k] = kb;
+    // the proxies -> three bf16 planes in LDS
+#pragma unroll
+    for (int i = 0; i < kTrips; ++i) {
+        const int e = tid + i * kFaWaves * 64, row = e >> 3, kq = (e & 7) * 4;
+        if (row < LpPad)
+            stash_parts<NP>(Pk + row * XROW + xswz(row, kq >> 3) + (kq & 4) * 2, kFaRowPlane,
+                            row < Lp ? pv[i] : make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+    // key bias of stage B: 0 = valid key, -inf = beyond the proxies, masked_fill(-1e9) of the SCALED scores (PRE:247) in
+    // raw units; and per key tile whether any key has one (most tiles have none: their 16 selects per lane are skipped)
+    if (tid < kFaChunk) {                                   // waves 0..3: two key tiles each
+        float kb = tid >= Lp ? -INFINITY : 0.0f;
+        if (tid < Lp && mk == 0) kb = -1e9f / ab.scale;
+        kbias[tid] = kb;
+        const unsigned long long nz = __ballot(kb != 0.0f);
+        if (lane == 0) {
+            tflag[2 * wv] = (unsigned)nz != 0u;
+            tflag[2 * wv + 1] = (unsigned)(nz >> 32) != 0u;
         }
     }
 
@@ -217,7 +251,7 @@ __global__ __launch_bounds__(kFaWaves * 64) void k_proxy_attn(FAttnBatch ab)
     f32x16 oA;
 #pragma unroll
     for (int i = 0; i < 16; ++i) oA[i] = 0.0f;
-    bf16x8 qb[2][3], ka[2][3], va[2][3], pb[2][3];
+    u32x4 qb[2][3], ka[2][3], va[2][3], pb[2][3];
     f32x16 sc;
     for (int c0 = 0; c0 < NKT; c0 += kFaWaves) {            // chunks of 8 key tiles staged through LDS
         if (c0 > 0) {
@@ -226,7 +260,7 @@ __global__ __launch_bounds__(kFaWaves * 64) void k_proxy_attn(FAttnBatch ab)
             load_kv(min(c0 + wv, NKT - 1), kf, vf);         // unconditional: the old values are dead for the allocator too
             __syncthreads();                                // every wave is done with the previous chunk
         }
-        if (c0 + wv < NKT) stash_kv(wv, kf, vf);
+        if (c0 + wv < NKT) stash_kv(wv, c0 + wv, kf, vf);
         __syncthreads();
         if (c0 == 0 && activeA) read_rows(Pk, qtA, qb);
         const int NT = min(kFaWaves, NKT - c0);                                  // tiles of this chunk
@@ -297,6 +331,7 @@ __global__ __launch_bounds__(kFaWaves * 64) void k_proxy_attn(FAttnBatch ab)
     __syncthreads();
 
     // ---- stage B: O = softmax_L(mask((Q scale) P^T)) PV (PRE:241-250); a wave owns whole query tiles (rounds of eight)
+    const unsigned bflags = (unsigned)__ballot(tflag[lane & 7] != 0) & 0xffu;      // bit j: key tile j has a bias somewhere
     const int rounds = (NKT + kFaWaves - 1) / kFaWaves;
     for (int rnd = 0; rnd < rounds; ++rnd) {
         const int qt = wv + kFaWaves * rnd;
@@ -330,7 +365,7 @@ __global__ __launch_bounds__(kFaWaves * 64) void k_proxy_attn(FAttnBatch ab)
             for (int i = 0; i < 16; ++i) sc[i] = 0.0f;
             mfma_one_chain<NP>(ka, qb, sc);
             if (j + 1 < NQ) read_rows(Pk, j + 1, ka);
-            bias_tile(j);
+            if ((bflags >> j) & 1u) bias_tile(j);
             const float alpha = softmax_tile<NP>(sc, c1, mb, l, pb);
 #pragma unroll
             for (int i = 0; i < 16; ++i) o[i] *= alpha;

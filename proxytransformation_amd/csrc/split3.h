@@ -16,6 +16,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ void split3_pair(float x, float y, unsigned &p1, unsigned &p2, unsigned &p3)
 {
+    // (forcing the residuals into v_pk_add_f32 -- inline assembly; the compiler takes a two-wide subtraction of freshly built
+    //  halves apart again -- halves these instructions and made k_proxy_attn 8 % SLOWER: r03, scratch/README.md)
     const f32x2 v = {x, y};
     p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
     const f32x2 r1 = {x - __uint_as_float(p1 << 16), y - __uint_as_float(p1 & 0xffff0000u)};
@@ -86,6 +88,39 @@ __device__ __forceinline__ f32x16 mfma_parts(const bf16x8 (&a)[3], const bf16x8 
 {
     if (NP == 3) return mfma_split6(a, b, acc);
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+}
+
+// The same on raw registers (four dwords = eight bf16).  Kernels that carry fragments around loops keep them in this type: a
+// bf16x8 value that crosses a conditional reload is taken apart into sixteen-bit halves by the compiler and put together
+// again with a v_lshrrev + v_perm per dword (48 VALU instructions per 32 x 32 x 32 step of k_proxy_attn, measured r03).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <int NP>
+__device__ __forceinline__ void frag_parts(const float (&x)[8], u32x4 (&f)[3])
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (NP == 3) {
+            unsigned a, b, c;
+            split3_pair(x[2 * i], x[2 * i + 1], a, b, c);
+            f[0][i] = a; f[1][i] = b; f[2][i] = c;
+        } else {
+            const f32x2 v = {x[2 * i], x[2 * i + 1]};
+            f[0][i] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+        }
+    }
+}
+template <int NP>
+__device__ __forceinline__ f32x16 mfma_parts(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x16 acc)
+{
+    auto bf = [](const u32x4 &q) { return __builtin_bit_cast(bf16x8, q); };
+    if (NP == 3) {                                  // the six products of mfma_split6, small terms first
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a[2]), bf(b[0]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a[1]), bf(b[1]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a[0]), bf(b[2]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a[1]), bf(b[0]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a[0]), bf(b[1]), acc, 0, 0, 0);
+    }
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(a[0]), bf(b[0]), acc, 0, 0, 0);
 }
 
 // LDS rows of the split tiles: 32 bf16 = 64 bytes, unpadded; the four 16-byte pieces of row r sit at piece ^ ((r >> 2) & 3),
