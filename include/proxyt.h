@@ -226,7 +226,11 @@ int ptx_affine_compact(const PtxShape *s, const float *points, const uint32_t *t
  *   pv  = softmax_n((P scale) K^T) V                      (proxy as query, unmasked, PRE:232-238)
  *   out = softmax_L(masked_fill((Q scale) P^T, -1e9)) pv  (proxy as key, PRE:241-250), heads merged: out (B*n, C).
  * impl 0: the library's choice for the shape; 1: one fused launch (csrc/fattn.hip; head_dim 32 only); 2: two launches of
- * the fp32 matrix-instruction kernel (csrc/attn.hip), which need scratch (B*Lp*C floats) for pv. */
+ * the fp32 matrix-instruction kernel (csrc/attn.hip), which need scratch for pv; 3: the fused launch with the proxies of
+ * every (scene, head) in four slices on four work-groups, merged by the last to arrive (what the forward uses when a call
+ * has few scenes), which needs scratch for tickets + partial results.  scratch: ptx_proxy_attention_scratch_bytes() bytes
+ * for the impl passed (0 and 2: B*Lp*C floats). */
+size_t ptx_proxy_attention_scratch_bytes(int B, int n, int Lp, int heads, int C, int impl);
 int ptx_proxy_attention(const float *qkv, const float *pt, const uint8_t *mask, float *out, float *scratch, int B, int n,
                         int Lp, int heads, int C, int impl, void *stream);
 

@@ -102,6 +102,7 @@ SIGNATURES.update({
     "ptx_forward_ex": (_I, [_P, _SH, _W, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z,
                             C.POINTER(PtxDebug), C.POINTER(PtxForwardOpts), _P]),
     "ptx_proxy_attention": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "ptx_proxy_attention_scratch_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
     "ptx_ingest_workspace_bytes": (_Z, [_I, _I, _I]),
     "ptx_ingest_index": (_I, [_P, _I, _I, _I, _I, _P, _Z, _P, _P]),
     "ptx_ingest_gather": (_I, [_P, _I, _F, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _Z, _P]),

@@ -129,6 +129,7 @@ WsLayout ws_layout(const PtxShape &s)
     L.mm_enc = take(B * 6 * 4);
     L.scene_acc = take(B * 2 * 4);
     L.tag = take(B * N * 4);
+    L.fa_ticket = take(2 * B * s.heads * 4);
     L.zero_bytes = o - L.zero_begin;
     L.minmax = take(B * 6 * 4);
     L.centers0 = take(B * M * 3 * 4); L.cluster1 = take(B * M * K * 3 * 4);
@@ -154,6 +155,8 @@ WsLayout ws_layout(const PtxShape &s)
         L.lnp_x1[i] = take(R * (C / 32) * 2 * 4);
     }
     L.lnp_img = take(nimg * (C / 32) * 2 * 4);
+    const size_t fsp = fattn_split_for(s.B, s.heads);
+    L.fa_part = take(fsp > 1 ? 2 * B * s.heads * fsp * Mk * kFaPartRow * 4 : 0);
     L.total = o;
     return L;
 }
@@ -386,6 +389,7 @@ static int run_blocks(const PtxShape &s, const Branch *br, int nb, const float *
     }
     FAttnBatch fa{}; fa.nb = nb; fa.B = s.B; fa.heads = s.heads; fa.hd = C / s.heads; fa.n = s.Mk; fa.C = C;
     fa.scale = attn_scale(C / s.heads); fa.compute_dtype = cd;
+    fa.split = fattn_split_for(s.B, s.heads); fa.part = at<float>(ws, L.fa_part); fa.tickets = at<int>(ws, L.fa_ticket);
     for (int i = 0; i < nb; ++i) {
         const int sl = br[i].slot;
         fa.p[i] = FAttnProb{at<float>(ws, L.qkv[sl]), at<float>(ws, L.pt[sl]), br[i].mask, at<float>(ws, L.ao[sl]), br[i].Lp};
@@ -718,18 +722,34 @@ int ptx_proxy_block(const PtxShape *s, const PtxWeights *w, const void *prep, in
     return run_blocks(*s, &br, 1, point_proxy, workspace, st);
 }
 
+size_t ptx_proxy_attention_scratch_bytes(int B, int n, int Lp, int heads, int C, int impl)
+{
+    if (B < 1 || n < 1 || Lp < 1 || heads < 1 || C < heads) return 0;
+    if (impl == 3) return 256 + (size_t)B * heads * 4 + (size_t)B * heads * kFaMaxSplit * n * kFaPartRow * sizeof(float);
+    return (size_t)B * Lp * C * sizeof(float);
+}
+
 int ptx_proxy_attention(const float *qkv, const float *pt, const uint8_t *mask, float *out, float *scratch, int B, int n,
                         int Lp, int heads, int C, int impl, void *stream)
 {
     PTX_REQUIRE(qkv && pt && out, "ptx_proxy_attention: null argument");
     PTX_REQUIRE(B >= 1 && n >= 1 && Lp >= 1 && heads >= 1 && C >= heads && C % heads == 0, "ptx_proxy_attention: B=%d n=%d Lp=%d heads=%d C=%d", B, n, Lp, heads, C);
-    PTX_REQUIRE(impl >= 0 && impl <= 2, "ptx_proxy_attention: impl=%d", impl);
+    PTX_REQUIRE(impl >= 0 && impl <= 3, "ptx_proxy_attention: impl=%d", impl);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int hd = C / heads;
     FAttnBatch fa{}; fa.nb = 1; fa.B = B; fa.heads = heads; fa.hd = hd; fa.n = n; fa.C = C; fa.scale = attn_scale(hd);
     fa.p[0] = FAttnProb{qkv, pt, mask, out, Lp};
+    fa.split = 1;
     const bool can = fused_attn_supported(fa);
-    PTX_REQUIRE(impl != 1 || can, "ptx_proxy_attention: the fused kernel does not support head_dim=%d, Lp=%d", hd, Lp);
+    PTX_REQUIRE((impl != 1 && impl != 3) || can, "ptx_proxy_attention: the fused kernel does not support head_dim=%d, Lp=%d", hd, Lp);
+    if (impl == 3) {        // the fused kernel with the proxies in four slices: tickets (cleared here) + partials in scratch
+        PTX_REQUIRE(scratch != nullptr, "ptx_proxy_attention: impl 3 needs ptx_proxy_attention_scratch_bytes() of scratch");
+        const size_t tb = align_up((size_t)B * heads * 4, 256);
+        PTX_HIP(hipMemsetAsync(scratch, 0, tb, st));
+        fa.split = kFaMaxSplit; fa.tickets = reinterpret_cast<int *>(scratch);
+        fa.part = reinterpret_cast<float *>(reinterpret_cast<char *>(scratch) + tb);
+        return launch_proxy_attn(fa, st);
+    }
     if (impl == 1 || (impl == 0 && can && (n <= 256 || (long)B * heads >= 96))) return launch_proxy_attn(fa, st);
     PTX_REQUIRE(scratch != nullptr, "ptx_proxy_attention: the two-launch form needs scratch for pv");
     AttnBatch a{}; a.n = 1; a.B = B; a.heads = heads; a.hd = hd; a.scale = attn_scale(hd);

@@ -117,12 +117,14 @@ struct WsLayout {
     size_t mm_enc;                  // (B,6) uint32 encoded min / max
     size_t scene_acc;               // (B,2) int32 survivor-count accumulator + arrival ticket
     size_t tag;                     // (B,N) uint32
+    size_t fa_ticket;               // (2, B*heads) int32 arrival tickets of the split fused attention
     size_t minmax, centers0, cluster1, offsets, centers, idx2, cluster2, pad_count;
     size_t order, picks, keep, ksrc, kcenter, kcluster, kidx, drop_idx, tile_counts;
     size_t point_proxy, x_in[2];    // x_in: LN1(x)+slot bias per branch (B*Mk,C)
     size_t fm, qkv0, we, pool, gbuf, obuf, cbuf, img_proxy;
     size_t qkv[2], pt[2], pv[2], ao[2], x1[2], xn2[2], hbuf[2], x2[2], guide[2], head[2];
     size_t lnp_img, lnp_x1[2];      // LayerNorm partials (rows, C/32, 2) of c_proj's / proj's output
+    size_t fa_part;                 // (2, B*heads, split, Mk, 34) partial results of the split fused attention
     size_t total;
 };
 WsLayout ws_layout(const PtxShape &s);
@@ -186,7 +188,15 @@ int launch_attn32(const AttnBatch &ab, hipStream_t st);
 // fused ProxyAttention of one (scene, head, branch) per work-group (fattn.hip): qkv (B*n, 3C) rows [q | k | v], pt (B*Lp, C)
 // projected proxies, mask (B,Lp) uint8 (1 = valid) or null, out (B*n, C)
 struct FAttnProb { const float *qkv, *pt; const uint8_t *mask; float *out; int Lp; };
-struct FAttnBatch { FAttnProb p[2]; int nb, B, heads, hd, n, C; float scale; int compute_dtype; };
+struct FAttnBatch {
+    FAttnProb p[2]; int nb, B, heads, hd, n, C; float scale; int compute_dtype;
+    // proxy split (calls with few (scene, head) pairs): `split` work-groups share a (scene, head, branch), each takes a
+    // slice of the proxies through both stages; partial results (un-normalised output, running maximum, sum per token) go
+    // through `part`, the last one to arrive (ticket) merges.  tickets: (nb, B*heads) int32, zero on entry, left zero.
+    int split; float *part; int *tickets;
+};
+int fattn_split_for(int B, int heads);                      // a pure function of the shape: the workspace is sized with it
+constexpr int kFaMaxSplit = 4, kFaPartRow = 34;             // floats per (split, token): 32 outputs + maximum + sum
 bool fused_attn_supported(const FAttnBatch &ab);
 int launch_proxy_attn(const FAttnBatch &ab, hipStream_t st);
 

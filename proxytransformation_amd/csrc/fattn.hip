@@ -53,6 +53,39 @@ __device__ __forceinline__ float half_sum(float x)
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+// agent-scope relaxed stores / loads (global_store / global_load ... sc1): visible across the XCDs' L2s without a fence
+__device__ __forceinline__ void st_agent(float *p, float a, float b, float c, float d)
+{
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 v = {a, b, c, d};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void st_agent(float *p, float a, float b)
+{
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 v = {a, b};
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+}
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+// (loads by inline assembly: the compiler does not count them -- every value is passed through wait_agent() before use)
+__device__ __forceinline__ f32x4v ld4_agent(const float *p)
+{
+    f32x4v v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ f32x2v ld2_agent(const float *p)
+{
+    f32x2v v;
+    asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void wait_agent(f32x4v &a, f32x4v &b, f32x4v &c, f32x4v &d, f32x2v &e, f32x2v &f, f32x2v &g, f32x2v &h)
+{
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) :: "memory");
+}
+
 constexpr int kFaChunk = 32 * kFaWaves;         // keys staged per pass of stage A: one key tile per wave
 
 // LDS geometry, fixed (so that every fragment address is one per-lane base + an immediate): planes of 256 rows x 64 B for
@@ -134,8 +167,13 @@ __global__ __launch_bounds__(kFaWaves * 64) void k_proxy_attn(FAttnBatch ab)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, hh = lane >> 5;
-    const int n = ab.n, C = ab.C, Lp = p.Lp;
-    const int NQ = (Lp + 31) >> 5, LpPad = NQ * 32, NKT = (n + 31) >> 5;
+    const int n = ab.n, C = ab.C, NKT = (n + 31) >> 5;
+    // proxy split: this work-group takes the proxy tiles [t0, t1) of the branch through both stages as if they were all
+    // (a slice of one tile is all fixed cost: branches with one or two proxy tiles -- the text branch -- stay whole)
+    const int NQall = (p.Lp + 31) >> 5, S = min(ab.split, (NQall + 1) >> 1), sp = blockIdx.z;
+    if (sp >= S) return;
+    const int t0 = sp * NQall / S, t1 = (sp + 1) * NQall / S;
+    const int Lp = min(p.Lp, 32 * t1) - 32 * t0, NQ = t1 - t0, LpPad = NQ * 32;
     char *Pk = smem;
     float *kbias = reinterpret_cast<float *>(smem + kFaBiasOff);
     int *tflag = reinterpret_cast<int *>(smem + kFaFlagOff);
@@ -209,7 +247,7 @@ __global__ __launch_bounds__(kFaWaves * 64) void k_proxy_attn(FAttnBatch ab)
     };
     // ---- prologue: every global load of the start-up is requested up front, branch-free (clamped rows, masked when they
     // are split): the projected proxies of this (scene, head), this wave's K / V tile, the key mask
-    const float *pt = p.pt + (size_t)b * Lp * C + h * 32;
+    const float *pt = p.pt + ((size_t)b * p.Lp + 32 * t0) * C + h * 32;
     constexpr int kTrips = kFaChunk * 8 / (kFaWaves * 64);
     float4 pv[kTrips];
 #pragma unroll
@@ -220,7 +258,7 @@ __global__ __launch_bounds__(kFaWaves * 64) void k_proxy_attn(FAttnBatch ab)
     float kf[16], vf[16];
     load_kv(min(wv, NKT - 1), kf, vf);
     int mk = 1;
-    if (p.mask != nullptr && tid < kFaChunk) mk = p.mask[(size_t)b * Lp + min(tid, Lp - 1)];     // (wave-uniform branch)
+    if (p.mask != nullptr && tid < kFaChunk) mk = p.mask[(size_t)b * p.Lp + 32 * t0 + min(tid, Lp - 1)];     // (wave-uniform branch)
 
     // the proxies -> three bf16 planes in LDS
 #pragma unroll
@@ -372,12 +410,69 @@ __global__ __launch_bounds__(kFaWaves * 64) void k_proxy_attn(FAttnBatch ab)
             mfma_one_chain<NP>(va, pb, o);
         }
         if (has && tok < n) {
-            const float inv = 1.0f / l;
-            float *dst = p.out + ((size_t)b * n + tok) * C + h * 32;
+            if (S == 1) {
+                const float inv = 1.0f / l;
+                float *dst = p.out + ((size_t)b * n + tok) * C + h * 32;
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<float4 *>(dst + 8 * g + 4 * hh) =
-                    make_float4(o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4 *>(dst + 8 * g + 4 * hh) =
+                        make_float4(o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+            } else {                                        // this slice's share: un-normalised, with its maximum and sum
+                float *po = ab.part + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * ab.split + sp) * n * kFaPartRow;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) st_agent(po + (size_t)tok * 32 + 8 * g + 4 * hh, o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]);
+                if (hh == 0) st_agent(po + (size_t)n * 32 + 2 * tok, mb, l);
+            }
+        }
+    }
+    if (S == 1) return;
+    // ---- the last slice of this (scene, head, branch) to arrive merges them (split soft-max, slices in index order).
+    // The partials travel as agent-scope stores and loads (sc1: written through / read past the XCD's L2) around a relaxed
+    // ticket -- NOT behind release / acquire fences: a fence is a write-back (buffer_wbl2) plus an invalidate (buffer_inv)
+    // of the whole L2 per wave, measured 41 instead of 23 us at 4 scenes and 264 instead of 29 us at 32.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int *tk = ab.tickets + blockIdx.y * gridDim.x + blockIdx.x;
+    if (tid == 0) tflag[0] = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (tflag[0] != S - 1) return;
+    if (tid == 0) __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // left zero for the next launch
+    const float *gp = ab.part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * ab.split * n * kFaPartRow;
+    // (every load of up to four (token, four outputs) items per thread is requested before the first is used: they come from
+    //  the memory side, one round trip instead of one per item -- 13-19 k cycles of the first version's 46 k)
+    constexpr int kItems = 4;
+    for (int i0 = tid; i0 < n * 8; i0 += kItems * kFaWaves * 64) {
+        f32x4v v[kItems][kFaMaxSplit];
+        f32x2v ml[kItems][kFaMaxSplit];
+#pragma unroll
+        for (int it = 0; it < kItems; ++it) {
+            const int idx = min(i0 + it * kFaWaves * 64, n * 8 - 1), tok = idx >> 3, d4 = (idx & 7) * 4;
+#pragma unroll
+            for (int s = 0; s < kFaMaxSplit; ++s) {
+                const float *ps = gp + (size_t)min(s, S - 1) * n * kFaPartRow;     // (slices that do not exist: re-read the last)
+                v[it][s] = ld4_agent(ps + (size_t)tok * 32 + d4);
+                ml[it][s] = ld2_agent(ps + (size_t)n * 32 + 2 * tok);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < kItems; ++it) {
+            wait_agent(v[it][0], v[it][1], v[it][2], v[it][3], ml[it][0], ml[it][1], ml[it][2], ml[it][3]);
+            const int idx = i0 + it * kFaWaves * 64, tok = idx >> 3, d4 = (idx & 7) * 4;
+            float m = -INFINITY;
+#pragma unroll
+            for (int s = 0; s < kFaMaxSplit; ++s) m = fmaxf(m, s < S ? ml[it][s][0] : -INFINITY);
+            float lsum = 0.0f, acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < kFaMaxSplit; ++s) {
+                const float w = s < S ? __builtin_amdgcn_exp2f(ml[it][s][0] - m) : 0.0f;
+                lsum = fmaf(ml[it][s][1], w, lsum);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) acc[d] = fmaf(v[it][s][d], w, acc[d]);
+            }
+            const float inv = 1.0f / lsum;
+            if (idx < n * 8)
+                *reinterpret_cast<float4 *>(p.out + ((size_t)b * n + tok) * C + h * 32 + d4) =
+                    make_float4(acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv);
         }
     }
 }
@@ -391,9 +486,21 @@ bool fused_attn_supported(const FAttnBatch &ab)
     return lpmax >= 1 && lpmax <= kFaChunk;
 }
 
+// Slices of the proxies per (scene, head, branch): with few pairs in a call one work-group each leaves most of the chip idle
+// (4 scenes x 8 heads x 2 branches = 64 of 256 CUs); up to four slices fill it.  PTX_FA_SPLIT forces a value (A/B runs).
+int fattn_split_for(int B, int heads)
+{
+    static const int env = getenv("PTX_FA_SPLIT") ? atoi(getenv("PTX_FA_SPLIT")) : 0;
+    if (env >= 1) return env > kFaMaxSplit ? kFaMaxSplit : env;
+    const long groups = (long)B * heads * 2;
+    const long s = 256 / (groups > 0 ? groups : 1);
+    return s < 1 ? 1 : s > kFaMaxSplit ? kFaMaxSplit : (int)s;
+}
+
 int launch_proxy_attn(const FAttnBatch &ab_in, hipStream_t st)
 {
     FAttnBatch ab = ab_in;
+    if (ab.split == 0) ab.split = 1;                        // callers that do not know about the proxy split
     PTX_REQUIRE(ab.nb >= 1 && ab.nb <= 2 && ab.hd == 32, "fused attention: nb=%d hd=%d", ab.nb, ab.hd);
     int lpmax = 0;
     for (int g = 0; g < ab.nb; ++g) {
@@ -402,7 +509,11 @@ int launch_proxy_attn(const FAttnBatch &ab_in, hipStream_t st)
     }
     PTX_REQUIRE(lpmax <= 32 * kFaWaves, "fused attention: at most %d proxies (got %d)", 32 * kFaWaves, lpmax);
     const int lds = kFaLds;
-    const dim3 grid(ab.B * ab.heads, ab.nb), block(kFaWaves * 64);
+    PTX_REQUIRE(ab.split >= 1 && ab.split <= kFaMaxSplit && (ab.split == 1 || (ab.part && ab.tickets)),
+                "fused attention: split=%d needs the partial buffers", ab.split);
+    // (work-groups are dealt to the XCDs round-robin by linear id, x fastest: with B * heads a multiple of eight every slice and
+    //  both branches of a (scene, head) run on XCD h % 8 and share its L2 for K, V and the partials)
+    const dim3 grid(ab.B * ab.heads, ab.nb, ab.split), block(kFaWaves * 64);
     if (ab.compute_dtype == 1) {
         PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_proxy_attn<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         hipLaunchKernelGGL(k_proxy_attn<1>, grid, block, lds, st, ab);

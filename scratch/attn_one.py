@@ -9,8 +9,8 @@ g = torch.Generator().manual_seed(1)
 qkv = torch.randn(B * n, 3 * C, generator=g).cuda()
 pt = torch.randn(B * Lp, C, generator=g).cuda()
 out = torch.empty((B * n, C), device="cuda")
-scratch = torch.empty(B * Lp * C, device="cuda")
 lib = _abi.lib()
+scratch = torch.zeros(lib.ptx_proxy_attention_scratch_bytes(B, n, Lp, heads, C, impl) // 4, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
 for _ in range(3):
     lib.ptx_proxy_attention(qkv.data_ptr(), pt.data_ptr(), None, out.data_ptr(), scratch.data_ptr(), B, n, Lp, heads, C, impl, st)

@@ -27,7 +27,7 @@ def _ref(qkv, pt, mask, B, n, Lp, heads, C):
     return out.transpose(1, 2).reshape(B * n, C)                            # PRE:252
 
 
-@pytest.mark.parametrize("impl", [1, 2], ids=["fused", "two-launch"])
+@pytest.mark.parametrize("impl", [1, 2, 3], ids=["fused", "two-launch", "fused-split"])
 @pytest.mark.parametrize("B,n,Lp,masked", [(2, 256, 196, False), (3, 256, 64, True), (1, 64, 16, True), (2, 100, 37, True),
                                            (1, 691, 50, False), (2, 691, 77, True), (1, 300, 256, False), (1, 1024, 5, True)])
 def test_proxy_attention_matches_float64(impl, B, n, Lp, masked):
@@ -43,7 +43,9 @@ def test_proxy_attention_matches_float64(impl, B, n, Lp, masked):
             mask[1, :] = 0                                                   # a scene with every token padded: uniform weights
         mask = mask.cuda()
     out = torch.full((B * n, C), float("nan"), device="cuda")
-    scratch = torch.empty(B * Lp * C, device="cuda")
+    nbytes = _abi.lib().ptx_proxy_attention_scratch_bytes(B, n, Lp, heads, C, impl)
+    assert nbytes >= (4 * B * Lp * C if impl != 3 else 4 * B * heads * 4 * n * 34)
+    scratch = torch.full((nbytes // 4,), float("nan"), device="cuda")
     _abi.check(_abi.lib().ptx_proxy_attention(qkv.data_ptr(), pt.data_ptr(), None if mask is None else mask.data_ptr(),
                                               out.data_ptr(), scratch.data_ptr(), B, n, Lp, heads, C, impl,
                                               torch.cuda.current_stream().cuda_stream), "ptx_proxy_attention")
@@ -60,12 +62,32 @@ def test_fused_and_two_launch_forms_agree_on_large_scores():
     qkv = (torch.randn(B * n, 3 * C, generator=g) * 6).cuda()
     pt = (torch.randn(B * Lp, C, generator=g) * 6).cuda()
     outs = []
-    for impl in (1, 2):
+    for impl in (1, 2, 3):
         out = torch.empty((B * n, C), device="cuda")
-        scratch = torch.empty(B * Lp * C, device="cuda")
+        scratch = torch.empty(_abi.lib().ptx_proxy_attention_scratch_bytes(B, n, Lp, heads, C, impl) // 4, device="cuda")
         _abi.check(_abi.lib().ptx_proxy_attention(qkv.data_ptr(), pt.data_ptr(), None, out.data_ptr(), scratch.data_ptr(),
                                                   B, n, Lp, heads, C, impl, torch.cuda.current_stream().cuda_stream), "attn")
         outs.append(out)
     ref = _ref(qkv, pt, None, B, n, Lp, heads, C)
     for o in outs:
         assert (o.double() - ref).abs().max().item() < 2e-4 * ref.abs().max().item()
+
+
+def test_split_form_leaves_its_tickets_zero_and_repeats_bit_for_bit():
+    """The forward reuses the ticket words call after call without clearing them: the merging work-group must leave them
+    zero, and the merge order is fixed (slices in index order), so two runs give identical bits."""
+    B, n, Lp, heads, C = 2, 256, 196, 8, 256
+    g = torch.Generator().manual_seed(9)
+    qkv = torch.randn(B * n, 3 * C, generator=g).cuda()
+    pt = torch.randn(B * Lp, C, generator=g).cuda()
+    lib = _abi.lib()
+    scratch = torch.empty(lib.ptx_proxy_attention_scratch_bytes(B, n, Lp, heads, C, 3) // 4, device="cuda")
+    outs = []
+    for _ in range(3):
+        out = torch.empty((B * n, C), device="cuda")
+        _abi.check(lib.ptx_proxy_attention(qkv.data_ptr(), pt.data_ptr(), None, out.data_ptr(), scratch.data_ptr(), B, n, Lp,
+                                           heads, C, 3, torch.cuda.current_stream().cuda_stream), "attn")
+        torch.cuda.synchronize()
+        assert int(scratch[:B * heads].view(torch.int32).abs().max()) == 0
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
