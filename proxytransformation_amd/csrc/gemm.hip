@@ -39,9 +39,16 @@ __device__ __forceinline__ float gelu_erf(float x)
 // consumer: mean / rstd of row `row` from the producer's per-tile partials
 __device__ __forceinline__ void ln_row_stats(const GemmProb &pr, int row, float &mu, float &rstd)
 {
+    // (all partials are requested before the first is added: as a loop the compiler waited for each load before issuing the
+    //  next -- eight or sixteen dependent L2 round trips in front of the K loop of the work-group's first wave)
     const float2 *pp = reinterpret_cast<const float2 *>(pr.lnp_in) + (size_t)row * pr.ln_parts;
+    constexpr int kMaxParts = 16;                           // embed_dim <= 512 (validate_shape)
+    float2 v[kMaxParts];
+#pragma unroll
+    for (int t = 0; t < kMaxParts; ++t) v[t] = pp[min(t, pr.ln_parts - 1)];
     float s1 = 0.0f, s2 = 0.0f;
-    for (int t = 0; t < pr.ln_parts; ++t) { const float2 v = pp[t]; s1 += v.x; s2 += v.y; }
+#pragma unroll
+    for (int t = 0; t < kMaxParts; ++t) { s1 += t < pr.ln_parts ? v[t].x : 0.0f; s2 += t < pr.ln_parts ? v[t].y : 0.0f; }
     const float inv = 1.0f / (float)pr.ln_C;
     mu = s1 * inv;
     const float var = fmaxf(fmaf(-mu, mu, s2 * inv), 0.0f);
@@ -458,20 +465,23 @@ __global__ __launch_bounds__(SK * 64) void k_gemm32(GemmBatch gb)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);         \
         }                                                                                 \
     } while (0)
-    // epilogue operands (used by wave 0 only) are requested up front: a dependent ~1 us round trip
-    // after the K loop otherwise
+    // epilogue operands (used by wave 0 only) are requested up front, branch-free (clamped row / column): after the K loop
+    // each would be a dependent round trip -- and the row-scaled addend was one PER OUTPUT ROW, sixteen in sequence, because a
+    // load behind the previous row's store cannot be hoisted above it (r03)
     const int n = col0 + li;
-    float bias = 0.0f, resv[16];
+    float bias = 0.0f, resv[16], adv[16], rsv[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) resv[r] = 0.0f;
-    if (wv == 0 && n < pr.N) {
-        if (pr.bias) bias = pr.bias[n];
-        if (pr.res) {
+    for (int r = 0; r < 16; ++r) { resv[r] = 0.0f; adv[r] = 0.0f; rsv[r] = 0.0f; }
+    const bool has_ad = AMODE == 1 || pr.rs != nullptr;      // work-group uniform
+    if (wv == 0) {
+        const int nc = min(n, pr.N - 1);
+        if (pr.bias) bias = pr.bias[nc];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                if (row < pr.R) resv[r] = pr.res[(size_t)row * pr.ldres + n];
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int row = min(row0 + (r & 3) + 8 * (r >> 2) + 4 * hh, pr.R - 1);
+            if (pr.res) resv[r] = pr.res[(size_t)row * pr.ldres + nc];
+            if (has_ad) adv[r] = pr.ad[(size_t)row * pr.ldad + nc];
+            if (AMODE != 1 && has_ad) rsv[r] = pr.rs[(size_t)row * pr.rs_stride];
         }
     }
     f32x16 acc;
@@ -532,8 +542,8 @@ __global__ __launch_bounds__(SK * 64) void k_gemm32(GemmBatch gb)
             if (pr.epi == EPI_GELU) v = gelu_erf(v);
             const bool ok = ncol && row < pr.R;
             if (ok) {
-                if (AMODE == 1) v = fmaf(cts[rl], pr.ad[(size_t)row * pr.ldad + n], v);
-                else if (pr.rs) v = fmaf(pr.rs[(size_t)row * pr.rs_stride], pr.ad[(size_t)row * pr.ldad + n], v);
+                if (AMODE == 1) v = fmaf(cts[rl], adv[r], v);
+                else if (pr.rs) v = fmaf(rsv[r], adv[r], v);
                 if (pr.res) v += resv[r];
                 pr.C[(size_t)row * pr.ldc + n] = v;
             }
@@ -557,12 +567,18 @@ __global__ __launch_bounds__(SK * 64) void k_gemm32(GemmBatch gb)
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) ya[kk] = *reinterpret_cast<const float4 *>(lds + li * LDT + kk * 8 + hh * 4);
         const int nt2 = (pr.n2 + 31) >> 5;
-        for (int t = wv; t < nt2; t += SK) {
-            const int m = t * 32 + li;
-            const float *wr = W2 + (size_t)min(m, pr.n2 - 1) * 32 + hh * 4;
-            float4 wb[4];
+        // (the next tile's W2 rows are requested before the current tile's MFMAs and stores: one exposed round trip per wave
+        //  instead of one per tile)
+        auto load_w2 = [&](int t, float4 (&wb)[4]) {
+            const float *wr = W2 + (size_t)min(t * 32 + li, pr.n2 - 1) * 32 + hh * 4;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) wb[kk] = *reinterpret_cast<const float4 *>(wr + kk * 8);
+        };
+        float4 wb[4], wn[4];
+        load_w2(min(wv, nt2 - 1), wb);
+        for (int t = wv; t < nt2; t += SK) {
+            const int m = t * 32 + li;
+            load_w2(min(t + SK, nt2 - 1), wn);
             f32x16 c2;
 #pragma unroll
             for (int i = 0; i < 16; ++i) c2[i] = 0.0f;
@@ -580,6 +596,8 @@ __global__ __launch_bounds__(SK * 64) void k_gemm32(GemmBatch gb)
                     if (row < pr.R) C2[(size_t)row * pr.ldc2 + m] = c2[r];
                 }
             }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) wb[kk] = wn[kk];
         }
     }
 }
