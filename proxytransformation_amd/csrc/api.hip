@@ -878,16 +878,23 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     int32_t *drop_idx = dbg && debug->drop_idx ? at<int32_t>(ws, L.drop_idx) : nullptr;
     int32_t *ksrc = at<int32_t>(ws, L.ksrc);
     static const bool ext_event = getenv("PTX_NO_EXT_EVENT") == nullptr;
+    static const int tail_env = getenv("PTX_TAGS_TAIL") ? atoi(getenv("PTX_TAGS_TAIL")) : 1;
+    const bool tags_tail = !cluster_on_caller && tail_env != 0;
     PTX_TIMED(KID_SELECT, cs, launch_select_order(S, centers, pad_count, order_override, order, picks, keep, kcenter,
-                                                  ksrc, bbox_in ? nullptr : mm_ws, cs, cluster_on_caller, ext_event ? side->aux : nullptr));
+                                                  ksrc, bbox_in ? nullptr : mm_ws, cs, cluster_on_caller, ext_event && !tags_tail ? side->aux : nullptr));
     int32_t *tile_counts = at<int32_t>(ws, L.tile_counts);
-    hipStream_t ts = side->lo;
-    // the slot tags / survivor counts (side stream) start before the point proxies when the image chain is the long
-    // one, after them when the clustering chain is (they share the chip with the kernel the step is waiting for)
-    const bool slots_first = !cluster_on_caller;
+    // The slot tags / survivor counts: only k_affine and the host need them.  When the clustering chain is the long one
+    // (it owns the caller's stream) they run on the low-priority stream next to it, after the point proxies.  When the
+    // image chain is the long one they go to the END of the clustering stream, behind its last kernel and in front of the
+    // join: one cross-queue wait on the caller's stream instead of two (each costs 6-7 us of idle between two dependent
+    // kernels wherever it is placed; r03: PTX_TAGS_TAIL=0 restores the third stream).
+    hipStream_t ts = tags_tail ? cs : side->lo;
+    const bool slots_first = !cluster_on_caller && !tags_tail;
     auto enqueue_tags = [&]() -> int {
-        if (!ext_event) PTX_HIP(hipEventRecord(side->aux, cs));     // else: recorded by k_select's own completion
-        PTX_HIP(hipStreamWaitEvent(ts, side->aux, 0));
+        if (!tags_tail) {
+            if (!ext_event) PTX_HIP(hipEventRecord(side->aux, cs));     // else: recorded by k_select's own completion
+            PTX_HIP(hipStreamWaitEvent(ts, side->aux, 0));
+        }
         // gathered copies of the kept clusters / the drop list: debug outputs only
         if (kcluster || kidx || drop_idx)
             PTX_TRY(launch_select_slots(S, idx2, cluster2, order, picks, keep, kcluster, kidx, drop_idx, nullptr, ts));
@@ -899,7 +906,7 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
             // ownership / drop tags + survivor counts (published early) in one launch, LDS atomics only
             PTX_TIMED(KID_SLOTS, ts, launch_tags(S, idx2, order, picks, ksrc, tag, tile_counts, counts, at<int32_t>(ws, L.scene_acc), ts));
         }
-        PTX_HIP(hipEventRecord(side->tags, ts));
+        if (!tags_tail) PTX_HIP(hipEventRecord(side->tags, ts));
         return PTX_OK;
     };
     if (slots_first) PTX_TRY(enqueue_tags());
@@ -910,7 +917,7 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     PTX_TIMED(KID_POINTNET, cs, launch_pointnet(pf + P.enc_ab, w->encoder, kcenter, cluster2, B * S.Mk, S.Mk, K,
                                                 S.C, point_proxy, &w->text, &w->img, pf + P.posb_t, pf + P.posb_i, xin_t,
                                                 xin_i, S.ln_eps, ksrc, M, cs));
-    if (!slots_first) PTX_TRY(enqueue_tags());
+    if (!slots_first && !tags_tail) PTX_TRY(enqueue_tags());
 
     // ---- both proxy blocks + heads in shared launches (PRE:440-455); the input projections that
     // do not need the image proxies still run on the clustering stream
@@ -925,6 +932,7 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     // branch after the join, was measured slower: 12.6k vs 13.7k scenes/s -- eight more launches, and its
     // small kernels take CUs from the image passes that are on the critical path.)
     PTX_TRY(run_blocks(S, br, 2, point_proxy, ws, cs, 1, compute_dtype));
+    if (tags_tail) PTX_TRY(enqueue_tags());
     if (!cluster_on_caller) PTX_HIP(hipEventRecord(side->join, cs));
     PTX_TRY(run_img_proxy(S, *w, pf, img_feat, img_proxy, ws, is, 2, want_img_proxy));      // rest of the image chain
     if (cluster_on_caller) PTX_HIP(hipEventRecord(side->join, is));
@@ -934,7 +942,7 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     // ---- submanifold reshape + scatter + drop (PRE:459-467); k_affine is the last reader of the tags and clears them
     // (r03: waiting for the tags next to the join instead -- they are final long before it at the benchmark shape -- does not
     //  shorten the heads -> affine boundary: 0.276 / 0.283 vs 0.271 / 0.275 ms per step)
-    PTX_HIP(hipStreamWaitEvent(st, side->tags, 0));
+    if (!tags_tail) PTX_HIP(hipStreamWaitEvent(st, side->tags, 0));
     PTX_DBG(tag, tag, (size_t)B * S.N * 4);
     PTX_TIMED(KID_AFFINE, st, launch_affine(S, sp, tag, kcenter, translate, transform, out, counts, tile_counts,
                                             true, true, st));
