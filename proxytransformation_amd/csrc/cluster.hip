@@ -991,9 +991,15 @@ struct AffineArgs {
     int clear_tag;      // forward only: this is the last reader of the tags; leave them zero for the next call
 };
 
-template <bool COMPACT>
+// TABLE: the scene's (centre, transform, translate) rows are staged in LDS (Mk x 15 floats) and every global load of the
+// work-group -- table, tags, points, the tile counts in front of this tile -- is requested before the first is waited
+// for: ONE round trip to memory.  (r03; before, a thread walked its eight points one after the other, each a tag load, a
+// wait, fifteen dependent gather loads, a wait: sixteen round trips in sequence were the whole 9 us of the launch.)
+// Without TABLE (more than 1024 kept clusters: the rows do not fit) the per-point gathers stay.
+template <bool COMPACT, bool TABLE>
 __global__ __launch_bounds__(256) void k_affine(AffineArgs a)
 {
+    extern __shared__ float s_tab[];                        // TABLE: [3 Mk centres | 9 Mk transforms | 3 Mk translations]
     const int b = blockIdx.y, tile = blockIdx.x, ntiles = gridDim.x;
     const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
     uint32_t *tg = a.tag + (size_t)b * a.N;
@@ -1002,34 +1008,86 @@ __global__ __launch_bounds__(256) void k_affine(AffineArgs a)
     constexpr int R = kTilePts / 256;
     __shared__ int s_cnt[R][4];
     __shared__ int s_base;
+    const float *kc = a.kcenter + (size_t)b * a.Mk * 3, *kT = a.transform + (size_t)b * a.Mk * 9, *kt = a.translate + (size_t)b * a.Mk * 3;
+    // ---- requests: table first (it is waited for first), then tags and points, then the counts
+    constexpr int kBatch = 8;
+    const int c3 = 3 * a.Mk, c12 = 12 * a.Mk, c15 = 15 * a.Mk;
+    auto tab_src = [&](int i) { return i < c3 ? kc[i] : i < c12 ? kT[i - c3] : kt[i - c12]; };
+    float tb[2][kBatch];
+    if (TABLE) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) tb[h][u] = tab_src(min((h * kBatch + u) * 256 + tid, c15 - 1));
+    }
+    uint32_t tgv[R]; float v[R][3];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int nc = min(tile * kTilePts + r * 256 + tid, a.N - 1);
+        tgv[r] = tg[nc];
+        v[r][0] = pts[(size_t)nc * 3]; v[r][1] = pts[(size_t)nc * 3 + 1]; v[r][2] = pts[(size_t)nc * 3 + 2];
+    }
+    int acc = 0;
+    if (COMPACT) {
+        acc = a.tile_counts[b * ntiles + min(tid, ntiles - 1)];
+        acc = tid < tile ? acc : 0;
+        for (int t = tid + 256; t < tile; t += 256) acc += a.tile_counts[b * ntiles + t];      // more than 256 tiles per scene
+    }
+    if (TABLE) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) {
+                const int i = (h * kBatch + u) * 256 + tid;
+                if (i < c15) s_tab[i] = tb[h][u];
+            }
+        for (int i0 = 2 * kBatch * 256; i0 < c15; i0 += kBatch * 256) {           // more than 273 kept clusters
+            float t2[kBatch];
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) t2[u] = tab_src(min(i0 + u * 256 + tid, c15 - 1));
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) {
+                const int i = i0 + u * 256 + tid;
+                if (i < c15) s_tab[i] = t2[u];
+            }
+        }
+    }
     int base = 0;
     if (COMPACT) {
-        int acc = 0;
-        for (int t = tid; t < tile; t += 256) acc += a.tile_counts[b * ntiles + t];
         acc = wave_sum(acc);
         if (lane == 0) s_cnt[0][wid] = acc;
-        __syncthreads();
-        if (tid == 0) s_base = s_cnt[0][0] + s_cnt[0][1] + s_cnt[0][2] + s_cnt[0][3];
-        __syncthreads();
-        base = s_base;
-        __syncthreads();
     }
-    float v[R][3]; bool keep[R]; unsigned long long bal[R];
+    __syncthreads();                                        // table (and count partials) visible
+    if (COMPACT) {
+        base = s_cnt[0][0] + s_cnt[0][1] + s_cnt[0][2] + s_cnt[0][3];
+        __syncthreads();                                    // s_cnt[0] is re-used below
+    }
+    (void)s_base;
+    bool keep[R]; unsigned long long bal[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int n = tile * kTilePts + r * 256 + tid;
         keep[r] = false;
         if (n < a.N) {
-            const uint32_t t = tg[n];
+            const uint32_t t = tgv[r];
             if (a.clear_tag && t != 0u) tg[n] = 0u;
-            float x = pts[(size_t)n * 3], y = pts[(size_t)n * 3 + 1], z = pts[(size_t)n * 3 + 2];
+            float x = v[r][0], y = v[r][1], z = v[r][2];
             keep[r] = !COMPACT || (t >> 31) == 0;
             const uint32_t own = t & 0x7fffffffu;
             if (own != 0 && keep[r]) {
                 const int j = (int)(own - 1) / a.K;
-                const float *c = a.kcenter + ((size_t)b * a.Mk + j) * 3;
-                const float *T = a.transform + ((size_t)b * a.Mk + j) * 9;
-                const float *tr = a.translate + ((size_t)b * a.Mk + j) * 3;
+                float c[3], T[9], tr[3];
+                if (TABLE) {
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) { c[d] = s_tab[3 * j + d]; tr[d] = s_tab[c12 + 3 * j + d]; }
+#pragma unroll
+                    for (int d = 0; d < 9; ++d) T[d] = s_tab[c3 + 9 * j + d];
+                } else {
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) { c[d] = kc[3 * j + d]; tr[d] = kt[3 * j + d]; }
+#pragma unroll
+                    for (int d = 0; d < 9; ++d) T[d] = kT[9 * j + d];
+                }
                 const float dx = x - c[0], dy = y - c[1], dz = z - c[2];
                 // (T (p-c)^T)^T + c + t     PRE:462
                 const float rx = fmaf(T[2], dz, fmaf(T[1], dy, T[0] * dx));
@@ -1072,8 +1130,14 @@ int launch_affine(const PtxShape &s, const ScenePts &points, uint32_t *tag, cons
 {
     AffineArgs a{points, tag, kcenter, translate, transform, out, counts, tile_counts, s.N, s.Mk, s.K, clear_tag ? 1 : 0};
     const dim3 grid(cdiv(s.N, kTilePts), s.B), block(256);
-    if (compact) hipLaunchKernelGGL(k_affine<true>, grid, block, 0, st, a);
-    else         hipLaunchKernelGGL(k_affine<false>, grid, block, 0, st, a);
+    const size_t tab = (size_t)s.Mk * 15 * sizeof(float);
+    if (tab <= 62 * 1024) {
+        if (compact) hipLaunchKernelGGL((k_affine<true, true>), grid, block, tab, st, a);
+        else         hipLaunchKernelGGL((k_affine<false, true>), grid, block, tab, st, a);
+    } else {
+        if (compact) hipLaunchKernelGGL((k_affine<true, false>), grid, block, 0, st, a);
+        else         hipLaunchKernelGGL((k_affine<false, false>), grid, block, 0, st, a);
+    }
     PTX_LAUNCHED("k_affine");
     return PTX_OK;
 }
