@@ -1009,16 +1009,24 @@ __global__ __launch_bounds__(256) void k_affine(AffineArgs a)
     __shared__ int s_cnt[R][4];
     __shared__ int s_base;
     const float *kc = a.kcenter + (size_t)b * a.Mk * 3, *kT = a.transform + (size_t)b * a.Mk * 9, *kt = a.translate + (size_t)b * a.Mk * 3;
-    // ---- requests: table first (it is waited for first), then tags and points, then the counts
+    // ---- requests: the counts of the tiles in front (one per thread), the table, then tags and points
+    int acc = 0;
+    if (COMPACT) acc = a.tile_counts[b * ntiles + min(tid, ntiles - 1)];
     constexpr int kBatch = 8;
     const int c3 = 3 * a.Mk, c12 = 12 * a.Mk, c15 = 15 * a.Mk;
-    auto tab_src = [&](int i) { return i < c3 ? kc[i] : i < c12 ? kT[i - c3] : kt[i - c12]; };
-    float tb[2][kBatch];
+    auto tab_src = [&](int i) {                             // (the address is selected, not the load: no branch per request)
+        const float *p = i < c3 ? kc + i : i < c12 ? kT + (i - c3) : kt + (i - c12);
+        return *p;
+    };
+    constexpr int kAhead = 4;                               // batches requested up front: 8192 floats = 546 clusters
+    float tb[kAhead][kBatch];
     if (TABLE) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < kAhead; ++h)
+            if (h * kBatch * 256 < c15) {                   // (work-group uniform)
 #pragma unroll
-            for (int u = 0; u < kBatch; ++u) tb[h][u] = tab_src(min((h * kBatch + u) * 256 + tid, c15 - 1));
+                for (int u = 0; u < kBatch; ++u) tb[h][u] = tab_src(min((h * kBatch + u) * 256 + tid, c15 - 1));
+            }
     }
     uint32_t tgv[R]; float v[R][3];
 #pragma unroll
@@ -1027,21 +1035,15 @@ __global__ __launch_bounds__(256) void k_affine(AffineArgs a)
         tgv[r] = tg[nc];
         v[r][0] = pts[(size_t)nc * 3]; v[r][1] = pts[(size_t)nc * 3 + 1]; v[r][2] = pts[(size_t)nc * 3 + 2];
     }
-    int acc = 0;
-    if (COMPACT) {
-        acc = a.tile_counts[b * ntiles + min(tid, ntiles - 1)];
-        acc = tid < tile ? acc : 0;
-        for (int t = tid + 256; t < tile; t += 256) acc += a.tile_counts[b * ntiles + t];      // more than 256 tiles per scene
-    }
     if (TABLE) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < kAhead; ++h)
 #pragma unroll
             for (int u = 0; u < kBatch; ++u) {
                 const int i = (h * kBatch + u) * 256 + tid;
                 if (i < c15) s_tab[i] = tb[h][u];
             }
-        for (int i0 = 2 * kBatch * 256; i0 < c15; i0 += kBatch * 256) {           // more than 273 kept clusters
+        for (int i0 = kAhead * kBatch * 256; i0 < c15; i0 += kBatch * 256) {      // more than 546 kept clusters
             float t2[kBatch];
 #pragma unroll
             for (int u = 0; u < kBatch; ++u) t2[u] = tab_src(min(i0 + u * 256 + tid, c15 - 1));
@@ -1054,6 +1056,8 @@ __global__ __launch_bounds__(256) void k_affine(AffineArgs a)
     }
     int base = 0;
     if (COMPACT) {
+        acc = tid < tile ? acc : 0;
+        for (int t = tid + 256; t < tile; t += 256) acc += a.tile_counts[b * ntiles + t];      // more than 256 tiles per scene
         acc = wave_sum(acc);
         if (lane == 0) s_cnt[0][wid] = acc;
     }
