@@ -77,6 +77,9 @@ def parse():
     ap.add_argument("--no-passes", action="store_true", help="skip roofline_passes / fp32-feature extras")
     ap.add_argument("--cpu-scenes", type=int, default=None, help="scenes in the CPU baseline sample")
     ap.add_argument("--breakdown", action="store_true", help="print per-kernel event timings to stderr")
+    ap.add_argument("--time-every", type=int, default=4,
+                    help="the roofline kernel is bracketed by HIP events on every n-th measured step (each event record costs "
+                         "the stream ~6 us of idle between two kernels; 1 = every step)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (nccl = RCCL)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="test aid for 1-GPU boxes: every rank uses cuda:0 (with --backend gloo); numbers are meaningless")
@@ -356,11 +359,13 @@ def main():
                 with torch.cuda.stream(streams[i % len(streams)]):
                     mod(*inputs.args(i))
         n_out = sum(int(o.shape[0]) for o in outs)
+        lib.ptx_timing_every(max(1, args.time_every))
         lib.ptx_timing_select(kid)
         elapsed, outs = timed_steps(mod, inputs, args.steps, barrier, streams)
         launches, total_ms = ctypes.c_int(0), ctypes.c_float(0.0)
         lib.ptx_timing_read(ctypes.byref(launches), ctypes.byref(total_ms))
         lib.ptx_timing_select(-1)
+        lib.ptx_timing_every(1)
 
         if not args.no_passes:
             steps2 = max(10, args.steps // 2)
@@ -441,6 +446,7 @@ def main():
                             traffic_source=os.path.relpath(PMC_FILE, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                            "this command; traffic_stale = taken with another build of the library)",
                             avg_launch_us=round(avg_s * 1e6, 2), launches=launches.value,
+                            timed="HIP events on the kernel's stream around every %d-th launch of the measured steps" % max(1, args.time_every),
                             algorithmic_bytes_per_launch=abytes, so_sha16=so_sha16())
         line = dict(metric="scenes/sec (100k pts, 256 clusters, 64 proxies)", value=round(total_scenes / elapsed, 2),
                     unit="scenes/s", n_gpus=world, steps=args.steps, warmup=args.warmup,

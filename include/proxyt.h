@@ -125,6 +125,9 @@ int         ptx_kernel_count(void);
 const char *ptx_kernel_name(int kid);
 int         ptx_timing_select(int kid);
 int         ptx_timing_read(int *launches, float *total_ms);
+/* Time only every n-th launch of a selected site (default 1 = every launch): an event record is a packet of its own and costs
+ * the stream ~6 us of idle between the two kernels around it. */
+int         ptx_timing_every(int n);
 /* Several launch sites at once (bit k of `mask` = site k); ptx_timing_read_sites fills two [host] arrays of
  * ptx_kernel_count() entries.  The event records perturb the step a little: use the single-site form inside a
  * timed region and the mask form for per-pass breakdowns. */

@@ -73,6 +73,7 @@ SIGNATURES = {
     "ptx_kernel_count": (C.c_int, []),
     "ptx_kernel_name": (C.c_char_p, [_I]),
     "ptx_timing_select": (_I, [_I]),
+    "ptx_timing_every": (_I, [_I]),
     "ptx_timing_read": (_I, [C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     "ptx_timing_select_mask": (_I, [C.c_uint64]),
     "ptx_timing_read_sites": (_I, [C.POINTER(C.c_int), C.POINTER(C.c_float), _I]),

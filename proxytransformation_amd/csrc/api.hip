@@ -45,6 +45,8 @@ struct TimingRec { int kid; hipEvent_t a, b; };
 struct TimingState {
     std::mutex mu;
     uint64_t mask = 0;                  // bit k = launch site k is bracketed by events
+    int every = 1;                      // ... on every `every`-th launch of the site (ptx_timing_every)
+    unsigned seen[64] = {};
     std::vector<TimingRec> pool;
     size_t used = 0;
 };
@@ -55,6 +57,7 @@ struct Timed {
     Timed(int kid, hipStream_t s) : st(s) {
         if (!((g_timing.mask >> kid) & 1u)) return;
         std::lock_guard<std::mutex> lk(g_timing.mu);
+        if (g_timing.seen[kid]++ % (unsigned)g_timing.every != 0) return;
         if (g_timing.used == g_timing.pool.size()) {
             hipEvent_t a, b;
             if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
@@ -503,6 +506,17 @@ int ptx_timing_select(int kid)
     std::lock_guard<std::mutex> lk(g_timing.mu);
     g_timing.mask = kid < 0 ? 0 : (1ull << kid);
     g_timing.used = 0;
+    for (unsigned &s : g_timing.seen) s = 0;
+    return PTX_OK;
+}
+
+// An event record is a packet of its own in the queue and costs ~6 us of idle between the two kernels around it (r03
+// timelines: 12 us per step for the one site bench.py times inside the measured steps): sample instead of timing every launch.
+int ptx_timing_every(int n)
+{
+    PTX_REQUIRE(n >= 1, "ptx_timing_every: n=%d", n);
+    std::lock_guard<std::mutex> lk(g_timing.mu);
+    g_timing.every = n;
     return PTX_OK;
 }
 
@@ -512,6 +526,7 @@ int ptx_timing_select_mask(uint64_t mask)
     std::lock_guard<std::mutex> lk(g_timing.mu);
     g_timing.mask = mask & ((KID_COUNT >= 64) ? ~0ull : ((1ull << KID_COUNT) - 1));
     g_timing.used = 0;
+    for (unsigned &s : g_timing.seen) s = 0;
     return PTX_OK;
 }
 

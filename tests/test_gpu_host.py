@@ -175,7 +175,7 @@ def test_bench_multi_rank_path_on_one_gpu():
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu",
-                        "--steps", "2", "--warmup", "1", "--no-passes", "--no-cpu-baseline"],
+                        "--steps", "2", "--warmup", "1", "--no-passes", "--no-cpu-baseline", "--time-every", "1"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
