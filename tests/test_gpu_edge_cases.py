@@ -314,3 +314,47 @@ def test_reduced_precision_compute_mode_is_opt_in_and_bounded():
         assert 1e-5 < rel < 5e-2, (k, rel)                    # really a different arithmetic, and a bounded one
     worst = max(float((a - b).abs().max()) for a, b in zip(d32["outputs"], d16["outputs"]))
     assert all(a.shape == b.shape for a, b in zip(d32["outputs"], d16["outputs"])) and 0 < worst < 0.3, worst
+
+
+@pytest.mark.parametrize("Mk", [40, 300, 700, 1500])
+def test_affine_scatter_over_the_table_sizes(Mk):
+    """k_affine stages the kept clusters' (centre, transform, translation) rows in LDS: 40 and 300 clusters fit the requests
+    made up front, 700 needs the loop behind them, 1500 does not fit and takes the per-point gathers -- all against the
+    reference's formula (PRE:459-467) in float64 on synthetic ownership tags."""
+    import copy
+    import ctypes
+    from proxytransformation_amd import _abi
+    from proxytransformation_amd.synth import PreshapeConfig
+    from tests.util import build_module
+    cfg = PreshapeConfig("affine", B=2, N=5000, grid_size=12, dynamic_drop_radio=0.5, L=4, V=2, seed_base=5)
+    m, _ = build_module(cfg)
+    m = m.cuda()
+    shape = copy.copy(m._shape(cfg.B, cfg.N, cfg.L, cfg.V))
+    shape.Mk = Mk
+    shape.Mt = max(shape.Mt, Mk)
+    K, B, N = shape.K, cfg.B, cfg.N
+    rng = np.random.default_rng(Mk)
+    pts = rng.normal(size=(B, N, 3)).astype(np.float32)
+    kc = rng.normal(size=(B, Mk, 3)).astype(np.float32)
+    T = (np.eye(3, dtype=np.float32) + 0.1 * rng.normal(size=(B, Mk, 3, 3))).astype(np.float32)
+    tr = (0.1 * rng.normal(size=(B, Mk, 3))).astype(np.float32)
+    slot = rng.integers(0, Mk * K + 1, size=(B, N)).astype(np.uint32)       # 0 = not owned, else 1 + flat slot
+    slot[rng.random((B, N)) < 0.3] = 0
+    dev = torch.device("cuda:0")
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    out = torch.full((B, N, 3), float("nan"), device=dev)
+    tag, dp, dc, dt, dT = d(slot.view(np.int32)), d(pts), d(kc), d(tr), d(T.reshape(B, Mk, 9))
+    _abi.check(_abi.lib().ptx_affine_scatter(ctypes.byref(shape), dp.data_ptr(), tag.data_ptr(), dc.data_ptr(),
+                                             dt.data_ptr(), dT.data_ptr(), out.data_ptr(),
+                                             torch.cuda.current_stream().cuda_stream), "ptx_affine_scatter")
+    ref = pts.astype(np.float64).copy()
+    for b in range(B):
+        own = slot[b] != 0
+        j = (slot[b][own].astype(np.int64) - 1) // K
+        p = pts[b][own].astype(np.float64)
+        c = kc[b][j].astype(np.float64)
+        ref[b][own] = np.einsum("nij,nj->ni", T[b][j].astype(np.float64), p - c) + c + tr[b][j]
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() < 1e-5
+    assert np.array_equal(got[slot == 0], pts[slot == 0])                   # points nobody owns are copied exactly
