@@ -18,6 +18,10 @@
 //     reductions are in-lane plus one xor-32 exchange and P never moves between lanes before the second contraction.
 // Larger n (the reference's gs = 12: 691 tokens) stage their keys in chunks of 256 with the running soft-max carried
 // across chunks; the next chunk's fragments are in flight in registers while the current one is consumed.
+// Calls with few scenes (4 scenes x 8 heads x 2 branches = 64 work-groups on 256 CUs): the proxies of a (scene, head,
+// branch) are dealt to up to four work-groups (FAttnBatch::split, at least two proxy tiles each), every one takes its
+// slice through both stages -- stage A is complete per proxy, stage B is a partial soft-max over the slice -- and the last
+// one to arrive merges the partials (23 -> 17.7 us alone at 4 scenes x 196 proxies, 58 -> 39 us at n = 691).
 #include <cstdlib>
 
 #include "common.h"

@@ -568,7 +568,11 @@ __global__ __launch_bounds__(SK * 64) void k_gemm32(GemmBatch gb)
         for (int kk = 0; kk < 4; ++kk) ya[kk] = *reinterpret_cast<const float4 *>(lds + li * LDT + kk * 8 + hh * 4);
         const int nt2 = (pr.n2 + 31) >> 5;
         // (the next tile's W2 rows are requested before the current tile's MFMAs and stores: one exposed round trip per wave
-        //  instead of one per tile)
+        //  instead of one per tile.  r03 stamps of the qkv0 launch, 600 work-groups on 512 slots: a chain work-group lives
+        //  41 k cycles -- K loop 12 k, slice sum 2 k, epilogue 4 k, this product 21 k = 3.5 k per tile for 1 k of MFMA time --
+        //  a plain one 23 k, and the launch is bounded by two rounds of plain ones.  Tried without effect on the 25 us launch:
+        //  K sliced two ways so that all 600 are resident (29 us); the stores issued behind the wait for the next rows; the
+        //  tile order rotated per row tile so that the 25 work-groups of a head do not read the same W2 lines at once.)
         auto load_w2 = [&](int t, float4 (&wb)[4]) {
             const float *wr = W2 + (size_t)min(t * 32 + li, pr.n2 - 1) * 32 + hh * 4;
 #pragma unroll
