@@ -8,6 +8,8 @@
 //
 // These kernels favour exactness and generality over speed (fp32 everywhere, fixed summation orders so that two runs
 // give the same bits); the eval path's tuned kernels are untouched.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace ptx {
@@ -147,6 +149,98 @@ __global__ __launch_bounds__(256) void k_bgemm(BGemmArgs g)
             const float v = g.alpha * acc[r];
             *dst = g.accumulate ? *dst + v : v;
         }
+    }
+}
+
+// ------------------------------------------------------------------------------ thin batched products
+// The training path's query-0 products of AttentionPool2d (one query row per (image, head): (1 x 32)(32 x 226), (1 x 226)
+// (226 x 32) and the outer products of their backward, 960 batches each) cost 38-56 us apiece as 64 x 64 MFMA tiles with one
+// valid row (r03: 280 us of a 5.4 ms step).  fp32 operands, no K slices.
+// k_bthin_out: a thread per output element, K <= 64 walked eight requests at a time (branch-free, clamped).
+template <bool KVEC>     // KVEC: both operands contiguous along k, K % 4 == 0, 16-byte aligned: four k per request
+__global__ __launch_bounds__(256) void k_bthin_out(BGemmArgs g, unsigned total)
+{
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= total) return;
+    // fastest index along C's unit stride (32-bit index arithmetic: a 64-bit division per thread is most of a K = 1 product)
+    const bool n_fast = g.c_cs == 1 || g.c_rs != 1;
+    const unsigned per = (unsigned)g.M * (unsigned)g.N, z = i / per, r = i - z * per;
+    const unsigned m = n_fast ? r / (unsigned)g.N : r % (unsigned)g.M, n = n_fast ? r % (unsigned)g.N : r / (unsigned)g.M;
+    const unsigned z1 = z / (unsigned)g.inner, z2 = z - z1 * (unsigned)g.inner;
+    const float *A = static_cast<const float *>(g.A) + z1 * g.a_s1 + z2 * g.a_s2 + (long)m * g.a_rs;
+    const float *B = static_cast<const float *>(g.B) + z1 * g.b_s1 + z2 * g.b_s2 + (long)n * g.b_cs;
+    float acc = 0.0f;
+    if (KVEC) {
+        for (int k0 = 0; k0 < g.K; k0 += 16) {
+            float4 a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = min(k0 + 4 * u, g.K - 4);
+                a[u] = *reinterpret_cast<const float4 *>(A + k); b[u] = *reinterpret_cast<const float4 *>(B + k);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float w = k0 + 4 * u < g.K ? 1.0f : 0.0f;
+                acc = fmaf(a[u].x * w, b[u].x, acc); acc = fmaf(a[u].y * w, b[u].y, acc);
+                acc = fmaf(a[u].z * w, b[u].z, acc); acc = fmaf(a[u].w * w, b[u].w, acc);
+            }
+        }
+    } else {
+        for (int k0 = 0; k0 < g.K; k0 += 8) {
+            float a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = min(k0 + u, g.K - 1);
+                a[u] = A[(long)k * g.a_cs]; b[u] = B[(long)k * g.b_rs];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = fmaf(k0 + u < g.K ? a[u] : 0.0f, b[u], acc);
+        }
+    }
+    float *dst = g.C + z1 * g.c_s1 + z2 * g.c_s2 + (long)m * g.c_rs + (long)n * g.c_cs;
+    const float v = g.alpha * acc;
+    *dst = g.accumulate ? *dst + v : v;
+}
+// k_bthin_row: a wave per (batch, row m), N <= 32 with B contiguous along n, K <= 256 dealt to the lanes four at a time: every
+// lane requests its rows of B up front (eight 16-B loads per row; N = 32 exactly), the 32 partial sums are reduced across the wave.
+__global__ __launch_bounds__(256) void k_bthin_row(BGemmArgs g, long rows)
+{
+    const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const long z = w / g.M;
+    const int m = (int)(w - z * g.M);
+    const long z1 = z / g.inner, z2 = z - z1 * g.inner;
+    const float *A = static_cast<const float *>(g.A) + z1 * g.a_s1 + z2 * g.a_s2 + (long)m * g.a_rs;
+    const float *B = static_cast<const float *>(g.B) + z1 * g.b_s1 + z2 * g.b_s2;
+    float acc[32];
+#pragma unroll
+    for (int n = 0; n < 32; ++n) acc[n] = 0.0f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int k = lane + 64 * u;                         // K <= 256
+        const int kc = min(k, g.K - 1);
+        const float a = k < g.K ? A[(long)kc * g.a_cs] : 0.0f;
+        const float4 *row = reinterpret_cast<const float4 *>(B + (long)kc * g.b_rs);       // N = 32, 16-byte aligned rows
+        float4 bv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) bv[q] = row[q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            acc[4 * q] = fmaf(a, bv[q].x, acc[4 * q]); acc[4 * q + 1] = fmaf(a, bv[q].y, acc[4 * q + 1]);
+            acc[4 * q + 2] = fmaf(a, bv[q].z, acc[4 * q + 2]); acc[4 * q + 3] = fmaf(a, bv[q].w, acc[4 * q + 3]);
+        }
+    }
+    float mine = 0.0f;
+#pragma unroll
+    for (int n = 0; n < 32; ++n) {
+        const float s = wave_sum(acc[n]);
+        if (lane == n) mine = s;
+    }
+    if (lane < g.N) {
+        float *dst = g.C + z1 * g.c_s1 + z2 * g.c_s2 + (long)m * g.c_rs + (long)lane * g.c_cs;
+        const float v = g.alpha * mine;
+        *dst = g.accumulate ? *dst + v : v;
     }
 }
 
@@ -744,6 +838,27 @@ int ptx_op_gemm(const void *A, const void *B, float *C, int M, int N, int K, lon
     const dim3 grid(cdiv(M, 64), cdiv(N, 64), batch * ksplit);
     hipStream_t st = static_cast<hipStream_t>(stream);
     PTX_REQUIRE(a_dtype == 0 || b_dtype == 0, "ptx_op_gemm: at most one 16-bit operand (a_dtype=%d, b_dtype=%d)", a_dtype, b_dtype);
+    static const int thin_env = getenv("PTX_BGEMM_THIN") ? atoi(getenv("PTX_BGEMM_THIN")) : 1;
+    if (thin_env && a_dtype == 0 && b_dtype == 0 && ksplit == 1 && batch >= 64 && (M <= 2 || N <= 2 || K <= 2)) {
+        // thin products of many batches: most of a 64 x 64 MFMA tile would be padding
+        const bool al16 = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0;
+        if (M <= 2 && N == 32 && b_cs == 1 && K <= 256 && K > 64 && al16 && b_rs % 4 == 0 && b_s1 % 4 == 0 && b_s2 % 4 == 0) {
+            const long rows = (long)batch * M;
+            hipLaunchKernelGGL(k_bthin_row, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, g, rows);
+            PTX_LAUNCHED("k_bthin_row");
+            return PTX_OK;
+        }
+        const long total = (long)batch * M * N;
+        if (K <= 64 && total < (1l << 31)) {
+            const bool kvec = al16 && a_cs == 1 && b_rs == 1 && K % 4 == 0 && a_rs % 4 == 0 && b_cs % 4 == 0 && a_s1 % 4 == 0 &&
+                              a_s2 % 4 == 0 && b_s1 % 4 == 0 && b_s2 % 4 == 0;
+            const dim3 tg((unsigned)((total + 255) / 256));
+            if (kvec) hipLaunchKernelGGL(k_bthin_out<true>, tg, dim3(256), 0, st, g, (unsigned)total);
+            else      hipLaunchKernelGGL(k_bthin_out<false>, tg, dim3(256), 0, st, g, (unsigned)total);
+            PTX_LAUNCHED("k_bthin_out");
+            return PTX_OK;
+        }
+    }
     if (a_dtype == 0 && b_dtype == 0) hipLaunchKernelGGL((k_bgemm<0, 0>), grid, dim3(256), 0, st, g);
     else if (a_dtype == 1) hipLaunchKernelGGL((k_bgemm<1, 0>), grid, dim3(256), 0, st, g);
     else if (a_dtype == 2) hipLaunchKernelGGL((k_bgemm<2, 0>), grid, dim3(256), 0, st, g);
