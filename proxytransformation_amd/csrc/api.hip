@@ -902,7 +902,10 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     // (it owns the caller's stream) they run on the low-priority stream next to it, after the point proxies.  When the
     // image chain is the long one they go to the END of the clustering stream, behind its last kernel and in front of the
     // join: one cross-queue wait on the caller's stream instead of two (each costs 6-7 us of idle between two dependent
-    // kernels wherever it is placed; r03: PTX_TAGS_TAIL=0 restores the third stream).
+    // kernels wherever it is placed; r03: PTX_TAGS_TAIL=0 restores the third stream).  (The mirror image -- the tags behind the
+    // image chain when the clustering chain owns the caller's stream -- puts them on the critical path at one scene per
+    // call, where only the short point-proxy kernels separate k_select from the join: cfg4 at 6 scenes +1 %, cfg1 -6 %,
+    // cfg5 -2 %: not done.)
     hipStream_t ts = tags_tail ? cs : side->lo;
     const bool slots_first = !cluster_on_caller && !tags_tail;
     auto enqueue_tags = [&]() -> int {
