@@ -252,11 +252,6 @@ __global__ __launch_bounds__(256) void k_gemm64x(GemmBatch gb)
     __shared__ __attribute__((aligned(16))) char smem[2 * kXBuf];
     __shared__ float s_mu[64], s_rs[64];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (pr.lnp_in != nullptr && tid < 64) {
-        float mu, rs;
-        ln_row_stats(pr, min(row0 + tid, pr.R - 1), mu, rs);
-        s_mu[tid] = mu; s_rs[tid] = rs;                    // read after the barriers of the K loop
-    }
     const int wr = wid >> 1, wc = wid & 1;
     const int li = lane & 31, hh = lane >> 5;
     const int sr = tid >> 3, kq = (tid & 7) * 4;        // staging: rows sr and sr + 32
@@ -269,6 +264,8 @@ __global__ __launch_bounds__(256) void k_gemm64x(GemmBatch gb)
     // epilogue operands are requested up front: a dependent ~1 us round trip after the K loop otherwise
     const int n = col0 + wc * 32 + li;
     const float bias = (pr.bias && n < pr.N) ? pr.bias[n] : 0.0f;
+    float lns = 0.0f, lnc = 0.0f;                           // LayerNorm-consumer column terms: requested here, not after the K loop
+    if (pr.lnp_in != nullptr) { lns = pr.ln_s[min(n, pr.N - 1)]; lnc = pr.ln_c[min(n, pr.N - 1)]; }
     float resv[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -294,6 +291,13 @@ __global__ __launch_bounds__(256) void k_gemm64x(GemmBatch gb)
     __syncthreads();                                                                       \
     ++it;
     PTX_X64_FETCH(A, 0); PTX_X64_FETCH(B, 1); PTX_X64_FETCH(C, 2); PTX_X64_FETCH(D, 3);
+    // (behind the first four tiles' requests: in front of them the statistics were a round trip of their own before the
+    //  work-group's first wave had requested anything -- r03 stamps: 3 k of the 6.5 k cycles in front of the K loop)
+    if (pr.lnp_in != nullptr && tid < 64) {
+        float mu, rs;
+        ln_row_stats(pr, min(row0 + tid, pr.R - 1), mu, rs);
+        s_mu[tid] = mu; s_rs[tid] = rs;                    // read after the barriers of the K loop
+    }
     PTX_X64_STASH(A, 0);
     __syncthreads();
     int kbase = 0;
@@ -309,8 +313,6 @@ __global__ __launch_bounds__(256) void k_gemm64x(GemmBatch gb)
 #undef PTX_X64_PIPE
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     const bool ncol = n < pr.N;
-    float lns = 0.0f, lnc = 0.0f;
-    if (pr.lnp_in != nullptr && ncol) { lns = pr.ln_s[n]; lnc = pr.ln_c[n]; }
     float fin[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -372,11 +374,6 @@ __global__ __launch_bounds__(SK * 64) void k_gemm32(GemmBatch gb)
     float fc0[4] = {0.f, 0.f, 0.f, 0.f}, fc1[4] = {0.f, 0.f, 0.f, 0.f}, fct[4] = {0.f, 0.f, 0.f, 0.f};
     float *cts = lds + (size_t)SK * (4 * 32 * LDT);         // [32] a_h(0) of the tile's rows (AMODE 1)
     float *lnst = cts + 32;                                 // [32][2] mean, rstd of the tile's rows (LayerNorm consumer)
-    if (pr.lnp_in != nullptr && wv == 0 && lane < 32) {     // written and read by wave 0 only
-        float mu, rs;
-        ln_row_stats(pr, min(row0 + lane, pr.R - 1), mu, rs);
-        lnst[2 * lane] = mu; lnst[2 * lane + 1] = rs;
-    }
     if (AMODE == 1) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -469,13 +466,14 @@ __global__ __launch_bounds__(SK * 64) void k_gemm32(GemmBatch gb)
     // each would be a dependent round trip -- and the row-scaled addend was one PER OUTPUT ROW, sixteen in sequence, because a
     // load behind the previous row's store cannot be hoisted above it (r03)
     const int n = col0 + li;
-    float bias = 0.0f, resv[16], adv[16], rsv[16];
+    float bias = 0.0f, lns = 0.0f, lnc = 0.0f, resv[16], adv[16], rsv[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { resv[r] = 0.0f; adv[r] = 0.0f; rsv[r] = 0.0f; }
     const bool has_ad = AMODE == 1 || pr.rs != nullptr;      // work-group uniform
     if (wv == 0) {
         const int nc = min(n, pr.N - 1);
         if (pr.bias) bias = pr.bias[nc];
+        if (pr.lnp_in != nullptr) { lns = pr.ln_s[nc]; lnc = pr.ln_c[nc]; }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = min(row0 + (r & 3) + 8 * (r >> 2) + 4 * hh, pr.R - 1);
@@ -496,6 +494,12 @@ __global__ __launch_bounds__(SK * 64) void k_gemm32(GemmBatch gb)
         // three stages: step j in LDS[cur], step j+1 in LDS[cur^1], step j+2 in flight (registers)
         PTX_FETCH(A, 0);
         PTX_FETCH(B, 1);
+        // LayerNorm-consumer row statistics (wave 0 only, which also reads them): requested behind the first two tiles
+        if (pr.lnp_in != nullptr && wv == 0 && lane < 32) {
+            float mu, rs;
+            ln_row_stats(pr, min(row0 + lane, pr.R - 1), mu, rs);
+            lnst[2 * lane] = mu; lnst[2 * lane + 1] = rs;
+        }
         PTX_STASH(A, 0);
         for (int j = 0; j < cnt; j += 2) {
             PTX_FETCH(A, j + 2);
@@ -531,8 +535,6 @@ __global__ __launch_bounds__(SK * 64) void k_gemm32(GemmBatch gb)
     }
     if (wv == 0) {
         const bool ncol = n < pr.N;
-        float lns = 0.0f, lnc = 0.0f;
-        if (pr.lnp_in != nullptr && ncol) { lns = pr.ln_s[n]; lnc = pr.ln_c[n]; }
         float fin[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
