@@ -145,6 +145,7 @@ def work_model(cfg, B, dt_bytes):
         "k_gemm_nt[qkv+proxy_proj]": 2.0 * 2 * R * 3 * C * C + 2.0 * B * L * C * C,
         "k_gemm_nt[pp_img]": 2.0 * B * V * C * C,
         "k_gemm_nt[proj]": 2.0 * 2 * R * C * C, "k_gemm_nt[fc1]": 2.0 * 2 * R * H * C, "k_gemm_nt[fc2]": 2.0 * 2 * R * H * C,
+        "k_mlp[fc1+gelu+fc2]": 2.0 * 2 * 2 * R * H * C,
     }
     return byts, flops
 
@@ -301,7 +302,7 @@ def passes_report(cfg, B, us, dt_bytes):
     rep["img_pool_pass_hbm"] = hbm(["img_pass2"])
     rep["proxy_attention_mfma"] = mfma(["k_attn32[proxy_as_query]", "k_attn32[proxy_as_key]", "k_proxy_attn[fused]"])
     rep["block_gemms_mfma"] = mfma(["k_gemm_nt[qkv+proxy_proj]", "k_gemm_nt[pp_img]", "k_gemm_nt[proj]",
-                                    "k_gemm_nt[fc1]", "k_gemm_nt[fc2]"])
+                                    "k_gemm_nt[fc1]", "k_gemm_nt[fc2]", "k_mlp[fc1+gelu+fc2]"])
     rep["site_us"] = {k: round(v, 2) for k, v in us.items()}
     return rep
 

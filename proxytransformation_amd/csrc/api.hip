@@ -33,12 +33,12 @@ static const char *const kKernelNames[] = {
     "k_gemm_nt[we]", "img_pass2", "img_pass3", "k_gemm_nt[o]", "k_gemm_nt[c_proj]",
     "k_ln_rows[norm_img]", "k_gemm_nt[qkv+proxy_proj]", "k_gemm_nt[pp_img]", "k_attn32[proxy_as_query]",
     "k_attn32[proxy_as_key]", "k_gemm_nt[proj]", "k_gemm_nt[fc1]", "k_gemm_nt[fc2]",
-    "k_heads", "k_affine<compact>", "k_proxy_attn[fused]"};
+    "k_heads", "k_affine<compact>", "k_proxy_attn[fused]", "k_mlp[fc1+gelu+fc2]"};
 enum Kid : int {
     KID_MINMAX = 0, KID_CLUSTER, KID_SELECT, KID_SLOTS, KID_TILECOUNT, KID_POINTNET,
     KID_IMG_MEAN, KID_IMG_QKV0, KID_IMG_WE, KID_IMG_SCORES, KID_IMG_GATHER, KID_IMG_O, KID_IMG_C,
     KID_IMG_LN, KID_BLK_QKV, KID_BLK_PP, KID_BLK_ATTN_A, KID_BLK_ATTN_B, KID_BLK_PROJ, KID_BLK_FC1,
-    KID_BLK_FC2, KID_BLK_HEADS, KID_AFFINE, KID_BLK_ATTN_F, KID_COUNT};
+    KID_BLK_FC2, KID_BLK_HEADS, KID_AFFINE, KID_BLK_ATTN_F, KID_BLK_MLP, KID_COUNT};
 static_assert(sizeof(kKernelNames) / sizeof(kKernelNames[0]) == KID_COUNT, "kernel name table");
 
 struct TimingRec { int kid; hipEvent_t a, b; };
@@ -113,6 +113,7 @@ PrepLayout prep_layout(const PtxShape &s)
     P.ppg_w = take((size_t)s.C * s.C); P.ppg_s = take(s.C); P.ppg_c = take(s.C);
     for (int i = 0; i < 2; ++i) {
         P.fc1g_w[i] = take((size_t)s.hidden * s.C); P.fc1g_s[i] = take(s.hidden); P.fc1g_c[i] = take(s.hidden);
+        P.mlp_w1p[i] = take((size_t)s.hidden * s.C * 3 / 2); P.mlp_w2p[i] = take((size_t)s.hidden * s.C * 3 / 2);
     }
     P.total = o;
     return P;
@@ -133,6 +134,7 @@ WsLayout ws_layout(const PtxShape &s)
     L.scene_acc = take(B * 2 * 4);
     L.tag = take(B * N * 4);
     L.fa_ticket = take(2 * B * s.heads * 4);
+    L.mlp_ticket = take(mlp_ticket_bytes((int)R));
     L.zero_bytes = o - L.zero_begin;
     L.minmax = take(B * 6 * 4);
     L.centers0 = take(B * M * 3 * 4); L.cluster1 = take(B * M * K * 3 * 4);
@@ -160,6 +162,7 @@ WsLayout ws_layout(const PtxShape &s)
     L.lnp_img = take(nimg * (C / 32) * 2 * 4);
     const size_t fsp = fattn_split_for(s.B, s.heads);
     L.fa_part = take(fsp > 1 ? 2 * B * s.heads * fsp * Mk * kFaPartRow * 4 : 0);
+    L.mlp_part = take(mlp_fused_supported(s.C, s.hidden, (int)R, 0) ? mlp_part_bytes((int)R) : 0);
     L.total = o;
     return L;
 }
@@ -347,6 +350,7 @@ struct Branch {
     // proxies given as RAW rows + LayerNorm partials (the forward's image branch): proxy_proj folds the LayerNorm
     const float *proxy_lnp, *pp_gw, *pp_gs, *pp_gc;
     const float *fc1_gw, *fc1_gs, *fc1_gc;      // norm2 folded into fc1
+    const float *prep;                          // the parameter tables (weight planes of the fused Mlp)
 };
 
 // One work-group per (scene, head, branch) must be enough parallelism: the two-launch form spreads the query tiles of the
@@ -428,6 +432,20 @@ static int run_blocks(const PtxShape &s, const Branch *br, int nb, const float *
         }
         PTX_TIMED(KID_BLK_PROJ, st, launch_gemm(g, st, cd));
     }
+    if (mlp_fused_supported(C, s.hidden, R, cd)) {
+        // x2 = x1 + fc2(GELU(fc1(norm2(x1)))) in one launch: 32 rows x a slice of 256 hidden units per work-group, the hidden
+        // activations stay in LDS, the four slices of a row tile are summed by the last to arrive (mlp.hip)
+        const PrepLayout P = prep_layout(s);
+        MlpBatch mb{}; mb.n = nb; mb.ln_eps = s.ln_eps;
+        mb.part = at<float>(ws, L.mlp_part); mb.tickets = at<int>(ws, L.mlp_ticket);
+        for (int i = 0; i < nb; ++i) {
+            const int sl = br[i].slot;
+            mb.p[i] = MlpProb{at<float>(ws, L.x1[sl]), at<float>(ws, L.lnp_x1[sl]), br[i].prep + P.mlp_w1p[sl],
+                              br[i].prep + P.mlp_w2p[sl], br[i].fc1_gs, br[i].fc1_gc, br[i].blk->fc2_b,
+                              at<float>(ws, L.x2[sl]), R};
+        }
+        PTX_TIMED(KID_BLK_MLP, st, launch_mlp(mb, st));
+    } else {
     {   // h = GELU(fc1(norm2(x1))) (PRE:275): norm2 folded into the GEMM (W1 diag(gamma), row statistics in the epilogue)
         GemmBatch g{}; g.n = nb;
         for (int i = 0; i < nb; ++i) {
@@ -449,6 +467,7 @@ static int run_blocks(const PtxShape &s, const Branch *br, int nb, const float *
                               s.hidden, s.hidden, C, C, 0, 0, EPI_NONE};
         }
         PTX_TIMED(KID_BLK_FC2, st, launch_gemm(g, st, cd));
+    }
     }
     HeadBatch hb{}; hb.n = nb; hb.C = C; hb.eps = s.ln_eps;
     for (int i = 0; i < nb; ++i) {
@@ -475,6 +494,7 @@ static Branch make_branch(const PtxShape &s, const PtxWeights &w, const float *p
     b.head_out = head_out; b.guide = guide; b.slot = which; b.late_proxy = which == 1;
     b.proxy_lnp = nullptr; b.pp_gw = prep + P.ppg_w; b.pp_gs = prep + P.ppg_s; b.pp_gc = prep + P.ppg_c;
     b.fc1_gw = prep + P.fc1g_w[which]; b.fc1_gs = prep + P.fc1g_s[which]; b.fc1_gc = prep + P.fc1g_c[which];
+    b.prep = prep;
     return b;
 }
 

@@ -92,6 +92,21 @@ __device__ __forceinline__ float dist2_nofma(float ax, float ay, float az, float
     return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
 }
 
+// GELU(erf) of the eval path: erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute) with the hardware
+// reciprocal and exponential -- a third of libm erff's instructions (16 values per lane in fc1's epilogue); the error in
+// GELU is <= |x| * 1e-7, against the 5e-5 bar of the float stages.  (Train mode keeps erff: its backward differentiates it.)
+__device__ __forceinline__ float gelu_erf(float x)
+{
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float erfz = 1.0f - p * t * __expf(-z * z);
+    return 0.5f * x * (1.0f + copysignf(erfz, x));
+}
+
 // ---- parameter-only tables (ptx_prepare) ------------------------------------
 struct PrepLayout {
     // all offsets in floats from the start of `prep`
@@ -104,6 +119,7 @@ struct PrepLayout {
     // LayerNorm folds (GemmProb::lnp_in): norm_img -> proxy_proj of the image block; norm2 -> fc1 of both blocks
     size_t ppg_w, ppg_s, ppg_c;     // (C,C), (C), (C)
     size_t fc1g_w[2], fc1g_s[2], fc1g_c[2];   // (hidden,C), (hidden), (hidden) for the text / image block
+    size_t mlp_w1p[2], mlp_w2p[2];  // fused Mlp (mlp.hip): fc1g_w / fc2_w as three bf16 planes in MFMA fragment order
     size_t total;                   // floats
     int KT1, KT2p, hd;
 };
@@ -118,6 +134,7 @@ struct WsLayout {
     size_t scene_acc;               // (B,2) int32 survivor-count accumulator + arrival ticket
     size_t tag;                     // (B,N) uint32
     size_t fa_ticket;               // (2, B*heads) int32 arrival tickets of the split fused attention
+    size_t mlp_ticket;              // (2, row tiles) int32 arrival tickets of the fused Mlp
     size_t minmax, centers0, cluster1, offsets, centers, idx2, cluster2, pad_count;
     size_t order, picks, keep, ksrc, kcenter, kcluster, kidx, drop_idx, tile_counts;
     size_t point_proxy, x_in[2];    // x_in: LN1(x)+slot bias per branch (B*Mk,C)
@@ -125,6 +142,7 @@ struct WsLayout {
     size_t qkv[2], pt[2], pv[2], ao[2], x1[2], xn2[2], hbuf[2], x2[2], guide[2], head[2];
     size_t lnp_img, lnp_x1[2];      // LayerNorm partials (rows, C/32, 2) of c_proj's / proj's output
     size_t fa_part;                 // (2, B*heads, split, Mk, 34) partial results of the split fused attention
+    size_t mlp_part;                // (2, row tiles, 4, 32, 256) partial fc2 sums of the fused Mlp
     size_t total;
 };
 WsLayout ws_layout(const PtxShape &s);
@@ -199,6 +217,20 @@ int fattn_split_for(int B, int heads);                      // a pure function o
 constexpr int kFaMaxSplit = 4, kFaPartRow = 34;             // floats per (split, token): 32 outputs + maximum + sum
 bool fused_attn_supported(const FAttnBatch &ab);
 int launch_proxy_attn(const FAttnBatch &ab, hipStream_t st);
+
+// ---- fused Mlp of a ProxyBlock (mlp.hip) -----------------------------------------------------------------------
+struct MlpProb {
+    const float *x1, *lnp;          // rows (R,256) and their LayerNorm partials (R,8,2) from the proj GEMM
+    const void *w1p, *w2p;          // weight planes (k_prep_planes) of fc1 (with norm2's gamma folded in) and fc2
+    const float *fc1_s, *fc1_c, *b2;
+    float *x2; int R;
+};
+struct MlpBatch { MlpProb p[2]; int n; float ln_eps; float *part; int *tickets; };
+bool mlp_fused_supported(int C, int hidden, int R, int compute_dtype);
+size_t mlp_part_bytes(int R);
+size_t mlp_ticket_bytes(int R);
+int launch_mlp(const MlpBatch &mb, hipStream_t st);
+int launch_prep_planes(const float *W, int rows, int K, void *out, hipStream_t st);
 
 // Per-scene base pointers of the point clouds, passed by value as a kernel argument: the caller's
 // list of (N,3) tensors is used in place (the reference stacks them into a copy, PRE:426-427; the

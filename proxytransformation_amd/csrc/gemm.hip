@@ -20,21 +20,6 @@ constexpr int BK = 32, LDT = BK + 4;   // 144-B LDS rows: 16-B aligned, b128 fra
 // the value is "re-defined" here: arithmetic on a prefetched register cannot be hoisted above this point (hipcc moves
 // pure VALU work across s_barrier, which turns a three-steps-ahead prefetch into a wait on the loads just issued)
 __device__ __forceinline__ void pin4(float4 &v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
-// GELU(erf) of the eval path: erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute) with the hardware
-// reciprocal and exponential -- a third of libm erff's instructions (16 values per lane in fc1's epilogue); the error in
-// GELU is <= |x| * 1e-7, against the 5e-5 bar of the float stages.  (Train mode keeps erff: its backward differentiates it.)
-__device__ __forceinline__ float gelu_erf(float x)
-{
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float erfz = 1.0f - p * t * __expf(-z * z);
-    return 0.5f * x * (1.0f + copysignf(erfz, x));
-}
-
 // ---- LayerNorm fold helpers (GemmProb::lnp_out / lnp_in) ----------------------------------------------------------
 // consumer: mean / rstd of row `row` from the producer's per-tile partials
 __device__ __forceinline__ void ln_row_stats(const GemmProb &pr, int row, float &mu, float &rstd)

@@ -1,0 +1,241 @@
+// The Mlp of a ProxyBlock in ONE launch for calls with few scenes (timm Mlp, PRE:275-276):
+//     x2 = x1 + fc2(GELU(fc1(norm2(x1))))                              x1 (R, 256), hidden 1024
+// As two GEMM launches (k_gemm64x with the LayerNorm fold + GELU epilogue, then k_gemm32 over K = 1024) this was 17 + 19 us of
+// the 4-scene step for 2 GFLOP: each launch is a prologue of cold round trips, eight K steps and an epilogue, and the hidden
+// activations (8 MB) make a round trip through memory in between (r03 stamps, gemm.hip).  Here a work-group owns 32 rows
+// of one branch and a SLICE of 256 hidden units:
+//   1. the x1 tile is split once into three bf16 planes in LDS (A operand of every MFMA of phase 1)
+//   2. phase 1   H = GELU(rstd (x1 Wg^T - mu s) + c)  for its 256 hidden units: eight waves, one 32 x 32 tile each, K = 256
+//   3. H goes back to LDS as split planes (A operand of phase 2) -- it never leaves the CU
+//   4. phase 2   P = H W2[:, slice]^T  (32 x 256, K = the slice): a partial sum of fc2 over the hidden units
+//   5. the four slices of a row tile leave their partials as agent-scope stores; the last one to arrive (ticket) adds them
+//      in slice order with the bias and the residual and writes x2 (the pattern of the split attention, fattn.hip).
+// 32 row tiles x 4 slices x 2 branches = 256 work-groups at the benchmark shape.  The WEIGHTS are parameter-only: ptx_prepare
+// stores them already split into bf16 planes in the order the MFMA B fragments are read (k_prep_planes), so a lane's
+// fragment is one coalesced 16-byte load straight from L2 -- no staging through LDS, no split arithmetic in the loop.
+// Every product is the six-term split product of split3.h (fp32 in another summation order).
+#include <cstdlib>
+
+#include "common.h"
+#include "split3.h"
+
+namespace ptx {
+
+constexpr int kMlpRows = 32, kMlpSlice = 256, kMlpWaves = 8;
+constexpr int kMlpPlane = 16 * 2 * 32 * 16;                 // one bf16 plane of a 32 x 256 A operand: [step][hh][row][8]
+constexpr int kMlpLds = 2 * 3 * kMlpPlane + 2 * 32 * 4;     // x1 planes, H planes, (mean, rstd) of the rows
+
+__device__ __forceinline__ int mlp_acc_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
+
+// byte offset of the 16-byte piece (step, hh, row) inside plane p of an A operand in LDS
+__device__ __forceinline__ int mlp_a_off(int p, int step, int hh, int row) { return p * kMlpPlane + ((step * 2 + hh) * 32 + row) * 16; }
+// 16-byte pieces of a weight matrix (rows x K) in memory: [row tile][step][plane][hh][row in tile]
+__host__ __device__ __forceinline__ size_t mlp_w_piece(int t, int steps, int step, int p, int hh, int li)
+{
+    return ((((size_t)t * steps + step) * 3 + p) * 2 + hh) * 32 + li;
+}
+
+// W (rows, K) fp32 -> three bf16 planes in fragment order (rows % 32 == 0, K % 16 == 0); a thread per pair of k
+__global__ void k_prep_planes(const float *W, int rows, int K, unsigned short *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * (K / 2)) return;
+    const int row = i / (K / 2), k = (i - row * (K / 2)) * 2;
+    unsigned q[3];
+    split3_pair(W[(size_t)row * K + k], W[(size_t)row * K + k + 1], q[0], q[1], q[2]);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const size_t piece = mlp_w_piece(row >> 5, K / 16, k >> 4, p, (k >> 3) & 1, row & 31);
+        *reinterpret_cast<unsigned *>(reinterpret_cast<char *>(out) + piece * 16 + (k & 7) * 2) = q[p];
+    }
+}
+
+int launch_prep_planes(const float *W, int rows, int K, void *out, hipStream_t st)
+{
+    PTX_REQUIRE(rows % 32 == 0 && K % 16 == 0, "weight planes: rows=%d K=%d", rows, K);
+    const int n = rows * (K / 2);
+    hipLaunchKernelGGL(k_prep_planes, dim3(cdiv(n, 256)), dim3(256), 0, st, W, rows, K, static_cast<unsigned short *>(out));
+    PTX_LAUNCHED("k_prep_planes");
+    return PTX_OK;
+}
+
+// agent-scope relaxed store / loads (see fattn.hip: visible across the XCDs' L2s without a fence)
+__device__ __forceinline__ void mlp_st_agent(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+typedef float mlp_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ mlp_f4 mlp_ld4_agent(const float *p)
+{
+    mlp_f4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void mlp_wait4(mlp_f4 &a, mlp_f4 &b, mlp_f4 &c, mlp_f4 &d)
+{
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) :: "memory");
+}
+
+__global__ __launch_bounds__(kMlpWaves * 64) void k_mlp(MlpBatch mb)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const MlpProb p = mb.p[blockIdx.z];
+    const int row0 = blockIdx.x * kMlpRows, sl = blockIdx.y, nsl = gridDim.y;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, hh = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int C = 256, R = p.R;
+    char *Xp = smem, *Hp = smem + 3 * kMlpPlane;
+    float *s_mu = reinterpret_cast<float *>(smem + 6 * kMlpPlane), *s_rs = s_mu + 32;
+
+    // ---- requests first: the x1 tile, the LayerNorm partials of its rows, the column terms, the first weight fragments
+    float4 xv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + 512 * i, row = min(row0 + (e >> 6), R - 1);
+        xv[i] = *reinterpret_cast<const float4 *>(p.x1 + (size_t)row * C + (e & 63) * 4);
+    }
+    float2 lp[8];
+    if (tid < 32) {
+        const float2 *pp = reinterpret_cast<const float2 *>(p.lnp) + (size_t)min(row0 + tid, R - 1) * 8;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) lp[t] = pp[t];
+    }
+    const int j = sl * kMlpSlice + 32 * wv + li;                    // this lane's hidden unit in phase 1
+    const float s_j = p.fc1_s[j], c_j = p.fc1_c[j];
+    const u32x4 *W1 = reinterpret_cast<const u32x4 *>(p.w1p), *W2 = reinterpret_cast<const u32x4 *>(p.w2p);
+    const int t1 = sl * (kMlpSlice / 32) + wv;                      // row tile of fc1's weight: 32 hidden units
+    auto load_b = [&](const u32x4 *W, int t, int steps, int step, u32x4 (&b)[3]) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) b[q] = W[mlp_w_piece(t, steps, step, q, hh, li)];
+    };
+    constexpr int kAhead = 4;                                       // weight fragments requested this many k steps ahead
+    u32x4 bq[kAhead][3];
+#pragma unroll
+    for (int s = 0; s < kAhead; ++s) load_b(W1, t1, 16, s, bq[s]);
+
+    // ---- the x1 tile -> three bf16 planes (A operand of phase 1); row statistics
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + 512 * i, row = e >> 6, k = (e & 63) * 4;
+        stash_split3(Xp + mlp_a_off(0, k >> 4, (k >> 3) & 1, row) + (k & 4) * 2, kMlpPlane, xv[i]);
+    }
+    if (tid < 32) {
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { s1 += lp[t].x; s2 += lp[t].y; }
+        const float mu = s1 * (1.0f / 256.0f);
+        const float var = fmaxf(fmaf(-mu, mu, s2 * (1.0f / 256.0f)), 0.0f);
+        s_mu[tid] = mu; s_rs[tid] = 1.0f / sqrtf(var + mb.ln_eps);
+    }
+    __syncthreads();
+
+    // ---- phase 1: H tile (32 rows x this wave's 32 hidden units), K = 256
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        u32x4 a[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) a[q] = *reinterpret_cast<const u32x4 *>(Xp + mlp_a_off(q, s, hh, li));
+        acc = mfma_parts<3>(a, bq[s % kAhead], acc);
+        if (s + kAhead < 16) load_b(W1, t1, 16, s + kAhead, bq[s % kAhead]);
+    }
+    // phase 2's first weight fragments: in flight under the GELU epilogue
+    const int st2 = sl * 16;                                        // first k step of this slice in fc2's K = 1024
+#pragma unroll
+    for (int s = 0; s < kAhead; ++s) load_b(W2, wv, 64, st2 + s, bq[s]);
+    {
+        float h[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = mlp_acc_row(r, hh);
+            h[r] = gelu_erf(fmaf(s_rs[row], fmaf(-s_mu[row], s_j, acc[r]), c_j));
+        }
+        // column j of H is k = 32 wv + li of phase 2: step 2 wv + (li >> 4), half (li >> 3) & 1, position li & 7
+        const int step = 2 * wv + (li >> 4), h2 = (li >> 3) & 1, pos = (li & 7) * 2;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            unsigned q1, q2, q3;
+            split3_pair(h[r], h[r + 1], q1, q2, q3);
+            char *d0 = Hp + mlp_a_off(0, step, h2, mlp_acc_row(r, hh)) + pos, *d1 = Hp + mlp_a_off(0, step, h2, mlp_acc_row(r + 1, hh)) + pos;
+            *reinterpret_cast<unsigned short *>(d0) = (unsigned short)(q1 & 0xffffu);
+            *reinterpret_cast<unsigned short *>(d1) = (unsigned short)(q1 >> 16);
+            *reinterpret_cast<unsigned short *>(d0 + kMlpPlane) = (unsigned short)(q2 & 0xffffu);
+            *reinterpret_cast<unsigned short *>(d1 + kMlpPlane) = (unsigned short)(q2 >> 16);
+            *reinterpret_cast<unsigned short *>(d0 + 2 * kMlpPlane) = (unsigned short)(q3 & 0xffffu);
+            *reinterpret_cast<unsigned short *>(d1 + 2 * kMlpPlane) = (unsigned short)(q3 >> 16);
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: partial fc2 output (32 rows x this wave's 32 output columns) over the slice's 256 hidden units
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        u32x4 a[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) a[q] = *reinterpret_cast<const u32x4 *>(Hp + mlp_a_off(q, s, hh, li));
+        acc = mfma_parts<3>(a, bq[s % kAhead], acc);
+        if (s + kAhead < 16) load_b(W2, wv, 64, st2 + s + kAhead, bq[s % kAhead]);
+    }
+    const int n = 32 * wv + li;                                     // this lane's output column
+    const int tile = blockIdx.x, ntiles = gridDim.x;
+    float *part = mb.part + (((size_t)blockIdx.z * ntiles + tile) * nsl + sl) * (kMlpRows * 256);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mlp_st_agent(part + mlp_acc_row(r, hh) * 256 + n, acc[r]);
+
+    // ---- the last slice of this row tile to arrive adds the partials (slice order), the bias and the residual
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int *tk = mb.tickets + blockIdx.z * ntiles + tile;
+    int *flag = reinterpret_cast<int *>(s_mu);                      // (the statistics are dead)
+    if (tid == 0) flag[0] = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (flag[0] != nsl - 1) return;
+    if (tid == 0) __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // left zero for the next launch
+    const float *gp = mb.part + ((size_t)blockIdx.z * ntiles + tile) * nsl * (kMlpRows * 256);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + 512 * i, row = e >> 6, c4 = (e & 63) * 4;
+        mlp_f4 v[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) v[s] = mlp_ld4_agent(gp + (size_t)min(s, nsl - 1) * (kMlpRows * 256) + row * 256 + c4);
+        const int grow = min(row0 + row, R - 1);
+        const float4 x = *reinterpret_cast<const float4 *>(p.x1 + (size_t)grow * C + c4);
+        const float4 b = *reinterpret_cast<const float4 *>(p.b2 + c4);
+        mlp_wait4(v[0], v[1], v[2], v[3]);
+        mlp_f4 sum = v[0];
+#pragma unroll
+        for (int s = 1; s < 4; ++s)
+            if (s < nsl) sum += v[s];
+        if (row0 + row < R)
+            *reinterpret_cast<float4 *>(p.x2 + (size_t)(row0 + row) * C + c4) =
+                make_float4((sum[0] + b.x) + x.x, (sum[1] + b.y) + x.y, (sum[2] + b.z) + x.z, (sum[3] + b.w) + x.w);
+    }
+}
+
+bool mlp_fused_supported(int C, int hidden, int R, int compute_dtype)
+{
+    static const int env = getenv("PTX_MLP_FUSED") ? atoi(getenv("PTX_MLP_FUSED")) : 1;
+    return env != 0 && compute_dtype == 0 && C == 256 && hidden == 1024 && R >= 1 && R <= 2048;
+}
+
+size_t mlp_part_bytes(int R) { return (size_t)2 * cdiv(R, kMlpRows) * 4 * kMlpRows * 256 * sizeof(float); }
+size_t mlp_ticket_bytes(int R) { return (size_t)2 * cdiv(R, kMlpRows) * sizeof(int); }
+
+int launch_mlp(const MlpBatch &mb, hipStream_t st)
+{
+    PTX_REQUIRE(mb.n >= 1 && mb.n <= 2 && mb.part && mb.tickets, "fused mlp: bad batch");
+    int rmax = 0;
+    for (int g = 0; g < mb.n; ++g) {
+        const MlpProb &p = mb.p[g];
+        PTX_REQUIRE(p.x1 && p.lnp && p.w1p && p.w2p && p.fc1_s && p.fc1_c && p.b2 && p.x2 && p.R >= 1, "fused mlp: null operand in group %d", g);
+        PTX_REQUIRE(p.R == mb.p[0].R, "fused mlp: the groups must have the same number of rows");
+        rmax = p.R;
+    }
+    PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp), hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
+    hipLaunchKernelGGL(k_mlp, dim3(cdiv(rmax, kMlpRows), 4, mb.n), dim3(kMlpWaves * 64), kMlpLds, st, mb);
+    PTX_LAUNCHED("k_mlp");
+    return PTX_OK;
+}
+
+}  // namespace ptx
