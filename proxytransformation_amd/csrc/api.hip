@@ -442,9 +442,12 @@ static int run_blocks(const PtxShape &s, const Branch *br, int nb, const float *
             const int sl = br[i].slot;
             mb.p[i] = MlpProb{at<float>(ws, L.x1[sl]), at<float>(ws, L.lnp_x1[sl]), br[i].prep + P.mlp_w1p[sl],
                               br[i].prep + P.mlp_w2p[sl], br[i].fc1_gs, br[i].fc1_gc, br[i].blk->fc2_b,
-                              at<float>(ws, L.x2[sl]), R};
+                              at<float>(ws, L.x2[sl]), R,
+                              br[i].blk->out_norm_w, br[i].blk->out_norm_b, br[i].head_w, br[i].head_b, br[i].head_ab,
+                              br[i].head_out, br[i].guide, br[i].nout};
         }
         PTX_TIMED(KID_BLK_MLP, st, launch_mlp(mb, st));
+        return PTX_OK;                  // the output heads ran on the finished rows inside that launch
     } else {
     {   // h = GELU(fc1(norm2(x1))) (PRE:275): norm2 folded into the GEMM (W1 diag(gamma), row statistics in the epilogue)
         GemmBatch g{}; g.n = nb;

@@ -224,6 +224,8 @@ struct MlpProb {
     const void *w1p, *w2p;          // weight planes (k_prep_planes) of fc1 (with norm2's gamma folded in) and fc2
     const float *fc1_s, *fc1_c, *b2;
     float *x2; int R;
+    // the block's output head, applied by the work-group that finishes a row tile (k_heads' arithmetic; head_out = NULL: not)
+    const float *nw, *nb, *hw, *hb, *ab; float *head_out, *guide; int nout;
 };
 struct MlpBatch { MlpProb p[2]; int n; float ln_eps; float *part; int *tickets; };
 bool mlp_fused_supported(int C, int hidden, int R, int compute_dtype);

@@ -9,7 +9,8 @@
 //   3. H goes back to LDS as split planes (A operand of phase 2) -- it never leaves the CU
 //   4. phase 2   P = H W2[:, slice]^T  (32 x 256, K = the slice): a partial sum of fc2 over the hidden units
 //   5. the four slices of a row tile leave their partials as agent-scope stores; the last one to arrive (ticket) adds them
-//      in slice order with the bias and the residual and writes x2 (the pattern of the split attention, fattn.hip).
+//      in slice order with the bias and the residual, writes x2 (the pattern of the split attention, fattn.hip) and applies
+//      the block's output head to the finished rows (k_heads is no launch of its own).
 // 32 row tiles x 4 slices x 2 branches = 256 work-groups at the benchmark shape.  The WEIGHTS are parameter-only: ptx_prepare
 // stores them already split into bf16 planes in the order the MFMA B fragments are read (k_prep_planes), so a lane's
 // fragment is one coalesced 16-byte load straight from L2 -- no staging through LDS, no split arithmetic in the loop.
@@ -193,6 +194,19 @@ __global__ __launch_bounds__(kMlpWaves * 64) void k_mlp(MlpBatch mb)
     if (flag[0] != nsl - 1) return;
     if (tid == 0) __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // left zero for the next launch
     const float *gp = mb.part + ((size_t)blockIdx.z * ntiles + tile) * nsl * (kMlpRows * 256);
+    // the output head of the block on the finished rows (trailing LayerNorm + Linear(256, 3 | 9) + eval BatchNorm1d, PRE:443-446,
+    // 452-455): a wave holds whole rows here -- lane l has columns 4 l .. 4 l + 3 -- so k_heads is no launch of its own
+    const bool heads = p.head_out != nullptr;
+    constexpr int kMaxOut = 9;
+    float4 hwt[kMaxOut], nw4 = make_float4(0.f, 0.f, 0.f, 0.f), nb4 = nw4;
+    float hbias = 0.0f, bn_a = 0.0f, bn_b = 0.0f;
+    if (heads) {
+        nw4 = *reinterpret_cast<const float4 *>(p.nw + 4 * lane); nb4 = *reinterpret_cast<const float4 *>(p.nb + 4 * lane);
+#pragma unroll
+        for (int o = 0; o < kMaxOut; ++o)
+            hwt[o] = *reinterpret_cast<const float4 *>(p.hw + (size_t)min(o, p.nout - 1) * C + 4 * lane);
+        if (lane < p.nout) { hbias = p.hb[lane]; bn_a = p.ab[lane]; bn_b = p.ab[p.nout + lane]; }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int e = tid + 512 * i, row = e >> 6, c4 = (e & 63) * 4;
@@ -207,9 +221,28 @@ __global__ __launch_bounds__(kMlpWaves * 64) void k_mlp(MlpBatch mb)
 #pragma unroll
         for (int s = 1; s < 4; ++s)
             if (s < nsl) sum += v[s];
-        if (row0 + row < R)
-            *reinterpret_cast<float4 *>(p.x2 + (size_t)(row0 + row) * C + c4) =
-                make_float4((sum[0] + b.x) + x.x, (sum[1] + b.y) + x.y, (sum[2] + b.z) + x.z, (sum[3] + b.w) + x.w);
+        const float y[4] = {(sum[0] + b.x) + x.x, (sum[1] + b.y) + x.y, (sum[2] + b.z) + x.z, (sum[3] + b.w) + x.w};
+        const bool live = row0 + row < R;                       // wave-uniform: a wave owns whole rows
+        if (live) *reinterpret_cast<float4 *>(p.x2 + (size_t)(row0 + row) * C + c4) = make_float4(y[0], y[1], y[2], y[3]);
+        if (!heads || !live) continue;
+        const float mean = wave_sum((y[0] + y[1]) + (y[2] + y[3])) * (1.0f / 256.0f);
+        float var = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const float d = y[q] - mean; var = fmaf(d, d, var); }
+        const float rstd = 1.0f / sqrtf(wave_sum(var) * (1.0f / 256.0f) + mb.ln_eps);
+        const float g[4] = {(y[0] - mean) * rstd * nw4.x + nb4.x, (y[1] - mean) * rstd * nw4.y + nb4.y,
+                            (y[2] - mean) * rstd * nw4.z + nb4.z, (y[3] - mean) * rstd * nw4.w + nb4.w};
+        if (p.guide) *reinterpret_cast<float4 *>(p.guide + (size_t)(row0 + row) * C + c4) = make_float4(g[0], g[1], g[2], g[3]);
+        float mine = 0.0f;
+#pragma unroll
+        for (int o = 0; o < kMaxOut; ++o) {
+            if (o < p.nout) {
+                const float part = fmaf(hwt[o].w, g[3], fmaf(hwt[o].z, g[2], fmaf(hwt[o].y, g[1], hwt[o].x * g[0])));
+                const float s = wave_sum(part);
+                if (lane == o) mine = s;
+            }
+        }
+        if (lane < p.nout) p.head_out[(size_t)(row0 + row) * p.nout + lane] = fmaf(mine + hbias, bn_a, bn_b);     // eval BatchNorm1d
     }
 }
 
