@@ -106,7 +106,8 @@ __global__ __launch_bounds__(kMlpWaves * 64) void k_mlp(MlpBatch mb)
 #pragma unroll
         for (int q = 0; q < 3; ++q) b[q] = W[mlp_w_piece(t, steps, step, q, hh, li)];
     };
-    constexpr int kAhead = 4;                                       // weight fragments requested this many k steps ahead
+    constexpr int kAhead = 8;                                       // weight fragments requested this many k steps ahead (r03
+                                                                    // stamps: with 4 a phase was 10 k cycles for 3 k of MFMA time)
     u32x4 bq[kAhead][3];
 #pragma unroll
     for (int s = 0; s < kAhead; ++s) load_b(W1, t1, 16, s, bq[s]);
@@ -131,12 +132,17 @@ __global__ __launch_bounds__(kMlpWaves * 64) void k_mlp(MlpBatch mb)
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    // (the A fragments of step s + 1 are read from LDS before the MFMAs of step s)
+    auto load_a = [&](const char *base, int s, u32x4 (&a)[3]) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) a[q] = *reinterpret_cast<const u32x4 *>(base + mlp_a_off(q, s, hh, li));
+    };
+    u32x4 aq[2][3];
+    load_a(Xp, 0, aq[0]);
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-        u32x4 a[3];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) a[q] = *reinterpret_cast<const u32x4 *>(Xp + mlp_a_off(q, s, hh, li));
-        acc = mfma_parts<3>(a, bq[s % kAhead], acc);
+        if (s + 1 < 16) load_a(Xp, s + 1, aq[(s + 1) & 1]);
+        acc = mfma_parts<3>(aq[s & 1], bq[s % kAhead], acc);
         if (s + kAhead < 16) load_b(W1, t1, 16, s + kAhead, bq[s % kAhead]);
     }
     // phase 2's first weight fragments: in flight under the GELU epilogue
@@ -170,12 +176,11 @@ __global__ __launch_bounds__(kMlpWaves * 64) void k_mlp(MlpBatch mb)
     // ---- phase 2: partial fc2 output (32 rows x this wave's 32 output columns) over the slice's 256 hidden units
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    load_a(Hp, 0, aq[0]);
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-        u32x4 a[3];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) a[q] = *reinterpret_cast<const u32x4 *>(Hp + mlp_a_off(q, s, hh, li));
-        acc = mfma_parts<3>(a, bq[s % kAhead], acc);
+        if (s + 1 < 16) load_a(Hp, s + 1, aq[(s + 1) & 1]);
+        acc = mfma_parts<3>(aq[s & 1], bq[s % kAhead], acc);
         if (s + kAhead < 16) load_b(W2, wv, 64, st2 + s + kAhead, bq[s % kAhead]);
     }
     const int n = 32 * wv + li;                                     // this lane's output column
@@ -207,20 +212,27 @@ __global__ __launch_bounds__(kMlpWaves * 64) void k_mlp(MlpBatch mb)
             hwt[o] = *reinterpret_cast<const float4 *>(p.hw + (size_t)min(o, p.nout - 1) * C + 4 * lane);
         if (lane < p.nout) { hbias = p.hb[lane]; bn_a = p.ab[lane]; bn_b = p.ab[p.nout + lane]; }
     }
+    // (every partial, residual and bias request of the four rows of this wave goes out before the first is used: as a loop
+    //  over the rows the merge was four round trips to memory in sequence, 10 k of the last slice's 46 k cycles)
+    mlp_f4 v[4][4];
+    float4 xr[4];
+    const float4 b = *reinterpret_cast<const float4 *>(p.b2 + 4 * lane);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int e = tid + 512 * i, row = e >> 6, c4 = (e & 63) * 4;
-        mlp_f4 v[4];
+        const int row = wv + 8 * i, c4 = 4 * lane;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) v[s] = mlp_ld4_agent(gp + (size_t)min(s, nsl - 1) * (kMlpRows * 256) + row * 256 + c4);
-        const int grow = min(row0 + row, R - 1);
-        const float4 x = *reinterpret_cast<const float4 *>(p.x1 + (size_t)grow * C + c4);
-        const float4 b = *reinterpret_cast<const float4 *>(p.b2 + c4);
-        mlp_wait4(v[0], v[1], v[2], v[3]);
-        mlp_f4 sum = v[0];
+        for (int s = 0; s < 4; ++s) v[i][s] = mlp_ld4_agent(gp + (size_t)min(s, nsl - 1) * (kMlpRows * 256) + row * 256 + c4);
+        xr[i] = *reinterpret_cast<const float4 *>(p.x1 + (size_t)min(row0 + row, R - 1) * C + c4);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = wv + 8 * i, c4 = 4 * lane;
+        mlp_wait4(v[i][0], v[i][1], v[i][2], v[i][3]);
+        const float4 x = xr[i];
+        mlp_f4 sum = v[i][0];
 #pragma unroll
         for (int s = 1; s < 4; ++s)
-            if (s < nsl) sum += v[s];
+            if (s < nsl) sum += v[i][s];
         const float y[4] = {(sum[0] + b.x) + x.x, (sum[1] + b.y) + x.y, (sum[2] + b.z) + x.z, (sum[3] + b.w) + x.w};
         const bool live = row0 + row < R;                       // wave-uniform: a wave owns whole rows
         if (live) *reinterpret_cast<float4 *>(p.x2 + (size_t)(row0 + row) * C + c4) = make_float4(y[0], y[1], y[2], y[3]);
