@@ -261,7 +261,8 @@ __global__ __launch_bounds__(kMlpWaves * 64) void k_mlp(MlpBatch mb)
 bool mlp_fused_supported(int C, int hidden, int R, int compute_dtype)
 {
     static const int env = getenv("PTX_MLP_FUSED") ? atoi(getenv("PTX_MLP_FUSED")) : 1;
-    return env != 0 && compute_dtype == 0 && C == 256 && hidden == 1024 && R >= 1 && R <= 2048;
+    static const int rmax = getenv("PTX_MLP_RMAX") ? atoi(getenv("PTX_MLP_RMAX")) : 2048;
+    return env != 0 && compute_dtype == 0 && C == 256 && hidden == 1024 && R >= 1 && R <= rmax;
 }
 
 size_t mlp_part_bytes(int R) { return (size_t)2 * cdiv(R, kMlpRows) * 4 * kMlpRows * 256 * sizeof(float); }
