@@ -261,7 +261,9 @@ __global__ __launch_bounds__(kMlpWaves * 64) void k_mlp(MlpBatch mb)
 bool mlp_fused_supported(int C, int hidden, int R, int compute_dtype)
 {
     static const int env = getenv("PTX_MLP_FUSED") ? atoi(getenv("PTX_MLP_FUSED")) : 1;
-    static const int rmax = getenv("PTX_MLP_RMAX") ? atoi(getenv("PTX_MLP_RMAX")) : 2048;
+    // up to ~6000 rows: measured r03 -- 4146 rows (the shipped configuration at 6 scenes) +4.5 % over the two GEMM launches,
+    // 4096 rows (cfg2 at 16 scenes) +0.7 %, 8192 rows (32 scenes) -3 %: there the 64 x 64-tile GEMMs run at 0.57 of their peak
+    static const int rmax = getenv("PTX_MLP_RMAX") ? atoi(getenv("PTX_MLP_RMAX")) : 6144;
     return env != 0 && compute_dtype == 0 && C == 256 && hidden == 1024 && R >= 1 && R <= rmax;
 }
 
