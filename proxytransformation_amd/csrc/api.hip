@@ -436,7 +436,7 @@ static int run_blocks(const PtxShape &s, const Branch *br, int nb, const float *
         // x2 = x1 + fc2(GELU(fc1(norm2(x1)))) in one launch: 32 rows x a slice of 256 hidden units per work-group, the hidden
         // activations stay in LDS, the four slices of a row tile are summed by the last to arrive (mlp.hip)
         const PrepLayout P = prep_layout(s);
-        MlpBatch mb{}; mb.n = nb; mb.ln_eps = s.ln_eps;
+        MlpBatch mb{}; mb.n = nb; mb.ln_eps = s.ln_eps; mb.compute_dtype = cd;
         mb.part = at<float>(ws, L.mlp_part); mb.tickets = at<int>(ws, L.mlp_ticket);
         for (int i = 0; i < nb; ++i) {
             const int sl = br[i].slot;

@@ -227,7 +227,7 @@ struct MlpProb {
     // the block's output head, applied by the work-group that finishes a row tile (k_heads' arithmetic; head_out = NULL: not)
     const float *nw, *nb, *hw, *hb, *ab; float *head_out, *guide; int nout;
 };
-struct MlpBatch { MlpProb p[2]; int n; float ln_eps; float *part; int *tickets; };
+struct MlpBatch { MlpProb p[2]; int n; float ln_eps; float *part; int *tickets; int compute_dtype; };
 bool mlp_fused_supported(int C, int hidden, int R, int compute_dtype);
 size_t mlp_part_bytes(int R);
 size_t mlp_ticket_bytes(int R);

@@ -74,6 +74,7 @@ __device__ __forceinline__ void mlp_wait4(mlp_f4 &a, mlp_f4 &b, mlp_f4 &c, mlp_f
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) :: "memory");
 }
 
+template <int NP>       // 3: split operands (fp32-equivalent); 1: plain bf16 operands = the first plane only (compute_dtype = 1)
 __global__ __launch_bounds__(kMlpWaves * 64) void k_mlp(MlpBatch mb)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(kMlpWaves * 64) void k_mlp(MlpBatch mb)
     const int t1 = sl * (kMlpSlice / 32) + wv;                      // row tile of fc1's weight: 32 hidden units
     auto load_b = [&](const u32x4 *W, int t, int steps, int step, u32x4 (&b)[3]) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) b[q] = W[mlp_w_piece(t, steps, step, q, hh, li)];
+        for (int q = 0; q < NP; ++q) b[q] = W[mlp_w_piece(t, steps, step, q, hh, li)];
     };
     constexpr int kAhead = 8;                                       // weight fragments requested this many k steps ahead (r03
                                                                     // stamps: with 4 a phase was 10 k cycles for 3 k of MFMA time)
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(kMlpWaves * 64) void k_mlp(MlpBatch mb)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int e = tid + 512 * i, row = e >> 6, k = (e & 63) * 4;
-        stash_split3(Xp + mlp_a_off(0, k >> 4, (k >> 3) & 1, row) + (k & 4) * 2, kMlpPlane, xv[i]);
+        stash_parts<NP>(Xp + mlp_a_off(0, k >> 4, (k >> 3) & 1, row) + (k & 4) * 2, kMlpPlane, xv[i]);
     }
     if (tid < 32) {
         float s1 = 0.0f, s2 = 0.0f;
@@ -135,14 +136,14 @@ __global__ __launch_bounds__(kMlpWaves * 64) void k_mlp(MlpBatch mb)
     // (the A fragments of step s + 1 are read from LDS before the MFMAs of step s)
     auto load_a = [&](const char *base, int s, u32x4 (&a)[3]) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) a[q] = *reinterpret_cast<const u32x4 *>(base + mlp_a_off(q, s, hh, li));
+        for (int q = 0; q < NP; ++q) a[q] = *reinterpret_cast<const u32x4 *>(base + mlp_a_off(q, s, hh, li));
     };
     u32x4 aq[2][3];
     load_a(Xp, 0, aq[0]);
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
         if (s + 1 < 16) load_a(Xp, s + 1, aq[(s + 1) & 1]);
-        acc = mfma_parts<3>(aq[s & 1], bq[s % kAhead], acc);
+        acc = mfma_parts<NP>(aq[s & 1], bq[s % kAhead], acc);
         if (s + kAhead < 16) load_b(W1, t1, 16, s + kAhead, bq[s % kAhead]);
     }
     // phase 2's first weight fragments: in flight under the GELU epilogue
@@ -160,15 +161,21 @@ __global__ __launch_bounds__(kMlpWaves * 64) void k_mlp(MlpBatch mb)
         const int step = 2 * wv + (li >> 4), h2 = (li >> 3) & 1, pos = (li & 7) * 2;
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-            unsigned q1, q2, q3;
-            split3_pair(h[r], h[r + 1], q1, q2, q3);
+            unsigned q1, q2 = 0u, q3 = 0u;
+            if (NP == 3) split3_pair(h[r], h[r + 1], q1, q2, q3);
+            else {
+                const f32x2 hv = {h[r], h[r + 1]};
+                q1 = __builtin_bit_cast(unsigned, __builtin_convertvector(hv, bf16x2));
+            }
             char *d0 = Hp + mlp_a_off(0, step, h2, mlp_acc_row(r, hh)) + pos, *d1 = Hp + mlp_a_off(0, step, h2, mlp_acc_row(r + 1, hh)) + pos;
             *reinterpret_cast<unsigned short *>(d0) = (unsigned short)(q1 & 0xffffu);
             *reinterpret_cast<unsigned short *>(d1) = (unsigned short)(q1 >> 16);
-            *reinterpret_cast<unsigned short *>(d0 + kMlpPlane) = (unsigned short)(q2 & 0xffffu);
-            *reinterpret_cast<unsigned short *>(d1 + kMlpPlane) = (unsigned short)(q2 >> 16);
-            *reinterpret_cast<unsigned short *>(d0 + 2 * kMlpPlane) = (unsigned short)(q3 & 0xffffu);
-            *reinterpret_cast<unsigned short *>(d1 + 2 * kMlpPlane) = (unsigned short)(q3 >> 16);
+            if (NP == 3) {
+                *reinterpret_cast<unsigned short *>(d0 + kMlpPlane) = (unsigned short)(q2 & 0xffffu);
+                *reinterpret_cast<unsigned short *>(d1 + kMlpPlane) = (unsigned short)(q2 >> 16);
+                *reinterpret_cast<unsigned short *>(d0 + 2 * kMlpPlane) = (unsigned short)(q3 & 0xffffu);
+                *reinterpret_cast<unsigned short *>(d1 + 2 * kMlpPlane) = (unsigned short)(q3 >> 16);
+            }
         }
     }
     __syncthreads();
@@ -180,7 +187,7 @@ __global__ __launch_bounds__(kMlpWaves * 64) void k_mlp(MlpBatch mb)
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
         if (s + 1 < 16) load_a(Hp, s + 1, aq[(s + 1) & 1]);
-        acc = mfma_parts<3>(aq[s & 1], bq[s % kAhead], acc);
+        acc = mfma_parts<NP>(aq[s & 1], bq[s % kAhead], acc);
         if (s + kAhead < 16) load_b(W2, wv, 64, st2 + s + kAhead, bq[s % kAhead]);
     }
     const int n = 32 * wv + li;                                     // this lane's output column
@@ -264,7 +271,7 @@ bool mlp_fused_supported(int C, int hidden, int R, int compute_dtype)
     // up to ~6000 rows: measured r03 -- 4146 rows (the shipped configuration at 6 scenes) +4.5 % over the two GEMM launches,
     // 4096 rows (cfg2 at 16 scenes) +0.7 %, 8192 rows (32 scenes) -3 %: there the 64 x 64-tile GEMMs run at 0.57 of their peak
     static const int rmax = getenv("PTX_MLP_RMAX") ? atoi(getenv("PTX_MLP_RMAX")) : 6144;
-    return env != 0 && compute_dtype == 0 && C == 256 && hidden == 1024 && R >= 1 && R <= rmax;
+    return env != 0 && (compute_dtype == 0 || compute_dtype == 1) && C == 256 && hidden == 1024 && R >= 1 && R <= rmax;
 }
 
 size_t mlp_part_bytes(int R) { return (size_t)2 * cdiv(R, kMlpRows) * 4 * kMlpRows * 256 * sizeof(float); }
@@ -280,8 +287,14 @@ int launch_mlp(const MlpBatch &mb, hipStream_t st)
         PTX_REQUIRE(p.R == mb.p[0].R, "fused mlp: the groups must have the same number of rows");
         rmax = p.R;
     }
-    PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp), hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
-    hipLaunchKernelGGL(k_mlp, dim3(cdiv(rmax, kMlpRows), 4, mb.n), dim3(kMlpWaves * 64), kMlpLds, st, mb);
+    const dim3 grid(cdiv(rmax, kMlpRows), 4, mb.n), block(kMlpWaves * 64);
+    if (mb.compute_dtype == 1) {
+        PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp<1>), hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
+        hipLaunchKernelGGL(k_mlp<1>, grid, block, kMlpLds, st, mb);
+    } else {
+        PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp<3>), hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
+        hipLaunchKernelGGL(k_mlp<3>, grid, block, kMlpLds, st, mb);
+    }
     PTX_LAUNCHED("k_mlp");
     return PTX_OK;
 }
