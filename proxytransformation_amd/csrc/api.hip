@@ -113,7 +113,8 @@ PrepLayout prep_layout(const PtxShape &s)
     P.ppg_w = take((size_t)s.C * s.C); P.ppg_s = take(s.C); P.ppg_c = take(s.C);
     for (int i = 0; i < 2; ++i) {
         P.fc1g_w[i] = take((size_t)s.hidden * s.C); P.fc1g_s[i] = take(s.hidden); P.fc1g_c[i] = take(s.hidden);
-        P.mlp_w1p[i] = take((size_t)s.hidden * s.C * 3 / 2); P.mlp_w2p[i] = take((size_t)s.hidden * s.C * 3 / 2);
+        const size_t planes = mlp_fused_supported(s.C, s.hidden, 1, 0) ? (size_t)s.hidden * s.C * 3 / 2 : 0;   // bf16 x 3, in floats
+        P.mlp_w1p[i] = take(planes); P.mlp_w2p[i] = take(planes);
     }
     P.total = o;
     return P;

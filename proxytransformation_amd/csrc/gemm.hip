@@ -485,6 +485,9 @@ __global__ __launch_bounds__(SK * 64) void k_gemm32(GemmBatch gb)
             ln_row_stats(pr, min(row0 + lane, pr.R - 1), mu, rs);
             lnst[2 * lane] = mu; lnst[2 * lane + 1] = rs;
         }
+        // (a fourth stage -- a third register set, fetches three MFMA phases ahead -- for the pooled-A o-projection, whose K
+        //  steps take 3.1 k cycles for 1 k of MFMA time next to the clustering stream's tail: 20.6 vs 21.8 us in the trace, no
+        //  change of the step (r03).  That launch reads 31 MB of pooling partials in ~8 us: it waits on bandwidth, not latency.)
         PTX_STASH(A, 0);
         for (int j = 0; j < cnt; j += 2) {
             PTX_FETCH(A, j + 2);

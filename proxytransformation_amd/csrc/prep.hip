@@ -159,7 +159,7 @@ int run_prepare(const PtxShape &s, const PtxWeights &w, float *prep, hipStream_t
                            prep + P.fc1g_c[i]);
     PTX_LAUNCHED("k_prep_lnfold");
     // the fused Mlp's weights, split once into bf16 planes in MFMA fragment order (mlp.hip)
-    if (C % 32 == 0 && s.hidden % 32 == 0)
+    if (mlp_fused_supported(C, s.hidden, 1, 0))
         for (int i = 0; i < 2; ++i) {
             PTX_TRY(launch_prep_planes(prep + P.fc1g_w[i], s.hidden, C, prep + P.mlp_w1p[i], st));
             PTX_TRY(launch_prep_planes(blk[i]->fc2_w, C, s.hidden, prep + P.mlp_w2p[i], st));
