@@ -313,6 +313,9 @@ int launch_img_mean16(const void *img, int dt, int nimg, int in_dim, int hw, flo
     const int ngroups = nimg * (in_dim / 8);
     const unsigned short *p = static_cast<const unsigned short *>(img);
     const dim3 grid(cdiv(ngroups, 4 * kMeanGroups));
+    // (r03: 26 KB of unused LDS per work-group -- six resident work-groups per CU instead of seven, so that the clustering
+    //  stream's k_minmax finds a slot at once instead of waiting for work-groups of this launch to retire -- shortens k_minmax
+    //  17 -> 13 us, but the step by 0.4 % over five alternating pairs of runs, and costs 0.6 % at 32 scenes: not kept)
     if (dt == 1) hipLaunchKernelGGL(k_img_mean16<1>, grid, dim3(256), 0, st, p, ngroups, hw, fm);
     else         hipLaunchKernelGGL(k_img_mean16<2>, grid, dim3(256), 0, st, p, ngroups, hw, fm);
     PTX_LAUNCHED("k_img_mean16");
