@@ -321,6 +321,9 @@ __global__ __launch_bounds__(256) void k_colsum(const float *__restrict__ x, con
     }
 }
 // stage 2: the splits, dealt to 16 lanes per column round-robin and combined in lane order (fixed order)
+// (r03: stage 2 inside stage 1 by the last split of a column tile to arrive -- agent-scope partials around a ticket, the pattern
+//  of fattn.hip / mlp.hip -- saves 54 launches per training step and made the step SLOWER, 5.4 vs 4.9 ms: up to 129 splits take
+//  their ticket from the same word, one after the other; with fewer splits the big reductions over 600 k slot rows starve)
 __global__ __launch_bounds__(256) void k_colsum_fin(const double *__restrict__ part, int N, int nsplit, float scale, int accumulate,
                                                     float *__restrict__ out)
 {
