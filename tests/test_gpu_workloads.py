@@ -76,6 +76,14 @@ def test_shipped_config_cfg4_full_size_vs_oracle():
     _compare(cfg, range(2), torch.float32)
 
 
+def test_shipped_config_at_its_training_batch_vs_oracle():
+    """cfg4 at the reference's batch of six scenes per GPU (CFG:145): 4146 cluster tokens per branch -- the fused Mlp kernel
+    runs several work-groups per CU there and its last row tile is partial (4146 = 129 x 32 + 18), the attention takes the
+    streaming key-tile path (691 tokens per scene)."""
+    cfg = CONFIGS["cfg4"]
+    _compare(cfg, range(6), torch.float32)
+
+
 @pytest.mark.parametrize("name, img_dtype, nscenes", [("cfg2", torch.bfloat16, 4), ("cfg4", torch.float32, 2)],
                          ids=["cfg2-bf16", "cfg4-f32"])
 def test_full_size_forward_without_injected_centres(name, img_dtype, nscenes):
