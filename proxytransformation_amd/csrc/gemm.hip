@@ -562,7 +562,10 @@ __global__ __launch_bounds__(SK * 64) void k_gemm32(GemmBatch gb)
         //  41 k cycles -- K loop 12 k, slice sum 2 k, epilogue 4 k, this product 21 k = 3.5 k per tile for 1 k of MFMA time --
         //  a plain one 23 k, and the launch is bounded by two rounds of plain ones.  Tried without effect on the 25 us launch:
         //  K sliced two ways so that all 600 are resident (29 us); the stores issued behind the wait for the next rows; the
-        //  tile order rotated per row tile so that the 25 work-groups of a head do not read the same W2 lines at once.)
+        //  tile order rotated per row tile so that the 25 work-groups of a head do not read the same W2 lines at once; ONE staging
+        //  buffer per wave instead of two (a wave's LDS operations execute in order, the area is wave-private) and the chained
+        //  variant under 170 VGPRs, so that all 600 work-groups are resident at once: correct, 24.2 us.  What bounds the launch
+        //  is neither latency nor residency: the 200 chain work-groups write the 19 MB of `we` in ~9 us -- 2 TB/s of stores.)
         auto load_w2 = [&](int t, float4 (&wb)[4]) {
             const float *wr = W2 + (size_t)min(t * 32 + li, pr.n2 - 1) * 32 + hh * 4;
 #pragma unroll
