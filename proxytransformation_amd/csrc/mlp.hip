@@ -29,7 +29,14 @@ constexpr int kMlpLds = 2 * 3 * kMlpPlane + 2 * 32 * 4;     // x1 planes, H plan
 __device__ __forceinline__ int mlp_acc_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 
 // byte offset of the 16-byte piece (step, hh, row) inside plane p of an A operand in LDS
-__device__ __forceinline__ int mlp_a_off(int p, int step, int hh, int row) { return p * kMlpPlane + ((step * 2 + hh) * 32 + row) * 16; }
+// (rows are swizzled by the (step, hh) index: the stash of a row -- one wave, its lanes walking k -- and the 2-byte stores of H
+//  -- lanes walking the hidden unit -- would otherwise hit pieces 512 B apart, i.e. the same banks: PMC before the swizzle,
+//  1.28 M bank-conflict cycles of 2.43 M LDS-active cycles per launch; a fragment read takes 32 consecutive pieces either way)
+__device__ __forceinline__ int mlp_a_off(int p, int step, int hh, int row)
+{
+    const int g = step * 2 + hh;
+    return p * kMlpPlane + (g * 32 + (row ^ (g & 31))) * 16;
+}
 // 16-byte pieces of a weight matrix (rows x K) in memory: [row tile][step][plane][hh][row in tile]
 __host__ __device__ __forceinline__ size_t mlp_w_piece(int t, int steps, int step, int p, int hh, int li)
 {
