@@ -60,6 +60,30 @@
 //     work-groups, 146 us on 128 -- 11.9-17.5 us per unit, i.e. no overlap at all: across the loop's back edge hipcc's
 //     wait-count pass falls back to s_waitcnt vmcnt(0) in stage 1, so the prefetch is drained before it can help;
 //     making it work needs the loads and their waits in inline assembly
+//   * r03, what the launch is bound by (profiles/r03_pool_phase_stamps.txt: s_memrealtime stamps of every unit;
+//     profiles/r03_pool_l2_requests.txt: TCP counters).  A CU keeps ~65 L2 read requests in flight in BOTH streaming passes
+//     over the features, ~850 cycles each: the mean pass moves 113 useful bytes per request (21 GB/s per CU = the HBM rate),
+//     this pass 67 -- a 256-B run at 2-byte alignment touches three 128-B lines and the line in the middle of a row is
+//     requested by both tiles: 2.70 M requests per launch for 1.41 M lines.  In the stamps that is the prologue: 7-8 us, the
+//     time a wave needs to get its 16 tile requests INTO the CU's miss queue; then 2.6 us to the end of stage 1.  The two
+//     resident work-groups of a CU already alternate (one of them in its request phase 57-72 % of the time, both 17-30 %):
+//     the queue is busy nearly all the time, a unit costs a CU ~9.5 us, the dispatch gap is 0.5 us.  Not HBM-bound, not
+//     compute-bound: request-bound at the CU, with 1.9 requests per line read.
+//   * r03, persistent work-groups (2 per CU, static stride over the units; loop-invariant lane values re-derived per stage
+//     from an opaque thread id and amdgpu_waves_per_eu(4, 4) to stay at 128 VGPRs -- as loop invariants they cost 160):
+//     plain loop 75 us in the step (59 fresh); with the next unit's tile requested into the registers stage 3 has just
+//     finished with (one load behind every bpermute group) the unit lives 15.5 instead of 18.2 us and the launch alone is
+//     7 % shorter at 16 scenes -- but inside the step, next to the clustering stream, 66 us at 4 scenes and 0.38 instead of
+//     0.45 of the HBM peak at 32: a work-group that gets its slot late still owes its whole share, and the slots never free
+//     up for the other stream's kernels
+//   * r03, whole rows: unit = (image, half of the channels, ALL pixels), a wave owns 32 rows and requests both 256-B runs of
+//     a row group back to back (the middle line and the run-on merge at the CU), the two halves of an image exchange their
+//     partial scores (8 heads x 256 pixels) through memory around a ticket and take one soft-max over the image; same
+//     register / lane maps, same result format.  No dead-lock (the halves are adjacent in dispatch order), but 98 us: the
+//     request phase of a unit doubles (13 + 7 us -- the spinning partners' agent-scope polls share the memory path) and a
+//     unit then waits 8 us for its partner with its registers idle; with two work-groups per CU nothing fills that hole.
+//     Fewer requests per line need a unit that sees whole rows WITHOUT a partner: a 16-wave work-group per image (both
+//     tiles side by side on one CU, the next image's rows requested as stage 3 frees registers) -- not built
 #include <cstdlib>
 
 #include "common.h"
