@@ -84,6 +84,10 @@
 //     unit then waits 8 us for its partner with its registers idle; with two work-groups per CU nothing fills that hole.
 //     Fewer requests per line need a unit that sees whole rows WITHOUT a partner: a 16-wave work-group per image (both
 //     tiles side by side on one CU, the next image's rows requested as stage 3 frees registers) -- not built
+//   * r03, tile-1 windows wholly beyond the row (pixels >= 232) re-reading the row's last window instead of running on into the
+//     next row (a 208-B run touches 2.6 instead of 3 lines on average: -6 % of the tile requests; branch-free, the columns are
+//     ignored anyway): 17.58k / 17.39k vs 17.66k / 17.51k scenes/s at 4 scenes, 25.25k / 25.19k vs 25.11k / 25.15k at 32 -- inside
+//     the box-to-box noise, not kept
 #include <cstdlib>
 
 #include "common.h"
