@@ -90,16 +90,19 @@ int main(int argc, char **argv)
     CK(hipMalloc(&out, 1 << 22));
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     const int iters = 30;
-    for (int v = 0; v < 5; ++v) {
+    for (int v = 0; v < 7; ++v) {
         const char *name = v == 0 ? "tile      (8 waves, 2 per CU)" : v == 1 ? "rowpair16 (16 waves, 1 per CU)" : v == 2 ? "rowpair8  (8 waves, 2 per CU)"
-                         : v == 3 ? "contig    (8 waves, 2 per CU)" : "rowpair8  (8 waves, 4 per CU: 32 KB LDS)";
+                         : v == 3 ? "contig    (8 waves, 2 per CU)" : v == 4 ? "rowpair8  (8 waves, 4 per CU: 32 KB LDS)"
+                         : v == 5 ? "tile      (8 waves, 1 per CU: 128 KB LDS)" : "rowpair8  (8 waves, 1 per CU: 128 KB LDS)";
         auto launch = [&](int k) {
             const unsigned short *p = img[k % 3];
             if (v == 0) hipLaunchKernelGGL(k_tile, dim3((nimg + 7) / 8 * 16), dim3(512), 65408, 0, p, nimg, out);
             else if (v == 1) hipLaunchKernelGGL(k_rowpair<16>, dim3((nimg + 7) / 8 * 8), dim3(1024), 131072, 0, p, nimg, out);
             else if (v == 2) hipLaunchKernelGGL(k_rowpair<8>, dim3((nimg + 7) / 8 * 16), dim3(512), 65408, 0, p, nimg, out);
             else if (v == 3) hipLaunchKernelGGL(k_contig, dim3((unsigned)((bytes + 131071) / 131072)), dim3(512), 65408, 0, p, nimg, out);
-            else hipLaunchKernelGGL(k_rowpair<8>, dim3((nimg + 7) / 8 * 16), dim3(512), 32768, 0, p, nimg, out);
+            else if (v == 4) hipLaunchKernelGGL(k_rowpair<8>, dim3((nimg + 7) / 8 * 16), dim3(512), 32768, 0, p, nimg, out);
+            else if (v == 5) hipLaunchKernelGGL(k_tile, dim3((nimg + 7) / 8 * 16), dim3(512), 131072, 0, p, nimg, out);
+            else hipLaunchKernelGGL(k_rowpair<8>, dim3((nimg + 7) / 8 * 16), dim3(512), 131072, 0, p, nimg, out);
         };
         for (int k = 0; k < 6; ++k) launch(k);
         CK(hipEventRecord(a));
