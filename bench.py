@@ -391,7 +391,9 @@ def main():
             extras["bf16c_err"] = max(float((a - b).abs().max()) if a.shape == b.shape else float("inf")
                                       for a, b in zip(got, ref_out))
             mod.compute_dtype = "fp32"
-            if rank == 0:
+            # per-pass reports: single-rank runs only -- this block is rank 0's alone, so nothing in it may touch the process group
+            # (its timed_steps get the local barrier); with N > 1 the other ranks would sit in the census all-gather meanwhile
+            if rank == 0 and world == 1:
                 extras["passes"] = [passes_report(cfg, B, site_times(lib, names, mod, inputs, 20), inputs.sets[0]["img"].element_size())]
                 if cfg.name == "cfg2" and B * 8 <= 32:
                     wide = inputs.widened(8)
@@ -405,7 +407,7 @@ def main():
                         mod.compute_dtype = cdt
                         for i in range(3):
                             mod(*wide.args(i))
-                        t32[cdt] = timed_steps(mod, wide, 9, barrier, None)[0] / 9
+                        t32[cdt] = timed_steps(mod, wide, 9, torch.cuda.synchronize, None)[0] / 9
                     mod.compute_dtype = "fp32"
                     extras["wide"] = dict(scenes_per_gpu=wide.B, value_fp32_compute=round(wide.B / t32["fp32"], 2),
                                           value_bf16_compute=round(wide.B / t32["bf16"], 2))

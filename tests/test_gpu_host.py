@@ -174,17 +174,22 @@ def test_bench_multi_rank_path_on_one_gpu():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu",
-                        "--steps", "2", "--warmup", "1", "--no-passes", "--no-cpu-baseline", "--time-every", "1"],
-                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout                        # rank 0 prints ONE line
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["config"]["global_scenes_per_step"] == 8 and d["config"]["scenes_per_gpu"] == 4
-    assert d["cpu_baseline"] is None and d["value"] > 0 and d["scaling"] == "weak"
-    assert [x[0] for x in d["ranks_seen"]] == [0, 1] and len({x[2] for x in d["ranks_seen"]}) == 2     # two processes
-    assert d["roofline"]["launches"] == 2 and 0 < d["roofline"]["frac"] < 1
+    # (a) the reduced line, (b) the DRIVER's flags -- `--gpus N --steps K --warmup W` and nothing else: the extra legs
+    # (fp32-stored features, bf16 compute) run on every rank behind real barriers, the rank-0-only reports are skipped
+    for extra in (["--no-passes", "--no-cpu-baseline", "--time-every", "1"], ["--time-every", "1"]):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu",
+                            "--steps", "2", "--warmup", "1"] + extra,
+                           env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout                        # rank 0 prints ONE line
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and d["config"]["global_scenes_per_step"] == 8 and d["config"]["scenes_per_gpu"] == 4
+        assert d["cpu_baseline"] is None and d["value"] > 0 and d["scaling"] == "weak"
+        assert [x[0] for x in d["ranks_seen"]] == [0, 1] and len({x[2] for x in d["ranks_seen"]}) == 2     # two processes
+        assert d["roofline"]["launches"] == 2 and 0 < d["roofline"]["frac"] < 1
+        if "--no-passes" not in extra:
+            assert d["value_f32_features"] > 0 and d["value_bf16_compute"] > 0 and "roofline_passes" not in d
 
 
 def test_launch_count_of_the_benchmark_shape():
