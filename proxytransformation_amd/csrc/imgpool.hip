@@ -107,6 +107,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kPoolHeads = 8;
+constexpr int kPoolNtImages = 4096;      // images per launch (~21 scenes of 196 views) from which the partials are stored as streaming lines (see the write-out)
 constexpr int kPoolWPad = 544;          // LDS row stride (elements) of the split weights: rows 16 words apart mod 64
 constexpr int kPoolPPad = 136;          // LDS row stride (elements) of the split numerators (128 pixels + 8)
 
@@ -182,7 +183,7 @@ struct PoolArgs {
 // fly (split softmax, gemm.hip k_gemm32<4, 1>): m = max(m_0, m_1, s(0)), l = l_0 e^(m_0-m) + l_1 e^(m_1-m) + e^(s(0)-m),
 // g = (G_0 e^(m_0-m) + G_1 e^(m_1-m)) / l, a(p) = e(p) e^(m_T-m) / l, a(0) = e^(s(0)-m) / l.
 
-template <int DT>   // storage type of the features: 1 = bf16, 2 = fp16
+template <int DT, bool NT>   // DT: storage type of the features, 1 = bf16, 2 = fp16; NT: streaming stores of the partials
 __global__ __launch_bounds__(512) void k_img_pool(PoolArgs a)
 {
     constexpr int heads = kPoolHeads;
@@ -393,8 +394,13 @@ __global__ __launch_bounds__(512) void k_img_pool(PoolArgs a)
         for (int i = tid * 4; i < heads * in_dim; i += 512 * 4)
         {   // write-through (sc1): the 25 MB of partials must not sit dirty in the L2s when the launch ends -- the
             // kernel boundary pays ~1 us per 6 MB of dirty lines (MI355X_MICROARCH.md, "boundary")
+            // (NT: with many images -- 40 KB of partials each, 250 MB at 32 scenes -- the write-through lines are also marked
+            // streaming: -11 % on this launch and +3-5 % on the step at 32 scenes per GPU, +1.7 % at 24, nothing at 12 and 16,
+            // -0.5 % at 4 and 8 where the consumer still finds them in the caches (interleaved A/B on one box, PTX_POOL_NT):
+            // chosen per launch from the image count)
             const f32x4 v = *reinterpret_cast<const f32x4 *>(G + i);
-            asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst + i), "v"(v) : "memory");
+            if (NT) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" :: "v"(dst + i), "v"(v) : "memory");
+            else    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst + i), "v"(v) : "memory");
         }
     }
 }
@@ -425,8 +431,11 @@ int launch_img_pool(const void *img, int dt, const float *we, const float *qkv0,
     PoolArgs pa{static_cast<const unsigned short *>(img), we, qkv0, nimg, in_dim, hw, C, KT1, EW, scale, Gs, E, ML};
     const size_t lds = sizeof(float) * 8 * kPoolHeads * 128 + sizeof(unsigned short) * 24 * (kPoolWPad + kPoolPPad);
     PTX_REQUIRE(lds <= 64 * 1024, "img pool: %zu B of LDS", lds);
-    if (dt == 1) hipLaunchKernelGGL(k_img_pool<1>, dim3(cdiv(nimg, 8) * 16), dim3(512), lds, st, pa);
-    else         hipLaunchKernelGGL(k_img_pool<2>, dim3(cdiv(nimg, 8) * 16), dim3(512), lds, st, pa);
+    static const int nt_env = getenv("PTX_POOL_NT") ? atoi(getenv("PTX_POOL_NT")) : -1;      // A/B runs: 0 / 1 force it
+    const bool nt = nt_env >= 0 ? nt_env != 0 : nimg >= kPoolNtImages;
+    const dim3 grid(cdiv(nimg, 8) * 16);
+    if (dt == 1) { if (nt) hipLaunchKernelGGL((k_img_pool<1, true>), grid, dim3(512), lds, st, pa); else hipLaunchKernelGGL((k_img_pool<1, false>), grid, dim3(512), lds, st, pa); }
+    else         { if (nt) hipLaunchKernelGGL((k_img_pool<2, true>), grid, dim3(512), lds, st, pa); else hipLaunchKernelGGL((k_img_pool<2, false>), grid, dim3(512), lds, st, pa); }
     PTX_LAUNCHED("k_img_pool");
     return PTX_OK;
 }
