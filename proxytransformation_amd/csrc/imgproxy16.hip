@@ -67,6 +67,10 @@ struct RowLanes {
 // ---- pass 1: per-channel means.  One wave per kMeanGroups x 8 rows: all 4 * kMeanGroups load instructions (2 rows
 // each) are issued before the first reduction, so a wave keeps 14 KB in flight instead of 3.6 KB (r02: one group per
 // wave ran at 3.5 TB/s at 4 scenes / GPU and 2.9 TB/s at 32 -- 400k short-lived waves).
+// r03: this pass's load map alone (scratch/rowspan_bench.hip, "rows2, 4 waves") runs at 6.3 / 6.7 TB/s at 4 / 32 scenes per GPU,
+// the pass inside the step at 5.4 / 4.5-4.7 -- next to the clustering stream's kernels.  The reduction is not what holds it:
+// with the eight values of a lane summed by four v_dot2c_f32_bf16 against a per-lane vector of ones / zeros (instead of 8
+// conversions + 8 selects + 8 adds; parity-green) the pass stays at 4.5 TB/s at 32 scenes and the step within +-0.7 % -- not kept.
 constexpr int kMeanGroups = 4;
 
 template <int DT>

@@ -62,6 +62,25 @@ __global__ __launch_bounds__(WAVES * 64) void k_rowpair(const unsigned short *im
     if (acc == 0x12345678u) out[blockIdx.x] = smem[0];
 }
 
+// whole rows at their own 2-byte alignment (what k_img_mean16 does): an instruction = 2 adjacent rows x 29 windows of 16 B
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_rows2(const unsigned short *img, int nimg, float *out)
+{
+    extern __shared__ unsigned char smem[];
+    const size_t wave = (size_t)blockIdx.x * WAVES + (threadIdx.x >> 6);       // 32 rows per wave
+    const size_t nrows = (size_t)nimg * CH;
+    if (wave * 32 >= nrows) return;
+    const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
+    unsigned acc = 0;
+    u32x4 L[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        L[i] = __builtin_nontemporal_load(reinterpret_cast<const u4u2 *>(img + (wave * 32 + 2 * i + h) * HW + (n < 28 ? 8 * n : HW - 8)));
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc ^= fold(L[i]);
+    if (acc == 0x12345678u) out[blockIdx.x] = smem[0];
+}
+
 __global__ __launch_bounds__(512) void k_contig(const unsigned short *img, int nimg, float *out)
 {
     extern __shared__ unsigned char smem[];
@@ -90,10 +109,11 @@ int main(int argc, char **argv)
     CK(hipMalloc(&out, 1 << 22));
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     const int iters = 30;
-    for (int v = 0; v < 7; ++v) {
+    for (int v = 0; v < 9; ++v) {
         const char *name = v == 0 ? "tile      (8 waves, 2 per CU)" : v == 1 ? "rowpair16 (16 waves, 1 per CU)" : v == 2 ? "rowpair8  (8 waves, 2 per CU)"
                          : v == 3 ? "contig    (8 waves, 2 per CU)" : v == 4 ? "rowpair8  (8 waves, 4 per CU: 32 KB LDS)"
-                         : v == 5 ? "tile      (8 waves, 1 per CU: 128 KB LDS)" : "rowpair8  (8 waves, 1 per CU: 128 KB LDS)";
+                         : v == 5 ? "tile      (8 waves, 1 per CU: 128 KB LDS)" : v == 6 ? "rowpair8  (8 waves, 1 per CU: 128 KB LDS)"
+                         : v == 7 ? "rows2     (8 waves, 2-B aligned whole rows)" : "rows2     (4 waves, no LDS: the mean pass)";
         auto launch = [&](int k) {
             const unsigned short *p = img[k % 3];
             if (v == 0) hipLaunchKernelGGL(k_tile, dim3((nimg + 7) / 8 * 16), dim3(512), 65408, 0, p, nimg, out);
@@ -102,7 +122,9 @@ int main(int argc, char **argv)
             else if (v == 3) hipLaunchKernelGGL(k_contig, dim3((unsigned)((bytes + 131071) / 131072)), dim3(512), 65408, 0, p, nimg, out);
             else if (v == 4) hipLaunchKernelGGL(k_rowpair<8>, dim3((nimg + 7) / 8 * 16), dim3(512), 32768, 0, p, nimg, out);
             else if (v == 5) hipLaunchKernelGGL(k_tile, dim3((nimg + 7) / 8 * 16), dim3(512), 131072, 0, p, nimg, out);
-            else hipLaunchKernelGGL(k_rowpair<8>, dim3((nimg + 7) / 8 * 16), dim3(512), 131072, 0, p, nimg, out);
+            else if (v == 6) hipLaunchKernelGGL(k_rowpair<8>, dim3((nimg + 7) / 8 * 16), dim3(512), 131072, 0, p, nimg, out);
+            else if (v == 7) hipLaunchKernelGGL(k_rows2<8>, dim3((unsigned)(((size_t)nimg * CH / 32 + 7) / 8)), dim3(512), 65408, 0, p, nimg, out);
+            else hipLaunchKernelGGL(k_rows2<4>, dim3((unsigned)(((size_t)nimg * CH / 32 + 3) / 4)), dim3(256), 0, 0, p, nimg, out);
         };
         for (int k = 0; k < 6; ++k) launch(k);
         CK(hipEventRecord(a));
