@@ -930,6 +930,10 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     // image chain when the clustering chain owns the caller's stream -- puts them on the critical path at one scene per
     // call, where only the short point-proxy kernels separate k_select from the join: cfg4 at 6 scenes +1 %, cfg1 -6 %,
     // cfg5 -2 %: not done.)
+    // (r03: the fork and the join as stream memory operations -- hipStreamWriteValue32 on the producing stream, hipStreamWaitValue32
+    // on the consuming one, signal memory from hipExtMallocWithFlags -- instead of event record + wait: parity-green, the join
+    // alone 17.63k / 17.53k / 17.06k vs 17.50k / 17.43k / 17.52k scenes/s, fork + join 17.47k / 17.47k / 16.63k vs 17.49k / 17.56k /
+    // 17.49k: the ~6 us between the two kernels around a cross-queue wait are not the event's.)
     hipStream_t ts = tags_tail ? cs : side->lo;
     const bool slots_first = !cluster_on_caller && !tags_tail;
     auto enqueue_tags = [&]() -> int {
