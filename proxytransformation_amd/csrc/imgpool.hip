@@ -73,6 +73,9 @@
 //     2.6 us to the end of stage 1 (5.7 us per unit in the loads-only kernel); the two resident work-groups of a CU
 //     alternate on their own (one of them requesting 57-72 % of the time, both 17-30 %), the dispatch gap is 0.5 us; ~65 L2
 //     requests are in flight per CU (118 in the loads-only kernel).
+//   * r03, load policy again, whole step, interleaved pairs (scratch/ld_policy_variants.py): plain instead of streaming loads in
+//     this kernel -1.0 % at 4 scenes and -1.5 % at 32; in the mean pass this kernel drops to 54 us at 4 scenes (it finds lines of
+//     the mean pass in the caches) but the mean pass loses more (41 vs 38 us between events): step -2 %; both -6 % / -3 %
 //   * r03, NOT the cause (each built, parity-green, timed in the step on one box against the shipped build): the number of
 //     memory instructions per wave (head weights as two 16-B loads per lane with wave = head, positional terms as one 8-B
 //     load: 21 instead of 28 instructions, 60.2 vs 60.5 us, 17.60k vs 17.60k scenes/s); stage 3 (above)
