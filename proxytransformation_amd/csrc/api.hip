@@ -934,6 +934,9 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     // on the consuming one, signal memory from hipExtMallocWithFlags -- instead of event record + wait: parity-green, the join
     // alone 17.63k / 17.53k / 17.06k vs 17.50k / 17.43k / 17.52k scenes/s, fork + join 17.47k / 17.47k / 16.63k vs 17.49k / 17.56k /
     // 17.49k: the ~6 us between the two kernels around a cross-queue wait are not the event's.)
+    // (r03, many scenes per call, where the clustering chain has slack: starting it only after the mean pass -- which runs 40 %
+    // slower next to it than alone -- moves the cost to the pooling pass: 24.4k vs 25.2k scenes/s at 32 scenes; the clustering
+    // stream at low instead of high priority: 25.4k vs 25.6k at 32 scenes, 21.9k vs 21.4k at 12: no shape rule worth having.)
     hipStream_t ts = tags_tail ? cs : side->lo;
     const bool slots_first = !cluster_on_caller && !tags_tail;
     auto enqueue_tags = [&]() -> int {
