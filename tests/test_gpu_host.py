@@ -192,6 +192,44 @@ def test_bench_multi_rank_path_on_one_gpu():
             assert d["value_f32_features"] > 0 and d["value_bf16_compute"] > 0 and "roofline_passes" not in d
 
 
+_NT_WORKER = r"""
+import os, sys, hashlib, torch
+sys.path.insert(0, %r)
+from proxytransformation_amd.synth import PreshapeConfig, make_scene_batch
+from tests.util import build_module
+cfg = PreshapeConfig("ntstore", B=2, N=20000, grid_size=8, dynamic_drop_radio=0.5, L=16, V=24, seed_base=321)
+m, _ = build_module(cfg)
+m = m.cuda()
+pts, text, mask, img = make_scene_batch(cfg)
+dev = torch.device("cuda:0")
+args = ([torch.from_numpy(p).to(dev) for p in pts],
+        {"text_feats": torch.from_numpy(text).to(dev), "text_token_mask": torch.from_numpy(mask).to(dev)},
+        torch.from_numpy(img).to(dev).to(torch.bfloat16))
+with torch.no_grad():
+    outs = m(*args)
+h = hashlib.sha256()
+for o in outs:
+    h.update(o.cpu().numpy().tobytes())
+print("DIGEST", h.hexdigest())
+"""
+
+
+@pytest.mark.gpu
+def test_streaming_partial_stores_do_not_change_the_result(tmp_path):
+    """k_img_pool stores its per-tile partials as plain or as streaming write-through lines depending on the image count of the
+    launch (>= 4096 images: csrc/imgpool.hip); the switch is a cache policy, so both forms must give the same bits.  PTX_POOL_NT
+    forces one or the other (read once per process: two processes)."""
+    script = tmp_path / "nt_worker.py"
+    script.write_text(_NT_WORKER % ROOT)
+    digests = []
+    for nt in ("0", "1"):
+        env = dict(os.environ, PTX_POOL_NT=nt)
+        r = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        digests.append([ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][0])
+    assert digests[0] == digests[1]
+
+
 def test_launch_count_of_the_benchmark_shape():
     """an eval forward at the benchmark's shape (bf16-stored features, head_dim 32) is 16 kernel launches (r02: 19; since r03 the two attention launches are one, and fc1 + fc2 + the output heads are one) --
     counted through the library's own launch-site bracketing (every launch of the forward sits in exactly one site)."""
