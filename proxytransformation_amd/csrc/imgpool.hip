@@ -65,11 +65,12 @@
 //     inside the bench step).  The tile map alone, cold, takes 33 us (5.5 TB/s; 34.7 with ONE work-group per CU: 8 requesting
 //     waves per CU are enough) with 1.70 L2 requests per 128-B line -- a 256-B run at 2-byte alignment touches three lines and
 //     the line in the middle of a row is requested by both tiles; whole rows as "row pairs" need 1.28 and take 29 us, the
-//     same as contiguous reads.  This kernel with stages 1-3 and every store removed: 41 us (head weights 18.5 MB, ramp,
-//     tail); with only the stores removed 52.8; with only stage 3 removed 59.7 = unchanged.  So: ~41 us of requests as these
-//     work-groups issue them, ~7 us for the 31.5 MB of write-through partials on the same memory path (fetch 220 MB + write
-//     31.5 MB at the 5.4 TB/s the mean pass reaches = 46.5 us is the floor of THIS decomposition), ~12 us of a unit's compute
-//     that the co-resident unit's requests do not cover.  In the stamps a unit's requests take 8 us to the first barrier +
+//     same as contiguous reads.  This kernel with stages 1-3 and every store removed (held at two work-groups per CU): 41-45 us
+//     (head weights 18.5 MB, ramp, tail); with only the stores removed 53-54.  So: ~42 us of requests as these work-groups
+//     issue them, ~8 us for the 31.5 MB of write-through partials on the same memory path (fetch 220 MB + write 31.5 MB at the
+//     5.4 TB/s the mean pass reaches = 46.5 us is the floor of THIS decomposition), ~10 us of a unit's compute that the
+//     co-resident unit's requests do not cover.  (Variants that drop single stages do not price them: without stage 3 the
+//     kernel compiles to 142 VGPRs -- one work-group per CU, 59.7 us -- and spills when capped at 128.)  In the stamps a unit's requests take 8 us to the first barrier +
 //     2.6 us to the end of stage 1 (5.7 us per unit in the loads-only kernel); the two resident work-groups of a CU
 //     alternate on their own (one of them requesting 57-72 % of the time, both 17-30 %), the dispatch gap is 0.5 us; ~65 L2
 //     requests are in flight per CU (118 in the loads-only kernel).
@@ -78,7 +79,7 @@
 //     the mean pass in the caches) but the mean pass loses more (41 vs 38 us between events): step -2 %; both -6 % / -3 %
 //   * r03, NOT the cause (each built, parity-green, timed in the step on one box against the shipped build): the number of
 //     memory instructions per wave (head weights as two 16-B loads per lane with wave = head, positional terms as one 8-B
-//     load: 21 instead of 28 instructions, 60.2 vs 60.5 us, 17.60k vs 17.60k scenes/s); stage 3 (above)
+//     load: 21 instead of 28 instructions, 60.2 vs 60.5 us, 17.60k vs 17.60k scenes/s)
 //   * r03, persistent work-groups (2 per CU, static stride over the units; loop-invariant lane values re-derived per stage
 //     from an opaque thread id and amdgpu_waves_per_eu(4, 4) to stay at 128 VGPRs -- as loop invariants they cost 160):
 //     plain loop 75 us in the step (59 fresh); with the next unit's tile requested into the registers stage 3 has just
