@@ -77,6 +77,13 @@
 //   * r03, load policy again, whole step, interleaved pairs (scratch/ld_policy_variants.py): plain instead of streaming loads in
 //     this kernel -1.0 % at 4 scenes and -1.5 % at 32; in the mean pass this kernel drops to 54 us at 4 scenes (it finds lines of
 //     the mean pass in the caches) but the mean pass loses more (41 vs 38 us between events): step -2 %; both -6 % / -3 %
+//   * r03, stage 3 as ONE basic block: hipcc turns `if (ps == 0) G[..] = x` and the ?: chain that picks the accumulator row into
+//     exec-masked control flow, so every (kb, i, hg) step is its own block and runs strictly after the previous one (bpermute
+//     latency, three dependent MFMAs, accumulator read, DPP adds).  With every lane storing (three of a quad into dump words
+//     behind G, one per-lane base + immediates) and the row picked by per-lane bit masks the scheduler interleaves the
+//     bpermutes of later steps with the MFMAs and pairs the stores -- parity-green, the launch 59.4-61.5 instead of 61.5-62.2 us
+//     in the step, the step itself unchanged (17.26k / 17.33k / 16.83k vs 17.52k / 17.42k / 17.38k at 4 scenes, 25.13k vs 25.23k
+//     at 32): the launch does not wait for stage 3 either.  Not kept
 //   * r03, NOT the cause (each built, parity-green, timed in the step on one box against the shipped build): the number of
 //     memory instructions per wave (head weights as two 16-B loads per lane with wave = head, positional terms as one 8-B
 //     load: 21 instead of 28 instructions, 60.2 vs 60.5 us, 17.60k vs 17.60k scenes/s)
