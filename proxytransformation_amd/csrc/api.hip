@@ -178,6 +178,7 @@ struct PtxContext {
     int dev = -1;
     hipStream_t st = nullptr, lo = nullptr;
     hipEvent_t fork = nullptr, join = nullptr, aux = nullptr, tags = nullptr;
+    uint32_t *gate = nullptr; uint32_t gate_seq = 0;      // device words of the in-kernel fork / join ("gates"); null: events
     std::mutex mu;                       // held for the whole enqueue section of a forward
 };
 namespace ptx {
@@ -195,11 +196,16 @@ static int context_init(PtxContext *c)
     PTX_HIP(hipEventCreateWithFlags(&c->join, hipEventDisableTiming));
     PTX_HIP(hipEventCreateWithFlags(&c->aux, hipEventDisableTiming));
     PTX_HIP(hipEventCreateWithFlags(&c->tags, hipEventDisableTiming));
+    if (!(getenv("PTX_GATE") && atoi(getenv("PTX_GATE")) == 0)) {       // PTX_GATE=0: event record + wait, as before r03
+        PTX_HIP(hipMalloc(reinterpret_cast<void **>(&c->gate), 256));
+        PTX_HIP(hipMemset(c->gate, 0, 256));
+    }
     return PTX_OK;
 }
 
 static void context_release(PtxContext *c)
 {
+    if (c->gate) (void)hipFree(c->gate);
     if (c->fork) (void)hipEventDestroy(c->fork);
     if (c->join) (void)hipEventDestroy(c->join);
     if (c->aux) (void)hipEventDestroy(c->aux);
@@ -248,9 +254,34 @@ static inline T *at(void *base, size_t off) { return reinterpret_cast<T *>(stati
 // 2: everything after it.
 // need_ln: also write the normalised proxies (stage API, debug); the forward consumes c_proj's raw rows through
 // the LayerNorm fold of the image block's proxy_proj GEMM (partials L.lnp_img) and skips that launch.
+// ---- gates: the fork and the join of the two chains through device words instead of event record + wait (r03) ---------------
+// An event record is a packet of its own on the recording stream and the wait a barrier packet on the other: each leaves ~5 us
+// of idle between the two kernels around it -- on the caller's stream once per forward in front of the mean pass (fork) and once
+// in front of the proxy blocks (join).  Instead: the FIRST kernel of the image chain (k_img_mean16 / k_img_mean) stores the
+// forward's sequence number into a word when its first thread starts -- which, the stream being in order, is when everything
+// the caller enqueued before the forward has completed -- and the clustering stream starts with k_gate, ONE wave that polls the
+// word (s_sleep between polls) and ends when it has arrived: the kernels behind it start exactly when they would have behind
+// the event wait.  The join is the mirror image: k_signal behind the clustering stream's last kernel (so its stores have been
+// released), k_gate on the caller's stream in front of the proxy blocks.  Kernel boundaries do the releasing and acquiring as
+// before; the words only order the two queues.  The waiting wave is bounded (~30 s, then it lets go) so that a forward whose
+// first kernel never runs cannot wedge the device.  Interleaved A/B on one box, 4 scenes per GPU: 17.71k (events) -> 17.97k (fork)
+// -> 18.39k (fork + join) scenes/s, 0.2258 -> 0.2176 ms per step; neutral at 32.  Used when the image chain owns the caller's
+// stream (the benchmark shapes); PTX_GATE=0 restores the events everywhere.
+__global__ void k_signal(uint32_t *flag, uint32_t seq)
+{
+    if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void k_gate(const uint32_t *flag, uint32_t seq)
+{
+    for (int it = 0; it < 16000000; ++it) {            // ~2 us per poll once backed off
+        if ((int32_t)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) >= 0) return;
+        if (it < 64) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(64);
+    }
+}
+
 static int run_img_proxy(const PtxShape &s, const PtxWeights &w, const float *prep, const void *img_any,
                          float *img_proxy, void *ws, hipStream_t st, int phase = 0, bool need_ln = true,
-                         int i0 = 0, int ni = -1)
+                         int i0 = 0, int ni = -1, uint32_t *gate = nullptr, uint32_t gate_seq = 0)
 {
     // images [i0, i0 + ni) of the B * V of this call (default: all): every buffer of the chain is per image
     const PrepLayout P = prep_layout(s);
@@ -271,8 +302,8 @@ static int run_img_proxy(const PtxShape &s, const PtxWeights &w, const float *pr
         Gs += (size_t)i0 * 2 * s.heads * s.in_dim; E += (size_t)i0 * s.heads * EW; ML += (size_t)i0 * s.heads * 5;
     }
     if (phase != 2) {
-        if (dt == 0) PTX_TIMED(KID_IMG_MEAN, st, launch_img_mean(img, nimg, s.in_dim, s.hw, fm, st));
-        else PTX_TIMED(KID_IMG_MEAN, st, launch_img_mean16(img_any, dt, nimg, s.in_dim, s.hw, fm, st));
+        if (dt == 0) PTX_TIMED(KID_IMG_MEAN, st, launch_img_mean(img, nimg, s.in_dim, s.hw, fm, st, gate, gate_seq));
+        else PTX_TIMED(KID_IMG_MEAN, st, launch_img_mean16(img_any, dt, nimg, s.in_dim, s.hw, fm, st, gate, gate_seq));
     }
     if (phase == 1) return PTX_OK;
     // head_dim 32: a 32-column tile of the qkv0 GEMM IS one head's q, and the work-group that finishes it goes on to that
@@ -882,12 +913,21 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     static const int swap_env = getenv("PTX_CHAIN_SWAP") ? atoi(getenv("PTX_CHAIN_SWAP")) : -1;
     const bool cluster_on_caller = swap_env >= 0 ? swap_env != 0 : est_cluster > est_image;
     hipStream_t cs = cluster_on_caller ? st : side->st, is = cluster_on_caller ? side->st : st;
-    PTX_HIP(hipEventRecord(side->fork, st));
-    PTX_HIP(hipStreamWaitEvent(side->st, side->fork, 0));
+    const bool gated = side->gate != nullptr && !cluster_on_caller;       // gates instead of events (see k_gate)
+    if (!gated) {
+        PTX_HIP(hipEventRecord(side->fork, st));
+        PTX_HIP(hipStreamWaitEvent(side->st, side->fork, 0));
+    }
     float *img_proxy = at<float>(ws, L.img_proxy);
     // (Two staggered slices of images on two streams -- slice B streaming its means under slice A's table GEMMs, A
     // pooling under B's tables -- measured again in r02 with the fused / folded chain: 0.319 vs 0.298 ms per step.
     // Twice the launches, and the half-size pooling launches each pay their own partial last round.)
+    if (gated) {
+        const uint32_t seq = ++side->gate_seq;
+        PTX_TRY(run_img_proxy(S, *w, pf, img_feat, img_proxy, ws, is, 1, true, 0, -1, side->gate, seq));
+        hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, cs, side->gate, seq);
+        PTX_LAUNCHED("k_gate");
+    } else
     PTX_TRY(run_img_proxy(S, *w, pf, img_feat, img_proxy, ws, is, 1));      // first pass starts at once
 
     // ---- clustering (PRE:430): bounding boxes, then everything per centre in one launch
@@ -982,10 +1022,17 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     // small kernels take CUs from the image passes that are on the critical path.)
     PTX_TRY(run_blocks(S, br, 2, point_proxy, ws, cs, 1, compute_dtype));
     if (tags_tail) PTX_TRY(enqueue_tags());
+    if (gated) {                        // the join through the second gate word: signalled behind the clustering stream's last kernel
+        hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, cs, side->gate + 32, side->gate_seq);
+        PTX_TRY(run_img_proxy(S, *w, pf, img_feat, img_proxy, ws, is, 2, want_img_proxy));
+        hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, side->gate + 32, side->gate_seq);
+        PTX_LAUNCHED("k_gate");
+    } else {
     if (!cluster_on_caller) PTX_HIP(hipEventRecord(side->join, cs));
     PTX_TRY(run_img_proxy(S, *w, pf, img_feat, img_proxy, ws, is, 2, want_img_proxy));      // rest of the image chain
     if (cluster_on_caller) PTX_HIP(hipEventRecord(side->join, is));
     PTX_HIP(hipStreamWaitEvent(st, side->join, 0));
+    }
     PTX_TRY(run_blocks(S, br, 2, point_proxy, ws, st, 2, compute_dtype));
 
     // ---- submanifold reshape + scatter + drop (PRE:459-467); k_affine is the last reader of the tags and clears them

@@ -280,14 +280,16 @@ int launch_affine(const PtxShape &s, const ScenePts &points, uint32_t *tag, cons
                   const int32_t *tile_counts, bool compact, bool clear_tag, hipStream_t st);
 
 // ---- image proxy (imgproxy.hip) ------------------------------------------------------------
-int launch_img_mean(const float *img, int nimg, int in_dim, int hw, float *fm, hipStream_t st);
+int launch_img_mean(const float *img, int nimg, int in_dim, int hw, float *fm, hipStream_t st,
+                    uint32_t *gate = nullptr, uint32_t gate_seq = 0);
 int launch_img_scores(const float *img, const float *we, const float *qkv0, int nimg, int in_dim,
                       int hw, int heads, int C, int KT1, int KT2p, float scale, float *gbuf,
                       hipStream_t st);
 int launch_img_gather(const float *img, int nimg, int in_dim, int hw, int heads, int KT2p,
                       float *gbuf, hipStream_t st);
 
-int launch_img_mean16(const void *img, int dt, int nimg, int in_dim, int hw, float *fm, hipStream_t st);
+int launch_img_mean16(const void *img, int dt, int nimg, int in_dim, int hw, float *fm, hipStream_t st,
+                      uint32_t *gate = nullptr, uint32_t gate_seq = 0);
 int launch_img_scores16(const void *img, int dt, const float *we, const float *qkv0, int nimg, int in_dim,
                         int hw, int heads, int C, int KT1, int KT2p, float scale, float *gbuf, hipStream_t st);
 int launch_img_gather16(const void *img, int dt, int nimg, int in_dim, int hw, int heads, int KT2p, float *gbuf,

@@ -26,8 +26,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // one wave per group of 4 channel rows = 4*hw contiguous floats = hw float4
 __global__ __launch_bounds__(256) void k_img_mean(const float *__restrict__ img, int ngroups,
-                                                  int hw, float *__restrict__ fm)
+                                                  int hw, float *__restrict__ fm, uint32_t *gate, uint32_t gate_seq)
 {
+    // the first thread of the launch tells the clustering stream that the caller's stream has reached this forward (api.hip, "gates")
+    if (gate != nullptr && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(gate, gate_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int lane = lane_id();
     const int g = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (g >= ngroups) return;
@@ -51,12 +53,12 @@ __global__ __launch_bounds__(256) void k_img_mean(const float *__restrict__ img,
     }
 }
 
-int launch_img_mean(const float *img, int nimg, int in_dim, int hw, float *fm, hipStream_t st)
+int launch_img_mean(const float *img, int nimg, int in_dim, int hw, float *fm, hipStream_t st, uint32_t *gate, uint32_t gate_seq)
 {
     PTX_REQUIRE(in_dim % 4 == 0, "img mean: in_dim=%d must be a multiple of 4", in_dim);
     PTX_REQUIRE((reinterpret_cast<uintptr_t>(img) & 15) == 0, "img_feat must be 16-byte aligned");
     const int ngroups = nimg * (in_dim / 4);
-    hipLaunchKernelGGL(k_img_mean, dim3(cdiv(ngroups, 4)), dim3(256), 0, st, img, ngroups, hw, fm);
+    hipLaunchKernelGGL(k_img_mean, dim3(cdiv(ngroups, 4)), dim3(256), 0, st, img, ngroups, hw, fm, gate, gate_seq);
     PTX_LAUNCHED("k_img_mean");
     return PTX_OK;
 }
