@@ -166,6 +166,46 @@ def test_real_module_sharded_over_two_ranks_matches_unsharded(tmp_path):
     assert seen == set(range(cfg.B))
 
 
+def test_forward_is_ordered_behind_in_place_input_writes():
+    """The fork of the two chains (device-word gates, csrc/api.hip: the clustering stream waits for the first thread of the
+    image chain's first kernel instead of an event) has to order the whole forward behind whatever the caller enqueued before
+    it: the inputs are rewritten IN PLACE on the caller's stream right before every call, from three resident variants, and
+    every output must equal the first pass over that variant bit for bit (a clustering stream that starts early, or reads
+    stale lines, picks other clusters)."""
+    # (a shape whose image chain is the longer one by the forward's estimate -- 40 + 0.18 B V > 80 + 0.42 Kd us -- so that the
+    # image chain owns the caller's stream and the gates, not the events, order the chains)
+    kw = dict(B=2, N=30000, grid_size=8, dynamic_drop_radio=0.4, L=16, V=180)
+    cfg = PreshapeConfig("forksoak", seed_base=4242, **kw)
+    assert 40 + 0.18 * cfg.B * cfg.V > 80 + 0.42 * cfg.Kd
+    m, _ = build_module(cfg)
+    m = m.cuda()
+    dev = torch.device("cuda:0")
+    variants = []
+    for k in range(3):
+        c = PreshapeConfig("forksoak", seed_base=4242 + 100 * k, **kw)
+        pts, text, mask, img = make_scene_batch(c)
+        variants.append(([torch.from_numpy(p).to(dev) for p in pts], torch.from_numpy(text).to(dev), torch.from_numpy(mask).to(dev),
+                         torch.from_numpy(img).to(dev).to(torch.bfloat16)))
+    pts = [p.clone() for p in variants[0][0]]
+    td = {"text_feats": variants[0][1].clone(), "text_token_mask": variants[0][2].clone()}
+    img = variants[0][3].clone()
+    ref = {}
+    with torch.no_grad():
+        for i in range(90):
+            key = (i * 7 + i // 5) % 3
+            v = variants[key]
+            for d, s_ in zip(pts, v[0]):
+                d.copy_(s_)
+            td["text_feats"].copy_(v[1]); td["text_token_mask"].copy_(v[2]); img.copy_(v[3])
+            outs = m(pts, td, img)
+            if key not in ref:
+                ref[key] = [o.clone() for o in outs]
+            else:
+                assert len(outs) == len(ref[key])
+                for a, b in zip(outs, ref[key]):
+                    assert a.shape == b.shape and torch.equal(a, b), f"forward {i} (variant {key}) differs from the first pass"
+
+
 def test_bench_multi_rank_path_on_one_gpu():
     """bench.py's own N > 1 path -- self-launch under torch.distributed.run, process-group init, barrier-bracketed timing,
     MAX all-reduce, the rank census -- exercised on the 1-GPU box: two ranks share cuda:0 over gloo (the numbers mean
