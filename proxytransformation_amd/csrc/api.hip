@@ -183,6 +183,26 @@ struct PtxContext {
 };
 namespace ptx {
 
+// The device-word gates (k_gate below) need the two streams' kernels to run CONCURRENTLY: a waiting wave on one queue is released
+// by a kernel on the other.  Anything that serialises kernel execution across queues -- counter collection (rocprofv3 --pmc sets
+// ROCPROF_COUNTER_COLLECTION / ROCPROF_COUNTERS), thread trace, PC sampling, AMD_SERIALIZE_KERNEL, HIP_LAUNCH_BLOCKING -- would leave
+// the waiting wave alone on the device until its bound runs out (seconds per forward): there the events are used.  PTX_GATE=0
+// forces the events, PTX_GATE=1 the gates.
+static bool env_on(const char *name)
+{
+    const char *v = getenv(name);
+    return v != nullptr && v[0] != '\0' && !(v[0] == '0' && v[1] == '\0');
+}
+static bool gates_allowed()
+{
+    if (const char *g = getenv("PTX_GATE")) return atoi(g) != 0;
+    for (const char *name : {"ROCPROF_COUNTER_COLLECTION", "ROCPROF_COUNTERS", "ROCPROF_COUNTER_GROUPS", "ROCPROF_ADVANCED_THREAD_TRACE",
+                             "ROCPROF_PC_SAMPLING_UNIT", "ROCPROF_PC_SAMPLING_METHOD", "AMD_SERIALIZE_KERNEL", "AMD_SERIALIZE_COPY",
+                             "HIP_LAUNCH_BLOCKING", "CUDA_LAUNCH_BLOCKING", "ROCPROFILER_METRICS_PATH", "ROCP_METRICS"})
+        if (env_on(name)) return false;
+    return true;
+}
+
 static int context_init(PtxContext *c)
 {
     PTX_HIP(hipGetDevice(&c->dev));
@@ -196,7 +216,7 @@ static int context_init(PtxContext *c)
     PTX_HIP(hipEventCreateWithFlags(&c->join, hipEventDisableTiming));
     PTX_HIP(hipEventCreateWithFlags(&c->aux, hipEventDisableTiming));
     PTX_HIP(hipEventCreateWithFlags(&c->tags, hipEventDisableTiming));
-    if (!(getenv("PTX_GATE") && atoi(getenv("PTX_GATE")) == 0)) {       // PTX_GATE=0: event record + wait, as before r03
+    if (gates_allowed()) {
         PTX_HIP(hipMalloc(reinterpret_cast<void **>(&c->gate), 256));
         PTX_HIP(hipMemset(c->gate, 0, 256));
     }
@@ -263,8 +283,8 @@ static inline T *at(void *base, size_t off) { return reinterpret_cast<T *>(stati
 // word (s_sleep between polls) and ends when it has arrived: the kernels behind it start exactly when they would have behind
 // the event wait.  The join is the mirror image: k_signal behind the clustering stream's last kernel (so its stores have been
 // released), k_gate on the caller's stream in front of the proxy blocks.  Kernel boundaries do the releasing and acquiring as
-// before; the words only order the two queues.  The waiting wave is bounded (~30 s, then it lets go) so that a forward whose
-// first kernel never runs cannot wedge the device.  Interleaved A/B on one box, 4 scenes per GPU: 17.71k (events) -> 17.97k (fork)
+// before; the words only order the two queues.  The waiting wave is bounded (~4 s, then it lets go) so that a forward whose
+// first kernel never runs cannot wedge the device, and the gates are not used where kernels are serialised (gates_allowed()).  Interleaved A/B on one box, 4 scenes per GPU: 17.71k (events) -> 17.97k (fork)
 // -> 18.39k (fork + join) scenes/s, 0.2258 -> 0.2176 ms per step; neutral at 32.  Used when the image chain owns the caller's
 // stream (the benchmark shapes); PTX_GATE=0 restores the events everywhere.
 __global__ void k_signal(uint32_t *flag, uint32_t seq)
@@ -273,7 +293,7 @@ __global__ void k_signal(uint32_t *flag, uint32_t seq)
 }
 __global__ void k_gate(const uint32_t *flag, uint32_t seq)
 {
-    for (int it = 0; it < 16000000; ++it) {            // ~2 us per poll once backed off
+    for (int it = 0; it < 2000000; ++it) {             // ~2 us per poll once backed off: ~4 s
         if ((int32_t)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) >= 0) return;
         if (it < 64) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(64);
     }
