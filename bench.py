@@ -48,7 +48,7 @@ from proxytransformation_amd.synth import CONFIGS, fill_state_dict, make_scene_b
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix (v_mfma_f32_32x32x2_f32), 256 CUs
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
 
 
 def so_sha16():
@@ -82,6 +82,9 @@ def parse():
                          "buffers, every input set paged in -- and the device out of its idle state: with 6 of them and the "
                          "driver's --steps 20 --warmup 5 the 5 ms that are timed start 3 ms after the first kernel and read 4 %% "
                          "low, 15.7k vs 16.3-16.5k scenes/s; reported in config.setup_forwards)")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="timed blocks of exactly --steps steps each (every block bracketed by barrier + synchronise, MAX over "
+                         "ranks per block); `value` is the MEDIAN block, the spread is reported beside it (timed_blocks)")
     ap.add_argument("--time-every", type=int, default=4,
                     help="the roofline kernel is bracketed by HIP events on every n-th measured step (each event record costs "
                          "the stream ~6 us of idle between two kernels; 1 = every step)")
@@ -136,7 +139,7 @@ def work_model(cfg, B, dt_bytes):
         "k_minmax": B * N * 12,
         # two ball-query passes (upper bound: every point read once per pass) + cluster writes of the second
         "k_cluster": B * (2 * 12 * N + M * K * (4 + 12) + M * 16),
-        "k_tile_count": B * N * 4,
+        "k_tags": B * N * 4,
         "k_affine<compact>": B * N * (12 + 4 + 12),
     }
     flops = {
@@ -252,14 +255,14 @@ class InputSets:
         return out
 
 
-def timed_steps(mod, inputs, steps, barrier, streams=None, f32=False):
+def timed_steps(mod, inputs, steps, barrier, streams=None, f32=False, start=0):
     barrier()
     t0 = time.perf_counter()
     if streams is None:
-        for i in range(steps):
+        for i in range(start, start + steps):
             outs = mod(*inputs.args(i, f32))
     else:
-        for i in range(steps):
+        for i in range(start, start + steps):
             with torch.cuda.stream(streams[i % len(streams)]):
                 outs = mod(*inputs.args(i, f32))
     barrier()
@@ -285,7 +288,7 @@ def passes_report(cfg, B, us, dt_bytes):
 
     def hbm(sites):
         t = sum(us[s] for s in sites if s in us)
-        b = sum(byts[s] for s in sites if byts.get(s))
+        b = sum(byts[s] for s in sites if byts.get(s) and s in us)
         return dict(us=round(t, 2), algorithmic_MB=round(b / 1e6, 2), achieved_GBs=round(b / t / 1e3, 1),
                     frac_of_hbm_peak=round(b / t / 1e3 / HBM_PEAK_GBS, 4)) if t > 0 else None
 
@@ -295,7 +298,7 @@ def passes_report(cfg, B, us, dt_bytes):
         return dict(us=round(t, 2), GFLOP=round(f / 1e9, 3), achieved_TFLOPs=round(f / t / 1e6, 2),
                     frac_of_f32_mfma_peak=round(f / t / 1e6 / MFMA_F32_PEAK_TFLOPS, 4)) if t > 0 else None
     rep["clustering_pass_hbm"] = hbm(["k_minmax", "k_cluster"])
-    rep["apply_pass_hbm"] = hbm(["k_tile_count", "k_affine<compact>"])
+    rep["apply_pass_hbm"] = hbm(["k_tags", "k_affine<compact>"])
     rep["k_minmax"] = hbm(["k_minmax"])
     rep["k_affine"] = hbm(["k_affine<compact>"])
     rep["img_mean_pass_hbm"] = hbm(["k_img_mean"])
@@ -367,7 +370,11 @@ def main():
         n_out = sum(int(o.shape[0]) for o in outs)
         lib.ptx_timing_every(max(1, args.time_every))
         lib.ptx_timing_select(kid)
-        elapsed, outs = timed_steps(mod, inputs, args.steps, barrier, streams)
+        # R blocks of exactly K steps; the input-set rotation continues across blocks
+        block_s = []
+        for r in range(max(1, args.repeats)):
+            el, outs = timed_steps(mod, inputs, args.steps, barrier, streams, start=r * args.steps)
+            block_s.append(el)
         launches, total_ms = ctypes.c_int(0), ctypes.c_float(0.0)
         lib.ptx_timing_read(ctypes.byref(launches), ctypes.byref(total_ms))
         lib.ptx_timing_select(-1)
@@ -430,11 +437,12 @@ def main():
         ranks_seen = [None] * world
         dist.all_gather_object(ranks_seen, me)
         ranks_seen = sorted([list(x) for x in ranks_seen])
-    vals = [elapsed, extras.get("f32", 0.0), extras.get("bf16c", 0.0)]
+    vals = [extras.get("f32", 0.0), extras.get("bf16c", 0.0)] + block_s
     t = torch.tensor(vals, device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
     if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed, f32_step, bf16c_step = (float(x) for x in t.tolist())
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)           # per block: the slowest rank
+    f32_step, bf16c_step, *block_s = (float(x) for x in t.tolist())
+    elapsed = sorted(block_s)[len(block_s) // 2]           # the median block is the reported one
 
     if rank == 0:
         total_scenes = world * B * args.steps
@@ -468,6 +476,11 @@ def main():
                                 arithmetic="fp32 (fp32 MFMA / VALU; the 16-bit matrix pipe only through 3-way operand splits with fp32 accumulate: exact in the pooling pass, dropped terms <= 2^-25 |xy| in the 64x64-tile GEMMs)",
                                 surviving_points_per_step=n_out),
                     roofline=roof)
+        per_block = [round(world * B * args.steps / x, 2) for x in block_s]
+        line["timed_blocks"] = dict(blocks=len(block_s), steps_per_block=args.steps, value_median=line["value"],
+                                    value_min=min(per_block), value_max=max(per_block), values=per_block,
+                                    what="each block = exactly `steps` forwards between barrier + device synchronise; "
+                                         "`value` / `ms_per_step` are the median block's")
         if ranks_seen is not None:
             line["ranks_seen"] = ranks_seen
             line["backend"] = args.backend + (" (RCCL)" if args.backend == "nccl" else "")

@@ -30,13 +30,14 @@
 extern "C" {
 #endif
 
-#define PTX_ABI_VERSION 5
+#define PTX_ABI_VERSION 6
 
 #define PTX_OK          0
 #define PTX_EINVAL     -1   /* bad shape / null pointer / unsupported size */
 #define PTX_ELAUNCH    -2   /* HIP launch or runtime error */
 #define PTX_ENOSPACE   -3   /* workspace / prep buffer too small */
 #define PTX_ETIMEOUT   -4   /* ptx_wait_counts: counts not published in time */
+#define PTX_EGATE      -5   /* a stream gate of an earlier forward timed out (ptx_context_check, ptx_forward) */
 
 /* Static shape of one forward (PRE:282-330 constructor values + input sizes). */
 typedef struct PtxShape {
@@ -115,6 +116,18 @@ const char *ptx_last_error(void);
 typedef struct PtxContext PtxContext;
 int ptx_context_create(PtxContext **ctx);
 int ptx_context_destroy(PtxContext *ctx);
+/* Stream gates (ABI 6).  Where the image chain owns the caller's stream the fork and the join of the two chains are device
+ * words instead of event record + wait (one waiting wave / one waiting work-group instead of two queue packets).  A waiter
+ * is bounded in wall-clock time (PTX_GATE_TIMEOUT_MS, default 10 s -- the fork legitimately waits for everything queued
+ * ahead of the forward on the caller's stream); when the bound runs out it does NOT let go silently: it stores a sticky
+ * error word in pinned host memory, the outputs of that forward become NaN, and (PTX_GATE_TRAP=1) it traps.
+ * ptx_context_check returns PTX_EGATE once for such a failure -- ptx_forward makes the same check on entry -- and the
+ * context orders its streams with events from then on.  The gates are used only after a probe per (context, caller
+ * stream) has shown that the two streams run concurrently (they may share a hardware queue); PTX_GATE=0 / 1 forces
+ * events / gates.  ptx_context_gates: 1 while the context uses gates.  There is no reference counterpart (PRE runs on
+ * one stream). */
+int ptx_context_check(PtxContext *ctx);
+int ptx_context_gates(const PtxContext *ctx);
 
 /* Per-kernel timing of ptx_forward for roofline measurement (bench.py): select ONE launch
  * site by id (0 .. ptx_kernel_count()-1, -1 = off); every later ptx_forward brackets that

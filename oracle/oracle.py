@@ -468,13 +468,14 @@ def _fma32(a, b, c):
 def reverse_3d_points(points, img_meta, coord_type="DEPTH"):
     """apply_3d_transformation(..., reverse=True) (point_fusion.py:20-107) step by step in fp32, as the reference applies
     it: the recorded flow back to front -- 'T': += -pcd_trans, 'S': *= 1 / pcd_scale_factor, 'R': @ inverse(pcd_rotation),
-    'HF' / 'VF': the BEV flips of DEPTH / LIDAR coordinates (x / y negated; depth_points.py:47-50)."""
+    'HF' / 'VF': the BEV flips of the coordinate type -- DEPTH negates x / y (depth_points.py:47-50), LIDAR y / x
+    (lidar_points.py:47-50), CAMERA x / z (cam_points.py:47-50)."""
     p = torch.from_numpy(_f32(points)).clone()
     flow = list(img_meta.get("transformation_3d_flow", []))
     rot = torch.from_numpy(_f32(img_meta["pcd_rotation"])) if "pcd_rotation" in img_meta else torch.eye(3)
     scale = img_meta.get("pcd_scale_factor", 1.0)
     trans = torch.from_numpy(_f32(img_meta["pcd_trans"])) if "pcd_trans" in img_meta else torch.zeros(3)
-    assert coord_type.upper() in ("DEPTH", "LIDAR")
+    hf_axis, vf_axis = {"DEPTH": (0, 1), "LIDAR": (1, 0), "CAMERA": (0, 2)}[coord_type.upper()]
     for op in flow[::-1]:
         if op == "T":
             p += -trans
@@ -484,10 +485,10 @@ def reverse_3d_points(points, img_meta, coord_type="DEPTH"):
             p = p @ rot.inverse()
         elif op == "HF":
             if img_meta.get("pcd_horizontal_flip", False):
-                p[:, 0] = -p[:, 0]
+                p[:, hf_axis] = -p[:, hf_axis]
         elif op == "VF":
             if img_meta.get("pcd_vertical_flip", False):
-                p[:, 1] = -p[:, 1]
+                p[:, vf_axis] = -p[:, vf_axis]
         else:
             raise AssertionError(op)
     return p.numpy()

@@ -27,18 +27,23 @@ void set_error(const char *fmt, ...)
 // is launched on; ptx_timing_read() returns launches and summed milliseconds.  Off by default.
 // img_pass2 / img_pass3 are the launch sites after the mean pass: k_img_pool (no third launch) for bf16 / fp16
 // features of the path's shape, k_img_scores / k_img_gather for fp32, k_img_scores16 / k_img_gather16 otherwise.
+// (k_gemm_nt[we]: from ~4000 images per call on and at head_dim 64; k_ln_rows[norm_img]: debug / stage API; k_attn32[...]: head_dim 64,
+//  more than 256 proxies, few (scene, head) pairs -- every site is live on some shape; the gate sites are the one-wave fork / join
+//  launches of the stream gates.)
 static const char *const kKernelNames[] = {
-    "k_minmax", "k_cluster", "k_select", "k_select_slots",
-    "k_tile_count", "k_slot_net<pointnet>", "k_img_mean", "k_gemm_nt[qkv0]",
+    "k_minmax", "k_cluster", "k_select", "k_tags",
+    "k_slot_net<pointnet>", "k_img_mean", "k_gemm_nt[qkv0]",
     "k_gemm_nt[we]", "img_pass2", "img_pass3", "k_gemm_nt[o]", "k_gemm_nt[c_proj]",
     "k_ln_rows[norm_img]", "k_gemm_nt[qkv+proxy_proj]", "k_gemm_nt[pp_img]", "k_attn32[proxy_as_query]",
     "k_attn32[proxy_as_key]", "k_gemm_nt[proj]", "k_gemm_nt[fc1]", "k_gemm_nt[fc2]",
-    "k_heads", "k_affine<compact>", "k_proxy_attn[fused]", "k_mlp[fc1+gelu+fc2]"};
+    "k_heads", "k_affine<compact>", "k_proxy_attn[fused]", "k_mlp[fc1+gelu+fc2]",
+    "k_gate[fork]", "k_signal[join]", "k_gate[join]"};
 enum Kid : int {
-    KID_MINMAX = 0, KID_CLUSTER, KID_SELECT, KID_SLOTS, KID_TILECOUNT, KID_POINTNET,
+    KID_MINMAX = 0, KID_CLUSTER, KID_SELECT, KID_TAGS, KID_POINTNET,
     KID_IMG_MEAN, KID_IMG_QKV0, KID_IMG_WE, KID_IMG_SCORES, KID_IMG_GATHER, KID_IMG_O, KID_IMG_C,
     KID_IMG_LN, KID_BLK_QKV, KID_BLK_PP, KID_BLK_ATTN_A, KID_BLK_ATTN_B, KID_BLK_PROJ, KID_BLK_FC1,
-    KID_BLK_FC2, KID_BLK_HEADS, KID_AFFINE, KID_BLK_ATTN_F, KID_BLK_MLP, KID_COUNT};
+    KID_BLK_FC2, KID_BLK_HEADS, KID_AFFINE, KID_BLK_ATTN_F, KID_BLK_MLP,
+    KID_GATE_FORK, KID_SIGNAL_JOIN, KID_GATE_JOIN, KID_COUNT};
 static_assert(sizeof(kKernelNames) / sizeof(kKernelNames[0]) == KID_COUNT, "kernel name table");
 
 struct TimingRec { int kid; hipEvent_t a, b; };
@@ -178,7 +183,14 @@ struct PtxContext {
     int dev = -1;
     hipStream_t st = nullptr, lo = nullptr;
     hipEvent_t fork = nullptr, join = nullptr, aux = nullptr, tags = nullptr;
-    uint32_t *gate = nullptr; uint32_t gate_seq = 0;      // device words of the in-kernel fork / join ("gates"); null: events
+    // device words of the in-kernel fork / join ("gates", below); null or !gates_on: events.  Word 0: fork, 32: join,
+    // 40 / 44: the two probe words, 48: poison (read by k_affine), the rest spare
+    uint32_t *gate = nullptr; uint32_t gate_seq = 0;
+    uint32_t *gate_err = nullptr;        // [host, pinned, device-mapped] sticky error word written by a waiter that timed out
+    bool gates_on = false;               // cleared for good by the first gate that times out or by a failed probe
+    bool probed = false; hipStream_t probed_st = nullptr;   // the caller stream the concurrency probe was run against
+    hipStream_t last_st = nullptr;       // caller stream of the latest forward (drained before the poison word is cleared)
+    uint64_t gate_ticks = 0, probe_ticks = 0; int gate_trap = 0;
     std::mutex mu;                       // held for the whole enqueue section of a forward
 };
 namespace ptx {
@@ -219,6 +231,18 @@ static int context_init(PtxContext *c)
     if (gates_allowed()) {
         PTX_HIP(hipMalloc(reinterpret_cast<void **>(&c->gate), 256));
         PTX_HIP(hipMemset(c->gate, 0, 256));
+        PTX_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->gate_err), 64, hipHostMallocMapped));
+        c->gate_err[0] = 0u;
+        int khz = 0;                    // s_memrealtime ticks per millisecond (100 MHz on gfx950)
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->dev) != hipSuccess || khz <= 0) khz = 100000;
+        // The bound of a waiting wave.  The fork legitimately waits for everything the caller queued ahead of the forward on its
+        // stream (seconds, in a training step), so the default is generous; PTX_GATE_TIMEOUT_MS overrides (tests: a few ms)
+        const char *ms_env = getenv("PTX_GATE_TIMEOUT_MS");
+        const long ms = ms_env ? atol(ms_env) : 10000;
+        c->gate_ticks = (uint64_t)(ms > 0 ? ms : 1) * (uint64_t)khz;
+        c->probe_ticks = (uint64_t)20 * (uint64_t)khz;          // probe: 20 ms on an idle pair of streams
+        c->gate_trap = env_on("PTX_GATE_TRAP") ? 1 : 0;
+        c->gates_on = true;
     }
     return PTX_OK;
 }
@@ -226,6 +250,8 @@ static int context_init(PtxContext *c)
 static void context_release(PtxContext *c)
 {
     if (c->gate) (void)hipFree(c->gate);
+    if (c->gate_err) (void)hipHostFree(c->gate_err);
+    c->gate = nullptr; c->gate_err = nullptr; c->gates_on = false;
     if (c->fork) (void)hipEventDestroy(c->fork);
     if (c->join) (void)hipEventDestroy(c->join);
     if (c->aux) (void)hipEventDestroy(c->aux);
@@ -291,12 +317,71 @@ __global__ void k_signal(uint32_t *flag, uint32_t seq)
 {
     if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__global__ void k_gate(const uint32_t *flag, uint32_t seq)
+// one wave that ends when the word has arrived -- or, after the bound, reports the failure (gate_wait, common.h): it never lets go silently
+__global__ void k_gate(GateRef g)
 {
-    for (int it = 0; it < 2000000; ++it) {             // ~2 us per poll once backed off: ~4 s
-        if ((int32_t)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) >= 0) return;
-        if (it < 64) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(64);
+    if (threadIdx.x == 0) gate_wait(g);
+}
+
+static GateRef gate_ref(const PtxContext *c, int word, uint32_t seq, uint32_t site, bool probe = false)
+{
+    return GateRef{c->gate + word, seq, c->gate_err, probe ? nullptr : c->gate + 48, probe ? c->probe_ticks : c->gate_ticks,
+                   site, probe ? 0 : c->gate_trap};
+}
+
+// A gate of a previous forward timed out (or the probe failed): report it ONCE as PTX_EGATE, switch the context to events for good.
+// The forward whose gate failed had its outputs turned into NaN by k_affine (poison word), so nothing plausible-looking survives.
+static int gate_check(PtxContext *c)
+{
+    if (c->gate_err == nullptr) return PTX_OK;
+    const uint32_t e = *reinterpret_cast<volatile uint32_t *>(c->gate_err);
+    if (e == 0u) return PTX_OK;
+    static const char *const site_name[] = {"?", "fork (clustering stream waiting for the caller's stream)",
+                                            "join (caller's stream waiting for the clustering stream)", "probe, fork direction",
+                                            "probe, join direction"};
+    const unsigned site = (e >> 24) & 0x7fu;
+    c->gates_on = false;
+    *reinterpret_cast<volatile uint32_t *>(c->gate_err) = 0u;
+    // the streams may still be running the poisoned forward (its k_affine has to see the word): drain them, then clear
+    (void)hipStreamSynchronize(c->st);
+    (void)hipStreamSynchronize(c->last_st);
+    (void)hipMemset(c->gate + 48, 0, 4);
+    set_error("stream gate timed out at the %s of forward #%u: the two chains of that forward were not ordered and its outputs "
+              "were set to NaN; this context now orders its streams with events (PTX_GATE=0 selects them from the start)",
+              site_name[site < 5 ? site : 0], e & 0xffffffu);
+    return PTX_EGATE;
+}
+
+// The gates need the caller's stream and the context's side stream to make progress side by side.  HIP maps streams onto a small
+// pool of hardware queues: two streams that share one run their kernels in enqueue order, and a waiting wave enqueued in front of
+// the kernel that releases it would sit there for its whole bound.  Checked once per (context, caller stream), in both directions,
+// with the WAITER enqueued first: if either wave reports a timeout (20 ms; the streams are drained first so nothing else is in
+// the way) the context uses events.
+static int gate_probe(PtxContext *c, hipStream_t st)
+{
+    c->probed = true; c->probed_st = st;
+    if (!c->gates_on) return PTX_OK;
+    if (getenv("PTX_GATE_NO_PROBE") != nullptr) return PTX_OK;
+    PTX_HIP(hipStreamSynchronize(st));
+    PTX_HIP(hipStreamSynchronize(c->st));
+    const uint32_t seq = ++c->gate_seq;
+    hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, c->st, gate_ref(c, 40, seq, 3, true));      // side waits for the caller
+    PTX_LAUNCHED("k_gate[probe]");
+    hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, st, c->gate + 40, seq);
+    PTX_LAUNCHED("k_signal[probe]");
+    PTX_HIP(hipStreamSynchronize(c->st));
+    PTX_HIP(hipStreamSynchronize(st));
+    hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, gate_ref(c, 44, seq, 4, true));         // caller waits for the side
+    PTX_LAUNCHED("k_gate[probe]");
+    hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, c->st, c->gate + 44, seq);
+    PTX_LAUNCHED("k_signal[probe]");
+    PTX_HIP(hipStreamSynchronize(st));
+    PTX_HIP(hipStreamSynchronize(c->st));
+    if (*reinterpret_cast<volatile uint32_t *>(c->gate_err) != 0u) {
+        *reinterpret_cast<volatile uint32_t *>(c->gate_err) = 0u;
+        c->gates_on = false;            // silent by design: events are the correct fallback, not an error
     }
+    return PTX_OK;
 }
 
 static int run_img_proxy(const PtxShape &s, const PtxWeights &w, const float *prep, const void *img_any,
@@ -419,8 +504,12 @@ static bool fused_attn_pays(const PtxShape &s, const Branch *br, int nb)
 
 // phase 0: everything; phase 1: only the projections that do not wait for late proxies
 // (qkv of every branch + proxy_proj of the early ones); phase 2: the rest.
+// join (phase 2 only, may be null): the cross-stream join folded into the first launch of the phase -- the proxy_proj GEMM of the
+// late branch needs nothing from the other stream, its work-group (0,0,0) ends with the wait, and the attention kernel behind
+// it starts when both the GEMM and the other stream are done (no k_gate launch on the critical path: -4.8 us in the r03 trace).
+// *join is cleared when it has been attached.
 static int run_blocks(const PtxShape &s, const Branch *br, int nb, const float *point_proxy, void *ws,
-                      hipStream_t st, int phase = 0, int cd = 0)
+                      hipStream_t st, int phase = 0, int cd = 0, GateRef *join = nullptr)
 {
     const WsLayout L = ws_layout(s);
     const int C = s.C, R = s.B * s.Mk;
@@ -443,6 +532,7 @@ static int run_blocks(const PtxShape &s, const Branch *br, int nb, const float *
                 }
             }
         }
+        if (g.n > 0 && phase == 2 && join != nullptr && join->flag != nullptr) { g.tail_gate = *join; join->flag = nullptr; }
         if (g.n > 0) PTX_TIMED(phase == 2 ? KID_BLK_PP : KID_BLK_QKV, st, launch_gemm(g, st, cd));
         if (phase == 1) return PTX_OK;
     }
@@ -656,6 +746,15 @@ int ptx_context_destroy(PtxContext *ctx)
     delete ctx;
     return PTX_OK;
 }
+
+int ptx_context_check(PtxContext *ctx)
+{
+    PTX_REQUIRE(ctx != nullptr, "ptx_context_check: null context");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return gate_check(ctx);
+}
+
+int ptx_context_gates(const PtxContext *ctx) { return ctx != nullptr && ctx->gates_on ? 1 : 0; }
 
 int ptx_wait_counts(const int32_t *counts_host, int B, int64_t timeout_us)
 {
@@ -926,6 +1025,9 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
         PTX_REQUIRE(dev == side->dev, "ptx_forward: context belongs to device %d, current device is %d", side->dev, dev);
     }
     std::lock_guard<std::mutex> enqueue_lock(side->mu);
+    PTX_TRY(gate_check(side));                                  // a gate of an EARLIER forward timed out: reported here, once
+    side->last_st = st;
+    if (side->gates_on && (!side->probed || side->probed_st != st)) PTX_TRY(gate_probe(side, st));
     // Which chain is the longer one depends on the shape: with many farthest-point picks (the reference's own gs = 12
     // configuration: 519 sequential picks) it is the clustering chain, and then THAT one stays on the caller's stream
     // and the image chain takes the side stream.  (Rough per-shape estimates in us: measured slopes.)
@@ -933,7 +1035,7 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     static const int swap_env = getenv("PTX_CHAIN_SWAP") ? atoi(getenv("PTX_CHAIN_SWAP")) : -1;
     const bool cluster_on_caller = swap_env >= 0 ? swap_env != 0 : est_cluster > est_image;
     hipStream_t cs = cluster_on_caller ? st : side->st, is = cluster_on_caller ? side->st : st;
-    const bool gated = side->gate != nullptr && !cluster_on_caller;       // gates instead of events (see k_gate)
+    const bool gated = side->gates_on && !cluster_on_caller;              // gates instead of events (see k_gate)
     if (!gated) {
         PTX_HIP(hipEventRecord(side->fork, st));
         PTX_HIP(hipStreamWaitEvent(side->st, side->fork, 0));
@@ -942,11 +1044,20 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     // (Two staggered slices of images on two streams -- slice B streaming its means under slice A's table GEMMs, A
     // pooling under B's tables -- measured again in r02 with the fused / folded chain: 0.319 vs 0.298 ms per step.
     // Twice the launches, and the half-size pooling launches each pay their own partial last round.)
+    // test aid (tests/test_gpu_host.py): PTX_GATE_FAULT=fork / join drops the releasing store of that gate, so that the waiter runs
+    // into its bound and the failure path (error word, NaN outputs, PTX_EGATE, fall-back to events) can be exercised
+    static const char *const fault = getenv("PTX_GATE_FAULT");
+    const bool fault_fork = gated && fault && fault[0] == 'f', fault_join = gated && fault && fault[0] == 'j';
+    auto launch_gate = [&](int kid, hipStream_t s_, const GateRef &g) -> int {
+        hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, s_, g);
+        PTX_LAUNCHED("k_gate");
+        (void)kid;
+        return PTX_OK;
+    };
     if (gated) {
         const uint32_t seq = ++side->gate_seq;
-        PTX_TRY(run_img_proxy(S, *w, pf, img_feat, img_proxy, ws, is, 1, true, 0, -1, side->gate, seq));
-        hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, cs, side->gate, seq);
-        PTX_LAUNCHED("k_gate");
+        PTX_TRY(run_img_proxy(S, *w, pf, img_feat, img_proxy, ws, is, 1, true, 0, -1, fault_fork ? nullptr : side->gate, seq));
+        PTX_TIMED(KID_GATE_FORK, cs, launch_gate(KID_GATE_FORK, cs, gate_ref(side, 0, seq, 1)));
     } else
     PTX_TRY(run_img_proxy(S, *w, pf, img_feat, img_proxy, ws, is, 1));      // first pass starts at once
 
@@ -1007,14 +1118,8 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
         // gathered copies of the kept clusters / the drop list: debug outputs only
         if (kcluster || kidx || drop_idx)
             PTX_TRY(launch_select_slots(S, idx2, cluster2, order, picks, keep, kcluster, kidx, drop_idx, nullptr, ts));
-        static const bool old_tags = getenv("PTX_TAGS_ATOMIC") != nullptr;
-        if (old_tags) {
-            PTX_TIMED(KID_SLOTS, ts, launch_select_slots(S, idx2, cluster2, order, picks, keep, nullptr, nullptr, nullptr, tag, ts));
-            PTX_TIMED(KID_TILECOUNT, ts, launch_tile_count(tag, B, S.N, tile_counts, counts, at<int32_t>(ws, L.scene_acc), ts));
-        } else {
-            // ownership / drop tags + survivor counts (published early) in one launch, LDS atomics only
-            PTX_TIMED(KID_SLOTS, ts, launch_tags(S, idx2, order, picks, ksrc, tag, tile_counts, counts, at<int32_t>(ws, L.scene_acc), ts));
-        }
+        // ownership / drop tags + survivor counts (published early) in one launch, LDS atomics only
+        PTX_TIMED(KID_TAGS, ts, launch_tags(S, idx2, order, picks, ksrc, tag, tile_counts, counts, at<int32_t>(ws, L.scene_acc), ts));
         if (!tags_tail) PTX_HIP(hipEventRecord(side->tags, ts));
         return PTX_OK;
     };
@@ -1042,18 +1147,32 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     // small kernels take CUs from the image passes that are on the critical path.)
     PTX_TRY(run_blocks(S, br, 2, point_proxy, ws, cs, 1, compute_dtype));
     if (tags_tail) PTX_TRY(enqueue_tags());
+    GateRef join{};                     // the join, folded into the first launch behind it (run_blocks) unless PTX_GATE_FOLD=0
     if (gated) {                        // the join through the second gate word: signalled behind the clustering stream's last kernel
-        hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, cs, side->gate + 32, side->gate_seq);
+        auto launch_signal = [&]() -> int {
+            hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, cs, side->gate + 32, side->gate_seq);
+            PTX_LAUNCHED("k_signal");
+            return PTX_OK;
+        };
+        if (!fault_join) PTX_TIMED(KID_SIGNAL_JOIN, cs, launch_signal());
         PTX_TRY(run_img_proxy(S, *w, pf, img_feat, img_proxy, ws, is, 2, want_img_proxy));
-        hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, side->gate + 32, side->gate_seq);
-        PTX_LAUNCHED("k_gate");
+        join = gate_ref(side, 32, side->gate_seq, 2);
+        static const bool fold = getenv("PTX_GATE_FOLD") == nullptr || atoi(getenv("PTX_GATE_FOLD")) != 0;
+        if (!fold) {
+            PTX_TIMED(KID_GATE_JOIN, st, launch_gate(KID_GATE_JOIN, st, join));
+            join.flag = nullptr;
+        }
     } else {
     if (!cluster_on_caller) PTX_HIP(hipEventRecord(side->join, cs));
     PTX_TRY(run_img_proxy(S, *w, pf, img_feat, img_proxy, ws, is, 2, want_img_proxy));      // rest of the image chain
     if (cluster_on_caller) PTX_HIP(hipEventRecord(side->join, is));
     PTX_HIP(hipStreamWaitEvent(st, side->join, 0));
     }
-    PTX_TRY(run_blocks(S, br, 2, point_proxy, ws, st, 2, compute_dtype));
+    PTX_TRY(run_blocks(S, br, 2, point_proxy, ws, st, 2, compute_dtype, &join));
+    if (join.flag != nullptr) {         // (not attached: no launch in front of the attention took it)
+        set_error("ptx_forward: the join gate was not attached to a launch");
+        return PTX_ELAUNCH;
+    }
 
     // ---- submanifold reshape + scatter + drop (PRE:459-467); k_affine is the last reader of the tags and clears them
     // (r03: waiting for the tags next to the join instead -- they are final long before it at the benchmark shape -- does not
@@ -1061,7 +1180,7 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     if (!tags_tail) PTX_HIP(hipStreamWaitEvent(st, side->tags, 0));
     PTX_DBG(tag, tag, (size_t)B * S.N * 4);
     PTX_TIMED(KID_AFFINE, st, launch_affine(S, sp, tag, kcenter, translate, transform, out, counts, tile_counts,
-                                            true, true, st));
+                                            true, true, st, gated ? side->gate + 48 : nullptr));
 
     PTX_DBG(centers0, centers0, (size_t)B * M * 3 * 4);
     PTX_DBG(cluster1, cluster1, (size_t)B * M * K * 3 * 4);

@@ -1001,6 +1001,7 @@ struct AffineArgs {
     ScenePts points; uint32_t *tag; const float *kcenter, *translate, *transform;
     float *out; int32_t *counts; const int32_t *tile_counts; int N, Mk, K;
     int clear_tag;      // forward only: this is the last reader of the tags; leave them zero for the next call
+    const uint32_t *poison;     // forward with stream gates: nonzero when a gate timed out (common.h, gate_wait) -- the outputs are NaN then
 };
 
 // TABLE: the scene's (centre, transform, translate) rows are staged in LDS (Mk x 15 floats) and every global load of the
@@ -1024,6 +1025,7 @@ __global__ __launch_bounds__(256) void k_affine(AffineArgs a)
     // ---- requests: the counts of the tiles in front (one per thread), the table, then tags and points
     int acc = 0;
     if (COMPACT) acc = a.tile_counts[b * ntiles + min(tid, ntiles - 1)];
+    const uint32_t poisoned = a.poison != nullptr ? __hip_atomic_load(a.poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     constexpr int kBatch = 8;
     const int c3 = 3 * a.Mk, c12 = 12 * a.Mk, c15 = 15 * a.Mk;
     auto tab_src = [&](int i) {                             // (the address is selected, not the load: no branch per request)
@@ -1111,6 +1113,7 @@ __global__ __launch_bounds__(256) void k_affine(AffineArgs a)
                 const float rz = fmaf(T[8], dz, fmaf(T[7], dy, T[6] * dx));
                 x = (rx + c[0]) + tr[0]; y = (ry + c[1]) + tr[1]; z = (rz + c[2]) + tr[2];
             }
+            if (poisoned) x = y = z = __uint_as_float(0x7fc00000u);
             v[r][0] = x; v[r][1] = y; v[r][2] = z;
         }
         bal[r] = __ballot(keep[r]);
@@ -1142,9 +1145,9 @@ __global__ __launch_bounds__(256) void k_affine(AffineArgs a)
 
 int launch_affine(const PtxShape &s, const ScenePts &points, uint32_t *tag, const float *kcenter,
                   const float *translate, const float *transform, float *out, int32_t *counts,
-                  const int32_t *tile_counts, bool compact, bool clear_tag, hipStream_t st)
+                  const int32_t *tile_counts, bool compact, bool clear_tag, hipStream_t st, const uint32_t *poison)
 {
-    AffineArgs a{points, tag, kcenter, translate, transform, out, counts, tile_counts, s.N, s.Mk, s.K, clear_tag ? 1 : 0};
+    AffineArgs a{points, tag, kcenter, translate, transform, out, counts, tile_counts, s.N, s.Mk, s.K, clear_tag ? 1 : 0, poison};
     const dim3 grid(cdiv(s.N, kTilePts), s.B), block(256);
     const size_t tab = (size_t)s.Mk * 15 * sizeof(float);
     if (tab <= 62 * 1024) {

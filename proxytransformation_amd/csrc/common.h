@@ -107,6 +107,33 @@ __device__ __forceinline__ float gelu_erf(float x)
     return 0.5f * x * (1.0f + copysignf(erfz, x));
 }
 
+// ---- stream gates (api.hip): ordering two HIP streams through a device word --------------------------------------
+// A kernel of stream X waits until a kernel of stream Y has stored the forward's sequence number into `flag`.  The wait is
+// bounded in WALL-CLOCK time (s_memrealtime ticks, 100 MHz on gfx950): when the bound runs out the waiter does not let go
+// silently -- it stores a nonzero word into `err` (device-mapped pinned host memory the host checks: ptx_context_check, the
+// next ptx_forward) and into `poison` (device memory: k_affine turns the outputs of that forward into NaN), and traps
+// if asked to (PTX_GATE_TRAP=1: the queue is torn down, the process aborts).
+struct GateRef {
+    const uint32_t *flag; uint32_t seq;
+    uint32_t *err;              // [host, pinned] sticky error word: 0x80000000 | site << 24 | low 24 bits of seq
+    uint32_t *poison;           // device word read by k_affine
+    uint64_t ticks;             // bound in s_memrealtime ticks
+    uint32_t site;              // 1 fork, 2 join, 3 probe (fork direction), 4 probe (join direction)
+    int trap;
+};
+__device__ __forceinline__ void gate_wait(const GateRef &g)
+{
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    for (unsigned it = 0;; ++it) {
+        if ((int32_t)(__hip_atomic_load(g.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - g.seq) >= 0) return;
+        if (it < 64) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(64);
+        if ((it & 7u) == 7u && __builtin_amdgcn_s_memrealtime() - t0 > g.ticks) break;
+    }
+    if (g.poison) __hip_atomic_store(g.poison, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (g.err) __hip_atomic_store(g.err, 0x80000000u | (g.site << 24) | (g.seq & 0xffffffu), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (g.trap) __builtin_trap();
+}
+
 // ---- parameter-only tables (ptx_prepare) ------------------------------------
 struct PrepLayout {
     // all offsets in floats from the start of `prep`
@@ -178,7 +205,12 @@ struct GemmProb {
     const float *w2; float *c2; int n2, ldc2, chain_tiles; long w2_stride, c2_stride;
 };
 constexpr int kMaxGroups = 8;
-struct GemmBatch { GemmProb p[kMaxGroups]; int n; int rotate; };
+struct GemmBatch {
+    GemmProb p[kMaxGroups]; int n; int rotate;
+    // join folded into this launch (api.hip, "gates"): work-group (0,0,0) ends with gate_wait(tail_gate), so the LAUNCH completes
+    // -- and the next kernel of its stream starts -- only when the other stream has signalled; flag == null: no wait
+    GateRef tail_gate;
+};
 int launch_gemm(const GemmBatch &gb, hipStream_t st, int compute_dtype = 0);     // 1: plain bf16 operands where supported
 
 struct LnProb { const float *x; float *y; const float *w; const float *b; const float *add; int R, add_rows; };
@@ -277,7 +309,8 @@ int launch_tile_count(const uint32_t *tag, int B, int N, int32_t *tile_counts, i
                       hipStream_t st);
 int launch_affine(const PtxShape &s, const ScenePts &points, uint32_t *tag, const float *kcenter,
                   const float *translate, const float *transform, float *out, int32_t *counts,
-                  const int32_t *tile_counts, bool compact, bool clear_tag, hipStream_t st);
+                  const int32_t *tile_counts, bool compact, bool clear_tag, hipStream_t st,
+                  const uint32_t *poison = nullptr);
 
 // ---- image proxy (imgproxy.hip) ------------------------------------------------------------
 int launch_img_mean(const float *img, int nimg, int in_dim, int hw, float *fm, hipStream_t st,

@@ -60,6 +60,14 @@ __device__ __forceinline__ void ln_tile_partials(const GemmProb &pr, const float
         *reinterpret_cast<float2 *>(pr.lnp_out + ((size_t)row * parts + part) * 2) = make_float2(s1, s2);
 }
 
+// the join of the two chains folded into a launch (GemmBatch::tail_gate): ONE thread of the launch waits for the other stream's
+// signal after its own work is done; the launch, and with it everything behind it on its stream, completes only then
+#define PTX_TAIL_GATE(gb_, first_thread_)                                                                          \
+    do {                                                                                                           \
+        if ((gb_).tail_gate.flag != nullptr && (first_thread_) && (blockIdx.x | blockIdx.y | blockIdx.z) == 0)     \
+            gate_wait((gb_).tail_gate);                                                                            \
+    } while (0)
+
 // Throughput-regime kernel: 64x64 output tile per 4-wave work-group, one 32x32 MFMA accumulator
 // per wave.  K loop, BK = 32 per step, three stages: tile it is consumed from LDS, tile it+1
 // sits in the other LDS buffer, tile it+2 is in flight in registers (two register sets, loop
@@ -164,6 +172,7 @@ __global__ __launch_bounds__(256) void k_gemm64(GemmBatch gb)
     }
     if (pr.lnp_out != nullptr)      // every wave is past its last LDS read (barrier after the last stash)
         ln_tile_partials(pr, fin, &As[0][0][0] + wid * (32 * 33), row0 + wr * 32, (col0 >> 5) + wc, (pr.N + 31) >> 5);
+    PTX_TAIL_GATE(gb, tid == 0);
 }
 #undef PTX_G64_FETCH
 #undef PTX_G64_STASH
@@ -316,6 +325,7 @@ __global__ __launch_bounds__(256) void k_gemm64x(GemmBatch gb)
     if (pr.lnp_out != nullptr)      // every wave is past its last LDS read (barrier after the last stash)
         ln_tile_partials(pr, fin, reinterpret_cast<float *>(smem) + wid * (32 * 33), row0 + wr * 32, (col0 >> 5) + wc,
                          (pr.N + 31) >> 5);
+    PTX_TAIL_GATE(gb, tid == 0);
 }
 #undef PTX_X64_FETCH
 #undef PTX_X64_STASH
@@ -547,6 +557,7 @@ __global__ __launch_bounds__(SK * 64) void k_gemm32(GemmBatch gb)
             for (int r = 0; r < 16; ++r) lds[((r & 3) + 8 * (r >> 2) + 4 * hh) * LDT + li] = fin[r];
         }
     }
+    PTX_TAIL_GATE(gb, threadIdx.x == 0);
     if (!chain) return;
     if (CHAIN) {
         __syncthreads();

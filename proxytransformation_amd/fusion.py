@@ -24,7 +24,8 @@ def reverse_3d_flow(img_meta: Optional[dict], coord_type: str = "DEPTH") -> Opti
     """``apply_3d_transformation(points, coord_type, img_meta, reverse=True)`` (point_fusion.py:20-107) as ONE (3,4) affine
     ``[A | t]`` (p' = A p + t), composed on the host in float64: the recorded ``transformation_3d_flow`` is undone back to
     front -- 'T': p - pcd_trans, 'S': p / pcd_scale_factor, 'R': p @ inverse(pcd_rotation), 'HF' / 'VF': the BEV flips of
-    the coordinate type (DEPTH / LIDAR: x -> -x / y -> -y, depth_points.py:47-50; CAMERA: x -> -x / z -> -z).  Returns
+    the coordinate type (DEPTH: x -> -x / y -> -y, depth_points.py:47-50; LIDAR: y -> -y / x -> -x, lidar_points.py:47-50;
+    CAMERA: x -> -x / z -> -z, cam_points.py:47-50).  Returns
     ``None`` when nothing was recorded."""
     flow = list(img_meta.get("transformation_3d_flow", [])) if img_meta else []
     if not flow:
@@ -51,7 +52,9 @@ def reverse_3d_flow(img_meta: Optional[dict], coord_type: str = "DEPTH") -> Opti
         elif op in ("HF", "VF"):
             flipped = bool(img_meta.get("pcd_horizontal_flip" if op == "HF" else "pcd_vertical_flip", False))
             if flipped:
-                axis = 0 if op == "HF" else (2 if ct == "CAMERA" else 1)
+                # the axis each Points class negates (structures/points/depth_points.py:47-50, lidar_points.py:47-50,
+                # cam_points.py:47-50): DEPTH x / y, LIDAR y / x, CAMERA x / z
+                axis = {"DEPTH": (0, 1), "LIDAR": (1, 0), "CAMERA": (0, 2)}[ct][op == "VF"]
                 F = np.eye(3)
                 F[axis, axis] = -1.0
                 A, t = F @ A, F @ t

@@ -111,6 +111,33 @@ class MultiViewIngest:
             out[v] = np.linalg.inv(pad)
         return out
 
+    # per-scene-slot scratch, kept across calls (a fresh pinned buffer per scene and call is a hipHostMalloc with an
+    # implicit device synchronise each): the index workspace, the pinned per-view counts the host polls, and one pinned
+    # staging buffer + its device twin for everything the gather needs from the host (composed choices, inverse intrinsics,
+    # LU factors, pivots, augmentation) -- ONE asynchronous copy per scene
+    class _Slot:
+        __slots__ = ("key", "ws", "counts", "counts_np", "stage", "stage_np", "stage_dev", "copied")
+
+    def _slot(self, b: int, V: int, H: int, W: int, N: int, dev) -> "MultiViewIngest._Slot":
+        slots = self.__dict__.setdefault("_slots", [])
+        while len(slots) <= b:
+            slots.append(None)
+        key = (V, H, W, N, str(dev))
+        sl = slots[b]
+        if sl is None or sl.key != key:
+            lib = _abi.lib()
+            sl = slots[b] = MultiViewIngest._Slot()
+            sl.key = key
+            sl.ws = torch.empty((lib.ptx_ingest_workspace_bytes(V, H, W),), dtype=torch.uint8, device=dev)
+            sl.counts = torch.empty((max(V, 1),), dtype=torch.int32).pin_memory()
+            sl.counts_np = sl.counts.numpy()
+            nstage = (8 * N + 15) // 16 * 16 + 4 * (32 * V + 16) + 16 * V
+            sl.stage = torch.empty((nstage,), dtype=torch.uint8).pin_memory()
+            sl.stage_np = sl.stage.numpy()
+            sl.stage_dev = torch.empty((nstage,), dtype=torch.uint8, device=dev)
+            sl.copied = None
+        return sl
+
     @torch.no_grad()
     def __call__(self, scenes: Sequence[Dict], rng=np.random) -> IngestedBatch:
         lib = _abi.lib()
@@ -123,7 +150,7 @@ class MultiViewIngest:
         st = torch.cuda.current_stream(dev)
         out = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
         bbox = torch.empty((B, 6), dtype=torch.int32, device=dev)
-        status = torch.zeros((B,), dtype=torch.int32, device=dev)
+        status = torch.empty((B,), dtype=torch.int32, device=dev)      # cleared by ptx_ingest_gather; a device-side safety net
         work = []
         for b, sc in enumerate(scenes):                          # 1. index every scene's depth maps (one pass each)
             depth = sc["depth_img"]
@@ -131,44 +158,55 @@ class MultiViewIngest:
                 raise RuntimeError(f"depth_img must be a contiguous (V,H,W) float32 / uint16 tensor on {dev}, got "
                                    f"{tuple(depth.shape)} {depth.dtype} on {depth.device}")
             V, H, W = depth.shape
-            nbytes = lib.ptx_ingest_workspace_bytes(V, H, W)
-            ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
-            counts = torch.empty((V,), dtype=torch.int32).pin_memory()
-            _abi.check(lib.ptx_ingest_index(depth.data_ptr(), _DEPTH_DTYPES[depth.dtype], V, H, W, ws.data_ptr(), nbytes,
-                                            counts.data_ptr(), st.cuda_stream), "ptx_ingest_index")
-            work.append((depth, ws, counts))
-        st.synchronize()                                         # the per-view counts decide `replace` on the host
-        keep, sels, vcs = [], [], []
-        for b, (sc, (depth, ws, counts)) in enumerate(zip(scenes, work)):   # 2. host RNG, 3. gather
+            sl = self._slot(b, V, H, W, N, dev)
+            sl.counts_np[:V] = -1                                # published by the scan kernel with system scope
+            _abi.check(lib.ptx_ingest_index(depth.data_ptr(), _DEPTH_DTYPES[depth.dtype], V, H, W, sl.ws.data_ptr(), sl.ws.numel(),
+                                            sl.counts.data_ptr(), st.cuda_stream), "ptx_ingest_index")
+            work.append((depth, sl))
+        sels, vcs = [], []
+        for b, (sc, (depth, sl)) in enumerate(zip(scenes, work)):           # 2. host RNG, 3. gather
             V, H, W = depth.shape
-            vc = counts.numpy().copy()
+            # the per-view counts decide `replace` on the host: wait for THESE V words (not for the stream to drain)
+            if lib.ptx_wait_counts(sl.counts.data_ptr(), V, 20_000_000) != 0:
+                st.synchronize()
+            vc = sl.counts_np[:V].copy()
+            if vc.min() < 0:
+                raise RuntimeError("ptx_ingest_index finished without publishing the per-view counts")
             sel = sc.get("choices")
             if sel is None:
                 sel = compose_choices(vc, self.per_view_points, N, rng)
             sel = np.ascontiguousarray(sel, dtype=np.int64)
             if sel.shape != (N,):
                 raise ValueError(f"choices must be ({N},), got {sel.shape}")
+            if sel.min() < 0 or sel.max() >= int(vc.sum()):      # checked where the counts are: no device round trip for it
+                raise IndexError(f"choices beyond the scene's depth != 0 pixels in scene {b}")
             inv_k = self._intrinsics(sc["depth_cam2img"], V)
             ext = np.asarray(sc["extrinsic"], dtype=np.float32).reshape(V, 4, 4)
             lus, pivs = zip(*(lu_factor_4x4(ext[v]) for v in range(V)))
-            small = np.concatenate([inv_k.reshape(-1), np.stack(lus).reshape(-1)]).astype(np.float32)
             aug = sc.get("aug")
+            if sl.copied is not None:
+                sl.copied.synchronize()                          # the previous call's copy out of the staging buffer (long done)
+            o_sel, o_small = 0, (8 * N + 15) // 16 * 16          # 16-byte aligned tables
+            o_piv = o_small + 4 * (32 * V + 16)
+            sl.stage_np[o_sel:o_sel + 8 * N].view(np.int64)[:] = sel
+            small = sl.stage_np[o_small:o_small + 4 * (32 * V + 13)].view(np.float32)
+            small[:16 * V] = inv_k.reshape(-1)
+            small[16 * V:32 * V] = np.stack(lus).reshape(-1)
             if aug is not None:
-                small = np.concatenate([small, np.asarray(aug["rot_mat_T"], np.float32).reshape(9),
-                                        np.asarray([aug["scale"]], np.float32), np.asarray(aug["trans"], np.float32).reshape(3)])
-            small_d = torch.from_numpy(small).to(dev, non_blocking=False)
-            piv_d = torch.from_numpy(np.stack(pivs).astype(np.int32)).to(dev)
-            sel_d = torch.from_numpy(sel).to(dev)
+                small[32 * V:32 * V + 9] = np.asarray(aug["rot_mat_T"], np.float32).reshape(9)
+                small[32 * V + 9] = np.float32(aug["scale"])
+                small[32 * V + 10:32 * V + 13] = np.asarray(aug["trans"], np.float32).reshape(3)
+            sl.stage_np[o_piv:o_piv + 16 * V].view(np.int32)[:] = np.stack(pivs).astype(np.int32).reshape(-1)
+            sl.stage_dev.copy_(sl.stage, non_blocking=True)
+            sl.copied = torch.cuda.Event()
+            sl.copied.record(st)
             shift = float(sc.get("depth_shift", 1.0))
-            fp = small_d.data_ptr()
+            dp = sl.stage_dev.data_ptr()
+            fp = dp + o_small
             _abi.check(lib.ptx_ingest_gather(
-                depth.data_ptr(), _DEPTH_DTYPES[depth.dtype], shift, V, H, W, fp, fp + 4 * V * 16, piv_d.data_ptr(),
-                sel_d.data_ptr(), N, (fp + 4 * V * 32) if aug is not None else None, out[b].data_ptr(), bbox[b].data_ptr(),
-                status[b:].data_ptr(), ws.data_ptr(), ws.numel(), st.cuda_stream), "ptx_ingest_gather")
-            keep.append((small_d, piv_d, sel_d, ws))
+                depth.data_ptr(), _DEPTH_DTYPES[depth.dtype], shift, V, H, W, fp, fp + 4 * V * 16, dp + o_piv,
+                dp + o_sel, N, (fp + 4 * V * 32) if aug is not None else None, out[b].data_ptr(), bbox[b].data_ptr(),
+                status[b:].data_ptr(), sl.ws.data_ptr(), sl.ws.numel(), st.cuda_stream), "ptx_ingest_gather")
             sels.append(sel)
             vcs.append(vc)
-        bad = status.cpu().numpy()                               # also keeps the temporaries alive until the kernels ran
-        if bad.any():
-            raise IndexError(f"choices beyond the scene's depth != 0 pixels in scenes {np.nonzero(bad)[0].tolist()}")
         return IngestedBatch(points=[out[b] for b in range(B)], bbox=bbox, view_counts=vcs, sel=sels)

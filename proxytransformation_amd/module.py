@@ -536,6 +536,11 @@ class ProxyTransformationNormReverse(nn.Module):
         lane.ws_dirty = False
         if debug or self.sync_outputs or lib.ptx_wait_counts(counts.data_ptr(), B, _COUNTS_TIMEOUT_US) != 0:
             tstream.synchronize()                          # full drain; also surfaces device faults
+        # a stream gate that ran out of time (csrc/api.hip, "gates") has stored its error word by now if it was the fork;
+        # a join that fails later turns this call's outputs into NaN and is reported by the next call
+        if lib.ptx_context_check(lane.ctx) != 0:
+            lane.ws_dirty = True                           # the workspace's clean-on-entry words cannot be trusted
+            raise RuntimeError("ptx_forward: " + lib.ptx_last_error().decode())
         n_keep = lane.counts_np[:B].tolist()
         if min(n_keep) < 0:
             raise RuntimeError("ptx_forward finished without publishing the survivor counts")
@@ -635,6 +640,14 @@ class ProxyTransformationNormReverse(nn.Module):
             bn.running_mean.add_(0)
             bn.running_var.add_(0)
         return res
+
+    def uses_stream_gates(self, stream=None) -> bool:
+        """True when the lane of ``stream`` (default: the current one) orders its two chains with device-word gates
+        rather than events (after its first forward: the concurrency probe runs there)."""
+        dev = next(self.parameters()).device
+        tstream = stream if stream is not None else torch.cuda.current_stream(dev)
+        lane = self._lanes.get((str(dev), tstream.cuda_stream))
+        return bool(lane is not None and _abi.lib().ptx_context_gates(lane.ctx))
 
     def _batch_norms(self):
         return (("get_deformable_cluster.get_offsets.mlp.1", self.get_deformable_cluster.get_offsets.mlp[1]),

@@ -488,6 +488,15 @@ def gen_point_sample():
         save[f"{name}_out"] = out.numpy()
         save[f"{name}_cfg"] = np.array([scale[0], scale[1], crop[0], crop[1], float(flip), 480 * 1.3], np.float32)
         print(f"g5_point_sample/{name}: {len(sel)} points, nonzero rows {(np.abs(out.numpy()).sum(1) > 0).sum()}")
+    # the reverse 3D flow alone, per coordinate type and flip (the flips negate different axes: depth_points.py:47-50,
+    # lidar_points.py:47-50, cam_points.py:47-50): apply_3d_transformation(reverse=True) itself
+    save["rev3d_points"] = points_aug3d[:256]
+    for ct in ("DEPTH", "LIDAR", "CAMERA"):
+        for fl in ("hf", "vf"):
+            meta_f = dict(transformation_3d_flow=["VF", "HF", "R", "S", "T"], pcd_horizontal_flip=fl == "hf",
+                          pcd_vertical_flip=fl == "vf", pcd_rotation=rot_T, pcd_scale_factor=1.07, pcd_trans=meta3d["pcd_trans"])
+            save[f"rev3d_{ct}_{fl}"] = pf.apply_3d_transformation(torch.from_numpy(points_aug3d[:256]), ct, meta_f,
+                                                                  reverse=True).numpy()
     path = os.path.join(HERE, "g5_point_sample.npz")
     np.savez_compressed(path, **save)
     print(f"g5_point_sample -> {os.path.getsize(path) / 1e6:.2f} MB")

@@ -149,7 +149,11 @@ def test_real_module_sharded_over_two_ranks_matches_unsharded(tmp_path):
     want_t = torch.cat([tf["kcenter"], tf["translate"], tf["transform"]], -1).cpu()
     script = tmp_path / "w.py"
     script.write_text(_WORKER % (ROOT, str(tmp_path)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import socket
+    with socket.socket() as sk:                 # a free port of this box, not a fixed one
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     for p in procs:
@@ -218,7 +222,7 @@ def test_bench_multi_rank_path_on_one_gpu():
     # (fp32-stored features, bf16 compute) run on every rank behind real barriers, the rank-0-only reports are skipped
     for extra in (["--no-passes", "--no-cpu-baseline", "--time-every", "1"], ["--time-every", "1"]):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu",
-                            "--steps", "2", "--warmup", "1"] + extra,
+                            "--steps", "2", "--warmup", "1", "--repeats", "2"] + extra,
                            env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-3000:]
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -227,7 +231,9 @@ def test_bench_multi_rank_path_on_one_gpu():
         assert d["n_gpus"] == 2 and d["config"]["global_scenes_per_step"] == 8 and d["config"]["scenes_per_gpu"] == 4
         assert d["cpu_baseline"] is None and d["value"] > 0 and d["scaling"] == "weak"
         assert [x[0] for x in d["ranks_seen"]] == [0, 1] and len({x[2] for x in d["ranks_seen"]}) == 2     # two processes
-        assert d["roofline"]["launches"] == 2 and 0 < d["roofline"]["frac"] < 1
+        assert d["roofline"]["launches"] == 4 and 0 < d["roofline"]["frac"] < 1          # 2 blocks x 2 steps, every launch timed
+        tb = d["timed_blocks"]
+        assert tb["blocks"] == 2 and len(tb["values"]) == 2 and tb["value_min"] <= d["value"] <= tb["value_max"]
         if "--no-passes" not in extra:
             assert d["value_f32_features"] > 0 and d["value_bf16_compute"] > 0 and "roofline_passes" not in d
 
@@ -301,3 +307,130 @@ def test_launch_count_of_the_benchmark_shape():
             lib.ptx_timing_select(-1)
     per_site = {lib.ptx_kernel_name(i).decode(): n[i] for i in range(nk) if n[i]}
     assert sum(per_site.values()) == 16, per_site
+    assert not any("k_gate" in k or "k_signal" in k for k in per_site), per_site      # clustering chain on the caller's stream: events
+
+
+def test_launch_count_with_stream_gates():
+    """The same count at a shape whose image chain owns the caller's stream (the benchmark's situation): the fork and the join are
+    device-word gates there, and THEIR launches are counted too -- 16 kernels + the fork's one-wave k_gate + the join's k_signal;
+    the join's wait is folded into the proxy_proj GEMM (no k_gate launch on the caller's stream)."""
+    import ctypes
+    from proxytransformation_amd import _abi
+    from proxytransformation_amd.synth import PreshapeConfig, make_scene_batch
+    from tests.util import build_module
+    cfg = PreshapeConfig("launches_g", B=2, N=20000, grid_size=8, dynamic_drop_radio=0.4, L=16, V=180, seed_base=78)
+    assert 40 + 0.18 * cfg.B * cfg.V > 80 + 0.42 * cfg.Kd
+    m, _ = build_module(cfg)
+    m = m.cuda()
+    pts, text, mask, img = make_scene_batch(cfg)
+    dev = torch.device("cuda:0")
+    args = ([torch.from_numpy(p).to(dev) for p in pts],
+            {"text_feats": torch.from_numpy(text).to(dev), "text_token_mask": torch.from_numpy(mask).to(dev)},
+            torch.from_numpy(img).to(dev).to(torch.bfloat16))
+    lib = _abi.lib()
+    nk = lib.ptx_kernel_count()
+    with torch.no_grad():
+        m(*args)
+        torch.cuda.synchronize()
+        if not m.uses_stream_gates():
+            pytest.skip("this environment orders the streams with events (profiler / serialised queues / failed probe)")
+        lib.ptx_timing_select_mask((1 << nk) - 1)
+        try:
+            m(*args)
+            torch.cuda.synchronize()
+            n = (ctypes.c_int * nk)()
+            ms = (ctypes.c_float * nk)()
+            lib.ptx_timing_read_sites(n, ms, nk)
+        finally:
+            lib.ptx_timing_select(-1)
+    per_site = {lib.ptx_kernel_name(i).decode(): n[i] for i in range(nk) if n[i]}
+    assert per_site.get("k_gate[fork]") == 1 and per_site.get("k_signal[join]") == 1 and "k_gate[join]" not in per_site, per_site
+    assert sum(per_site.values()) == 18, per_site
+
+
+_GATE_WORKER = r"""
+import os, sys, hashlib, torch
+sys.path.insert(0, %r)
+from proxytransformation_amd.synth import PreshapeConfig, make_scene_batch
+from tests.util import build_module
+cfg = PreshapeConfig("gatefault", B=2, N=30000, grid_size=8, dynamic_drop_radio=0.4, L=16, V=180, seed_base=4242)
+m, _ = build_module(cfg)
+m = m.cuda()
+pts, text, mask, img = make_scene_batch(cfg)
+dev = torch.device("cuda:0")
+args = ([torch.from_numpy(p).to(dev) for p in pts],
+        {"text_feats": torch.from_numpy(text).to(dev), "text_token_mask": torch.from_numpy(mask).to(dev)},
+        torch.from_numpy(img).to(dev).to(torch.bfloat16))
+mode = os.environ.get("GATE_TEST_MODE", "plain")
+def digest(outs):
+    h = hashlib.sha256()
+    for o in outs:
+        h.update(o.cpu().numpy().tobytes())
+    return h.hexdigest()
+with torch.no_grad():
+    if mode == "stall":
+        outs = m(*args)                                   # a clean first call: probe, tables
+        torch.cuda.synchronize()
+        print("GATES_BEFORE", m.uses_stream_gates())
+        torch.cuda._sleep(int(2.0e9 * 0.4))              # ~0.2-0.4 s of work queued AHEAD of the forward on the caller's stream
+    calls = []
+    for i in range(3):
+        try:
+            outs = m(*args)
+            torch.cuda.synchronize()
+            calls.append("ok nan=%%d" %% int(all(bool(torch.isnan(o).all()) for o in outs)))
+        except RuntimeError as e:
+            calls.append("raised: " + str(e)[:160].replace("\n", " "))
+        if i == 0 and mode != "stall":
+            print("GATES_BEFORE", m.uses_stream_gates() or "raised" in calls[0])
+    for c in calls:
+        print("CALL", c)
+    print("GATES_AFTER", m.uses_stream_gates())
+    outs = m(*args)
+    torch.cuda.synchronize()
+    print("DIGEST", digest(outs))
+"""
+
+
+def _run_gate_worker(tmp_path, **env_extra):
+    script = tmp_path / "gate_worker.py"
+    script.write_text(_GATE_WORKER % ROOT)
+    env = dict(os.environ, **env_extra)
+    r = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = {}
+    for ln in r.stdout.splitlines():
+        k, _, v = ln.partition(" ")
+        out.setdefault(k, []).append(v)
+    return out
+
+
+@pytest.mark.parametrize("fault", ["fork", "join", "stall"])
+def test_stream_gate_timeout_fails_loudly(tmp_path, fault):
+    """A stream gate that runs out of time must not let go silently: the waiter stores an error word,
+    the outputs of that forward become NaN, Python gets a RuntimeError -- from the same call when the fork fails (the error word is
+    there before the survivor counts), from the next call when the join fails (the counts are published before the join) -- and
+    the context then orders its streams with events and computes the right result again.  fork / join: the releasing store is
+    dropped (PTX_GATE_FAULT); stall: nothing is injected, the caller's stream simply has more work queued ahead of the forward
+    than the bound allows (PTX_GATE_TIMEOUT_MS = 30)."""
+    ref = _run_gate_worker(tmp_path, PTX_GATE="0")                      # events from the start: the reference digest
+    assert ref["GATES_AFTER"] == ["False"] and all(c == "ok nan=0" for c in ref["CALL"])
+    env = dict(PTX_GATE_TIMEOUT_MS="30")
+    if fault == "stall":
+        env["GATE_TEST_MODE"] = "stall"
+    else:
+        env["PTX_GATE_FAULT"] = fault
+    got = _run_gate_worker(tmp_path, **env)
+    if got["GATES_BEFORE"] == ["False"]:
+        pytest.skip("this environment orders the streams with events (profiler / serialised queues / failed probe)")
+    calls = got["CALL"]
+    if fault == "join":
+        assert calls[0] == "ok nan=1", calls                            # returned (counts were out), outputs poisoned
+        assert calls[1].startswith("raised:") and "stream gate timed out" in calls[1] and "join" in calls[1], calls
+    else:
+        assert calls[0].startswith("raised:") and "stream gate timed out" in calls[0] and "fork" in calls[0], calls
+        assert calls[1] == "ok nan=0", calls
+    assert calls[2] == "ok nan=0", calls
+    assert got["GATES_AFTER"] == ["False"]                              # events from the failure on
+    assert got["DIGEST"] == ref["DIGEST"]                               # and the result is right again
+

@@ -106,6 +106,25 @@ def test_point_sample_restatement_matches_the_reference(case):
     assert (nvalid > 0).sum() == (np.abs(g[f"{case}_out"]).sum(1) > 0).sum()
 
 
+@pytest.mark.parametrize("ct", ["DEPTH", "LIDAR", "CAMERA"])
+@pytest.mark.parametrize("fl", ["hf", "vf"])
+def test_reverse_3d_flow_per_coordinate_type(ct, fl):
+    """The reverse 3D augmentation flow per coordinate type and flip against the reference's own
+    apply_3d_transformation(reverse=True) (g5_point_sample: rev3d_*): LiDARPoints.flip negates y for 'horizontal' and x for
+    'vertical', the opposite of DepthPoints, CameraPoints x / z -- the oracle's step-by-step form and the product's
+    composed (3,4) affine (proxytransformation_amd.fusion.reverse_3d_flow, host arithmetic) must both follow."""
+    from proxytransformation_amd.fusion import reverse_3d_flow
+    g = load_golden("g5_point_sample")
+    meta = dict(_meta3d(g), transformation_3d_flow=["VF", "HF", "R", "S", "T"], pcd_horizontal_flip=fl == "hf",
+                pcd_vertical_flip=fl == "vf")
+    pts, want = g["rev3d_points"], g[f"rev3d_{ct}_{fl}"]
+    assert_close(oracle.reverse_3d_points(pts, meta, ct), want, atol=2e-6, what=f"oracle reverse flow ({ct}, {fl})")
+    A = reverse_3d_flow(meta, ct).numpy().astype(np.float64)
+    assert_close(pts.astype(np.float64) @ A[:, :3].T + A[:, 3], want, atol=5e-6, what=f"composed reverse flow ({ct}, {fl})")
+    if ct == "LIDAR":
+        assert np.abs(want - g[f"rev3d_DEPTH_{fl}"]).max() > 0.1    # the types really differ
+
+
 # ------------------------------------------------------------------ multi-view depth ingest (SURVEY 8f N4)
 @pytest.mark.parametrize("case", ["plain", "aug"])
 def test_ingest_restatement_matches_the_reference_transforms(case):
