@@ -141,6 +141,7 @@ WsLayout ws_layout(const PtxShape &s)
     L.tag = take(B * N * 4);
     L.fa_ticket = take(2 * B * s.heads * 4);
     L.mlp_ticket = take(mlp_ticket_bytes((int)R));
+    L.mm_ticket = take(4);
     L.zero_bytes = o - L.zero_begin;
     L.minmax = take(B * 6 * 4);
     L.centers0 = take(B * M * 3 * 4); L.cluster1 = take(B * M * K * 3 * 4);
@@ -386,7 +387,7 @@ static int gate_probe(PtxContext *c, hipStream_t st)
 
 static int run_img_proxy(const PtxShape &s, const PtxWeights &w, const float *prep, const void *img_any,
                          float *img_proxy, void *ws, hipStream_t st, int phase = 0, bool need_ln = true,
-                         int i0 = 0, int ni = -1, uint32_t *gate = nullptr, uint32_t gate_seq = 0)
+                         int i0 = 0, int ni = -1, uint32_t *gate = nullptr, uint32_t gate_seq = 0, const MinmaxFuse *mm = nullptr)
 {
     // images [i0, i0 + ni) of the B * V of this call (default: all): every buffer of the chain is per image
     const PrepLayout P = prep_layout(s);
@@ -407,8 +408,8 @@ static int run_img_proxy(const PtxShape &s, const PtxWeights &w, const float *pr
         Gs += (size_t)i0 * 2 * s.heads * s.in_dim; E += (size_t)i0 * s.heads * EW; ML += (size_t)i0 * s.heads * 5;
     }
     if (phase != 2) {
-        if (dt == 0) PTX_TIMED(KID_IMG_MEAN, st, launch_img_mean(img, nimg, s.in_dim, s.hw, fm, st, gate, gate_seq));
-        else PTX_TIMED(KID_IMG_MEAN, st, launch_img_mean16(img_any, dt, nimg, s.in_dim, s.hw, fm, st, gate, gate_seq));
+        if (dt == 0) PTX_TIMED(KID_IMG_MEAN, st, launch_img_mean(img, nimg, s.in_dim, s.hw, fm, st, gate, gate_seq, mm));
+        else PTX_TIMED(KID_IMG_MEAN, st, launch_img_mean16(img_any, dt, nimg, s.in_dim, s.hw, fm, st, gate, gate_seq, mm));
     }
     if (phase == 1) return PTX_OK;
     // head_dim 32: a 32-column tile of the qkv0 GEMM IS one head's q, and the work-group that finishes it goes on to that
@@ -1054,9 +1055,19 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
         (void)kid;
         return PTX_OK;
     };
+    // gated forwards reduce the bounding boxes in the first work-groups of the mean launch (MinmaxFuse, common.h): the fork's
+    // word is stored when the boxes are final and the clustering stream starts at k_cluster (PTX_MM_FUSE=0: separate k_minmax)
+    static const bool mm_fuse_env = getenv("PTX_MM_FUSE") == nullptr || atoi(getenv("PTX_MM_FUSE")) != 0;
+    const bool mm_fused = gated && mm_fuse_env && bbox_in == nullptr;
+    MinmaxFuse mmf{};
+    if (mm_fused) {
+        mmf.points = sp; mmf.B = B; mmf.N = S.N; mmf.chunks = minmax_chunks(S.N);
+        mmf.mm_enc = at<uint32_t>(ws, L.mm_enc); mmf.ticket = at<int>(ws, L.mm_ticket);
+    }
     if (gated) {
         const uint32_t seq = ++side->gate_seq;
-        PTX_TRY(run_img_proxy(S, *w, pf, img_feat, img_proxy, ws, is, 1, true, 0, -1, fault_fork ? nullptr : side->gate, seq));
+        PTX_TRY(run_img_proxy(S, *w, pf, img_feat, img_proxy, ws, is, 1, true, 0, -1, fault_fork ? nullptr : side->gate, seq,
+                              mm_fused ? &mmf : nullptr));
         PTX_TIMED(KID_GATE_FORK, cs, launch_gate(KID_GATE_FORK, cs, gate_ref(side, 0, seq, 1)));
     } else
     PTX_TRY(run_img_proxy(S, *w, pf, img_feat, img_proxy, ws, is, 1));      // first pass starts at once
@@ -1074,7 +1085,7 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     float *offsets = dbg && debug->offsets ? at<float>(ws, L.offsets) : nullptr;
     float *centers = at<float>(ws, L.centers), *cluster2 = at<float>(ws, L.cluster2);
     int32_t *idx2 = at<int32_t>(ws, L.idx2), *pad_count = at<int32_t>(ws, L.pad_count);
-    if (!bbox_in) PTX_TIMED(KID_MINMAX, cs, launch_minmax(sp, B, S.N, mm_ws, cs));
+    if (!bbox_in && !mm_fused) PTX_TIMED(KID_MINMAX, cs, launch_minmax(sp, B, S.N, mm_ws, cs));
     PTX_TIMED(KID_CLUSTER, cs, launch_cluster(S, mm_enc, lin, sp, pf + P.off_ab, w->offset, w->offset_map_w,
                                               centers_override, nullptr, centers0, cluster1, offsets, centers, idx2,
                                               cluster2, pad_count, cs));

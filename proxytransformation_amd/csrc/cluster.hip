@@ -22,72 +22,13 @@ namespace ptx {
 __global__ __launch_bounds__(256) void k_minmax(ScenePts points, int N,
                                                 uint32_t *__restrict__ mm_enc)
 {
-    const int b = blockIdx.y;
-    const float *__restrict__ p = points.p[b];
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int nth = gridDim.x * blockDim.x;
-    const bool vec = ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(p) & 15) == 0);
-    if (vec) {
-        // 4 points = 12 floats = 3 float4; a thread's quads are all requested before the first is reduced (clamped: a
-        // repeated quad does not change a minimum).  As a loop with one quad per trip the kernel was four dependent round
-        // trips next to the mean pass, which keeps the memory system loaded: 20 us for 4.8 MB (r03).
-        const float4 *p4 = reinterpret_cast<const float4 *>(p);
-        const int nq = N >> 2;
-        constexpr int U = 4;
-        for (int q0 = tid; q0 < nq; q0 += nth * U) {         // one trip with launch_minmax's grid
-            float4 v[U][3];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int q = min(q0 + u * nth, nq - 1);
-                v[u][0] = p4[3 * q]; v[u][1] = p4[3 * q + 1]; v[u][2] = p4[3 * q + 2];
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const float4 a = v[u][0], c = v[u][1], e = v[u][2];
-                // a = x0 y0 z0 x1 | c = y1 z1 x2 y2 | e = z2 x3 y3 z3
-                const float xs[4] = {a.x, a.w, c.z, e.y}, ys[4] = {a.y, c.x, c.w, e.z}, zs[4] = {a.z, c.y, e.x, e.w};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    lo[0] = fminf(lo[0], xs[i]); hi[0] = fmaxf(hi[0], xs[i]);
-                    lo[1] = fminf(lo[1], ys[i]); hi[1] = fmaxf(hi[1], ys[i]);
-                    lo[2] = fminf(lo[2], zs[i]); hi[2] = fmaxf(hi[2], zs[i]);
-                }
-            }
-        }
-    } else {
-        for (int i = tid; i < N; i += nth) {
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                float v = p[(size_t)i * 3 + d];
-                lo[d] = fminf(lo[d], v); hi[d] = fmaxf(hi[d], v);
-            }
-        }
-    }
     __shared__ float red[4][6];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) { lo[d] = wave_min(lo[d]); hi[d] = wave_max(hi[d]); }
-    const int w = threadIdx.x >> 6;
-    if (lane_id() == 0) {
-#pragma unroll
-        for (int d = 0; d < 3; ++d) { red[w][d] = lo[d]; red[w][3 + d] = hi[d]; }
-    }
-    __syncthreads();
-    if (threadIdx.x < 6) {
-        const int d = threadIdx.x;
-        float v = red[0][d];
-        for (int i = 1; i < 4; ++i) v = d < 3 ? fminf(v, red[i][d]) : fmaxf(v, red[i][d]);
-        if (d < 3) { if (v != INFINITY) atomicMax(&mm_enc[b * 6 + d], ~f2ord(v)); }
-        else       { if (v != -INFINITY) atomicMax(&mm_enc[b * 6 + d], f2ord(v)); }
-    }
+    minmax_block(points.p[blockIdx.y], N, mm_enc, blockIdx.y, blockIdx.x, gridDim.x, red);      // common.h
 }
 
 int launch_minmax(const ScenePts &points, int B, int N, uint32_t *mm_enc, hipStream_t st)
 {
-    int per_scene = cdiv(N, 256 * 16);
-    if (per_scene < 1) per_scene = 1;
-    if (per_scene > 256) per_scene = 256;
-    hipLaunchKernelGGL(k_minmax, dim3(per_scene, B), dim3(256), 0, st, points, N, mm_enc);
+    hipLaunchKernelGGL(k_minmax, dim3(minmax_chunks(N), B), dim3(256), 0, st, points, N, mm_enc);
     PTX_LAUNCHED("k_minmax");
     return PTX_OK;
 }

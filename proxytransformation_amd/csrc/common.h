@@ -134,6 +134,114 @@ __device__ __forceinline__ void gate_wait(const GateRef &g)
     if (g.trap) __builtin_trap();
 }
 
+// Per-scene base pointers of the point clouds, passed by value as a kernel argument (see make_scene_pts)
+constexpr int kMaxScenes = 32;
+struct ScenePts { const float *p[kMaxScenes]; };
+// ---- per-scene bounding boxes (PRE:37-38) -----------------------------------------------------------------------------
+// mm_enc[b][0..2] = ~ord(min_d)   (so that atomicMax over a zeroed word yields the minimum), mm_enc[b][3..5] = ord(max_d).
+// One work-group reduces chunk `chunk` of `nchunks` of scene b's points and folds its result into the scene's six words
+// with RETURNING atomics (the caller may publish a ticket afterwards: the atomics have been performed by then).
+// 4 points = 12 floats = 3 float4; a thread's quads are all requested before the first is reduced (clamped: a repeated
+// quad does not change a minimum).  As a loop with one quad per trip the pass was four dependent round trips next to the
+// mean pass, which keeps the memory system loaded: 20 us for 4.8 MB (r03).
+__device__ __forceinline__ void minmax_block(const float *__restrict__ p, int N, uint32_t *__restrict__ mm_enc, int b,
+                                             int chunk, int nchunks, float (*red)[6])
+{
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    const int tid = chunk * 256 + threadIdx.x;
+    const int nth = nchunks * 256;
+    const bool vec = ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(p) & 15) == 0);
+    if (vec) {
+        const float4 *p4 = reinterpret_cast<const float4 *>(p);
+        const int nq = N >> 2;
+        constexpr int U = 4;
+        for (int q0 = tid; q0 < nq; q0 += nth * U) {         // one trip with minmax_chunks()'s decomposition
+            float4 v[U][3];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int q = min(q0 + u * nth, nq - 1);
+                v[u][0] = p4[3 * q]; v[u][1] = p4[3 * q + 1]; v[u][2] = p4[3 * q + 2];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float4 a = v[u][0], c = v[u][1], e = v[u][2];
+                // a = x0 y0 z0 x1 | c = y1 z1 x2 y2 | e = z2 x3 y3 z3
+                const float xs[4] = {a.x, a.w, c.z, e.y}, ys[4] = {a.y, c.x, c.w, e.z}, zs[4] = {a.z, c.y, e.x, e.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    lo[0] = fminf(lo[0], xs[i]); hi[0] = fmaxf(hi[0], xs[i]);
+                    lo[1] = fminf(lo[1], ys[i]); hi[1] = fmaxf(hi[1], ys[i]);
+                    lo[2] = fminf(lo[2], zs[i]); hi[2] = fmaxf(hi[2], zs[i]);
+                }
+            }
+        }
+    } else {
+        for (int i = tid; i < N; i += nth) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                float v = p[(size_t)i * 3 + d];
+                lo[d] = fminf(lo[d], v); hi[d] = fmaxf(hi[d], v);
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { lo[d] = wave_min(lo[d]); hi[d] = wave_max(hi[d]); }
+    const int w = threadIdx.x >> 6;
+    if (lane_id() == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { red[w][d] = lo[d]; red[w][3 + d] = hi[d]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int d = threadIdx.x;
+        float v = red[0][d];
+        for (int i = 1; i < 4; ++i) v = d < 3 ? fminf(v, red[i][d]) : fmaxf(v, red[i][d]);
+        uint32_t old = 0u;
+        if (d < 3) { if (v != INFINITY) old = atomicMax(&mm_enc[b * 6 + d], ~f2ord(v)); }
+        else       { if (v != -INFINITY) old = atomicMax(&mm_enc[b * 6 + d], f2ord(v)); }
+        asm volatile("" :: "v"(old));                       // the returned value is waited for: the atomic has been performed
+    }
+}
+inline int minmax_chunks(int N) { int c = (N + 256 * 16 - 1) / (256 * 16); return c < 1 ? 1 : (c > 256 ? 256 : c); }
+
+// The bounding boxes computed by the FIRST work-groups of the image chain's mean pass (r04): at the benchmark shape the
+// clustering stream began with k_gate (waiting for the mean pass to start) and then k_minmax, 18 us next to a pass that
+// saturates the memory system.  Inside the mean launch the B * chunks box work-groups are dispatched first, the last one to
+// finish (ticket) stores the fork's sequence number, and the clustering stream starts at k_cluster.
+struct MinmaxFuse {
+    ScenePts points; int B, N, chunks;
+    uint32_t *mm_enc;           // (B,6), zero on entry
+    int *ticket;                // one word, zero on entry, left zero
+};
+
+// The fork of the two chains (api.hip, "gates"): the clustering stream waits for `gate` to reach gate_seq.  Without fused
+// boxes the first thread of the launch stores it (the stream being in order, everything the caller enqueued before the forward
+// has completed by then); with them (MM) the first mm.B * mm.chunks work-groups reduce the scenes' bounding boxes instead of
+// image rows and the last of them to finish stores it -- boxes final, clustering stream released straight into k_cluster.
+template <bool MM>
+__device__ __forceinline__ bool mean_prologue(const MinmaxFuse &mm, uint32_t *gate, uint32_t gate_seq, int &blk)
+{
+    blk = blockIdx.x;
+    if (!MM) {
+        if (gate != nullptr && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(gate, gate_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+    }
+    const int nmm = mm.B * mm.chunks;
+    if ((int)blockIdx.x >= nmm) { blk = blockIdx.x - nmm; return false; }
+    __shared__ float red[4][6];
+    const int b = blockIdx.x / mm.chunks, chunk = blockIdx.x - b * mm.chunks;
+    minmax_block(mm.points.p[b], mm.N, mm.mm_enc, b, chunk, mm.chunks, red);
+    __syncthreads();                                    // the six returning atomics of this work-group have been performed
+    if (threadIdx.x == 0) {
+        const int t = __hip_atomic_fetch_add(mm.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == nmm - 1) {
+            __hip_atomic_store(mm.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (gate != nullptr) __hip_atomic_store(gate, gate_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    return true;
+}
+
 // ---- parameter-only tables (ptx_prepare) ------------------------------------
 struct PrepLayout {
     // all offsets in floats from the start of `prep`
@@ -162,6 +270,7 @@ struct WsLayout {
     size_t tag;                     // (B,N) uint32
     size_t fa_ticket;               // (2, B*heads) int32 arrival tickets of the split fused attention
     size_t mlp_ticket;              // (2, row tiles) int32 arrival tickets of the fused Mlp
+    size_t mm_ticket;               // one int32: arrival ticket of the bounding-box work-groups inside the mean launch
     size_t minmax, centers0, cluster1, offsets, centers, idx2, cluster2, pad_count;
     size_t order, picks, keep, ksrc, kcenter, kcluster, kidx, drop_idx, tile_counts;
     size_t point_proxy, x_in[2];    // x_in: LN1(x)+slot bias per branch (B*Mk,C)
@@ -269,8 +378,6 @@ int launch_prep_planes(const float *W, int rows, int K, void *out, hipStream_t s
 // Per-scene base pointers of the point clouds, passed by value as a kernel argument: the caller's
 // list of (N,3) tensors is used in place (the reference stacks them into a copy, PRE:426-427; the
 // path never writes to its input, so no copy is needed).
-constexpr int kMaxScenes = 32;
-struct ScenePts { const float *p[kMaxScenes]; };
 int make_scene_pts(const float *stacked, const float *const *list, int B, int N, ScenePts *out);
 
 // ---- clustering / apply (cluster.hip) ---------------------------------------------------
@@ -314,7 +421,7 @@ int launch_affine(const PtxShape &s, const ScenePts &points, uint32_t *tag, cons
 
 // ---- image proxy (imgproxy.hip) ------------------------------------------------------------
 int launch_img_mean(const float *img, int nimg, int in_dim, int hw, float *fm, hipStream_t st,
-                    uint32_t *gate = nullptr, uint32_t gate_seq = 0);
+                    uint32_t *gate = nullptr, uint32_t gate_seq = 0, const MinmaxFuse *mm = nullptr);
 int launch_img_scores(const float *img, const float *we, const float *qkv0, int nimg, int in_dim,
                       int hw, int heads, int C, int KT1, int KT2p, float scale, float *gbuf,
                       hipStream_t st);
@@ -322,7 +429,7 @@ int launch_img_gather(const float *img, int nimg, int in_dim, int hw, int heads,
                       float *gbuf, hipStream_t st);
 
 int launch_img_mean16(const void *img, int dt, int nimg, int in_dim, int hw, float *fm, hipStream_t st,
-                      uint32_t *gate = nullptr, uint32_t gate_seq = 0);
+                      uint32_t *gate = nullptr, uint32_t gate_seq = 0, const MinmaxFuse *mm = nullptr);
 int launch_img_scores16(const void *img, int dt, const float *we, const float *qkv0, int nimg, int in_dim,
                         int hw, int heads, int C, int KT1, int KT2p, float scale, float *gbuf, hipStream_t st);
 int launch_img_gather16(const void *img, int dt, int nimg, int in_dim, int hw, int heads, int KT2p, float *gbuf,

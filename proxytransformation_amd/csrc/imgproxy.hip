@@ -25,13 +25,14 @@ typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-B loa
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // one wave per group of 4 channel rows = 4*hw contiguous floats = hw float4
+template <bool MM>       // MM: the first work-groups reduce the scenes' bounding boxes (common.h, mean_prologue)
 __global__ __launch_bounds__(256) void k_img_mean(const float *__restrict__ img, int ngroups,
-                                                  int hw, float *__restrict__ fm, uint32_t *gate, uint32_t gate_seq)
+                                                  int hw, float *__restrict__ fm, uint32_t *gate, uint32_t gate_seq, MinmaxFuse mm)
 {
-    // the first thread of the launch tells the clustering stream that the caller's stream has reached this forward (api.hip, "gates")
-    if (gate != nullptr && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(gate, gate_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int blk;
+    if (mean_prologue<MM>(mm, gate, gate_seq, blk)) return;
     const int lane = lane_id();
-    const int g = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int g = __builtin_amdgcn_readfirstlane(blk * 4 + (threadIdx.x >> 6));
     if (g >= ngroups) return;
     const f32x4 *src = reinterpret_cast<const f32x4 *>(img + (size_t)g * 4 * hw);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -53,12 +54,14 @@ __global__ __launch_bounds__(256) void k_img_mean(const float *__restrict__ img,
     }
 }
 
-int launch_img_mean(const float *img, int nimg, int in_dim, int hw, float *fm, hipStream_t st, uint32_t *gate, uint32_t gate_seq)
+int launch_img_mean(const float *img, int nimg, int in_dim, int hw, float *fm, hipStream_t st, uint32_t *gate, uint32_t gate_seq,
+                    const MinmaxFuse *mm)
 {
     PTX_REQUIRE(in_dim % 4 == 0, "img mean: in_dim=%d must be a multiple of 4", in_dim);
     PTX_REQUIRE((reinterpret_cast<uintptr_t>(img) & 15) == 0, "img_feat must be 16-byte aligned");
     const int ngroups = nimg * (in_dim / 4);
-    hipLaunchKernelGGL(k_img_mean, dim3(cdiv(ngroups, 4)), dim3(256), 0, st, img, ngroups, hw, fm, gate, gate_seq);
+    if (mm != nullptr) hipLaunchKernelGGL(k_img_mean<true>, dim3(cdiv(ngroups, 4) + mm->B * mm->chunks), dim3(256), 0, st, img, ngroups, hw, fm, gate, gate_seq, *mm);
+    else hipLaunchKernelGGL(k_img_mean<false>, dim3(cdiv(ngroups, 4)), dim3(256), 0, st, img, ngroups, hw, fm, gate, gate_seq, MinmaxFuse{});
     PTX_LAUNCHED("k_img_mean");
     return PTX_OK;
 }

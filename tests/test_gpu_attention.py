@@ -91,3 +91,41 @@ def test_split_form_leaves_its_tickets_zero_and_repeats_bit_for_bit():
         assert int(scratch[:B * heads].view(torch.int32).abs().max()) == 0
         outs.append(out)
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_split_merge_is_stable_under_uneven_load(B):
+    """the slices of a (scene, head) publish their partials with write-through (sc1) stores around a relaxed
+    agent-scope ticket instead of release / acquire fences, so visibility across XCDs rests on the write-through path.  The
+    guide's hand-off rule: test under UNEVEN load with the consumer's caches warm and check every word.  300 back-to-back calls
+    (the partial buffer is re-used call after call: a stale line would be the previous call's values, so the inputs alternate
+    between two sets), a second stream keeps the memory system busy with copies of changing size, every output word is compared
+    with the quiet first pass of its input set."""
+    n, Lp, heads, C = 256, 196, 8, 256
+    lib = _abi.lib()
+    g = torch.Generator().manual_seed(77 + B)
+    sets = [(torch.randn(B * n, 3 * C, generator=g).cuda(), (torch.randn(B * Lp, C, generator=g) * 1.5).cuda()) for _ in range(2)]
+    scratch = torch.zeros(lib.ptx_proxy_attention_scratch_bytes(B, n, Lp, heads, C, 3) // 4, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(k):
+        out = torch.empty((B * n, C), device="cuda")
+        _abi.check(lib.ptx_proxy_attention(sets[k][0].data_ptr(), sets[k][1].data_ptr(), None, out.data_ptr(), scratch.data_ptr(),
+                                           B, n, Lp, heads, C, 3, st), "attn")
+        return out
+    ref = [run(0), run(1)]
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    big = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    dst = torch.empty_like(big)
+    bad = 0
+    for it in range(300):
+        if it % 3 != 2:                                         # uneven: bursts of copies, then nothing
+            with torch.cuda.stream(side):
+                m = (1 + it % 7) << 22
+                dst[:m].copy_(big[:m], non_blocking=True)
+        k = (it * 5 + it // 3) & 1
+        out = run(k)
+        bad += int((out != ref[k]).sum())
+    torch.cuda.synchronize()
+    assert bad == 0, f"{bad} output words differ from the quiet pass"

@@ -312,8 +312,9 @@ def test_launch_count_of_the_benchmark_shape():
 
 def test_launch_count_with_stream_gates():
     """The same count at a shape whose image chain owns the caller's stream (the benchmark's situation): the fork and the join are
-    device-word gates there, and THEIR launches are counted too -- 16 kernels + the fork's one-wave k_gate + the join's k_signal;
-    the join's wait is folded into the proxy_proj GEMM (no k_gate launch on the caller's stream)."""
+    device-word gates there, and THEIR launches are counted too -- 15 kernels (the bounding boxes are reduced by the first
+    work-groups of the mean launch: no k_minmax) + the fork's one-wave k_gate + the join's k_signal; the join's wait is folded
+    into the proxy_proj GEMM (no k_gate launch on the caller's stream)."""
     import ctypes
     from proxytransformation_amd import _abi
     from proxytransformation_amd.synth import PreshapeConfig, make_scene_batch
@@ -345,7 +346,7 @@ def test_launch_count_with_stream_gates():
             lib.ptx_timing_select(-1)
     per_site = {lib.ptx_kernel_name(i).decode(): n[i] for i in range(nk) if n[i]}
     assert per_site.get("k_gate[fork]") == 1 and per_site.get("k_signal[join]") == 1 and "k_gate[join]" not in per_site, per_site
-    assert sum(per_site.values()) == 18, per_site
+    assert "k_minmax" not in per_site and sum(per_site.values()) == 17, per_site
 
 
 _GATE_WORKER = r"""
