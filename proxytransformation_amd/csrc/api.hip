@@ -1055,9 +1055,13 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
         (void)kid;
         return PTX_OK;
     };
-    // gated forwards reduce the bounding boxes in the first work-groups of the mean launch (MinmaxFuse, common.h): the fork's
-    // word is stored when the boxes are final and the clustering stream starts at k_cluster (PTX_MM_FUSE=0: separate k_minmax)
-    static const bool mm_fuse_env = getenv("PTX_MM_FUSE") == nullptr || atoi(getenv("PTX_MM_FUSE")) != 0;
+    // PTX_MM_FUSE=1 (opt-in): gated forwards reduce the bounding boxes in the first work-groups of the mean launch (MinmaxFuse,
+    // common.h); the fork's word is stored when the boxes are final and the clustering stream starts at k_cluster.  r04, 4 scenes
+    // per GPU, interleaved pairs: 18.93k / 18.98k scenes/s without, 18.65k / 18.45k with -- the clustering stream does get 12 us
+    // ahead (k_cluster starts at 10.6 instead of 22 us) but it is not the critical chain at that shape, its kernels stretch
+    // next to the mean pass (k_cluster 32 -> 37, k_select 41 -> 46 us) and the mean launch itself takes 36.4 instead of 32.3 us
+    // on the chain that IS critical.  Kept for shapes / builds where the clustering chain sets the join.
+    static const bool mm_fuse_env = getenv("PTX_MM_FUSE") != nullptr && atoi(getenv("PTX_MM_FUSE")) != 0;
     const bool mm_fused = gated && mm_fuse_env && bbox_in == nullptr;
     MinmaxFuse mmf{};
     if (mm_fused) {

@@ -312,9 +312,10 @@ def test_launch_count_of_the_benchmark_shape():
 
 def test_launch_count_with_stream_gates():
     """The same count at a shape whose image chain owns the caller's stream (the benchmark's situation): the fork and the join are
-    device-word gates there, and THEIR launches are counted too -- 15 kernels (the bounding boxes are reduced by the first
-    work-groups of the mean launch: no k_minmax) + the fork's one-wave k_gate + the join's k_signal; the join's wait is folded
-    into the proxy_proj GEMM (no k_gate launch on the caller's stream)."""
+    device-word gates there, and THEIR launches are counted too -- the 16 kernels + the fork's one-wave k_gate + the join's
+    k_signal; the join's wait is folded into the proxy_proj GEMM (no k_gate launch on the caller's stream).  (One kernel less
+    with PTX_MM_FUSE=1, where the first work-groups of the mean launch reduce the bounding boxes; one more where the
+    attention runs as two launches.)"""
     import ctypes
     from proxytransformation_amd import _abi
     from proxytransformation_amd.synth import PreshapeConfig, make_scene_batch
@@ -346,7 +347,9 @@ def test_launch_count_with_stream_gates():
             lib.ptx_timing_select(-1)
     per_site = {lib.ptx_kernel_name(i).decode(): n[i] for i in range(nk) if n[i]}
     assert per_site.get("k_gate[fork]") == 1 and per_site.get("k_signal[join]") == 1 and "k_gate[join]" not in per_site, per_site
-    assert "k_minmax" not in per_site and sum(per_site.values()) == 17, per_site
+    fused_boxes = "k_minmax" not in per_site                     # PTX_MM_FUSE=1: the boxes ride in the mean launch
+    two_launch_attn = "k_attn32[proxy_as_key]" in per_site      # few (scene, head) pairs at this shape: PV through memory
+    assert sum(per_site.values()) == 16 + 2 - int(fused_boxes) + int(two_launch_attn), per_site
 
 
 _GATE_WORKER = r"""
