@@ -303,6 +303,7 @@ def passes_report(cfg, B, us, dt_bytes):
     rep["k_affine"] = hbm(["k_affine<compact>"])
     rep["img_mean_pass_hbm"] = hbm(["k_img_mean"])
     rep["img_pool_pass_hbm"] = hbm(["img_pass2"])
+    rep["img_features_hbm"] = hbm(["k_img_mean", "img_pass2", "img_pass3"])       # every streaming pass over img_feat together
     rep["proxy_attention_mfma"] = mfma(["k_attn32[proxy_as_query]", "k_attn32[proxy_as_key]", "k_proxy_attn[fused]"])
     rep["block_gemms_mfma"] = mfma(["k_gemm_nt[qkv+proxy_proj]", "k_gemm_nt[pp_img]", "k_gemm_nt[proj]",
                                     "k_gemm_nt[fc1]", "k_gemm_nt[fc2]", "k_mlp[fc1+gelu+fc2]"])

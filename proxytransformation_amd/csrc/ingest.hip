@@ -18,6 +18,8 @@
 //   k_ingest_gather  one thread per output point: binary search chunk -> group, select the r-th set bit of the group's
 //                    mask, read ONE depth value, un-project, transform, (augment,) store; the scene's bounding box is
 //                    reduced on the way and published in the encoding k_cluster reads (the forward then skips k_minmax)
+#include <cstdlib>
+
 #include "common.h"
 
 namespace ptx {
@@ -44,8 +46,12 @@ template <typename T> __device__ __forceinline__ bool depth_nonzero(T d);
 template <> __device__ __forceinline__ bool depth_nonzero<float>(float d) { return d != 0.0f; }       // nonzero(): NaN counts
 template <> __device__ __forceinline__ bool depth_nonzero<uint16_t>(uint16_t d) { return d != 0; }
 
-// grid (cpv, V), 256 threads: wave w of chunk c owns groups 64 w .. 64 w + 63 of the chunk
-template <typename T>
+// grid (cpv, V), 256 threads: wave w of chunk c owns groups 64 w .. 64 w + 63 of the chunk = 4096 consecutive pixels.
+// VEC (r04; the view's rows are 16-byte aligned): a lane reads EIGHT consecutive pixels per step with 16-byte loads (one for
+// uint16, two for float), all eight steps of the wave requested up front, turns them into one byte of "depth != 0" bits and
+// drops it into a 512-byte wave-private LDS image of the wave's 64 group masks; lane g then reads group g's 64-bit mask.
+// (r03: one 2-byte load per lane and step + a ballot -- 64 dependent trips per wave, 1.0 TB/s.)
+template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void k_ingest_index(const T *__restrict__ depth, long hw, int gpv, int cpv,
                                                       unsigned long long *__restrict__ masks, uint32_t *__restrict__ prefix,
                                                       uint32_t *__restrict__ chunk_tot)
@@ -54,12 +60,48 @@ __global__ __launch_bounds__(256) void k_ingest_index(const T *__restrict__ dept
     const T *__restrict__ d = depth + (size_t)v * hw;
     const int g0 = c * kGroupsPerChunk + wv * 64;           // first group (of the view) of this wave
     unsigned long long mine = 0ull;
+    __shared__ __attribute__((aligned(16))) unsigned char s_bits[4][512];
+    if (VEC) {
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        constexpr int PER = 16 / (int)sizeof(T);            // pixels per 16-byte load: 8 (uint16) or 4 (float)
+        constexpr int NL = 8 / PER;                         // loads per lane and step
+        const long p0 = (long)g0 << 6;                      // first pixel of the wave
+        u32x4 q[8][NL];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const long p = p0 + (long)(k * 64 + lane) * 8;
+#pragma unroll
+            for (int u = 0; u < NL; ++u) {
+                const long pp = p + u * PER;                // (hw is a multiple of PER here: a 16-byte load is inside or outside)
+                q[k][u] = pp < hw ? __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(d + pp)) : u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            unsigned int bits = 0u;
+#pragma unroll
+            for (int u = 0; u < NL; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned int w = q[k][u][e];
+                    if (sizeof(T) == 2) {
+                        bits |= ((w & 0xffffu) != 0u ? 1u : 0u) << (2 * e) | ((w >> 16) != 0u ? 1u : 0u) << (2 * e + 1);
+                    } else {
+                        bits |= (__uint_as_float(w) != 0.0f ? 1u : 0u) << (4 * u + e);      // nonzero(): NaN counts, -0.0 does not
+                    }
+                }
+            s_bits[wv][k * 64 + lane] = (unsigned char)bits;
+        }
+        // wave-private image: the wave's LDS operations complete in order, no barrier needed
+        mine = *reinterpret_cast<const unsigned long long *>(&s_bits[wv][8 * lane]);
+    } else {
 #pragma unroll 8
-    for (int i = 0; i < 64; ++i) {
-        const long p = ((long)(g0 + i) << 6) + lane;
-        const bool nz = p < hw && depth_nonzero<T>(d[p]);
-        const unsigned long long m = __ballot(nz);
-        if (lane == i) mine = m;
+        for (int i = 0; i < 64; ++i) {
+            const long p = ((long)(g0 + i) << 6) + lane;
+            const bool nz = p < hw && depth_nonzero<T>(d[p]);
+            const unsigned long long m = __ballot(nz);
+            if (lane == i) mine = m;
+        }
     }
     const int cnt = __popcll(mine);
     int incl = cnt;
@@ -254,10 +296,19 @@ int ptx_ingest_index(const void *depth, int depth_dtype, int V, int H, int W, vo
     auto *coff = reinterpret_cast<unsigned long long *>(ws + L.chunk_off);
     const long hw = (long)H * W;
     const dim3 grid(L.cpv, V);
-    if (depth_dtype == 0)
-        hipLaunchKernelGGL(k_ingest_index<float>, grid, dim3(256), 0, st, static_cast<const float *>(depth), hw, L.gpv, L.cpv, masks, prefix, ctot);
-    else
-        hipLaunchKernelGGL(k_ingest_index<uint16_t>, grid, dim3(256), 0, st, static_cast<const uint16_t *>(depth), hw, L.gpv, L.cpv, masks, prefix, ctot);
+    // 16-byte loads where every view starts on a 16-byte boundary (480 x 640 maps do); PTX_INGEST_SCALAR=1 forces the element form
+    static const bool scalar_env = getenv("PTX_INGEST_SCALAR") != nullptr;
+    const size_t esz = depth_dtype == 0 ? 4 : 2;
+    const bool vec = !scalar_env && (reinterpret_cast<uintptr_t>(depth) & 15) == 0 && ((size_t)hw * esz) % 16 == 0;
+    if (depth_dtype == 0) {
+        const float *dp = static_cast<const float *>(depth);
+        if (vec) hipLaunchKernelGGL((k_ingest_index<float, true>), grid, dim3(256), 0, st, dp, hw, L.gpv, L.cpv, masks, prefix, ctot);
+        else     hipLaunchKernelGGL((k_ingest_index<float, false>), grid, dim3(256), 0, st, dp, hw, L.gpv, L.cpv, masks, prefix, ctot);
+    } else {
+        const uint16_t *dp = static_cast<const uint16_t *>(depth);
+        if (vec) hipLaunchKernelGGL((k_ingest_index<uint16_t, true>), grid, dim3(256), 0, st, dp, hw, L.gpv, L.cpv, masks, prefix, ctot);
+        else     hipLaunchKernelGGL((k_ingest_index<uint16_t, false>), grid, dim3(256), 0, st, dp, hw, L.gpv, L.cpv, masks, prefix, ctot);
+    }
     PTX_LAUNCHED("k_ingest_index");
     hipLaunchKernelGGL(k_ingest_scan, dim3(1), dim3(256), 0, st, ctot, V, L.cpv, coff, view_counts);
     PTX_LAUNCHED("k_ingest_scan");

@@ -135,3 +135,35 @@ def test_forward_takes_the_ingested_bounding_box():
     outs2 = m(batch.points, td, t(img))
     for a, b, c in zip(outs, outs2, d0["outputs"]):
         assert torch.equal(a, c) and torch.equal(b, c)
+
+
+@pytest.mark.parametrize("as_u16", [False, True], ids=["f32", "u16"])
+@pytest.mark.parametrize("H,W", [(96, 128), (100, 200), (75, 131)], ids=["vec-aligned", "vec-ragged-chunks", "scalar"])
+def test_index_kernel_forms_agree_with_the_oracle(H, W, as_u16):
+    """k_ingest_index reads eight pixels per lane with 16-byte loads where every view starts on a 16-byte boundary (r04) and one
+    element per lane otherwise (75 x 131: 9 825 pixels per view, views at odd element offsets): per-view counts, the composed
+    selection and the points against the CPU restatement for both, float32 and decoded uint16 depth, with an empty view, NaN
+    depth (counts as nonzero, like torch.nonzero) and a ragged last group / chunk."""
+    from oracle import oracle
+    rng = np.random.default_rng(H * W)
+    V, N = 5, 6000
+    raw = (300 + 5000 * rng.random((V, H, W))).astype(np.uint16)
+    raw[rng.random((V, H, W)) < 0.35] = 0
+    raw[3] = 0
+    depth = raw.astype(np.float32) / 1000.0
+    K = np.array([[0.8 * W, 0.0, W / 2], [0.0, 0.8 * W, H / 2], [0.0, 0.0, 1.0]])
+    ext = np.stack([np.eye(4, dtype=np.float32) for _ in range(V)])
+    for v in range(V):
+        a = 0.9 * v
+        ext[v, :3, :3] = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], np.float32)
+        ext[v, :3, 3] = [0.2 * v, -0.1 * v, 1.0]
+    ref = oracle.ingest(depth, K, ext, N, rng=np.random.RandomState(5))
+    if as_u16:
+        dimg = torch.from_numpy(raw.view(np.int16)).to(_dev()).view(torch.uint16)
+    else:
+        dimg = torch.from_numpy(depth).to(_dev())
+    sc = dict(depth_img=dimg, depth_shift=1000.0, depth_cam2img=K, extrinsic=ext)
+    b = MultiViewIngest(N)([sc], rng=np.random.RandomState(5))
+    assert np.array_equal(b.view_counts[0], ref["view_counts"]) and b.view_counts[0][3] == 0
+    assert np.array_equal(b.sel[0], ref["sel"])
+    assert_close(b.points[0].cpu().numpy(), ref["points"], atol=1e-5, what="ingest vs oracle")

@@ -170,3 +170,29 @@ def test_cfg5_full_size_properties():
         assert np.array_equal(d[k].cpu().numpy().astype(np.int64), ref[k]), k
     check_forward_properties(cfg, d, pts, range(cfg.B))
     assert np.isfinite(d["transform"].cpu().numpy()).all() and np.isfinite(d["translate"].cpu().numpy()).all()
+
+
+def test_cfg5_batch_of_16_clustering_vs_oracle():
+    """cfg5 as the roofline run BASELINE calls it (SURVEY H7: its streaming passes only matter from ~16 scenes per GPU on;
+    profiles/r04_final_bench_cfg5_b16.json): the clustering half of a 16-scene call -- 8 M points, 65 536 grid clusters, 16 x 1 844
+    farthest-point picks side by side -- against the oracle, every index tensor bit-identical (centres injected).  The
+    float half is covered at reduced N above (embed_dim = 512 has no reference); here it runs with a single view."""
+    from oracle import oracle
+    base = CONFIGS["cfg5"]
+    cfg = PreshapeConfig("cfg5b16", B=16, N=base.N, grid_size=base.grid_size, dynamic_drop_radio=base.dynamic_drop_radio,
+                         L=8, V=1, embed_dim=base.embed_dim, seed_base=base.seed_base)
+    assert (cfg.M, cfg.Mt, cfg.M_keep, cfg.Kd) == (4096, 2868, 1024, 1844)
+    m, sd = build_module(cfg)
+    m = m.cuda()
+    pts, text, mask, img = make_scene_batch(cfg)
+    ref = oracle.forward(sd, **oracle_kwargs(cfg), points=pts, text_feats=text, text_mask=mask, img_feat=img,
+                         stop_after="select", num_threads=min(16, os.cpu_count() or 1))
+    m._centers_override = torch.from_numpy(ref["centers"])
+    d = m.forward_debug([_t(p) for p in pts], {"text_feats": _t(text), "text_token_mask": _t(mask)},
+                        torch.from_numpy(img).to(torch.float16).cuda())
+    for k in INT_KEYS:
+        assert np.array_equal(d[k].cpu().numpy().astype(np.int64), ref[k]), k
+    assert np.array_equal(d["pad_count"].cpu().numpy().astype(np.int64), ref["pad_counts"])
+    lens = [int(o.shape[0]) for o in d["outputs"]]
+    assert len(set(lens)) > 1 and all(0 < n < cfg.N for n in lens)        # ragged outputs, something dropped everywhere
+    assert all(bool(torch.isfinite(o).all()) for o in d["outputs"])
