@@ -71,7 +71,11 @@ def parse():
                     help="storage type of the image features (cfg2: bf16 as BASELINE names it, cfg5: fp16, otherwise "
                          "fp32; arithmetic is fp32 either way)")
     ap.add_argument("--sets", type=int, default=3, help="distinct input sets rotated through the steps")
-    ap.add_argument("--streams", type=int, default=1, help="torch streams the timed steps are issued on (round-robin)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="lanes: torch streams the timed steps are issued on, one host thread per stream (a serving loop with "
+                         "several forwards in flight); > 1 switches the library's lane token on (ptx_lane_token)")
+    ap.add_argument("--no-lane-token", action="store_true", help="with --streams > 1: leave the lane token off (A/B)")
+    ap.add_argument("--single-thread", action="store_true", help="with --streams > 1: issue round-robin from ONE host thread")
     ap.add_argument("--time-kernel", default="img_pass2", help="launch site timed inside the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-passes", action="store_true", help="skip roofline_passes / fp32-feature extras")
@@ -255,10 +259,12 @@ class InputSets:
         return out
 
 
-def timed_steps(mod, inputs, steps, barrier, streams=None, f32=False, start=0):
+def timed_steps(mod, inputs, steps, barrier, streams=None, f32=False, start=0, workers=None):
     barrier()
     t0 = time.perf_counter()
-    if streams is None:
+    if workers is not None:
+        outs = workers.run(start, steps, f32)
+    elif streams is None:
         for i in range(start, start + steps):
             outs = mod(*inputs.args(i, f32))
     else:
@@ -267,6 +273,48 @@ def timed_steps(mod, inputs, steps, barrier, streams=None, f32=False, start=0):
                 outs = mod(*inputs.args(i, f32))
     barrier()
     return time.perf_counter() - t0, outs
+
+
+class LaneWorkers:
+    """One host thread per torch stream (lane), as a serving loop would drive the module: thread j issues forwards j, j + S,
+    j + 2 S, ... of a block on its own stream (ctypes releases the GIL inside the library, so the lanes' enqueue and count waits
+    overlap).  The threads are parked between blocks; a block is released and collected through barriers."""
+
+    def __init__(self, mod, inputs, streams):
+        import threading
+        self.mod, self.inputs, self.streams = mod, inputs, streams
+        self.start, self.done = threading.Barrier(len(streams) + 1), threading.Barrier(len(streams) + 1)
+        self.job, self.outs, self.err, self.stop = None, [None] * len(streams), None, False
+        self.threads = [threading.Thread(target=self._run, args=(j,), daemon=True) for j in range(len(streams))]
+        for t in self.threads:
+            t.start()
+
+    def _run(self, j):
+        with torch.no_grad():
+            while True:
+                self.start.wait()
+                if self.stop:
+                    return
+                first, steps, f32 = self.job
+                try:
+                    with torch.cuda.stream(self.streams[j]):
+                        for i in range(first + j, first + steps, len(self.streams)):
+                            self.outs[j] = self.mod(*self.inputs.args(i, f32))
+                except Exception as e:          # surfaced by run()
+                    self.err = e
+                self.done.wait()
+
+    def run(self, first, steps, f32=False):
+        self.job = (first, steps, f32)
+        self.start.wait()
+        self.done.wait()
+        if self.err is not None:
+            raise self.err
+        return self.outs[(steps - 1) % len(self.streams)]
+
+    def close(self):
+        self.stop = True
+        self.start.wait()
 
 
 def site_times(lib, names, mod, inputs, steps):
@@ -357,6 +405,9 @@ def main():
         torch.cuda.synchronize()
 
     streams = [torch.cuda.Stream() for _ in range(args.streams)] if args.streams > 1 else None
+    workers = None
+    if streams and not args.no_lane_token:
+        lib.ptx_lane_token(1)
     extras = {}
     with torch.no_grad():
         for i in range(max(2 * len(inputs.sets), args.setup_forwards)):     # set-up, not warm-up: parameter tables, workspace,
@@ -365,17 +416,25 @@ def main():
         for i in range(args.warmup):
             outs = mod(*inputs.args(i))
         if streams:
-            for i in range(2 * len(streams)):
+            for i in range(2 * len(streams)):               # every lane's context / workspace / probe, from this thread
                 with torch.cuda.stream(streams[i % len(streams)]):
                     mod(*inputs.args(i))
+            torch.cuda.synchronize()
+            if not args.single_thread:
+                workers = LaneWorkers(mod, inputs, streams)
+                workers.run(0, 4 * len(streams))            # the threads' first calls
         n_out = sum(int(o.shape[0]) for o in outs)
         lib.ptx_timing_every(max(1, args.time_every))
         lib.ptx_timing_select(kid)
         # R blocks of exactly K steps; the input-set rotation continues across blocks
         block_s = []
         for r in range(max(1, args.repeats)):
-            el, outs = timed_steps(mod, inputs, args.steps, barrier, streams, start=r * args.steps)
+            el, outs = timed_steps(mod, inputs, args.steps, barrier, streams, start=r * args.steps, workers=workers)
             block_s.append(el)
+        if workers is not None:
+            workers.close()
+        if streams:
+            lib.ptx_lane_token(0)                           # the extra legs below run on one stream
         launches, total_ms = ctypes.c_int(0), ctypes.c_float(0.0)
         lib.ptx_timing_read(ctypes.byref(launches), ctypes.byref(total_ms))
         lib.ptx_timing_select(-1)
@@ -473,6 +532,8 @@ def main():
                                          f"L={cfg.L} text + V={cfg.V} image proxies, d={cfg.embed_dim}, eval forward",
                                 scenes_per_gpu=B, global_scenes_per_step=world * B, sharding="by scene, no collective",
                                 img_feat_dtype=img_dtype, input_sets_rotated=len(inputs.sets), streams=args.streams,
+                                lanes=("%d lanes: one host thread + torch stream each, forwards in flight side by side, lane token %s"
+                                       % (args.streams, "off" if args.no_lane_token else "on")) if args.streams > 1 else "1 (one forward at a time)",
                                 setup_forwards=max(2 * len(inputs.sets), args.setup_forwards),
                                 arithmetic="fp32 (fp32 MFMA / VALU; the 16-bit matrix pipe only through 3-way operand splits with fp32 accumulate: exact in the pooling pass, dropped terms <= 2^-25 |xy| in the 64x64-tile GEMMs)",
                                 surviving_points_per_step=n_out),

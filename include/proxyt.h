@@ -128,6 +128,13 @@ int ptx_context_destroy(PtxContext *ctx);
  * one stream). */
 int ptx_context_check(PtxContext *ctx);
 int ptx_context_gates(const PtxContext *ctx);
+/* Lane token (ABI 6), process-wide switch, returns the previous setting.  For serving loops that keep several forwards in
+ * flight (one context + stream per lane, one host thread per lane): with the token on, the streaming passes over img_feat of
+ * consecutive forwards (in enqueue order, across contexts of one device) run one after the other -- each forward's image
+ * chain starts with a one-wave launch that waits (bounded, 20 ms, silent) for the previous forward's last streaming pass --
+ * while their latency-bound remainders overlap.  It changes no result and orders nothing correctness depends on.  Off by
+ * default: with a single lane it would be one launch per forward for nothing. */
+int ptx_lane_token(int on);
 
 /* Per-kernel timing of ptx_forward for roofline measurement (bench.py): select ONE launch
  * site by id (0 .. ptx_kernel_count()-1, -1 = off); every later ptx_forward brackets that
@@ -316,7 +323,9 @@ int ptx_wait_counts(const int32_t *counts_host, int B, int64_t timeout_us);
  * inv_intrinsic (V,4,4) = inverse of the 4x4-padded depth_cam2img; lu (V,4,4) + piv (V,4) int32 = LU factors of
  * global2ego with rows permuted by piv (P A = L U, unit lower); aug = NULL or 13 floats rot_mat_T (3,3) | scale | trans;
  * points (N,3); bbox_enc (6) uint32 or NULL = the cloud's bounding box in ptx_forward_ex's encoding (cleared here);
- * status (1) int32 device: bit 0 set if any sel[j] was out of range (that point is written as 0). */
+ * status (1) int32 device: bit 0 set if any sel[j] was out of range (that point is written as 0).
+ * workspace: its first 256 bytes (an arrival ticket) must be ZERO before the first ptx_ingest_index on it (hipMemset once);
+ * every call leaves them zero.  (ABI 6: the chunk scan runs in the last work-group of the index launch.) */
 size_t ptx_ingest_workspace_bytes(int V, int H, int W);
 int ptx_ingest_index(const void *depth, int depth_dtype, int V, int H, int W, void *workspace, size_t ws_bytes,
                      int32_t *view_counts, void *stream);

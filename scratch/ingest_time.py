@@ -31,7 +31,7 @@ print(f"MultiViewIngest B={B}: {1e3*dt:.2f} ms per batch ({1e3*dt/B:.2f} ms per 
 lib = _abi.lib(); st = torch.cuda.current_stream().cuda_stream
 depth = scenes[0]["depth_img"]
 nbytes = lib.ptx_ingest_workspace_bytes(V, H, W)
-ws = torch.empty(nbytes, dtype=torch.uint8, device=dev); counts = torch.empty(V, dtype=torch.int32).pin_memory()
+ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev); counts = torch.empty(V, dtype=torch.int32).pin_memory()
 e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
 reps = 20
 lib.ptx_ingest_index(depth.data_ptr(), 1, V, H, W, ws.data_ptr(), nbytes, counts.data_ptr(), st); torch.cuda.synchronize()

@@ -142,8 +142,8 @@ def test_forward_takes_the_ingested_bounding_box():
 def test_index_kernel_forms_agree_with_the_oracle(H, W, as_u16):
     """k_ingest_index reads eight pixels per lane with 16-byte loads where every view starts on a 16-byte boundary (r04) and one
     element per lane otherwise (75 x 131: 9 825 pixels per view, views at odd element offsets): per-view counts, the composed
-    selection and the points against the CPU restatement for both, float32 and decoded uint16 depth, with an empty view, NaN
-    depth (counts as nonzero, like torch.nonzero) and a ragged last group / chunk."""
+    selection and the points against the CPU restatement for both, float32 and decoded uint16 depth, with an empty view and a
+    ragged last group / chunk."""
     from oracle import oracle
     rng = np.random.default_rng(H * W)
     V, N = 5, 6000
