@@ -73,8 +73,8 @@ def parse():
     ap.add_argument("--sets", type=int, default=3, help="distinct input sets rotated through the steps")
     ap.add_argument("--streams", type=int, default=1,
                     help="lanes: torch streams the timed steps are issued on, one host thread per stream (a serving loop with "
-                         "several forwards in flight); > 1 switches the library's lane token on (ptx_lane_token)")
-    ap.add_argument("--no-lane-token", action="store_true", help="with --streams > 1: leave the lane token off (A/B)")
+                         "several forwards in flight).  Measured SLOWER than one lane at every count (profiles/r04_lanes_pipelining.txt): "
+                         "the pooling pass needs every CU's register file, the neighbouring forward's small kernels take its slots")
     ap.add_argument("--single-thread", action="store_true", help="with --streams > 1: issue round-robin from ONE host thread")
     ap.add_argument("--time-kernel", default="img_pass2", help="launch site timed inside the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -406,8 +406,6 @@ def main():
 
     streams = [torch.cuda.Stream() for _ in range(args.streams)] if args.streams > 1 else None
     workers = None
-    if streams and not args.no_lane_token:
-        lib.ptx_lane_token(1)
     extras = {}
     with torch.no_grad():
         for i in range(max(2 * len(inputs.sets), args.setup_forwards)):     # set-up, not warm-up: parameter tables, workspace,
@@ -433,8 +431,6 @@ def main():
             block_s.append(el)
         if workers is not None:
             workers.close()
-        if streams:
-            lib.ptx_lane_token(0)                           # the extra legs below run on one stream
         launches, total_ms = ctypes.c_int(0), ctypes.c_float(0.0)
         lib.ptx_timing_read(ctypes.byref(launches), ctypes.byref(total_ms))
         lib.ptx_timing_select(-1)
@@ -532,8 +528,8 @@ def main():
                                          f"L={cfg.L} text + V={cfg.V} image proxies, d={cfg.embed_dim}, eval forward",
                                 scenes_per_gpu=B, global_scenes_per_step=world * B, sharding="by scene, no collective",
                                 img_feat_dtype=img_dtype, input_sets_rotated=len(inputs.sets), streams=args.streams,
-                                lanes=("%d lanes: one host thread + torch stream each, forwards in flight side by side, lane token %s"
-                                       % (args.streams, "off" if args.no_lane_token else "on")) if args.streams > 1 else "1 (one forward at a time)",
+                                lanes=("%d lanes: one host thread + torch stream each, forwards in flight side by side" % args.streams)
+                                if args.streams > 1 else "1 (one forward at a time)",
                                 setup_forwards=max(2 * len(inputs.sets), args.setup_forwards),
                                 arithmetic="fp32 (fp32 MFMA / VALU; the 16-bit matrix pipe only through 3-way operand splits with fp32 accumulate: exact in the pooling pass, dropped terms <= 2^-25 |xy| in the 64x64-tile GEMMs)",
                                 surviving_points_per_step=n_out),

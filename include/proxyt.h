@@ -128,13 +128,6 @@ int ptx_context_destroy(PtxContext *ctx);
  * one stream). */
 int ptx_context_check(PtxContext *ctx);
 int ptx_context_gates(const PtxContext *ctx);
-/* Lane token (ABI 6), process-wide switch, returns the previous setting.  For serving loops that keep several forwards in
- * flight (one context + stream per lane, one host thread per lane): with the token on, the streaming passes over img_feat of
- * consecutive forwards (in enqueue order, across contexts of one device) run one after the other -- each forward's image
- * chain starts with a one-wave launch that waits (bounded, 20 ms, silent) for the previous forward's last streaming pass --
- * while their latency-bound remainders overlap.  It changes no result and orders nothing correctness depends on.  Off by
- * default: with a single lane it would be one launch per forward for nothing. */
-int ptx_lane_token(int on);
 
 /* Per-kernel timing of ptx_forward for roofline measurement (bench.py): select ONE launch
  * site by id (0 .. ptx_kernel_count()-1, -1 = off); every later ptx_forward brackets that

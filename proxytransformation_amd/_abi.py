@@ -96,7 +96,6 @@ SIGNATURES = {
     "ptx_context_destroy": (_I, [_P]),
     "ptx_context_check": (_I, [_P]),
     "ptx_context_gates": (_I, [_P]),
-    "ptx_lane_token": (_I, [_I]),
     "ptx_forward": (_I, [_P, _SH, _W, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z,
                          C.POINTER(PtxDebug), _P]),
 }

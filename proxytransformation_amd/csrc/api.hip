@@ -265,47 +265,6 @@ static void context_release(PtxContext *c)
 static std::mutex g_default_mu;
 static PtxContext *g_default_ctx[16] = {};
 
-// ---- lane token (r04): serving loops that keep several forwards in flight (one lane = context + torch stream each, driven from
-// one host thread per lane) pipeline best when the forwards' STREAMING passes over img_feat -- the only chip-filling part of a
-// forward -- run one after the other while everything else (the clustering chain, the table GEMMs, the proxy blocks: latency-
-// bound launches of a few hundred work-groups) of the neighbouring forwards fills the gaps.  With the token on, every forward
-// draws a ticket t when it is enqueued; its image chain begins with a one-wave k_gate that waits until the forward with ticket
-// t - 1 has finished its last streaming pass (the first thread of that forward's o-projection GEMM stores t - 1: GemmBatch::
-// head_flag), and hands over the same way.  It orders nothing that correctness depends on: the wait is bounded (20 ms) and
-// lets go silently.  Off by default (one lane: the wait would be a launch for nothing); ptx_lane_token(1) switches it on for
-// the process.
-static std::atomic<int> g_token_on{0};
-static std::atomic<uint32_t> g_token_next[16];
-static uint32_t *g_token_done[16] = {};
-
-static int token_word(int dev, uint32_t **out)
-{
-    std::lock_guard<std::mutex> lk(g_default_mu);
-    if (g_token_done[dev] == nullptr) {
-        PTX_HIP(hipMalloc(reinterpret_cast<void **>(&g_token_done[dev]), 256));
-        PTX_HIP(hipMemset(g_token_done[dev], 0, 256));
-        g_token_next[dev].store(0);
-    }
-    *out = g_token_done[dev];
-    return PTX_OK;
-}
-
-static int default_context(PtxContext **out)
-{
-    int dev = 0;
-    PTX_HIP(hipGetDevice(&dev));
-    PTX_REQUIRE(dev >= 0 && dev < 16, "device %d out of range", dev);
-    std::lock_guard<std::mutex> lk(g_default_mu);
-    if (g_default_ctx[dev] == nullptr) {
-        PtxContext *c = new PtxContext();
-        const int rc = context_init(c);
-        if (rc != PTX_OK) { context_release(c); delete c; return rc; }
-        g_default_ctx[dev] = c;
-    }
-    *out = g_default_ctx[dev];
-    return PTX_OK;
-}
-
 int make_scene_pts(const float *stacked, const float *const *list, int B, int N, ScenePts *out)
 {
     PTX_REQUIRE(B >= 1 && B <= kMaxScenes, "at most %d scenes per call (got %d): split the batch", kMaxScenes, B);
@@ -412,8 +371,7 @@ static int gate_probe(PtxContext *c, hipStream_t st)
 
 static int run_img_proxy(const PtxShape &s, const PtxWeights &w, const float *prep, const void *img_any,
                          float *img_proxy, void *ws, hipStream_t st, int phase = 0, bool need_ln = true,
-                         int i0 = 0, int ni = -1, uint32_t *gate = nullptr, uint32_t gate_seq = 0, const MinmaxFuse *mm = nullptr,
-                         uint32_t *token = nullptr, uint32_t token_seq = 0)
+                         int i0 = 0, int ni = -1, uint32_t *gate = nullptr, uint32_t gate_seq = 0, const MinmaxFuse *mm = nullptr)
 {
     // images [i0, i0 + ni) of the B * V of this call (default: all): every buffer of the chain is per image
     const PrepLayout P = prep_layout(s);
@@ -489,7 +447,6 @@ static int run_img_proxy(const PtxShape &s, const PtxWeights &w, const float *pr
                 g.p[h].kg = s.in_dim;
             }
         }
-        g.head_flag = token; g.head_seq = token_seq;        // lane token: the streaming passes of this forward are over
         PTX_TIMED(KID_IMG_O, st, launch_gemm(g, st));
     }
     {   // c_proj
@@ -784,12 +741,6 @@ int ptx_context_check(PtxContext *ctx)
 
 int ptx_context_gates(const PtxContext *ctx) { return ctx != nullptr && ctx->gates_on ? 1 : 0; }
 
-int ptx_lane_token(int on)
-{
-    const int prev = g_token_on.exchange(on != 0 ? 1 : 0);
-    return prev;
-}
-
 int ptx_wait_counts(const int32_t *counts_host, int B, int64_t timeout_us)
 {
     PTX_REQUIRE(counts_host && B > 0, "ptx_wait_counts: null argument");
@@ -1078,23 +1029,6 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     // (Two staggered slices of images on two streams -- slice B streaming its means under slice A's table GEMMs, A
     // pooling under B's tables -- measured again in r02 with the fused / folded chain: 0.319 vs 0.298 ms per step.
     // Twice the launches, and the half-size pooling launches each pay their own partial last round.)
-    // lane token: this forward's streaming passes wait for the previous ticket's (see g_token_on)
-    uint32_t *token = nullptr; uint32_t ticket = 0;
-    if (g_token_on.load(std::memory_order_relaxed) != 0) {
-        PTX_TRY(token_word(side->dev, &token));
-        ticket = ++g_token_next[side->dev];
-        if (ticket > 1) {
-            int khz = 100000;
-            const GateRef tg{token, ticket - 1, nullptr, nullptr, side->probe_ticks ? side->probe_ticks : (uint64_t)20 * khz, 5, 0};
-            hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, is, tg);
-            PTX_LAUNCHED("k_gate[token]");
-        }
-    }
-    // (if anything below fails after the ticket was drawn, the hand-over is made up for here: later forwards must not wait their bound)
-    struct TokenGuard {
-        uint32_t *w; uint32_t t; hipStream_t s; bool armed;
-        ~TokenGuard() { if (armed && w) hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, s, w, t); }
-    } token_guard{token, ticket, is, token != nullptr};
     // test aid (tests/test_gpu_host.py): PTX_GATE_FAULT=fork / join drops the releasing store of that gate, so that the waiter runs
     // into its bound and the failure path (error word, NaN outputs, PTX_EGATE, fall-back to events) can be exercised
     static const char *const fault = getenv("PTX_GATE_FAULT");
@@ -1220,8 +1154,7 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
             return PTX_OK;
         };
         if (!fault_join) PTX_TIMED(KID_SIGNAL_JOIN, cs, launch_signal());
-        PTX_TRY(run_img_proxy(S, *w, pf, img_feat, img_proxy, ws, is, 2, want_img_proxy, 0, -1, nullptr, 0, nullptr, token, ticket));
-        token_guard.armed = false;
+        PTX_TRY(run_img_proxy(S, *w, pf, img_feat, img_proxy, ws, is, 2, want_img_proxy));
         join = gate_ref(side, 32, side->gate_seq, 2);
         static const bool fold = getenv("PTX_GATE_FOLD") == nullptr || atoi(getenv("PTX_GATE_FOLD")) != 0;
         if (!fold) {
@@ -1230,8 +1163,7 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
         }
     } else {
     if (!cluster_on_caller) PTX_HIP(hipEventRecord(side->join, cs));
-    PTX_TRY(run_img_proxy(S, *w, pf, img_feat, img_proxy, ws, is, 2, want_img_proxy, 0, -1, nullptr, 0, nullptr, token, ticket));      // rest of the image chain
-    token_guard.armed = false;
+    PTX_TRY(run_img_proxy(S, *w, pf, img_feat, img_proxy, ws, is, 2, want_img_proxy));      // rest of the image chain
     if (cluster_on_caller) PTX_HIP(hipEventRecord(side->join, is));
     PTX_HIP(hipStreamWaitEvent(st, side->join, 0));
     }

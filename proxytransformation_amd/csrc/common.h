@@ -319,9 +319,6 @@ struct GemmBatch {
     // join folded into this launch (api.hip, "gates"): work-group (0,0,0) ends with gate_wait(tail_gate), so the LAUNCH completes
     // -- and the next kernel of its stream starts -- only when the other stream has signalled; flag == null: no wait
     GateRef tail_gate;
-    // lane token (api.hip): the first thread of the launch stores `head_seq` into `head_flag` (null: nothing) -- the stream being
-    // in order, everything in front of this launch on its stream (the streaming passes over img_feat) has completed by then
-    uint32_t *head_flag; uint32_t head_seq;
 };
 int launch_gemm(const GemmBatch &gb, hipStream_t st, int compute_dtype = 0);     // 1: plain bf16 operands where supported
 

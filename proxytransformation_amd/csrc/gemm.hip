@@ -68,12 +68,6 @@ __device__ __forceinline__ void ln_tile_partials(const GemmProb &pr, const float
             gate_wait((gb_).tail_gate);                                                                            \
     } while (0)
 
-#define PTX_HEAD_SIGNAL(gb_)                                                                                       \
-    do {                                                                                                           \
-        if ((gb_).head_flag != nullptr && threadIdx.x == 0 && (blockIdx.x | blockIdx.y | blockIdx.z) == 0)         \
-            __hip_atomic_store((gb_).head_flag, (gb_).head_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       \
-    } while (0)
-
 // Throughput-regime kernel: 64x64 output tile per 4-wave work-group, one 32x32 MFMA accumulator
 // per wave.  K loop, BK = 32 per step, three stages: tile it is consumed from LDS, tile it+1
 // sits in the other LDS buffer, tile it+2 is in flight in registers (two register sets, loop
@@ -110,7 +104,6 @@ __device__ __forceinline__ void ln_tile_partials(const GemmProb &pr, const float
 
 __global__ __launch_bounds__(256) void k_gemm64(GemmBatch gb)
 {
-    PTX_HEAD_SIGNAL(gb);
     const GemmProb pr = gb.p[blockIdx.z];          // by value: fields live in SGPRs, not re-read from kernarg
     const int row0 = blockIdx.x * 64, col0 = blockIdx.y * 64;
     if (row0 >= pr.R || col0 >= pr.N) return;
@@ -247,7 +240,6 @@ __global__ __launch_bounds__(256) void k_gemm64x(GemmBatch gb)
 {
     constexpr int kXPlane = 64 * XROW, kXBuf = 6 * kXPlane;     // one plane of a 64 x 32 tile; [A1 A2 A3 W1 W2 W3] per buffer
     static_assert(2 * kXBuf >= 4 * 32 * 33 * 4, "the LayerNorm-partials scratch re-uses the staging area");
-    PTX_HEAD_SIGNAL(gb);
     const GemmProb pr = gb.p[blockIdx.z];          // by value: fields live in SGPRs, not re-read from kernarg
     const int row0 = blockIdx.x * 64, col0 = blockIdx.y * 64;
     if (row0 >= pr.R || col0 >= pr.N) return;
@@ -351,7 +343,6 @@ __global__ __launch_bounds__(256) void k_gemm64x(GemmBatch gb)
 template <int SK, int AMODE, bool CHAIN = false>   // AMODE 1: A merged on the fly from the k_img_pool tiles; CHAIN: see GemmProb::w2
 __global__ __launch_bounds__(SK * 64) void k_gemm32(GemmBatch gb)
 {
-    PTX_HEAD_SIGNAL(gb);
     const GemmProb pr = gb.p[blockIdx.z];
     const int row0 = blockIdx.x * 32, col0 = blockIdx.y * 32;
     if (row0 >= pr.R || col0 >= pr.N) return;
