@@ -265,6 +265,22 @@ static void context_release(PtxContext *c)
 static std::mutex g_default_mu;
 static PtxContext *g_default_ctx[16] = {};
 
+static int default_context(PtxContext **out)
+{
+    int dev = 0;
+    PTX_HIP(hipGetDevice(&dev));
+    PTX_REQUIRE(dev >= 0 && dev < 16, "device %d out of range", dev);
+    std::lock_guard<std::mutex> lk(g_default_mu);
+    if (g_default_ctx[dev] == nullptr) {
+        PtxContext *c = new PtxContext();
+        const int rc = context_init(c);
+        if (rc != PTX_OK) { context_release(c); delete c; return rc; }
+        g_default_ctx[dev] = c;
+    }
+    *out = g_default_ctx[dev];
+    return PTX_OK;
+}
+
 int make_scene_pts(const float *stacked, const float *const *list, int B, int N, ScenePts *out)
 {
     PTX_REQUIRE(B >= 1 && B <= kMaxScenes, "at most %d scenes per call (got %d): split the batch", kMaxScenes, B);
