@@ -316,9 +316,7 @@ int ptx_wait_counts(const int32_t *counts_host, int B, int64_t timeout_us);
  * inv_intrinsic (V,4,4) = inverse of the 4x4-padded depth_cam2img; lu (V,4,4) + piv (V,4) int32 = LU factors of
  * global2ego with rows permuted by piv (P A = L U, unit lower); aug = NULL or 13 floats rot_mat_T (3,3) | scale | trans;
  * points (N,3); bbox_enc (6) uint32 or NULL = the cloud's bounding box in ptx_forward_ex's encoding (cleared here);
- * status (1) int32 device: bit 0 set if any sel[j] was out of range (that point is written as 0).
- * workspace: its first 256 bytes (an arrival ticket) must be ZERO before the first ptx_ingest_index on it (hipMemset once);
- * every call leaves them zero.  (ABI 6: the chunk scan runs in the last work-group of the index launch.) */
+ * status (1) int32 device: bit 0 set if any sel[j] was out of range (that point is written as 0). */
 size_t ptx_ingest_workspace_bytes(int V, int H, int W);
 int ptx_ingest_index(const void *depth, int depth_dtype, int V, int H, int W, void *workspace, size_t ws_bytes,
                      int32_t *view_counts, void *stream);
@@ -334,8 +332,8 @@ int ptx_ingest_gather(const void *depth, int depth_dtype, float depth_shift, int
  * points (B,Ncap,3) with counts[b] valid rows per scene (device int32) = exactly the `out` / `counts` of ptx_forward;
  * coords (B*Ncap,4) int32 and feats (B*Ncap,3) capacity; inverse (B,Ncap) int32 voxel row of every point (-1 past the
  * valid rows) or NULL; nvox_overflow: 2 int32 = {voxel rows written, points whose voxel index left +-2^18}, device memory or
- * device-mapped pinned host memory: published with system scope as soon as the rows are written (preset to -1 and poll
- * with ptx_wait_counts instead of draining the stream). */
+ * device-mapped pinned host memory: published with system scope as soon as the count is KNOWN (preset to -1 and poll with
+ * ptx_wait_counts instead of draining the stream); the rows themselves are ordered on `stream` like any other result. */
 size_t ptx_voxel_workspace_bytes(int B, int Ncap);
 int ptx_voxelize(const float *points, const int32_t *counts, int B, int Ncap, float voxel_size, int32_t *coords,
                  float *feats, int32_t *inverse, int32_t *nvox_overflow, void *workspace, size_t ws_bytes, void *stream);

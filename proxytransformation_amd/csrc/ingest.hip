@@ -26,7 +26,7 @@ namespace ptx {
 
 constexpr int kGroupsPerChunk = 256;            // 16384 pixels per work-group of k_ingest_index
 
-struct IngestLayout { size_t ticket, masks, prefix, chunk_tot, chunk_off, total; int gpv, cpv; };
+struct IngestLayout { size_t masks, prefix, chunk_tot, chunk_off, total; int gpv, cpv; };
 
 static IngestLayout ingest_layout(int V, int H, int W)
 {
@@ -37,7 +37,6 @@ static IngestLayout ingest_layout(int V, int H, int W)
     const size_t G = (size_t)V * L.cpv * kGroupsPerChunk, NC = (size_t)V * L.cpv;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o += align_up(bytes, 256); return r; };
-    L.ticket = take(4);             // arrival ticket of k_ingest_index: ZERO before the first call, left zero by every call
     L.masks = take(G * 8); L.prefix = take(G * 4); L.chunk_tot = take(NC * 4); L.chunk_off = take((NC + 1) * 8);
     L.total = o;
     return L;
@@ -47,46 +46,6 @@ template <typename T> __device__ __forceinline__ bool depth_nonzero(T d);
 template <> __device__ __forceinline__ bool depth_nonzero<float>(float d) { return d != 0.0f; }       // nonzero(): NaN counts
 template <> __device__ __forceinline__ bool depth_nonzero<uint16_t>(uint16_t d) { return d != 0; }
 
-// one work-group: chunk_off[i] = number of depth != 0 pixels before chunk i (view-major), chunk_off[NC] = total;
-// view_counts[v] (device or pinned host memory) = pixels of view v.  Run by the LAST work-group of k_ingest_index to arrive
-// (r04: as a launch of its own it was 4 of the 11 us of the index step), which reads the other work-groups' totals with
-// agent-scope loads (they were stored write-through in front of the ticket).
-__device__ __forceinline__ void ingest_scan(const uint32_t *chunk_tot, int V, int cpv, unsigned long long *__restrict__ chunk_off,
-                                            int32_t *view_counts, unsigned long long *s_w, unsigned long long *s_carry)
-{
-    const int tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
-    const int NC = V * cpv;
-    if (tid == 0) *s_carry = 0ull;
-    __syncthreads();
-    for (int i0 = 0; i0 < NC; i0 += 256) {
-        const int i = i0 + tid;
-        const unsigned long long x = i < NC ? __hip_atomic_load(chunk_tot + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-        unsigned long long incl = x;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned long long n = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += n;
-        }
-        if (lane == 63) s_w[wv] = incl;
-        __syncthreads();
-        unsigned long long base = *s_carry;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) base += w < wv ? s_w[w] : 0ull;
-        if (i < NC) chunk_off[i] = base + incl - x;
-        __syncthreads();
-        if (tid == 255) *s_carry = base + incl;
-        __syncthreads();
-    }
-    if (tid == 0) chunk_off[NC] = *s_carry;
-    __syncthreads();
-    // per-view totals: differences of the chunk offsets at the view boundaries (written above by this work-group)
-    __threadfence_block();
-    for (int v = tid; v < V; v += 256) {
-        const unsigned long long a = chunk_off[(size_t)v * cpv], b = chunk_off[(size_t)(v + 1) * cpv];
-        __hip_atomic_store(view_counts + v, (int32_t)(b - a), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-
 // grid (cpv, V), 256 threads: wave w of chunk c owns groups 64 w .. 64 w + 63 of the chunk = 4096 consecutive pixels.
 // VEC (r04; the view's rows are 16-byte aligned): a lane reads EIGHT consecutive pixels per step with 16-byte loads (one for
 // uint16, two for float), all eight steps of the wave requested up front, turns them into one byte of "depth != 0" bits and
@@ -95,8 +54,7 @@ __device__ __forceinline__ void ingest_scan(const uint32_t *chunk_tot, int V, in
 template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void k_ingest_index(const T *__restrict__ depth, long hw, int gpv, int cpv,
                                                       unsigned long long *__restrict__ masks, uint32_t *__restrict__ prefix,
-                                                      uint32_t *chunk_tot, int *ticket, unsigned long long *__restrict__ chunk_off,
-                                                      int32_t *view_counts)
+                                                      uint32_t *__restrict__ chunk_tot)
 {
     const int v = blockIdx.y, c = blockIdx.x, lane = lane_id(), wv = threadIdx.x >> 6;
     const T *__restrict__ d = depth + (size_t)v * hw;
@@ -158,20 +116,50 @@ __global__ __launch_bounds__(256) void k_ingest_index(const T *__restrict__ dept
     const size_t g = ((size_t)v * cpv + c) * kGroupsPerChunk + wv * 64 + lane;
     masks[g] = mine;
     prefix[g] = (uint32_t)(base + incl - cnt);
-    __shared__ unsigned long long s_w[4], s_carry;
-    __shared__ int s_last;
-    if (threadIdx.x == 0) {
-        // the total leaves write-through (agent scope), is waited for, then the ticket: the last work-group to arrive scans
-        __hip_atomic_store(chunk_tot + (size_t)v * cpv + c, (uint32_t)(s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3]), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int nwg = gridDim.x * gridDim.y;
-        const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = t == nwg - 1;
-        if (t == nwg - 1) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (threadIdx.x == 0) chunk_tot[(size_t)v * cpv + c] = (uint32_t)(s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3]);
+}
+
+// one work-group: chunk_off[i] = number of depth != 0 pixels before chunk i (view-major), chunk_off[NC] = total;
+// view_counts[v] (device or pinned host memory) = pixels of view v
+// (r04: run by the last work-group of k_ingest_index to arrive instead of as a launch of its own -- with one arrival word for
+//  ~1000 work-groups their atomics serialise, 11 -> 19 us; with per-view words + one for the views 15 us: every work-group then ends
+//  with a write-through store, a wait and an atomic, which costs the index launch more than the 4 us launch it saves.  Not kept.)
+__global__ __launch_bounds__(256) void k_ingest_scan(const uint32_t *__restrict__ chunk_tot, int V, int cpv,
+                                                     unsigned long long *__restrict__ chunk_off, int32_t *view_counts)
+{
+    __shared__ unsigned long long s_w[4];
+    __shared__ unsigned long long s_carry;
+    const int tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
+    const int NC = V * cpv;
+    if (tid == 0) s_carry = 0ull;
     __syncthreads();
-    if (s_last) ingest_scan(chunk_tot, gridDim.y, cpv, chunk_off, view_counts, s_w, &s_carry);
+    for (int i0 = 0; i0 < NC; i0 += 256) {
+        const int i = i0 + tid;
+        const unsigned long long x = i < NC ? chunk_tot[i] : 0ull;
+        unsigned long long incl = x;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long n = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += n;
+        }
+        if (lane == 63) s_w[wv] = incl;
+        __syncthreads();
+        unsigned long long base = s_carry;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) base += w < wv ? s_w[w] : 0ull;
+        if (i < NC) chunk_off[i] = base + incl - x;
+        __syncthreads();
+        if (tid == 255) s_carry = base + incl;
+        __syncthreads();
+    }
+    if (tid == 0) chunk_off[NC] = s_carry;
+    __syncthreads();
+    // per-view totals: differences of the chunk offsets at the view boundaries (written above by this work-group)
+    __threadfence_block();
+    for (int v = tid; v < V; v += 256) {
+        const unsigned long long a = chunk_off[(size_t)v * cpv], b = chunk_off[(size_t)(v + 1) * cpv];
+        __hip_atomic_store(view_counts + v, (int32_t)(b - a), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 struct IngestGatherArgs {
@@ -309,7 +297,6 @@ int ptx_ingest_index(const void *depth, int depth_dtype, int V, int H, int W, vo
     auto *prefix = reinterpret_cast<uint32_t *>(ws + L.prefix);
     auto *ctot = reinterpret_cast<uint32_t *>(ws + L.chunk_tot);
     auto *coff = reinterpret_cast<unsigned long long *>(ws + L.chunk_off);
-    int *ticket = reinterpret_cast<int *>(ws + L.ticket);
     const long hw = (long)H * W;
     const dim3 grid(L.cpv, V);
     // 16-byte loads where every view starts on a 16-byte boundary (480 x 640 maps do); PTX_INGEST_SCALAR=1 forces the element form
@@ -318,14 +305,16 @@ int ptx_ingest_index(const void *depth, int depth_dtype, int V, int H, int W, vo
     const bool vec = !scalar_env && (reinterpret_cast<uintptr_t>(depth) & 15) == 0 && ((size_t)hw * esz) % 16 == 0;
     if (depth_dtype == 0) {
         const float *dp = static_cast<const float *>(depth);
-        if (vec) hipLaunchKernelGGL((k_ingest_index<float, true>), grid, dim3(256), 0, st, dp, hw, L.gpv, L.cpv, masks, prefix, ctot, ticket, coff, view_counts);
-        else     hipLaunchKernelGGL((k_ingest_index<float, false>), grid, dim3(256), 0, st, dp, hw, L.gpv, L.cpv, masks, prefix, ctot, ticket, coff, view_counts);
+        if (vec) hipLaunchKernelGGL((k_ingest_index<float, true>), grid, dim3(256), 0, st, dp, hw, L.gpv, L.cpv, masks, prefix, ctot);
+        else     hipLaunchKernelGGL((k_ingest_index<float, false>), grid, dim3(256), 0, st, dp, hw, L.gpv, L.cpv, masks, prefix, ctot);
     } else {
         const uint16_t *dp = static_cast<const uint16_t *>(depth);
-        if (vec) hipLaunchKernelGGL((k_ingest_index<uint16_t, true>), grid, dim3(256), 0, st, dp, hw, L.gpv, L.cpv, masks, prefix, ctot, ticket, coff, view_counts);
-        else     hipLaunchKernelGGL((k_ingest_index<uint16_t, false>), grid, dim3(256), 0, st, dp, hw, L.gpv, L.cpv, masks, prefix, ctot, ticket, coff, view_counts);
+        if (vec) hipLaunchKernelGGL((k_ingest_index<uint16_t, true>), grid, dim3(256), 0, st, dp, hw, L.gpv, L.cpv, masks, prefix, ctot);
+        else     hipLaunchKernelGGL((k_ingest_index<uint16_t, false>), grid, dim3(256), 0, st, dp, hw, L.gpv, L.cpv, masks, prefix, ctot);
     }
     PTX_LAUNCHED("k_ingest_index");
+    hipLaunchKernelGGL(k_ingest_scan, dim3(1), dim3(256), 0, st, ctot, V, L.cpv, coff, view_counts);
+    PTX_LAUNCHED("k_ingest_scan");
     return PTX_OK;
 }
 

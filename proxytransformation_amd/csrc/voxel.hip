@@ -8,20 +8,26 @@
 // map ("random subsample") -- pinned here to the FIRST point of every voxel in (scene, point) order, rows in that
 // order.  "Parity unpinned" against ME itself; bit-exact against the CPU restatement the tests hold.
 //
-// HBM-bound integer work: one hash insert per point (64-bit CAS on a table of 2x the points, linear probing), a
-// count pass and an ordered emit pass over 2048-point tiles (same compaction scheme as k_affine).
+// HBM-bound integer work.  r04 (r03: three memsets + insert + count + emit + publish = seven launches, 134 us for 399k
+// points): ONE memset (the hash table stores key + 1 and the complemented owner index, so that zero means empty for both; the
+// tile words and the overflow counter lie in the same region), then
+//   k_vox_insert  one hash insert per point (64-bit CAS on a table of >= 2x the points, linear probing) + atomicMax of the
+//                 complemented point index on the slot: the FIRST point of the voxel in (scene, point) order owns it
+//   k_vox_emit    per 2048-point tile: representatives counted, the tile's count published (agent scope) at once, the
+//                 counts of ALL tiles in front summed as soon as they appear (every work-group publishes before it waits
+//                 and only waits for lower-numbered tiles, which were dispatched earlier: no order assumption beyond
+//                 that), rows emitted in order; the last tile publishes the row count / overflow count to the host
 #include "common.h"
 
 namespace ptx {
 
-constexpr unsigned long long kVoxEmpty = ~0ull;
 constexpr int kVoxBias = 1 << 18;          // voxel indices in [-2^18, 2^18): +-2.6 km at 1 cm
 
 struct VoxArgs {
     const float *points; const int32_t *counts; int B, Ncap; float voxel_size;
-    unsigned long long *keys; int32_t *minidx; int32_t *slot_of; int32_t *row_of_slot; int32_t *tile_counts;
+    unsigned long long *keys; uint32_t *owner; int32_t *first; int32_t *slot_of; int32_t *row_of_slot; unsigned long long *tile_word;
     unsigned int mask;
-    int32_t *coords; float *feats; int32_t *inverse; int32_t *nvox; int32_t *overflow;
+    int32_t *coords; float *feats; int32_t *inverse; int32_t *overflow; int32_t *nvox_overflow;
 };
 
 __device__ __forceinline__ bool vox_key(const VoxArgs &a, int b, int i, int (&v)[3], unsigned long long &key)
@@ -44,7 +50,12 @@ __device__ __forceinline__ unsigned int vox_hash(unsigned long long k)
     return (unsigned int)k;
 }
 
-// pass 1: every valid point claims (or finds) the slot of its voxel and lowers the slot's owner to its own index
+// pass 1: every valid point claims (or finds) the slot of its voxel.  ONE device-scope atomic per point in the common case
+// (r04: CAS + atomicMax per point were 46 us for 399k points -- the table is shared by the whole chip, its atomics execute at
+// the memory side): a slot is probed with a plain load first (slots only ever go empty -> key, so a stale "empty" is put
+// right by the CAS and an occupied slot of another voxel is skipped without an atomic); the point whose CAS claims the slot
+// stores its index with a plain store into `first`, and only points that FIND their voxel already there (duplicates: rare at
+// 1 cm) raise the complemented minimum in `owner`.  The representative of a voxel is min(first, ~owner).
 __global__ __launch_bounds__(256) void k_vox_insert(VoxArgs a)
 {
     const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
@@ -52,88 +63,108 @@ __global__ __launch_bounds__(256) void k_vox_insert(VoxArgs a)
     int v[3]; unsigned long long key;
     if (!vox_key(a, b, i, v, key)) { atomicAdd(a.overflow, 1); }
     const int gi = b * a.Ncap + i;
+    const unsigned long long k1 = key + 1ull;               // 0 = empty (the table is cleared with one memset)
     unsigned int slot = vox_hash(key) & a.mask;
     for (;;) {
-        const unsigned long long prev = atomicCAS(&a.keys[slot], kVoxEmpty, key);
-        if (prev == kVoxEmpty || prev == key) break;
+        unsigned long long cur = a.keys[slot];
+        bool claimed = false;
+        if (cur == 0ull) {
+            cur = atomicCAS(&a.keys[slot], 0ull, k1);       // (a stale "empty" is put right here)
+            claimed = cur == 0ull;
+        }
+        if (claimed) { a.first[slot] = gi; break; }         // the one plain store of this slot
+        if (cur == k1) { atomicMax(&a.owner[slot], ~(uint32_t)gi); break; }     // my voxel was there already: a duplicate
         slot = (slot + 1) & a.mask;
     }
-    atomicMin(&a.minidx[slot], gi);
     a.slot_of[gi] = (int)slot;
 }
 
-// pass 2: representatives (first point of a voxel) per 2048-point tile
-__global__ __launch_bounds__(256) void k_vox_count(VoxArgs a)
-{
-    const int b = blockIdx.y, tile = blockIdx.x, nb = a.counts[b];
-    int c = 0;
-#pragma unroll
-    for (int r = 0; r < kTilePts / 256; ++r) {
-        const int i = tile * kTilePts + r * 256 + threadIdx.x;
-        if (i < nb) { const int gi = b * a.Ncap + i; c += a.minidx[a.slot_of[gi]] == gi; }
-    }
-    c = wave_sum(c);
-    __shared__ int red[4];
-    if (lane_id() == 0) red[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) a.tile_counts[b * gridDim.x + tile] = red[0] + red[1] + red[2] + red[3];
-}
-
-// pass 3: ordered emit: row = number of representatives before this point in (scene, point) order
+// pass 2: representatives (first point of a voxel) counted and emitted in (scene, point) order, tile by tile
 __global__ __launch_bounds__(256) void k_vox_emit(VoxArgs a)
 {
     const int b = blockIdx.y, tile = blockIdx.x, ntiles = gridDim.x, nb = a.counts[b];
     const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
     constexpr int R = kTilePts / 256;
     __shared__ int s_cnt[R][4];
-    __shared__ int s_base;
-    int acc = 0;
-    const int before_tiles = b * ntiles + tile;
-    for (int t = tid; t < before_tiles; t += 256) acc += a.tile_counts[t];
-    acc = wave_sum(acc);
-    if (lane == 0) s_cnt[0][wid] = acc;
-    __syncthreads();
-    if (tid == 0) {
-        s_base = s_cnt[0][0] + s_cnt[0][1] + s_cnt[0][2] + s_cnt[0][3];
-        if (b == (int)gridDim.y - 1 && tile == ntiles - 1) *a.nvox = s_base + a.tile_counts[before_tiles];
-    }
-    __syncthreads();
-    const int base = s_base;
-    __syncthreads();
-    bool rep[R]; unsigned long long bal[R];
+    __shared__ int s_red[4];
+    const int me = b * ntiles + tile;
+    bool rep[R]; unsigned long long bal[R]; int slot[R];
+    int mine = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int i = tile * kTilePts + r * 256 + tid;
-        rep[r] = false;
-        if (i < nb) { const int gi = b * a.Ncap + i; rep[r] = a.minidx[a.slot_of[gi]] == gi; }
-        bal[r] = __ballot(rep[r]);
-        if (lane == 0) s_cnt[r][wid] = __popcll(bal[r]);
+        slot[r] = i < nb ? a.slot_of[b * a.Ncap + i] : -1;
     }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = tile * kTilePts + r * 256 + tid;
+        // first point of the voxel in (scene, point) order = min(the claimer's index, the smallest duplicate arrival)
+        rep[r] = false;
+        if (slot[r] >= 0) {
+            const uint32_t dup = ~a.owner[slot[r]];         // owner 0 (no duplicate) -> 0xffffffff
+            rep[r] = min((uint32_t)a.first[slot[r]], dup) == (uint32_t)(b * a.Ncap + i);
+        }
+        bal[r] = __ballot(rep[r]);
+        if (lane == 0) { s_cnt[r][wid] = __popcll(bal[r]); }
+        mine += rep[r];
+    }
+    mine = wave_sum(mine);
+    if (lane == 0) s_red[wid] = mine;
     __syncthreads();
+    const int total = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    // publish this tile's count at once (bit 63 = present), then add up everything in front as it appears
+    if (tid == 0) __hip_atomic_store(a.tile_word + me, 0x8000000000000000ull | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();                                        // s_red is re-used below
+    long long before = 0;
+    for (int t = tid; t < me; t += 256) {
+        unsigned long long w;
+        unsigned spins = 0;
+        while (((w = __hip_atomic_load(a.tile_word + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 63) == 0ull) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1u << 24)) break;                // (a lower tile that never publishes: give up rather than hang the device)
+        }
+        before += (long long)(w & 0x7fffffffull);
+    }
+    int acc = (int)before;
+    acc = wave_sum(acc);
+    if (lane == 0) s_red[wid] = acc;
+    __syncthreads();
+    const int base = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    if (tid == 0 && b == (int)gridDim.y - 1 && tile == ntiles - 1) {
+        // the row count and the overflow count with system scope (nvox_overflow may be device-mapped pinned host memory preset
+        // to -1: the host spins on it with ptx_wait_counts instead of draining the stream); rows first: the count releases them
+        __hip_atomic_store(a.nvox_overflow + 1, __hip_atomic_load(a.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     const unsigned long long lt = (1ull << lane) - 1ull;
     int run = base;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        int before = 0;
+        int front = 0;
 #pragma unroll
-        for (int ww = 0; ww < 4; ++ww) before += ww < wid ? s_cnt[r][ww] : 0;
+        for (int ww = 0; ww < 4; ++ww) front += ww < wid ? s_cnt[r][ww] : 0;
         if (rep[r]) {
             const int i = tile * kTilePts + r * 256 + tid, gi = b * a.Ncap + i;
-            const int row = run + before + __popcll(bal[r] & lt);
+            const int row = run + front + __popcll(bal[r] & lt);
             int v[3]; unsigned long long key;
             vox_key(a, b, i, v, key);
             int32_t *c = a.coords + (size_t)row * 4;
-            c[0] = b; c[1] = v[0]; c[2] = v[1]; c[3] = v[2];
+            *reinterpret_cast<int4 *>(c) = make_int4(b, v[0], v[1], v[2]);
             const float *p = a.points + (size_t)gi * 3;
             float *f = a.feats + (size_t)row * 3;
             f[0] = p[0]; f[1] = p[1]; f[2] = p[2];
-            a.row_of_slot[a.slot_of[gi]] = row;
+            a.row_of_slot[slot[r]] = row;
         }
         run += s_cnt[r][0] + s_cnt[r][1] + s_cnt[r][2] + s_cnt[r][3];
     }
+    if (b == (int)gridDim.y - 1 && tile == ntiles - 1) {
+        // every row of the call is written when the LAST tile's rows are?  No: other tiles may still be emitting.  The count is
+        // only a size; the rows themselves are ordered on the stream like any other result (ptx_voxelize's contract).
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(a.nvox_overflow, base + total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
-// pass 4 (optional): voxel row of every input point
+// pass 3 (optional): voxel row of every input point
 __global__ __launch_bounds__(256) void k_vox_inverse(VoxArgs a)
 {
     const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
@@ -142,15 +173,7 @@ __global__ __launch_bounds__(256) void k_vox_inverse(VoxArgs a)
     a.inverse[gi] = i < a.counts[b] ? a.row_of_slot[a.slot_of[gi]] : -1;
 }
 
-// last launch: the row count and the overflow count with system scope (nvox_overflow may be device-mapped pinned host
-// memory preset to -1: the host spins on it with ptx_wait_counts instead of draining the stream and copying)
-__global__ void k_vox_publish(const int32_t *acc, int32_t *nvox_overflow)
-{
-    __hip_atomic_store(nvox_overflow + 1, acc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(nvox_overflow, acc[0], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-struct VoxLayout { size_t keys, minidx, slot_of, row_of_slot, tile_counts, overflow, total; unsigned int slots; };
+struct VoxLayout { size_t zero_begin, keys, owner, tile_word, overflow, zero_bytes, first, slot_of, row_of_slot, total; unsigned int slots; };
 static VoxLayout vox_layout(int B, int Ncap)
 {
     VoxLayout L{};
@@ -160,9 +183,11 @@ static VoxLayout vox_layout(int B, int Ncap)
     L.slots = slots;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o += align_up(bytes, 256); return r; };
-    L.keys = take((size_t)slots * 8); L.minidx = take((size_t)slots * 4);
-    L.slot_of = take(total * 4); L.row_of_slot = take((size_t)slots * 4);
-    L.tile_counts = take((size_t)B * cdiv(Ncap, kTilePts) * 4); L.overflow = take(8);
+    L.zero_begin = o;                                       // cleared by ONE memset per call
+    L.keys = take((size_t)slots * 8); L.owner = take((size_t)slots * 4);
+    L.tile_word = take((size_t)B * cdiv(Ncap, kTilePts) * 8); L.overflow = take(8);
+    L.zero_bytes = o - L.zero_begin;
+    L.first = take((size_t)slots * 4); L.slot_of = take(total * 4); L.row_of_slot = take((size_t)slots * 4);
     L.total = o;
     return L;
 }
@@ -191,22 +216,16 @@ int ptx_voxelize(const float *points, const int32_t *counts, int B, int Ncap, fl
     hipStream_t st = static_cast<hipStream_t>(stream);
     char *ws = static_cast<char *>(workspace);
     VoxArgs a{points, counts, B, Ncap, voxel_size,
-              reinterpret_cast<unsigned long long *>(ws + L.keys), reinterpret_cast<int32_t *>(ws + L.minidx),
-              reinterpret_cast<int32_t *>(ws + L.slot_of), reinterpret_cast<int32_t *>(ws + L.row_of_slot),
-              reinterpret_cast<int32_t *>(ws + L.tile_counts), L.slots - 1, coords, feats, inverse,
-              reinterpret_cast<int32_t *>(ws + L.overflow), reinterpret_cast<int32_t *>(ws + L.overflow) + 1};
-    PTX_HIP(hipMemsetAsync(ws + L.keys, 0xFF, (size_t)L.slots * 8, st));
-    PTX_HIP(hipMemsetAsync(ws + L.minidx, 0x7F, (size_t)L.slots * 4, st));
-    PTX_HIP(hipMemsetAsync(ws + L.overflow, 0, 8, st));
+              reinterpret_cast<unsigned long long *>(ws + L.keys), reinterpret_cast<uint32_t *>(ws + L.owner),
+              reinterpret_cast<int32_t *>(ws + L.first), reinterpret_cast<int32_t *>(ws + L.slot_of), reinterpret_cast<int32_t *>(ws + L.row_of_slot),
+              reinterpret_cast<unsigned long long *>(ws + L.tile_word), L.slots - 1, coords, feats, inverse,
+              reinterpret_cast<int32_t *>(ws + L.overflow), nvox_overflow};
+    PTX_HIP(hipMemsetAsync(ws + L.zero_begin, 0, L.zero_bytes, st));
     const dim3 per_point(cdiv(Ncap, 256), B), per_tile(cdiv(Ncap, kTilePts), B);
     hipLaunchKernelGGL(k_vox_insert, per_point, dim3(256), 0, st, a);
     PTX_LAUNCHED("k_vox_insert");
-    hipLaunchKernelGGL(k_vox_count, per_tile, dim3(256), 0, st, a);
-    PTX_LAUNCHED("k_vox_count");
     hipLaunchKernelGGL(k_vox_emit, per_tile, dim3(256), 0, st, a);
     PTX_LAUNCHED("k_vox_emit");
-    hipLaunchKernelGGL(k_vox_publish, dim3(1), dim3(1), 0, st, reinterpret_cast<const int32_t *>(ws + L.overflow), nvox_overflow);
-    PTX_LAUNCHED("k_vox_publish");
     if (inverse) {
         hipLaunchKernelGGL(k_vox_inverse, per_point, dim3(256), 0, st, a);
         PTX_LAUNCHED("k_vox_inverse");

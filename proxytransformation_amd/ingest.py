@@ -128,7 +128,7 @@ class MultiViewIngest:
             lib = _abi.lib()
             sl = slots[b] = MultiViewIngest._Slot()
             sl.key = key
-            sl.ws = torch.zeros((lib.ptx_ingest_workspace_bytes(V, H, W),), dtype=torch.uint8, device=dev)      # ticket word: zero once
+            sl.ws = torch.empty((lib.ptx_ingest_workspace_bytes(V, H, W),), dtype=torch.uint8, device=dev)
             sl.counts = torch.empty((max(V, 1),), dtype=torch.int32).pin_memory()
             sl.counts_np = sl.counts.numpy()
             nstage = (8 * N + 15) // 16 * 16 + 4 * (32 * V + 16) + 16 * V
