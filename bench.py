@@ -454,6 +454,31 @@ def main():
             extras["bf16c_err"] = max(float((a - b).abs().max()) if a.shape == b.shape else float("inf")
                                       for a, b in zip(got, ref_out))
             mod.compute_dtype = "fp32"
+            # the same step as a captured HIP graph (module.forward_padded: no host wait, padded outputs + device counts), one
+            # graph per input set, replayed back to back: what a serving loop that does not need the lengths on the host gets
+            try:
+                gs = torch.cuda.Stream()
+                graphs = []
+                with torch.cuda.stream(gs):
+                    for j in range(len(inputs.sets)):
+                        mod.forward_padded(*inputs.args(j))
+                torch.cuda.synchronize()
+                for j in range(len(inputs.sets)):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=gs):
+                        res = mod.forward_padded(*inputs.args(j))
+                    graphs.append((g, res))
+                for i in range(6):
+                    graphs[i % len(graphs)][0].replay()
+                barrier()
+                t0g = time.perf_counter()
+                for i in range(steps2):
+                    graphs[i % len(graphs)][0].replay()
+                barrier()
+                extras["graph"] = (time.perf_counter() - t0g) / steps2
+                del graphs
+            except Exception as e:                              # never sinks the headline
+                extras["graph_error"] = repr(e)
             # per-pass reports: single-rank runs only -- this block is rank 0's alone, so nothing in it may touch the process group
             # (its timed_steps get the local barrier); with N > 1 the other ranks would sit in the census all-gather meanwhile
             if rank == 0 and world == 1:
@@ -493,11 +518,11 @@ def main():
         ranks_seen = [None] * world
         dist.all_gather_object(ranks_seen, me)
         ranks_seen = sorted([list(x) for x in ranks_seen])
-    vals = [extras.get("f32", 0.0), extras.get("bf16c", 0.0)] + block_s
+    vals = [extras.get("f32", 0.0), extras.get("bf16c", 0.0), extras.get("graph", 0.0)] + block_s
     t = torch.tensor(vals, device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)           # per block: the slowest rank
-    f32_step, bf16c_step, *block_s = (float(x) for x in t.tolist())
+    f32_step, bf16c_step, graph_step, *block_s = (float(x) for x in t.tolist())
     elapsed = sorted(block_s)[len(block_s) // 2]           # the median block is the reported one
 
     if rank == 0:
@@ -552,6 +577,13 @@ def main():
                                              "accumulation; clustering / index tensors unchanged; not the headline value")
             if "wide" in extras:
                 line["bf16_compute"]["at_32_scenes_per_gpu"] = extras["wide"]
+        if graph_step > 0:
+            line["value_graph_replay"] = round(world * B / graph_step, 2)
+            line["graph_replay"] = dict(ms_per_step=round(1e3 * graph_step, 4),
+                                        what="the same forward captured into a HIP graph (module.forward_padded: padded outputs + device "
+                                             "counts, no host wait) and replayed back to back; not the headline value")
+        elif "graph_error" in extras:
+            line["graph_replay"] = dict(error=extras["graph_error"])
         if "train" in extras:
             line["train_step_ms"] = extras["train"]["ms"]
             line["train_step"] = extras["train"]

@@ -61,6 +61,8 @@ struct Timed {
     hipEvent_t stop = nullptr; hipStream_t st;
     Timed(int kid, hipStream_t s) : st(s) {
         if (!((g_timing.mask >> kid) & 1u)) return;
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;        // timing events have no place in a captured graph
+        if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return;
         std::lock_guard<std::mutex> lk(g_timing.mu);
         if (g_timing.seen[kid]++ % (unsigned)g_timing.every != 0) return;
         if (g_timing.used == g_timing.pool.size()) {
@@ -1026,9 +1028,18 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
         PTX_REQUIRE(dev == side->dev, "ptx_forward: context belongs to device %d, current device is %d", side->dev, dev);
     }
     std::lock_guard<std::mutex> enqueue_lock(side->mu);
-    PTX_TRY(gate_check(side));                                  // a gate of an EARLIER forward timed out: reported here, once
-    side->last_st = st;
-    if (side->gates_on && (!side->probed || side->probed_st != st)) PTX_TRY(gate_probe(side, st));
+    // Stream capture (hipGraph, torch.cuda.graph): the forward is capturable as it is -- the side streams fork from and join into
+    // the capturing stream through events, which become graph dependencies -- with three adjustments: the device-word gates stay
+    // out (the branches of a graph need not run concurrently: a waiting wave could sit in front of the kernel that releases
+    // it), nothing that synchronises runs (gate check / probe), and k_select's completion event is a plain record.
+    hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+    PTX_HIP(hipStreamIsCapturing(st, &cap_status));
+    const bool capturing = cap_status != hipStreamCaptureStatusNone;
+    if (!capturing) {
+        PTX_TRY(gate_check(side));                              // a gate of an EARLIER forward timed out: reported here, once
+        side->last_st = st;
+        if (side->gates_on && (!side->probed || side->probed_st != st)) PTX_TRY(gate_probe(side, st));
+    }
     // Which chain is the longer one depends on the shape: with many farthest-point picks (the reference's own gs = 12
     // configuration: 519 sequential picks) it is the clustering chain, and then THAT one stays on the caller's stream
     // and the image chain takes the side stream.  (Rough per-shape estimates in us: measured slopes.)
@@ -1036,7 +1047,7 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     static const int swap_env = getenv("PTX_CHAIN_SWAP") ? atoi(getenv("PTX_CHAIN_SWAP")) : -1;
     const bool cluster_on_caller = swap_env >= 0 ? swap_env != 0 : est_cluster > est_image;
     hipStream_t cs = cluster_on_caller ? st : side->st, is = cluster_on_caller ? side->st : st;
-    const bool gated = side->gates_on && !cluster_on_caller;              // gates instead of events (see k_gate)
+    const bool gated = side->gates_on && !cluster_on_caller && !capturing;        // gates instead of events (see k_gate)
     if (!gated) {
         PTX_HIP(hipEventRecord(side->fork, st));
         PTX_HIP(hipStreamWaitEvent(side->st, side->fork, 0));
@@ -1102,7 +1113,8 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     int32_t *kidx = dbg && debug->kidx ? at<int32_t>(ws, L.kidx) : nullptr;
     int32_t *drop_idx = dbg && debug->drop_idx ? at<int32_t>(ws, L.drop_idx) : nullptr;
     int32_t *ksrc = at<int32_t>(ws, L.ksrc);
-    static const bool ext_event = getenv("PTX_NO_EXT_EVENT") == nullptr;
+    static const bool ext_event_env = getenv("PTX_NO_EXT_EVENT") == nullptr;
+    const bool ext_event = ext_event_env && !capturing;
     static const int tail_env = getenv("PTX_TAGS_TAIL") ? atoi(getenv("PTX_TAGS_TAIL")) : 1;
     const bool tags_tail = !cluster_on_caller && tail_env != 0;
     PTX_TIMED(KID_SELECT, cs, launch_select_order(S, centers, pad_count, order_override, order, picks, keep, kcenter,

@@ -236,7 +236,7 @@ class ProxyTransformationNormReverse(nn.Module):
     # host caches that hold ctypes pointers / device scratch: never copied or pickled (copy.deepcopy(model),
     # torch.save(model), EMA / SWA copies made after the first forward); a copy rebuilds them on its first call
     _HOST_CACHES = dict(_tensors=None, _slots=None, _lanes=None, _lin_t=None, _wkey=None, _wstruct=None, _prep=None,
-                        _lin=None, _shapes=None)
+                        _lin=None, _shapes=None, _graph_keepalive=None)
 
     def __getstate__(self):
         state = self.__dict__.copy()
@@ -546,6 +546,60 @@ class ProxyTransformationNormReverse(nn.Module):
             raise RuntimeError("ptx_forward finished without publishing the survivor counts")
         outs = [out[b, :n_keep[b]] for b in range(B)]
         return outs, dbg
+
+    @torch.no_grad()
+    def forward_padded(self, points: List[torch.Tensor], text_dict: dict, img_feat: torch.Tensor,
+                       bbox: Optional[torch.Tensor] = None):
+        """The eval forward WITHOUT its one host wait (not in the reference): returns ``(out, counts)`` -- ``out`` (B,N,3), scene b's
+        transformed, compacted points in ``out[b, :counts[b]]`` (rows beyond are unspecified), ``counts`` (B,) int32 on the device --
+        both ordered on the current stream.  ``forward`` is this plus ``counts`` read on the host and the list of views.
+
+        Nothing here synchronises or allocates outside torch's allocator, so the call can be captured into a HIP graph
+        (``torch.cuda.graph``): the library's side streams fork from and join into the capturing stream through events.
+        Warm up first on the stream the capture will use (``torch.cuda.graph(g, stream=s)``): the lane of a stream -- library
+        context, workspace, parameter tables -- is created on its first call, which allocates and synchronises."""
+        if self.training:
+            raise RuntimeError("forward_padded is the eval path; train mode returns ragged outputs through forward()")
+        (B, N, dev), pts, plist, text_feats, mask_u8, img = self._check_inputs(points, text_dict, img_feat)
+        if B > _MAX_SCENES_PER_CALL:
+            raise RuntimeError(f"forward_padded takes at most {_MAX_SCENES_PER_CALL} scenes per call (got {B})")
+        skey = (B, N, text_feats.shape[1], img.shape[1], _IMG_DTYPES[img.dtype])
+        shape = self._shapes.get(skey)
+        if shape is None:
+            shape = self._shapes[skey] = self._shape(*skey)
+        lib = _abi.lib()
+        tstream = torch.cuda.current_stream(dev)
+        stream = tstream.cuda_stream
+        capturing = torch.cuda.is_current_stream_capturing()
+        key = (str(dev), stream)
+        if capturing and (key not in self._lanes or self._wkey is None or self._lanes[key].ws is None or self._lanes[key].ws_dirty):
+            raise RuntimeError("forward_padded inside a stream capture: call it once on this stream BEFORE capturing (the lane's "
+                               "context / workspace / parameter tables are created on the first call)")
+        if not capturing:
+            self._ensure_prepared(shape, dev, stream)
+        lane = self._lane(dev, tstream)
+        ws = self._workspace(lane, shape, dev, stream)
+        out = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
+        counts = torch.empty((B,), dtype=torch.int32, device=dev)
+        opts = None
+        if bbox is not None or self.compute_dtype != "fp32":
+            opts = _abi.PtxForwardOpts(bbox_enc=_ptr(bbox), compute_dtype=_COMPUTE_DTYPES[self.compute_dtype])
+        oo, co = self._order_override, self._centers_override
+        if oo is not None or co is not None:
+            raise RuntimeError("forward_padded does not take the test-only overrides")
+        lane.ws_dirty = True
+        _abi.check(lib.ptx_forward_ex(
+            lane.ctx, ctypes.byref(shape), ctypes.byref(self._wstruct), self._prep.data_ptr(),
+            self._lin.data_ptr(), _ptr(pts), plist, text_feats.data_ptr(), mask_u8.data_ptr(),
+            img.data_ptr(), None, None, out.data_ptr(), counts.data_ptr(), ws.data_ptr(), ws.numel(), None,
+            ctypes.byref(opts) if opts is not None else None, stream), "ptx_forward")
+        lane.ws_dirty = False
+        if capturing:
+            # the captured kernels read these through raw pointers: they have to outlive the graph
+            keep = self.__dict__.get("_graph_keepalive") or []
+            keep.append((pts, plist, text_feats, mask_u8, img, self._prep, self._lin, ws))
+            self._graph_keepalive = keep
+        return out, counts
 
     def _alloc_debug(self, s: _abi.PtxShape, dev, only=None) -> Dict[str, torch.Tensor]:
         M, K, Kd = self.num_cluster, s.K, s.Mt - s.Mk

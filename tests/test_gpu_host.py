@@ -438,3 +438,50 @@ def test_stream_gate_timeout_fails_loudly(tmp_path, fault):
     assert got["GATES_AFTER"] == ["False"]                              # events from the failure on
     assert got["DIGEST"] == ref["DIGEST"]                               # and the result is right again
 
+
+
+@pytest.mark.parametrize("shape", ["image-chain-long", "cluster-chain-long"])
+def test_eval_forward_is_capturable_into_a_hip_graph(shape):
+    """SURVEY 7.2 step 6 / VERDICT r03 missing #3: ``forward_padded`` (the eval forward without its host wait) captured with
+    torch.cuda.graph and replayed on new input values written into the captured tensors -- both stream layouts of the forward (the
+    image chain or the clustering chain on the caller's stream; inside a capture the two chains are ordered by events, which
+    become graph edges) -- must give exactly what the eager forward gives on the same values, replay after replay (the
+    workspace's clean-on-entry words are left clean by every forward, so a replay needs no clearing node)."""
+    kw = dict(B=2, N=20000, grid_size=8, L=16, seed_base=6100)
+    kw.update(dict(dynamic_drop_radio=0.4, V=180) if shape == "image-chain-long" else dict(dynamic_drop_radio=0.75, V=6))
+    cfg = PreshapeConfig("graph", **kw)
+    assert (40 + 0.18 * cfg.B * cfg.V > 80 + 0.42 * cfg.Kd) == (shape == "image-chain-long")
+    m, _ = build_module(cfg)
+    m = m.cuda()
+    dev = torch.device("cuda:0")
+    variants = []
+    for k in range(3):
+        c = PreshapeConfig("graph", **dict(kw, seed_base=6100 + 100 * k))
+        pts, text, mask, img = make_scene_batch(c)
+        variants.append(([torch.from_numpy(p).to(dev) for p in pts], torch.from_numpy(text).to(dev), torch.from_numpy(mask).to(dev),
+                         torch.from_numpy(img).to(dev).to(torch.bfloat16)))
+    pts = [p.clone() for p in variants[0][0]]
+    td = {"text_feats": variants[0][1].clone(), "text_token_mask": variants[0][2].clone()}
+    img = variants[0][3].clone()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for _ in range(2):                                      # the lane of this stream: context, workspace, tables
+            m.forward_padded(pts, td, img)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        out_g, cnt_g = m.forward_padded(pts, td, img)
+    for rep in range(6):
+        v = variants[(rep * 2 + 1) % 3]
+        for d, s_ in zip(pts, v[0]):
+            d.copy_(s_)
+        td["text_feats"].copy_(v[1]); td["text_token_mask"].copy_(v[2]); img.copy_(v[3])
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        want = m(v[0], {"text_feats": v[1], "text_token_mask": v[2]}, v[3])        # eager, its own lane (default stream)
+        torch.cuda.synchronize()
+        n = cnt_g.cpu().tolist()
+        assert n == [int(o.shape[0]) for o in want], (rep, n)
+        for b, o in enumerate(want):
+            assert torch.equal(out_g[b, : n[b]], o), f"replay {rep}, scene {b}"
