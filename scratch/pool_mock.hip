@@ -15,6 +15,7 @@ typedef unsigned int u4u2 __attribute__((ext_vector_type(4), aligned(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ unsigned fold(const u32x4 &v) { return v[0] ^ v[1] ^ v[2] ^ v[3]; }
 constexpr int HW = 225, CH = 512;
+static int LDSB = 43000;
 __device__ __forceinline__ void spin(unsigned ticks) {            // 100 MHz ticks
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(2);
@@ -101,6 +102,7 @@ __global__ __launch_bounds__(1024) void k_img16(const unsigned short *img, int n
 int main(int argc, char **argv)
 {
     const int nimg = argc > 1 ? atoi(argv[1]) : 784;
+    if (argc > 2) LDSB = atoi(argv[2]);
     const size_t bytes = (size_t)nimg * CH * HW * 2;
     unsigned short *img[3]; float *out;
     for (int k = 0; k < 3; ++k) { CK(hipMalloc(&img[k], bytes + 4096)); CK(hipMemset(img[k], 0x3f, bytes + 4096)); }
@@ -122,11 +124,11 @@ int main(int argc, char **argv)
             const unsigned tk = (v != 1) ? ticks : (unsigned)(ticks * 1.6);
             auto launch = [&](int k) {
                 const unsigned short *p = img[k % 3];
-                if (v == 0) hipLaunchKernelGGL(k_tile, dim3((nimg + 7) / 8 * 16), dim3(512), 43000, 0, p, nimg, out, tk, 1280, 0, we);
-                else if (v == 4) hipLaunchKernelGGL(k_tile, dim3((nimg + 7) / 8 * 16), dim3(512), 43000, 0, p, nimg, out, tk, 0, 0, we);
-                else if (v == 5) hipLaunchKernelGGL(k_tile, dim3((nimg + 7) / 8 * 16), dim3(512), 43000, 0, p, nimg, out, tk, 1280, 1, we);
-                else if (v == 6) hipLaunchKernelGGL(k_tile, dim3((nimg + 7) / 8 * 16), dim3(512), 43000, 0, p, nimg, out, tk, 1280, 2, we);
-                else if (v == 7) hipLaunchKernelGGL(k_tile, dim3((nimg + 7) / 8 * 16), dim3(512), 43000, 0, p, nimg, out, tk, 1280, 3, we);
+                if (v == 0) hipLaunchKernelGGL(k_tile, dim3((nimg + 7) / 8 * 16), dim3(512), LDSB, 0, p, nimg, out, tk, 1280, 0, we);
+                else if (v == 4) hipLaunchKernelGGL(k_tile, dim3((nimg + 7) / 8 * 16), dim3(512), LDSB, 0, p, nimg, out, tk, 0, 0, we);
+                else if (v == 5) hipLaunchKernelGGL(k_tile, dim3((nimg + 7) / 8 * 16), dim3(512), LDSB, 0, p, nimg, out, tk, 1280, 1, we);
+                else if (v == 6) hipLaunchKernelGGL(k_tile, dim3((nimg + 7) / 8 * 16), dim3(512), LDSB, 0, p, nimg, out, tk, 1280, 2, we);
+                else if (v == 7) hipLaunchKernelGGL(k_tile, dim3((nimg + 7) / 8 * 16), dim3(512), LDSB, 0, p, nimg, out, tk, 1280, 3, we);
                 else if (v == 1) hipLaunchKernelGGL(k_img16<0>, dim3(nimg), dim3(1024), 160000, 0, p, nimg, out, tk, 1536);
                 else if (v == 2) hipLaunchKernelGGL(k_img16<1>, dim3(256), dim3(1024), 160000, 0, p, nimg, out, tk, 1536);
                 else hipLaunchKernelGGL(k_img16<2>, dim3(256), dim3(1024), 160000, 0, p, nimg, out, tk, 1536);
