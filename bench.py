@@ -543,7 +543,8 @@ def main():
                             traffic_source=os.path.relpath(PMC_FILE, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                            "this command; traffic_stale = taken with another build of the library)",
                             avg_launch_us=round(avg_s * 1e6, 2), launches=launches.value,
-                            timed="HIP events on the kernel's stream around every %d-th launch of the measured steps" % max(1, args.time_every),
+                            timed="HIP events attached to the kernel's own dispatch packet (hipExtLaunchKernel start / stop events: begin and end of "
+                                  "the kernel itself, on its stream) on every %d-th launch of the measured steps" % max(1, args.time_every),
                             algorithmic_bytes_per_launch=abytes, so_sha16=so_sha16())
         line = dict(metric="scenes/sec (100k pts, 256 clusters, 64 proxies)", value=round(total_scenes / elapsed, 2),
                     unit="scenes/s", n_gpus=world, steps=args.steps, warmup=args.warmup,

@@ -57,9 +57,21 @@ struct TimingState {
 };
 static TimingState g_timing;
 
+// Events attached to the kernel's own dispatch packet (hipExtLaunchKernel): begin / end of the kernel itself, what a kernel trace
+// reports.  Events recorded around a launch are packets of their own: they add the dispatch latency of the kernel behind the first
+// record and the second record's own turn (3-5 us on a 55 us kernel).  A launcher that supports it takes the armed pair.
+static thread_local hipEvent_t g_ext_a = nullptr, g_ext_b = nullptr;
+bool timing_ext_take(hipEvent_t *a, hipEvent_t *b)
+{
+    if (g_ext_a == nullptr) return false;
+    *a = g_ext_a; *b = g_ext_b;
+    g_ext_a = g_ext_b = nullptr;
+    return true;
+}
+
 struct Timed {
     hipEvent_t stop = nullptr; hipStream_t st;
-    Timed(int kid, hipStream_t s) : st(s) {
+    Timed(int kid, hipStream_t s, bool ext = false) : st(s) {
         if (!((g_timing.mask >> kid) & 1u)) return;
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;        // timing events have no place in a captured graph
         if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return;
@@ -72,12 +84,20 @@ struct Timed {
         }
         TimingRec &pr = g_timing.pool[g_timing.used++];
         pr.kid = kid;
+        if (ext) { g_ext_a = pr.a; g_ext_b = pr.b; return; }        // the launcher attaches both to the kernel's packet
         (void)hipEventRecord(pr.a, st);
         stop = pr.b;
     }
-    ~Timed() { if (stop) (void)hipEventRecord(stop, st); }
+    ~Timed() {
+        if (stop) (void)hipEventRecord(stop, st);
+        if (g_ext_a != nullptr) {       // armed but not taken (a launcher without support): fall back to records around nothing
+            (void)hipEventRecord(g_ext_a, st); (void)hipEventRecord(g_ext_b, st);
+            g_ext_a = g_ext_b = nullptr;
+        }
+    }
 };
 #define PTX_TIMED(kid, st, call) do { ::ptx::Timed t_(kid, st); PTX_TRY(call); } while (0)
+#define PTX_TIMED_EXT(kid, st, call) do { ::ptx::Timed t_(kid, st, true); PTX_TRY(call); } while (0)
 
 static inline float attn_scale(int hd) { return (float)(1.0 / std::sqrt((double)hd)); }   // head_dim ** -0.5
 
@@ -443,7 +463,7 @@ static int run_img_proxy(const PtxShape &s, const PtxWeights &w, const float *pr
                                                         P.KT2p, attn_scale(hd), gbuf, st));
         PTX_TIMED(KID_IMG_GATHER, st, launch_img_gather(img, nimg, s.in_dim, s.hw, s.heads, P.KT2p, gbuf, st));
     } else if (pooled) {
-        PTX_TIMED(KID_IMG_SCORES, st, launch_img_pool(img_any, dt, we, qkv0, nimg, s.in_dim, s.hw, C, P.KT1,
+        PTX_TIMED_EXT(KID_IMG_SCORES, st, launch_img_pool(img_any, dt, we, qkv0, nimg, s.in_dim, s.hw, C, P.KT1,
                                                       EW, attn_scale(hd), Gs, E, ML, st));
     } else {
         PTX_TIMED(KID_IMG_SCORES, st, launch_img_scores16(img_any, dt, we, qkv0, nimg, s.in_dim, s.hw, s.heads, C,

@@ -10,6 +10,8 @@
 namespace ptx {
 
 void set_error(const char *fmt, ...);
+// per-kernel timing (api.hip): a launcher that can attach events to its kernel's own dispatch packet takes the armed pair
+bool timing_ext_take(hipEvent_t *start, hipEvent_t *stop);
 
 #define PTX_REQUIRE(cond, ...)                                   \
     do {                                                         \
