@@ -368,6 +368,13 @@ __global__ __launch_bounds__(512) void k_img_pool(PoolArgs a)
     // row 8 kq + i, window n.  MFMA map: A row m = (channel sub-block cr = m >> 2, window set ps = m & 3),
     // K-lane kq' = windows ps + 4 kq'; B column = (head hh = m >> 2 of the group, window set ps).  Lane
     // (m, kq') therefore takes register i of lane (n = ps + 4 kq', kq = cr): one ds_bpermute per dword.
+    // r04: ONE basic block per half of the channels.  The r03 form ran a (register, head group) step at a time -- four
+    // bpermutes, a wait, three DEPENDENT matrix instructions, a ?: chain that hipcc turned into nested exec-mask regions with
+    // branches, a masked LDS store -- 32 strictly sequential steps of ~280 cycles, 3.3 of a unit's 12.3 us.  Now the eight
+    // registers of a half are permuted in place up front (32 bpermutes in flight, one wait), four independent accumulator
+    // chains (two registers x two head groups) are interleaved so that the matrix pipe never waits for its own result, the
+    // lane's element of an accumulator is picked with per-lane bit masks, and the finished sums of eight consecutive
+    // channels go to LDS as two 16-byte pieces per head group.
     {
         const int ps = n & 3, hh = n >> 2;                      // also cr = n >> 2 for the A side
         const int src = ((ps + 4 * kq) + 16 * (n >> 2)) * 4;    // byte index of the source lane
@@ -377,27 +384,53 @@ __global__ __launch_bounds__(512) void k_img_pool(PoolArgs a)
 #pragma unroll
             for (int pt = 0; pt < 3; ++pt)
                 bfr[hg][pt] = *reinterpret_cast<const u32x4 *>(parts + (size_t)(pt * 8 + 4 * hg + hh) * kPoolPPad + 8 * (ps + 4 * kq));
+        const unsigned m0 = ps == 0 ? ~0u : 0u, m1 = ps == 1 ? ~0u : 0u, m2 = ps == 2 ? ~0u : 0u, m3 = ps == 3 ? ~0u : 0u;
         float *G = partial;                                     // [heads][in_dim]; the slices are dead (barrier above)
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                u32x4 av;
+            for (int i = 0; i < 8; ++i)
 #pragma unroll
-                for (int d = 0; d < 4; ++d) av[d] = (unsigned int)__builtin_amdgcn_ds_bpermute(src, (int)L[kb][i][d]);
+                for (int d = 0; d < 4; ++d) L[kb][i][d] = (unsigned int)__builtin_amdgcn_ds_bpermute(src, (int)L[kb][i][d]);
+            float xs[2][8];
 #pragma unroll
-                for (int hg = 0; hg < 2; ++hg) {
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int ig = 0; ig < 4; ++ig) {
+                f32x4 c[2][2];
 #pragma unroll
-                    for (int pt = 0; pt < 3; ++pt) acc = mfma16<DT>(av, bfr[hg][pt], acc);
-                    // D[row 4 kq + r][col n]: row = (channel sub-block kq, set r), col = (head hh, set ps): keep r == ps
-                    float x = ps == 0 ? acc[0] : ps == 1 ? acc[1] : ps == 2 ? acc[2] : acc[3];
-                    x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
-                    x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
-                    // channel of this row: cw + 32 kb + 8 kq + i; one lane of the quad stores it
-                    if (ps == 0) G[(size_t)(4 * hg + hh) * in_dim + cw + 32 * kb + 8 * kq + i] = DT == 2 ? x * (1.0f / kPoolEScale) : x;
-                }
+                for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                    for (int hg = 0; hg < 2; ++hg) c[ii][hg] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int pt = 0; pt < 3; ++pt)
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                        for (int hg = 0; hg < 2; ++hg) c[ii][hg] = mfma16<DT>(L[kb][2 * ig + ii], bfr[hg][pt], c[ii][hg]);
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                    for (int hg = 0; hg < 2; ++hg) {
+                        // D[row 4 kq + r][col n]: row = (channel sub-block kq, set r), col = (head hh, set ps): keep r == ps
+                        const f32x4 &acc = c[ii][hg];
+                        float x = __uint_as_float((__float_as_uint(acc[0]) & m0) | (__float_as_uint(acc[1]) & m1) |
+                                                  (__float_as_uint(acc[2]) & m2) | (__float_as_uint(acc[3]) & m3));
+                        x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+                        x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+                        xs[hg][2 * ig + ii] = DT == 2 ? x * (1.0f / kPoolEScale) : x;
+                    }
             }
+            // channels cw + 32 kb + 8 kq + (0..7) of head 4 hg + hh: one lane of the quad parks them in LDS (the score slices
+            // are dead: barrier above).  (r04: stored straight from these registers -- 16 lanes x 32 B per instruction, half lines --
+            // the launch was 2 us SLOWER at 4 scenes and 507 instead of 369 us at 32: the write-through path wants whole lines.)
+            if (ps == 0) {
+#pragma unroll
+                for (int hg = 0; hg < 2; ++hg)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        *reinterpret_cast<f32x4 *>(G + (size_t)(4 * hg + hh) * in_dim + cw + 32 * kb + 8 * kq + 4 * q) =
+                            f32x4{xs[hg][4 * q], xs[hg][4 * q + 1], xs[hg][4 * q + 2], xs[hg][4 * q + 3]};
+            }
+        }
     }
     __syncthreads();
     {
