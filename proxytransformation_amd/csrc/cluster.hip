@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void k_minmax(ScenePts points, int N,
                                                 uint32_t *__restrict__ mm_enc)
 {
     __shared__ float red[4][6];
-    minmax_block(points.p[blockIdx.y], N, mm_enc, blockIdx.y, blockIdx.x, gridDim.x, red);      // common.h
+    minmax_block<false>(points.p[blockIdx.y], N, mm_enc, blockIdx.y, blockIdx.x, gridDim.x, red);      // common.h
 }
 
 int launch_minmax(const ScenePts &points, int B, int N, uint32_t *mm_enc, hipStream_t st)

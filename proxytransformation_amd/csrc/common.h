@@ -146,6 +146,7 @@ struct ScenePts { const float *p[kMaxScenes]; };
 // 4 points = 12 floats = 3 float4; a thread's quads are all requested before the first is reduced (clamped: a repeated
 // quad does not change a minimum).  As a loop with one quad per trip the pass was four dependent round trips next to the
 // mean pass, which keeps the memory system loaded: 20 us for 4.8 MB (r03).
+template <bool WAIT>     // WAIT: the six atomics are RETURNING and waited for (a ticket follows); else fire and forget
 __device__ __forceinline__ void minmax_block(const float *__restrict__ p, int N, uint32_t *__restrict__ mm_enc, int b,
                                              int chunk, int nchunks, float (*red)[6])
 {
@@ -201,7 +202,7 @@ __device__ __forceinline__ void minmax_block(const float *__restrict__ p, int N,
         uint32_t old = 0u;
         if (d < 3) { if (v != INFINITY) old = atomicMax(&mm_enc[b * 6 + d], ~f2ord(v)); }
         else       { if (v != -INFINITY) old = atomicMax(&mm_enc[b * 6 + d], f2ord(v)); }
-        asm volatile("" :: "v"(old));                       // the returned value is waited for: the atomic has been performed
+        if (WAIT) asm volatile("" :: "v"(old));             // the returned value is waited for: the atomic has been performed
     }
 }
 inline int minmax_chunks(int N) { int c = (N + 256 * 16 - 1) / (256 * 16); return c < 1 ? 1 : (c > 256 ? 256 : c); }
@@ -232,7 +233,7 @@ __device__ __forceinline__ bool mean_prologue(const MinmaxFuse &mm, uint32_t *ga
     if ((int)blockIdx.x >= nmm) { blk = blockIdx.x - nmm; return false; }
     __shared__ float red[4][6];
     const int b = blockIdx.x / mm.chunks, chunk = blockIdx.x - b * mm.chunks;
-    minmax_block(mm.points.p[b], mm.N, mm.mm_enc, b, chunk, mm.chunks, red);
+    minmax_block<true>(mm.points.p[b], mm.N, mm.mm_enc, b, chunk, mm.chunks, red);
     __syncthreads();                                    // the six returning atomics of this work-group have been performed
     if (threadIdx.x == 0) {
         const int t = __hip_atomic_fetch_add(mm.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
