@@ -37,13 +37,13 @@ static const char *const kKernelNames[] = {
     "k_ln_rows[norm_img]", "k_gemm_nt[qkv+proxy_proj]", "k_gemm_nt[pp_img]", "k_attn32[proxy_as_query]",
     "k_attn32[proxy_as_key]", "k_gemm_nt[proj]", "k_gemm_nt[fc1]", "k_gemm_nt[fc2]",
     "k_heads", "k_affine<compact>", "k_proxy_attn[fused]", "k_mlp[fc1+gelu+fc2]",
-    "k_gate[fork]", "k_signal[join]", "k_gate[join]"};
+    "k_gate[fork]", "k_signal[join]", "k_gate[join]", "k_gate[tags]", "k_signal[tags]"};
 enum Kid : int {
     KID_MINMAX = 0, KID_CLUSTER, KID_SELECT, KID_TAGS, KID_POINTNET,
     KID_IMG_MEAN, KID_IMG_QKV0, KID_IMG_WE, KID_IMG_SCORES, KID_IMG_GATHER, KID_IMG_O, KID_IMG_C,
     KID_IMG_LN, KID_BLK_QKV, KID_BLK_PP, KID_BLK_ATTN_A, KID_BLK_ATTN_B, KID_BLK_PROJ, KID_BLK_FC1,
     KID_BLK_FC2, KID_BLK_HEADS, KID_AFFINE, KID_BLK_ATTN_F, KID_BLK_MLP,
-    KID_GATE_FORK, KID_SIGNAL_JOIN, KID_GATE_JOIN, KID_COUNT};
+    KID_GATE_FORK, KID_SIGNAL_JOIN, KID_GATE_JOIN, KID_GATE_TAGS, KID_SIGNAL_TAGS, KID_COUNT};
 static_assert(sizeof(kKernelNames) / sizeof(kKernelNames[0]) == KID_COUNT, "kernel name table");
 
 struct TimingRec { int kid; hipEvent_t a, b; };
@@ -212,6 +212,7 @@ struct PtxContext {
     uint32_t *gate_err = nullptr;        // [host, pinned, device-mapped] sticky error word written by a waiter that timed out
     bool gates_on = false;               // cleared for good by the first gate that times out or by a failed probe
     bool probed = false; hipStream_t probed_st = nullptr;   // the caller stream the concurrency probe was run against
+    bool lo_ok = false;                  // ... and the low-priority stream runs beside both (the slot tags may leave the chain)
     hipStream_t last_st = nullptr;       // caller stream of the latest forward (drained before the poison word is cleared)
     uint64_t gate_ticks = 0, probe_ticks = 0; int gate_trap = 0;
     std::mutex mu;                       // held for the whole enqueue section of a forward
@@ -361,7 +362,8 @@ static int gate_check(PtxContext *c)
     if (e == 0u) return PTX_OK;
     static const char *const site_name[] = {"?", "fork (clustering stream waiting for the caller's stream)",
                                             "join (caller's stream waiting for the clustering stream)", "probe, fork direction",
-                                            "probe, join direction"};
+                                            "probe, join direction", "?", "slot tags' fork (tag stream waiting for the selection)",
+                                            "slot tags' join (caller's stream waiting for the tags)"};
     const unsigned site = (e >> 24) & 0x7fu;
     c->gates_on = false;
     *reinterpret_cast<volatile uint32_t *>(c->gate_err) = 0u;
@@ -371,7 +373,7 @@ static int gate_check(PtxContext *c)
     (void)hipMemset(c->gate + 48, 0, 4);
     set_error("stream gate timed out at the %s of forward #%u: the two chains of that forward were not ordered and its outputs "
               "were set to NaN; this context now orders its streams with events (PTX_GATE=0 selects them from the start)",
-              site_name[site < 5 ? site : 0], e & 0xffffffu);
+              site_name[site < 8 ? site : 0], e & 0xffffffu);
     return PTX_EGATE;
 }
 
@@ -380,30 +382,34 @@ static int gate_check(PtxContext *c)
 // the kernel that releases it would sit there for its whole bound.  Checked once per (context, caller stream), in both directions,
 // with the WAITER enqueued first: if either wave reports a timeout (20 ms; the streams are drained first so nothing else is in
 // the way) the context uses events.
+static int gate_probe_pair(PtxContext *c, hipStream_t waiter, hipStream_t releaser, int word, uint32_t site, bool *ok)
+{
+    const uint32_t seq = ++c->gate_seq;
+    hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, waiter, gate_ref(c, word, seq, site, true));
+    PTX_LAUNCHED("k_gate[probe]");
+    hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, releaser, c->gate + word, seq);
+    PTX_LAUNCHED("k_signal[probe]");
+    PTX_HIP(hipStreamSynchronize(waiter));
+    PTX_HIP(hipStreamSynchronize(releaser));
+    *ok = *reinterpret_cast<volatile uint32_t *>(c->gate_err) == 0u;
+    *reinterpret_cast<volatile uint32_t *>(c->gate_err) = 0u;
+    return PTX_OK;
+}
 static int gate_probe(PtxContext *c, hipStream_t st)
 {
-    c->probed = true; c->probed_st = st;
+    c->probed = true; c->probed_st = st; c->lo_ok = false;
     if (!c->gates_on) return PTX_OK;
-    if (getenv("PTX_GATE_NO_PROBE") != nullptr) return PTX_OK;
+    if (getenv("PTX_GATE_NO_PROBE") != nullptr) { c->lo_ok = true; return PTX_OK; }
     PTX_HIP(hipStreamSynchronize(st));
     PTX_HIP(hipStreamSynchronize(c->st));
-    const uint32_t seq = ++c->gate_seq;
-    hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, c->st, gate_ref(c, 40, seq, 3, true));      // side waits for the caller
-    PTX_LAUNCHED("k_gate[probe]");
-    hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, st, c->gate + 40, seq);
-    PTX_LAUNCHED("k_signal[probe]");
-    PTX_HIP(hipStreamSynchronize(c->st));
-    PTX_HIP(hipStreamSynchronize(st));
-    hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, gate_ref(c, 44, seq, 4, true));         // caller waits for the side
-    PTX_LAUNCHED("k_gate[probe]");
-    hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, c->st, c->gate + 44, seq);
-    PTX_LAUNCHED("k_signal[probe]");
-    PTX_HIP(hipStreamSynchronize(st));
-    PTX_HIP(hipStreamSynchronize(c->st));
-    if (*reinterpret_cast<volatile uint32_t *>(c->gate_err) != 0u) {
-        *reinterpret_cast<volatile uint32_t *>(c->gate_err) = 0u;
-        c->gates_on = false;            // silent by design: events are the correct fallback, not an error
-    }
+    PTX_HIP(hipStreamSynchronize(c->lo));
+    bool fork_ok = false, join_ok = false, t1 = false, t2 = false;
+    PTX_TRY(gate_probe_pair(c, c->st, st, 40, 3, &fork_ok));        // side waits for the caller
+    PTX_TRY(gate_probe_pair(c, st, c->st, 44, 4, &join_ok));        // caller waits for the side
+    if (!fork_ok || !join_ok) { c->gates_on = false; return PTX_OK; }      // silent by design: events are the correct fallback, not an error
+    PTX_TRY(gate_probe_pair(c, c->lo, c->st, 40, 3, &t1));          // tag stream waits for the side stream
+    PTX_TRY(gate_probe_pair(c, st, c->lo, 44, 4, &t2));             // caller waits for the tag stream
+    c->lo_ok = t1 && t2;
     return PTX_OK;
 }
 
@@ -532,7 +538,7 @@ static bool fused_attn_pays(const PtxShape &s, const Branch *br, int nb)
 // it starts when both the GEMM and the other stream are done (no k_gate launch on the critical path: -4.8 us in the r03 trace).
 // *join is cleared when it has been attached.
 static int run_blocks(const PtxShape &s, const Branch *br, int nb, const float *point_proxy, void *ws,
-                      hipStream_t st, int phase = 0, int cd = 0, GateRef *join = nullptr)
+                      hipStream_t st, int phase = 0, int cd = 0, GateRef *join = nullptr, GateRef *tags_join = nullptr)
 {
     const WsLayout L = ws_layout(s);
     const int C = s.C, R = s.B * s.Mk;
@@ -595,6 +601,8 @@ static int run_blocks(const PtxShape &s, const Branch *br, int nb, const float *
                               br[i].blk->proj_b, point_proxy, nullptr, nullptr, R, C, C, C, C, C, C, 0, 0, EPI_NONE};
             g.p[i].lnp_out = at<float>(ws, L.lnp_x1[sl]);
         }
+        // the slot tags (needed by k_affine only) come from a third stream: their join rides on this launch
+        if (tags_join != nullptr && tags_join->flag != nullptr) { g.tail_gate = *tags_join; tags_join->flag = nullptr; }
         PTX_TIMED(KID_BLK_PROJ, st, launch_gemm(g, st, cd));
     }
     if (mlp_fused_supported(C, s.hidden, R, cd)) {
@@ -1136,7 +1144,15 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     static const bool ext_event_env = getenv("PTX_NO_EXT_EVENT") == nullptr;
     const bool ext_event = ext_event_env && !capturing;
     static const int tail_env = getenv("PTX_TAGS_TAIL") ? atoi(getenv("PTX_TAGS_TAIL")) : 1;
-    const bool tags_tail = !cluster_on_caller && tail_env != 0;
+    // r04, opt-in (PTX_TAGS_GATED=1): with the gates the tags can leave the chain altogether -- a third (low-priority) stream waits
+    // for the first thread of the point-proxy kernel (k_select in front of it has completed), runs k_tags beside the point proxies /
+    // qkv GEMM and signals a word that the proj GEMM's work-group 0 waits for in front of k_affine: no event record or wait on
+    // either chain.  Measured (profiles/r04_tags_off_chain_ab.txt): 18.44-18.75k against 18.68-19.09k scenes/s at 4 scenes per GPU,
+    // neutral at 8 and 32 -- k_tags (16 work-groups of 1024 threads, 128 KB of LDS each) now runs beside the qkv GEMM of the same
+    // stream's tail, which takes 22 instead of 13 us: the clustering stream ends where it did.
+    static const bool tags_gated_env = getenv("PTX_TAGS_GATED") != nullptr && atoi(getenv("PTX_TAGS_GATED")) != 0;
+    const bool tags_gated = gated && side->lo_ok && tags_gated_env;
+    const bool tags_tail = !cluster_on_caller && tail_env != 0 && !tags_gated;
     PTX_TIMED(KID_SELECT, cs, launch_select_order(S, centers, pad_count, order_override, order, picks, keep, kcenter,
                                                   ksrc, bbox_in ? nullptr : mm_ws, cs, cluster_on_caller, ext_event && !tags_tail ? side->aux : nullptr));
     int32_t *tile_counts = at<int32_t>(ws, L.tile_counts);
@@ -1158,7 +1174,9 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     hipStream_t ts = tags_tail ? cs : side->lo;
     const bool slots_first = !cluster_on_caller && !tags_tail;
     auto enqueue_tags = [&]() -> int {
-        if (!tags_tail) {
+        if (tags_gated) {
+            PTX_TIMED(KID_GATE_TAGS, ts, launch_gate(KID_GATE_TAGS, ts, gate_ref(side, 36, side->gate_seq, 6)));
+        } else if (!tags_tail) {
             if (!ext_event) PTX_HIP(hipEventRecord(side->aux, cs));     // else: recorded by k_select's own completion
             PTX_HIP(hipStreamWaitEvent(ts, side->aux, 0));
         }
@@ -1167,17 +1185,31 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
             PTX_TRY(launch_select_slots(S, idx2, cluster2, order, picks, keep, kcluster, kidx, drop_idx, nullptr, ts));
         // ownership / drop tags + survivor counts (published early) in one launch, LDS atomics only
         PTX_TIMED(KID_TAGS, ts, launch_tags(S, idx2, order, picks, ksrc, tag, tile_counts, counts, at<int32_t>(ws, L.scene_acc), ts));
-        if (!tags_tail) PTX_HIP(hipEventRecord(side->tags, ts));
+        if (tags_gated) {
+            auto sig = [&]() -> int {
+                hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, ts, side->gate + 38, side->gate_seq);
+                PTX_LAUNCHED("k_signal[tags]");
+                return PTX_OK;
+            };
+            PTX_TIMED(KID_SIGNAL_TAGS, ts, sig());
+        } else if (!tags_tail) PTX_HIP(hipEventRecord(side->tags, ts));
         return PTX_OK;
     };
     if (slots_first) PTX_TRY(enqueue_tags());
+
+    // ---- the rest of the image chain is ENQUEUED here, in front of the clustering stream's later launches (host order only: the two
+    // chains are different streams).  Its first GEMM is wanted ~30 us after the mean pass started; behind the point proxies, the qkv
+    // GEMM, the tags and the join's signal -- eight launches of ~3 us of host time -- it could arrive late on a slow host (under
+    // rocprofv3 the caller's stream sat idle for 7 us between the mean pass and that GEMM: profiles/r04_timeline_tags_gated.txt)
+    const bool want_img_proxy = debug != nullptr && debug->img_proxy != nullptr;
+    PTX_TRY(run_img_proxy(S, *w, pf, img_feat, img_proxy, ws, is, 2, want_img_proxy));
 
     // ---- point proxies (PRE:437) + norm1 / slot bias of both blocks; the kept clusters are read through the selection
     float *point_proxy = at<float>(ws, L.point_proxy);
     float *xin_t = at<float>(ws, L.x_in[0]), *xin_i = at<float>(ws, L.x_in[1]);
     PTX_TIMED(KID_POINTNET, cs, launch_pointnet(pf + P.enc_ab, w->encoder, kcenter, cluster2, B * S.Mk, S.Mk, K,
                                                 S.C, point_proxy, &w->text, &w->img, pf + P.posb_t, pf + P.posb_i, xin_t,
-                                                xin_i, S.ln_eps, ksrc, M, cs));
+                                                xin_i, S.ln_eps, ksrc, M, cs, tags_gated ? side->gate + 36 : nullptr, side->gate_seq));
     if (!slots_first && !tags_tail) PTX_TRY(enqueue_tags());
 
     // ---- both proxy blocks + heads in shared launches (PRE:440-455); the input projections that
@@ -1188,7 +1220,6 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     Branch br[2] = {make_branch(S, *w, pf, 0, xin_t, text_feats, S.L, text_mask, translate, guide_t),
                     make_branch(S, *w, pf, 1, xin_i, at<float>(ws, L.cbuf), S.V, nullptr, transform, guide_i)};
     br[1].proxy_lnp = at<float>(ws, L.lnp_img);       // norm_img is applied inside the image block's proxy_proj
-    const bool want_img_proxy = debug != nullptr && debug->img_proxy != nullptr;
     // (The whole text branch on a third stream while the image chain finishes, leaving only the image
     // branch after the join, was measured slower: 12.6k vs 13.7k scenes/s -- eight more launches, and its
     // small kernels take CUs from the image passes that are on the critical path.)
@@ -1202,7 +1233,6 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
             return PTX_OK;
         };
         if (!fault_join) PTX_TIMED(KID_SIGNAL_JOIN, cs, launch_signal());
-        PTX_TRY(run_img_proxy(S, *w, pf, img_feat, img_proxy, ws, is, 2, want_img_proxy));
         join = gate_ref(side, 32, side->gate_seq, 2);
         static const bool fold = getenv("PTX_GATE_FOLD") == nullptr || atoi(getenv("PTX_GATE_FOLD")) != 0;
         if (!fold) {
@@ -1211,11 +1241,12 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
         }
     } else {
     if (!cluster_on_caller) PTX_HIP(hipEventRecord(side->join, cs));
-    PTX_TRY(run_img_proxy(S, *w, pf, img_feat, img_proxy, ws, is, 2, want_img_proxy));      // rest of the image chain
     if (cluster_on_caller) PTX_HIP(hipEventRecord(side->join, is));
     PTX_HIP(hipStreamWaitEvent(st, side->join, 0));
     }
-    PTX_TRY(run_blocks(S, br, 2, point_proxy, ws, st, 2, compute_dtype, &join));
+    GateRef tags_join{};
+    if (tags_gated) tags_join = gate_ref(side, 38, side->gate_seq, 7);
+    PTX_TRY(run_blocks(S, br, 2, point_proxy, ws, st, 2, compute_dtype, &join, &tags_join));
     if (join.flag != nullptr) {         // (not attached: no launch in front of the attention took it)
         set_error("ptx_forward: the join gate was not attached to a launch");
         return PTX_ELAUNCH;
@@ -1224,7 +1255,7 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     // ---- submanifold reshape + scatter + drop (PRE:459-467); k_affine is the last reader of the tags and clears them
     // (r03: waiting for the tags next to the join instead -- they are final long before it at the benchmark shape -- does not
     //  shorten the heads -> affine boundary: 0.276 / 0.283 vs 0.271 / 0.275 ms per step)
-    if (!tags_tail) PTX_HIP(hipStreamWaitEvent(st, side->tags, 0));
+    if (!tags_tail && !tags_gated) PTX_HIP(hipStreamWaitEvent(st, side->tags, 0));
     PTX_DBG(tag, tag, (size_t)B * S.N * 4);
     PTX_TIMED(KID_AFFINE, st, launch_affine(S, sp, tag, kcenter, translate, transform, out, counts, tile_counts,
                                             true, true, st, gated ? side->gate + 48 : nullptr));

@@ -160,6 +160,8 @@ struct SlotNetArgs {
     float *proxy; const float *n1w[2]; const float *n1b[2]; const float *posb[2]; float *xin[2];
     float ln_eps;
     const int32_t *ksrc; int Msrc;                  // MODE 1: cluster rows gathered through the selection when ksrc != null
+    uint32_t *head_flag; uint32_t head_seq;         // the first thread of the launch stores head_seq (api.hip, "gates": the stream being
+                                                    // in order, k_select in front of this launch has completed by then), or null
 };
 
 // pooled hidden features of one cluster: lane k (< K) holds slot k's input x[6]; returns acc[q] = channel
@@ -244,6 +246,8 @@ __global__ __launch_bounds__(256) void k_slot_net(SlotNetArgs a)
 {
     constexpr int W = 64 * Q;
     const int lane = lane_id();
+    if (a.head_flag != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(a.head_flag, a.head_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (w >= a.BM) return;
     // MODE 1 may read its cluster through the selection (row ksrc[w] of the un-gathered array, written by k_select next
@@ -403,14 +407,14 @@ int launch_pointnet(const float *ab, const PtxSlotMlp &mlp, const float *kcenter
                     const float *kcluster, int BM, int Mk, int K, int width, float *point_proxy,
                     const PtxBlock *blk_t, const PtxBlock *blk_i, const float *posb_t,
                     const float *posb_i, float *xin_t, float *xin_i, float ln_eps,
-                    const int32_t *ksrc, int Msrc, hipStream_t st)
+                    const int32_t *ksrc, int Msrc, hipStream_t st, uint32_t *head_flag, uint32_t head_seq)
 {
     // ksrc given: kcluster is the UN-gathered (B,Msrc,K,3) array and kept cluster j of scene b reads row ksrc[b][j]
     // (kcenter is always the gathered (B,Mk,3) array)
     SlotNetArgs a{};
     a.ab = ab; a.conv_w = mlp.conv_w; a.conv_b = mlp.conv_b; a.center = kcenter; a.cluster = kcluster;
     a.BM = BM; a.Mper = Mk; a.K = K; a.proxy = point_proxy; a.ln_eps = ln_eps;
-    a.ksrc = ksrc; a.Msrc = Msrc;
+    a.ksrc = ksrc; a.Msrc = Msrc; a.head_flag = head_flag; a.head_seq = head_seq;
     if (blk_t && xin_t) { a.n1w[0] = blk_t->norm1_w; a.n1b[0] = blk_t->norm1_b; a.posb[0] = posb_t; a.xin[0] = xin_t; }
     if (blk_i && xin_i) { a.n1w[1] = blk_i->norm1_w; a.n1b[1] = blk_i->norm1_b; a.posb[1] = posb_i; a.xin[1] = xin_i; }
     PTX_REQUIRE(width == 256 || width == 512, "pointnet: width=%d (supported: 256, 512)", width);

@@ -397,7 +397,7 @@ int launch_pointnet(const float *ab, const PtxSlotMlp &mlp, const float *kcenter
                     const float *kcluster, int BM, int Mk, int K, int width, float *point_proxy,
                     const PtxBlock *blk_t, const PtxBlock *blk_i, const float *posb_t,
                     const float *posb_i, float *xin_t, float *xin_i, float ln_eps,
-                    const int32_t *ksrc, int Msrc, hipStream_t st);
+                    const int32_t *ksrc, int Msrc, hipStream_t st, uint32_t *head_flag = nullptr, uint32_t head_seq = 0);
 int launch_cluster(const PtxShape &s, const uint32_t *mm_enc, const float *lin, const ScenePts &points,
                    const float *off_ab, const PtxSlotMlp &mlp, const float *map_w, const float *centers_override,
                    float *minmax_out, float *centers0, float *cluster1, float *offsets, float *centers,

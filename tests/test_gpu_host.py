@@ -349,7 +349,9 @@ def test_launch_count_with_stream_gates():
     assert per_site.get("k_gate[fork]") == 1 and per_site.get("k_signal[join]") == 1 and "k_gate[join]" not in per_site, per_site
     fused_boxes = "k_minmax" not in per_site                     # PTX_MM_FUSE=1: the boxes ride in the mean launch
     two_launch_attn = "k_attn32[proxy_as_key]" in per_site      # few (scene, head) pairs at this shape: PV through memory
-    assert sum(per_site.values()) == 16 + 2 - int(fused_boxes) + int(two_launch_attn), per_site
+    tags_off_chain = "k_gate[tags]" in per_site                 # the slot tags on the third stream: its one-wave gate + signal
+    assert per_site.get("k_signal[tags]", 0) == int(tags_off_chain)
+    assert sum(per_site.values()) == 16 + 2 - int(fused_boxes) + int(two_launch_attn) + 2 * int(tags_off_chain), per_site
 
 
 _GATE_WORKER = r"""
