@@ -702,8 +702,18 @@ int launch_select_order(const PtxShape &s, const float *centers, const int32_t *
     SelectArgs a = select_args(s, nullptr, centers, nullptr, pad_count, order_override, order, picks, keep, kcenter,
                                nullptr, nullptr, nullptr, nullptr, mm_clear);
     a.ksrc = ksrc;
-    const size_t lds = select_lds_bytes(s);
+    size_t lds = select_lds_bytes(s);
     PTX_REQUIRE(lds <= 160 * 1024, "select: Mt=%d needs %zu B of LDS (> 160 KiB)", s.Mt, lds);
+    // r04: where the step waits for this kernel (`critical`: the clustering chain owns the caller's stream -- the shipped gs = 12
+    // configuration, cfg1, cfg5) the one work-group per scene asks for (nearly) the whole LDS of its CU, so that no work-group of
+    // the image chain's passes on the other stream can become its neighbour and bring 8 or 16 more waves to the CU's four SIMDs:
+    // the picks are a chain of dependent instructions and run slower with neighbours.  cfg4 at 6 scenes per GPU: 11.38k / 11.37k ->
+    // 11.82k / 11.81k scenes/s (+3.8 %), one scene and cfg1 neutral.  Not at the benchmark shape: there the image chain is the
+    // critical one and gives up four CUs for it (k_img_pool 57.5 -> 62 us, step -0.6 %; profiles/r04_select_alone_ab.txt).
+    // PTX_SEL_ALONE=0 / 1 forces it off / on.
+    static const int alone_env = getenv("PTX_SEL_ALONE") ? atoi(getenv("PTX_SEL_ALONE")) : -1;
+    const bool alone = alone_env >= 0 ? alone_env != 0 : critical;
+    if (alone && s.B <= 8 && lds < 150 * 1024) lds = 150 * 1024;
     static const int one_env = getenv("PTX_FPS_ONE") ? atoi(getenv("PTX_FPS_ONE")) : -1;
     // one wave only when the step waits for this kernel: beside a longer image chain the four-wave form finishes early
     // enough and leaves the point-proxy / qkv kernels later, i.e. less of them under the pooling pass
@@ -712,9 +722,13 @@ int launch_select_order(const PtxShape &s, const float *centers, const int32_t *
     const dim3 grid(s.B), block(256);
 #define PTX_SEL(P_)                                                                          \
     do {                                                                                     \
-        if (lds > 64 * 1024)                                                                 \
+        if (lds > 64 * 1024) {                                                               \
             PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_select<P_, false>), \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            if (one && P_ <= 6)                                                              \
+                PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_select<(P_ <= 6 ? P_ : 1), true>), \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        }                                                                                    \
         /* `done` rides on the kernel's own completion signal: a separate event record is one more packet (~6 us) */ \
         if (one && P_ <= 6) hipExtLaunchKernelGGL((k_select<(P_ <= 6 ? P_ : 1), true>), grid, block, lds, st, nullptr, done, 0, a); \
         else hipExtLaunchKernelGGL((k_select<P_, false>), grid, block, lds, st, nullptr, done, 0, a); \
