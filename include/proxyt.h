@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PTX_ABI_VERSION 6
+#define PTX_ABI_VERSION 7
 
 #define PTX_OK          0
 #define PTX_EINVAL     -1   /* bad shape / null pointer / unsupported size */
@@ -442,6 +442,53 @@ int ptx_op_affine_bwd(const float *dout, const int32_t *opos, const int32_t *kid
 /* AttentionPool2d tokens (PRE:155-157): token 0 = mean of the pixel tokens, then + positional embedding; backward of the mean */
 int ptx_op_tokens_finish(float *tok, const float *pos, int nimg, int hw, int C, void *stream);
 int ptx_op_tokens_finish_bwd(float *dtok, int nimg, int hw, int C, void *stream);
+
+/* ---- one ProxyBlock of the training step as two calls (csrc/train_fused.hip)
+ * ProxyBlock in train mode (PRE:273-276: x + DropPath(attn(norm1(x) [+ slot bias], proxy)), x + DropPath(mlp(norm2(x))))
+ * followed by the trailing LayerNorm, the Linear head and its BatchNorm1d with batch statistics (PRE:441-446, 450-455):
+ * the forward and the whole backward of that chain, each enqueued by ONE call (the step was host-bound at ~400 launches
+ * issued one ctypes call at a time: r04, 4.9 ms of enqueue for 3.7 ms of kernels).  Inside: the tuned NT GEMMs of the
+ * eval path, proxy attention forward / backward as five kernels (both soft-maxes, both dropouts and all eight
+ * contractions), residual + Dropout + DropPath + LayerNorm in one pass, every bias / LayerNorm gradient as partial
+ * column sums emitted by the kernel that produces the rows and summed in one fixed-order pass at the end.
+ * rows R = B * n tokens (scene-major), proxies B * L; param[] / grad[] in the order of PTX_TB_*; a NULL qkv bias is
+ * allowed (qkv_bias = False).  save: activations the backward needs; tmp: scratch (sizes from ptx_train_block_sizes;
+ * the backward's tmp need not be the forward's).  seed[0..5]: the six dropout sites of train.site_seeds (the
+ * attention maps use seed[0] and seed[0] + 1).  Proxy attention is fused for L * head_dim <= 4096. */
+enum { PTX_TB_LN1_W = 0, PTX_TB_LN1_B, PTX_TB_PB, PTX_TB_PC, PTX_TB_PR, PTX_TB_QKV_W, PTX_TB_QKV_B, PTX_TB_PP_W,
+       PTX_TB_PP_B, PTX_TB_PROJ_W, PTX_TB_PROJ_B, PTX_TB_LN2_W, PTX_TB_LN2_B, PTX_TB_FC1_W, PTX_TB_FC1_B, PTX_TB_FC2_W,
+       PTX_TB_FC2_B, PTX_TB_LN3_W, PTX_TB_LN3_B, PTX_TB_HEAD_W, PTX_TB_HEAD_B, PTX_TB_BN_W, PTX_TB_BN_B, PTX_TB_NPARAM };
+typedef struct {
+    int32_t B, n, L, C, H, heads, s, nout;     /* s: bias grid side (pc / pr), nout: head width (3 / 9) */
+    float eps1, eps2, eps3, bn_eps, bn_momentum;
+    float p_attn, p_drop, p_path;
+    uint64_t seed[6];
+    const float *x;                            /* (R, C) point proxies */
+    const float *proxy;                        /* (B*L, C) */
+    const uint8_t *mask;                       /* (B, L), 1 = valid, or NULL */
+    const float *param[PTX_TB_NPARAM];
+    float *bn_run_mean, *bn_run_var;           /* updated by the forward (momentum, unbiased variance) */
+    float *out;                                /* forward: (R, nout) */
+    float *save; size_t save_floats;
+    float *tmp; size_t tmp_floats;
+    /* backward only */
+    const float *dout;                         /* (R, nout) */
+    float *dx;                                 /* (R, C) */
+    float *dproxy;                             /* (B*L, C) */
+    float *grad[PTX_TB_NPARAM];                /* shaped like param[] */
+} PtxTrainBlock;
+int ptx_train_block_sizes(const PtxTrainBlock *a, size_t *save_floats, size_t *tmp_fwd_floats, size_t *tmp_bwd_floats);
+int ptx_train_block_fwd(const PtxTrainBlock *a, void *stream);
+int ptx_train_block_bwd(const PtxTrainBlock *a, void *stream);
+/* the attention core alone (train._ProxyAttnCore): qkv (B*n,3C), pt (B*L,C) -> o (B*n,C), saving P1 (B,heads,L,n),
+ * PV (B,heads,L,hd), P2 (B,heads,n,L); backward -> dqkv, dpt; tmp: ptx_train_attn_tmp_floats() floats.  Returns
+ * PTX_EINVAL when the shape is outside the fused range (the caller falls back to the generic products). */
+size_t ptx_train_attn_tmp_floats(int B, int n, int L, int heads, int C);
+int ptx_train_attn_fwd(const float *qkv, const float *pt, const uint8_t *mask, int B, int n, int L, int heads, int C,
+                       float p_drop, uint64_t seed, float *P1, float *PV, float *P2, float *o, void *stream);
+int ptx_train_attn_bwd(const float *qkv, const float *pt, const uint8_t *mask, int B, int n, int L, int heads, int C,
+                       float p_drop, uint64_t seed, const float *P1, const float *PV, const float *P2, const float *dO,
+                       float *dqkv, float *dpt, float *tmp, size_t tmp_floats, void *stream);
 
 #ifdef __cplusplus
 }

@@ -13,7 +13,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libproxyt_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 c_float_p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 
@@ -58,6 +58,20 @@ DEBUG_FIELDS = ("centers0", "cluster1", "offsets", "centers", "cluster2",
 
 class PtxDebug(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in DEBUG_FIELDS]
+
+
+TB_PARAMS = ("ln1_w", "ln1_b", "pb", "pc", "pr", "qkv_w", "qkv_b", "pp_w", "pp_b", "proj_w", "proj_b", "ln2_w", "ln2_b",
+             "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ln3_w", "ln3_b", "head_w", "head_b", "bn_w", "bn_b")      # PTX_TB_*
+
+
+class PtxTrainBlock(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("B", "n", "L", "C", "H", "heads", "s", "nout")] + \
+               [(n, C.c_float) for n in ("eps1", "eps2", "eps3", "bn_eps", "bn_momentum", "p_attn", "p_drop", "p_path")] + \
+               [("seed", C.c_uint64 * 6), ("x", C.c_void_p), ("proxy", C.c_void_p), ("mask", C.c_void_p),
+                ("param", C.c_void_p * len(TB_PARAMS)), ("bn_run_mean", C.c_void_p), ("bn_run_var", C.c_void_p),
+                ("out", C.c_void_p), ("save", C.c_void_p), ("save_floats", C.c_size_t), ("tmp", C.c_void_p),
+                ("tmp_floats", C.c_size_t), ("dout", C.c_void_p), ("dx", C.c_void_p), ("dproxy", C.c_void_p),
+                ("grad", C.c_void_p * len(TB_PARAMS))]
 
 
 class PtxForwardOpts(C.Structure):
@@ -143,6 +157,12 @@ SIGNATURES.update({
     "ptx_op_affine_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "ptx_op_tokens_finish": (_I, [_P, _P, _I, _I, _I, _P]),
     "ptx_op_tokens_finish_bwd": (_I, [_P, _I, _I, _I, _P]),
+    "ptx_train_block_sizes": (_I, [C.POINTER(PtxTrainBlock), C.POINTER(_Z), C.POINTER(_Z), C.POINTER(_Z)]),
+    "ptx_train_block_fwd": (_I, [C.POINTER(PtxTrainBlock), _P]),
+    "ptx_train_block_bwd": (_I, [C.POINTER(PtxTrainBlock), _P]),
+    "ptx_train_attn_tmp_floats": (_Z, [_I, _I, _I, _I, _I]),
+    "ptx_train_attn_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _U64, _P, _P, _P, _P, _P]),
+    "ptx_train_attn_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _U64, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
 })
 
 _lib: Optional[C.CDLL] = None

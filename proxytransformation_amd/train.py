@@ -27,6 +27,7 @@ checked against gradients captured from the reference itself (tests/golden/g4_tr
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import List, Optional
 
 import torch
@@ -34,6 +35,9 @@ import torch
 from . import _abi
 
 _F32 = torch.float32
+# test switches: the generic one-launch-per-operator composition stays available (shapes outside the fused kernels' range use it)
+_FUSED_ATTN = os.environ.get("PTX_TRAIN_FUSED_ATTN", "1") != "0"
+_FUSED_BLOCK = os.environ.get("PTX_TRAIN_FUSED_BLOCK", "1") != "0"
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -418,6 +422,19 @@ class _ProxyAttnCore(torch.autograd.Function):
         dev = qkv.device
         lib = _abi.lib()
         Z = B * heads
+        ctx.fused = False
+        if _FUSED_ATTN and lib.ptx_train_attn_tmp_floats(B, n, L, heads, C) > 0:
+            # five kernels (csrc/train_fused.hip) instead of 22 launches of small batched products, soft-maxes and dropouts
+            P1 = torch.empty((B, heads, L, n), dtype=_F32, device=dev)
+            PV = torch.empty((B, heads, L, hd), dtype=_F32, device=dev)
+            P2 = torch.empty((B, heads, n, L), dtype=_F32, device=dev)
+            O = torch.empty((B * n, C), dtype=_F32, device=dev)
+            _ck(lib.ptx_train_attn_fwd(_p(qkv), _p(pt), _p(mask), B, n, L, heads, C, p_drop, seed & 0xFFFFFFFFFFFFFFFF, _p(P1),
+                                       _p(PV), _p(P2), _p(O), _st()), "ptx_train_attn_fwd")
+            ctx.save_for_backward(qkv, pt, P1, PV, P2, mask if mask is not None else P1)
+            ctx.cfg = (B, n, L, heads, C, hd, scale, p_drop, seed, mask is not None)
+            ctx.fused = True
+            return O
         q = dict(a=(3 * C, 1), a_bs=(n * 3 * C, hd))            # views of qkv as the A operand
         # S1[b,h,l,i] = scale Pt[b,l,h,:] . K[b,i,h,:]
         S1 = torch.empty((B, heads, L, n), dtype=_F32, device=dev)
@@ -445,11 +462,20 @@ class _ProxyAttnCore(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dO):
-        qkv, pt, P1, D1, PV, P2, D2, mask = ctx.saved_tensors
         B, n, L, heads, C, hd, scale, p_drop, seed, has_mask = ctx.cfg
         dO = _c(dO)
         dev = dO.device
         lib = _abi.lib()
+        if ctx.fused:
+            qkv, pt, P1, PV, P2, mask = ctx.saved_tensors
+            dqkv, dpt = torch.empty_like(qkv), torch.empty_like(pt)
+            nt = lib.ptx_train_attn_tmp_floats(B, n, L, heads, C)
+            tmp = torch.empty((nt,), dtype=_F32, device=dev)
+            _ck(lib.ptx_train_attn_bwd(_p(qkv), _p(pt), _p(mask) if has_mask else None, B, n, L, heads, C, p_drop,
+                                       seed & 0xFFFFFFFFFFFFFFFF, _p(P1), _p(PV), _p(P2), _p(dO), _p(dqkv), _p(dpt), _p(tmp), nt,
+                                       _st()), "ptx_train_attn_bwd")
+            return dqkv, dpt, None, None, None, None, None, None, None
+        qkv, pt, P1, D1, PV, P2, D2, mask = ctx.saved_tensors
         Z = B * heads
         dqkv = torch.empty_like(qkv)
         dpt = torch.empty_like(pt)
@@ -641,10 +667,91 @@ def site_seeds(torch_seed: int, call: int, salt: int = 0):
     return [[base + _SITES_PER_BLOCK * b + (0 if i == 0 else i + 1) for i in range(6)] for b in range(2)]
 
 
+class _BlockFused(torch.autograd.Function):
+    """ProxyBlock + trailing LayerNorm + Linear head + BatchNorm1d as ONE node: forward and backward are one C call each
+    (ptx_train_block_fwd / _bwd, csrc/train_fused.hip) that enqueue every kernel of the chain from C++."""
+
+    @staticmethod
+    def forward(ctx, x, proxy, mask, cfg, run_mean, run_var, *params):
+        lib = _abi.lib()
+        x, proxy = _c(x), _c(proxy)
+        a = _abi.PtxTrainBlock()
+        (a.B, a.n, a.L, a.C, a.H, a.heads, a.s, a.nout, a.eps1, a.eps2, a.eps3, a.bn_eps, a.bn_momentum, a.p_attn, a.p_drop,
+         a.p_path, seeds) = cfg
+        for i, sd in enumerate(seeds):
+            a.seed[i] = sd & 0xFFFFFFFFFFFFFFFF
+        a.x, a.proxy, a.mask = _p(x), _p(proxy), _p(mask)
+        params = tuple(None if t is None else _c(t) for t in params)
+        for i, t in enumerate(params):
+            a.param[i] = _p(t)
+        a.bn_run_mean, a.bn_run_var = _p(run_mean), _p(run_var)
+        s0, s1, s2 = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+        _ck(lib.ptx_train_block_sizes(ctypes.byref(a), ctypes.byref(s0), ctypes.byref(s1), ctypes.byref(s2)), "ptx_train_block_sizes")
+        sz = (s0.value, s1.value, s2.value)
+        dev = x.device
+        save = torch.empty((sz[0],), dtype=_F32, device=dev)
+        tmp = torch.empty((sz[1],), dtype=_F32, device=dev)
+        out = torch.empty((a.B * a.n, a.nout), dtype=_F32, device=dev)
+        a.out, a.save, a.save_floats, a.tmp, a.tmp_floats = _p(out), _p(save), sz[0], _p(tmp), sz[1]
+        _ck(lib.ptx_train_block_fwd(ctypes.byref(a), _st()), "ptx_train_block_fwd")
+        ctx.save_for_backward(x, proxy, save, *[t for t in params if t is not None])
+        ctx.present = [t is not None for t in params]
+        ctx.mask = mask
+        ctx.args, ctx.bwd_floats = a, sz[2]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _abi.lib()
+        saved = ctx.saved_tensors
+        x, proxy, save = saved[0], saved[1], saved[2]
+        params, k = [], 3
+        for pres in ctx.present:
+            params.append(saved[k] if pres else None)
+            k += 1 if pres else 0
+        a = ctx.args
+        dout = _c(dout)
+        dev = dout.device
+        numel = [0 if t is None else (t.numel() + 63) // 64 * 64 for t in params]
+        flat = torch.empty((sum(numel),), dtype=_F32, device=dev)           # every parameter gradient, one allocation
+        grads, off = [], 0
+        for i, t in enumerate(params):
+            if t is None:
+                grads.append(None); a.grad[i] = None
+            else:
+                g = flat[off: off + t.numel()].view(t.shape)
+                grads.append(g); a.grad[i] = _p(g); off += numel[i]
+        dx, dproxy = torch.empty_like(x), torch.empty_like(proxy)
+        tmp = torch.empty((ctx.bwd_floats,), dtype=_F32, device=dev)
+        a.dout, a.dx, a.dproxy, a.tmp, a.tmp_floats = _p(dout), _p(dx), _p(dproxy), _p(tmp), ctx.bwd_floats
+        _ck(lib.ptx_train_block_bwd(ctypes.byref(a), _st()), "ptx_train_block_bwd")
+        return (dx, dproxy, None, None, None, None, *grads)
+
+
+def _block_fused_ok(mod, blk, head, n, L):
+    lib = _abi.lib()
+    return (_FUSED_BLOCK and lib.ptx_train_attn_tmp_floats(1, n, L, mod.num_heads, mod.embed_dim) > 0 and head.weight.shape[0] <= 9
+            and mod.embed_dim <= 512 and blk.mlp.fc1.weight.shape[0] <= 2048)
+
+
 def _block(mod, blk, out_norm, head, head_bn, xa, xb, proxy2d, mask_u8, B, n, L, seeds):
     """One ProxyBlock in train mode (PRE:273-276) + trailing LayerNorm + Linear head + BatchNorm1d (PRE:441-446)."""
     C, heads = mod.embed_dim, mod.num_heads
     a = blk.attn
+    if xa is xb and _block_fused_ok(mod, blk, head, n, L):
+        cfg = (B, n, L, C, blk.mlp.fc1.weight.shape[0], heads, a.pc_bias.shape[2], head.weight.shape[0], blk.norm1.eps,
+               blk.norm2.eps, out_norm.eps, head_bn.eps, head_bn.momentum, float(mod.attn_drop_rate), float(mod.drop_rate),
+               float(mod._dpr_last(blk)), tuple(seeds))
+        t = _BlockFused.apply(xa, proxy2d, mask_u8, cfg, head_bn.running_mean, head_bn.running_var,
+                              blk.norm1.weight, blk.norm1.bias, a.pb_bias, a.pc_bias, a.pr_bias, a.qkv.weight, a.qkv.bias,
+                              a.proxy_proj.weight, a.proxy_proj.bias, a.proj.weight, a.proj.bias, blk.norm2.weight, blk.norm2.bias,
+                              blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias, out_norm.weight,
+                              out_norm.bias, head.weight, head.bias, head_bn.weight, head_bn.bias)
+        if head_bn.num_batches_tracked is not None:
+            head_bn.num_batches_tracked.add_(1)
+        return t
+    if xa is xb:
+        xa, xb = fork(xa, 2)
     s = a.pc_bias.shape[2]
     eps = blk.norm1.eps
     x = _LayerNorm.apply(xa, blk.norm1.weight, blk.norm1.bias, eps)
@@ -742,7 +849,11 @@ def forward_train(mod, points: List[torch.Tensor], text_feats, text_mask, img_fe
     pp = _SlotNet.apply(kc_enc, kcluster, enc.mlp[0].weight, enc.mlp[0].bias, ebn.weight, ebn.bias, ebn.running_mean,
                         ebn.running_var, ebn.eps, ebn.momentum, True)            # (B*Mk, C)
     ebn.num_batches_tracked.add_(1)
-    pp_t1, pp_t2, pp_i1, pp_i2 = fork(pp, 4)
+    if _FUSED_BLOCK:                      # the fused block node sums its two uses of the point proxies itself
+        pp_t1, pp_i1 = fork(pp, 2)
+        pp_t2, pp_i2 = pp_t1, pp_i1
+    else:
+        pp_t1, pp_t2, pp_i1, pp_i2 = fork(pp, 4)
 
     # ---- text branch (PRE:440-446)
     L = text_feats.shape[1]

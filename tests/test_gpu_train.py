@@ -87,10 +87,13 @@ def test_batchnorm_rows_node_updates_running_stats():
         _rel(rm, rmd, 1e-5, "running_mean"); _rel(rv, rvd, 1e-5, "running_var")
 
 
-def test_proxy_attention_core_node():
-    """Both contractions + masked softmax against a float64 torch restatement of PRE:230-252."""
+@pytest.mark.parametrize("fused,C,n,L", [(True, 256, 40, 13), (False, 256, 40, 13), (True, 512, 150, 7), (True, 256, 691, 20)])
+def test_proxy_attention_core_node(monkeypatch, fused, C, n, L):
+    """Both contractions + masked softmax against a float64 torch restatement of PRE:230-252: the five fused kernels of
+    csrc/train_fused.hip and the generic one-product-per-launch composition."""
     from proxytransformation_amd import train as T
-    B, n, L, heads, C = 2, 40, 13, 8, 256
+    monkeypatch.setattr(T, "_FUSED_ATTN", fused)
+    B, heads = 2, 8
     hd = C // heads
     qkv = _rand(B * n, 3 * C, seed=21, scale=0.5).requires_grad_(True)
     pt = _rand(B * L, C, seed=22, scale=0.5).requires_grad_(True)
@@ -110,6 +113,62 @@ def test_proxy_attention_core_node():
     _rel(o, od, 2e-5, "attention out")
     _rel(qkv.grad, qd.grad, 5e-5, "dqkv")
     _rel(pt.grad, pd.grad, 5e-5, "dproxy tokens")
+
+
+def test_fused_attention_draws_the_masks_of_the_generic_nodes(monkeypatch):
+    """With attention dropout on, the fused kernels recompute the masks from (seed, element) exactly as k_dropout lays
+    them over P1 (B,heads,L,n) and P2 (B,heads,n,L): same outputs and gradients as the generic composition."""
+    from proxytransformation_amd import train as T
+    B, n, L, heads, C = 3, 100, 9, 8, 256
+    mask = torch.ones(B, L, dtype=torch.uint8, device=_dev())
+    mask[2, 5:] = 0
+    go = _rand(B * n, C, seed=33)
+    res = []
+    for fused in (True, False):
+        monkeypatch.setattr(T, "_FUSED_ATTN", fused)
+        qkv = _rand(B * n, 3 * C, seed=31, scale=0.5).requires_grad_(True)
+        pt = _rand(B * L, C, seed=32, scale=0.5).requires_grad_(True)
+        o = T._ProxyAttnCore.apply(qkv, pt, mask, B, n, L, heads, 0.3, 777)
+        o.backward(go)
+        res.append((o.detach(), qkv.grad, pt.grad))
+    assert (res[0][0] == 0).float().mean() < 0.01          # dropout acts on the maps, not on the output
+    for a, b, nm in zip(res[0], res[1], ("out", "dqkv", "dpt")):
+        _rel(a, b, 2e-5, "fused vs generic " + nm)
+
+
+@pytest.mark.parametrize("embed,rates", [(256, (0.0, 0.0, 0.0)), (256, (0.2, 0.2, 0.3)), (512, (0.1, 0.2, 0.0))])
+def test_fused_block_matches_the_node_by_node_block(monkeypatch, embed, rates):
+    """ptx_train_block_fwd / _bwd (one call each) against the same ProxyBlock + trailing LayerNorm + head + BatchNorm1d built
+    from the single-operator nodes, same seeds: output, running statistics and every gradient."""
+    from proxytransformation_amd import MODELS, train as T
+    cfg = PreshapeConfig("fb", B=3, N=2000, grid_size=4, dynamic_drop_radio=0.5, L=6, V=3, embed_dim=embed, seed_base=8600)
+    res = []
+    for fused in (True, False):
+        monkeypatch.setattr(T, "_FUSED_BLOCK", fused)
+        m = MODELS.build(dict(type="ProxyTransformationNormReverse", drop_rate=rates[0], attn_drop_rate=rates[1],
+                              drop_path_rate=rates[2], **cfg.module_kwargs()))
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in fill_state_dict(m.state_dict()).items()})
+        m = m.cuda().train()
+        B, n, L = 3, m.real_cluster_num, 6
+        x = _rand(B * n, embed, seed=51).requires_grad_(True)
+        proxy = _rand(B * L, embed, seed=52).requires_grad_(True)
+        mask = torch.ones(B, L, dtype=torch.uint8, device=_dev())
+        mask[1, 4:] = 0
+        seeds = T.site_seeds(99, 1, 1)[0]
+        xa, xb = (x, x) if fused else T.fork(x, 2)
+        t = T._block(m, m.imgformer[-1], m.img_norm[-1], m.img_trans, m.img_trans_norm, xa, xb, proxy, mask, B, n, L, seeds)
+        t.backward(_rand(B * n, 9, seed=53))
+        grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+        grads.update({"x": x.grad, "proxy": proxy.grad})
+        res.append((t.detach(), grads, m.img_trans_norm.running_mean.clone(), m.img_trans_norm.running_var.clone()))
+    _rel(res[0][0], res[1][0], 2e-5, "block output")
+    _rel(res[0][2], res[1][2], 1e-5, "running_mean"); _rel(res[0][3], res[1][3], 1e-5, "running_var")
+    assert sorted(res[0][1]) == sorted(res[1][1])
+    for k in res[0][1]:
+        if float(res[1][1][k].abs().max()) < 1e-4:     # structurally zero (BatchNorm removes the mean: the bias gradients in front of it)
+            assert float(res[0][1][k].abs().max()) < 1e-4, k
+            continue
+        _rel(res[0][1][k], res[1][1][k], 1e-4, "grad " + k)
 
 
 def test_dropout_nodes_statistics_and_mask_consistency():
