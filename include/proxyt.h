@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PTX_ABI_VERSION 7
+#define PTX_ABI_VERSION 8
 
 #define PTX_OK          0
 #define PTX_EINVAL     -1   /* bad shape / null pointer / unsupported size */
@@ -489,6 +489,29 @@ int ptx_train_attn_fwd(const float *qkv, const float *pt, const uint8_t *mask, i
 int ptx_train_attn_bwd(const float *qkv, const float *pt, const uint8_t *mask, int B, int n, int L, int heads, int C,
                        float p_drop, uint64_t seed, const float *P1, const float *PV, const float *P2, const float *dO,
                        float *dqkv, float *dpt, float *tmp, size_t tmp_floats, void *stream);
+
+/* ---- AttentionPool2d in train mode without materialised pixel tokens (csrc/train_img.hip; PRE:144-177, 338)
+ * img (nimg, Cin, hw) in its storage type (img_dtype 0 fp32 / 1 bf16 / 2 fp16) -> o (nimg, C), the attention output of the
+ * one query that is returned (token 0), BEFORE c_proj; wc / bc: channel_mapper (C, Cin), (C); pos: positional_embedding
+ * (hw + 1, C); wq .. bv: q_proj / k_proj / v_proj.  Because only token 0 queries, keys, values and every gradient collapse
+ * onto `heads` vectors per image: two streaming passes over img forward, two backward (+ one write of dimg), all other
+ * products a few hundred rows.  heads must be 8, hw <= 256, Cin % 8 == 0, Cin <= 2048, C <= 512.  The backward needs the
+ * forward's `save`; dimg may be NULL (features without gradient).  dbk is the rounding-level zero the reference produces
+ * too (the soft-max gradient sums to zero). */
+typedef struct {
+    int32_t nimg, Cin, hw, C, heads, img_dtype;
+    const void *img;
+    const float *wc, *bc, *pos, *wq, *bq, *wk, *bk, *wv, *bv;
+    float *o;
+    float *save; size_t save_floats;
+    float *tmp; size_t tmp_floats;
+    const float *dout;                         /* backward: (nimg, C) */
+    void *dimg;                                /* (nimg, Cin, hw) in img's storage type, or NULL */
+    float *dwc, *dbc, *dpos, *dwq, *dbq, *dwk, *dbk, *dwv, *dbv;
+} PtxTrainImgPool;
+int ptx_train_imgpool_sizes(const PtxTrainImgPool *a, size_t *save_floats, size_t *tmp_fwd_floats, size_t *tmp_bwd_floats);
+int ptx_train_imgpool_fwd(const PtxTrainImgPool *a, void *stream);
+int ptx_train_imgpool_bwd(const PtxTrainImgPool *a, void *stream);
 
 #ifdef __cplusplus
 }

@@ -13,7 +13,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libproxyt_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 c_float_p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 
@@ -72,6 +72,13 @@ class PtxTrainBlock(C.Structure):
                 ("out", C.c_void_p), ("save", C.c_void_p), ("save_floats", C.c_size_t), ("tmp", C.c_void_p),
                 ("tmp_floats", C.c_size_t), ("dout", C.c_void_p), ("dx", C.c_void_p), ("dproxy", C.c_void_p),
                 ("grad", C.c_void_p * len(TB_PARAMS))]
+
+
+class PtxTrainImgPool(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("nimg", "Cin", "hw", "C", "heads", "img_dtype")] + \
+               [(n, C.c_void_p) for n in ("img", "wc", "bc", "pos", "wq", "bq", "wk", "bk", "wv", "bv", "o", "save")] + \
+               [("save_floats", C.c_size_t), ("tmp", C.c_void_p), ("tmp_floats", C.c_size_t)] + \
+               [(n, C.c_void_p) for n in ("dout", "dimg", "dwc", "dbc", "dpos", "dwq", "dbq", "dwk", "dbk", "dwv", "dbv")]
 
 
 class PtxForwardOpts(C.Structure):
@@ -160,6 +167,9 @@ SIGNATURES.update({
     "ptx_train_block_sizes": (_I, [C.POINTER(PtxTrainBlock), C.POINTER(_Z), C.POINTER(_Z), C.POINTER(_Z)]),
     "ptx_train_block_fwd": (_I, [C.POINTER(PtxTrainBlock), _P]),
     "ptx_train_block_bwd": (_I, [C.POINTER(PtxTrainBlock), _P]),
+    "ptx_train_imgpool_sizes": (_I, [C.POINTER(PtxTrainImgPool), C.POINTER(_Z), C.POINTER(_Z), C.POINTER(_Z)]),
+    "ptx_train_imgpool_fwd": (_I, [C.POINTER(PtxTrainImgPool), _P]),
+    "ptx_train_imgpool_bwd": (_I, [C.POINTER(PtxTrainImgPool), _P]),
     "ptx_train_attn_tmp_floats": (_Z, [_I, _I, _I, _I, _I]),
     "ptx_train_attn_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _U64, _P, _P, _P, _P, _P]),
     "ptx_train_attn_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _U64, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),

@@ -51,7 +51,8 @@ __device__ __forceinline__ float tf_gelu_g(float x)
     return cdf + x * 0.3989422804014327f * expf(-0.5f * x * x);
 }
 
-constexpr int kRowsPerChunk = 16;      // rows of one work-group in the backward row kernels (4 waves x 4 rows)
+constexpr int kRowsPerChunk = 8;       // rows of one work-group in the backward row kernels (4 waves x 2 rows: ~R / 8 work-groups
+                                       // fill the chip; 16 rows left these passes latency-bound at 260 work-groups, r04)
 constexpr int kMaxQ = 8;               // C <= 512: eight values per lane
 
 // ------------------------------------------------------------------------------ residual + dropouts + LayerNorm, forward
@@ -383,30 +384,38 @@ __global__ __launch_bounds__(256) void k_t_head_bwd(const float *__restrict__ dt
 }
 
 // ------------------------------------------------------------------------------ fixed-order sums of partials (one launch, many jobs)
-// out[c] (+)= scale * sum_p part[p * pstride + c], p in order, accumulated in double
+// out[c] = sum_p part[p * pstride + c]: 16 interleaved slices of the parts per column, each in part order, combined in slice
+// order; accumulated in double
 constexpr int kMaxJobs = 28;
 struct FinJob { const float *part; float *out; int nparts; int ncols; long pstride; };
 struct FinJobs { FinJob j[kMaxJobs]; int blk0[kMaxJobs + 1]; int n; };
 __global__ __launch_bounds__(256) void k_t_finalize(FinJobs J)
 {
-    __shared__ double red[4][64];
+    __shared__ double red[256];
     int k = 0;
     while (k + 1 < J.n && (int)blockIdx.x >= J.blk0[k + 1]) ++k;
     const FinJob jb = J.j[k];
-    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6, c = ((int)blockIdx.x - J.blk0[k]) * 64 + cl;
+    // few parts (K slices of a weight gradient: wide rows, 256-B requests) -> 64 columns x 4 slices per work-group;
+    // many parts (row chunks) -> 16 columns x 16 slices, so that a thread's walk over the parts stays short
+    const int cpb = jb.nparts <= 64 ? 64 : 16, ns = 256 / cpb;
+    const int cl = threadIdx.x % cpb, sl = threadIdx.x / cpb, c = ((int)blockIdx.x - J.blk0[k]) * cpb + cl;
     double t = 0.0;
     if (c < jb.ncols) {
         int p = sl;
-        for (; p + 12 < jb.nparts; p += 16) {            // four loads in flight, added in part order
-            const float a0 = jb.part[(size_t)p * jb.pstride + c], a1 = jb.part[(size_t)(p + 4) * jb.pstride + c];
-            const float a2 = jb.part[(size_t)(p + 8) * jb.pstride + c], a3 = jb.part[(size_t)(p + 12) * jb.pstride + c];
+        for (; p + 3 * ns < jb.nparts; p += 4 * ns) {            // four loads in flight, added in part order
+            const float a0 = jb.part[(size_t)p * jb.pstride + c], a1 = jb.part[(size_t)(p + ns) * jb.pstride + c];
+            const float a2 = jb.part[(size_t)(p + 2 * ns) * jb.pstride + c], a3 = jb.part[(size_t)(p + 3 * ns) * jb.pstride + c];
             t += (double)a0; t += (double)a1; t += (double)a2; t += (double)a3;
         }
-        for (; p < jb.nparts; p += 4) t += (double)jb.part[(size_t)p * jb.pstride + c];
+        for (; p < jb.nparts; p += ns) t += (double)jb.part[(size_t)p * jb.pstride + c];
     }
-    red[sl][cl] = t;
+    red[sl * cpb + cl] = t;
     __syncthreads();
-    if (sl == 0 && c < jb.ncols) jb.out[c] = (float)(((red[0][cl] + red[1][cl]) + red[2][cl]) + red[3][cl]);
+    if (sl == 0 && c < jb.ncols) {
+        double tot = 0.0;
+        for (int i = 0; i < ns; ++i) tot += red[i * cpb + cl];
+        jb.out[c] = (float)tot;
+    }
 }
 struct FinList {
     FinJobs J; int blocks;
@@ -415,7 +424,7 @@ struct FinList {
     {
         if (J.n >= kMaxJobs || out == nullptr) return out == nullptr;
         J.j[J.n] = FinJob{part, out, nparts, (int)ncols, pstride};
-        blocks += (int)((ncols + 63) / 64);
+        blocks += (int)((ncols + (nparts <= 64 ? 63 : 15)) / (nparts <= 64 ? 64 : 16));
         J.n += 1; J.blk0[J.n] = blocks;
         return true;
     }
@@ -443,6 +452,8 @@ struct TAttn {
 };
 constexpr int kLT = 4;          // proxies per work-group in the per-proxy kernels
 constexpr int kTT = 64;         // tokens per work-group in the per-token kernels
+
+__device__ __forceinline__ float strided_dot(const float *s, const float *g, size_t stride, int i0, int i1);
 
 template <int HD>
 __global__ __launch_bounds__(256) void k_tattn_fwd_a(TAttn a)
@@ -482,12 +493,12 @@ __global__ __launch_bounds__(256) void k_tattn_fwd_a(TAttn a)
         for (int i = lane; i < n; i += 64) mx = fmaxf(mx, sr[i]);
         mx = wave_max(mx);
         float sum = 0.0f;
-        for (int i = lane; i < n; i += 64) sum += expf(sr[i] - mx);
+        for (int i = lane; i < n; i += 64) { const float e = expf(sr[i] - mx); sr[i] = e; sum += e; }
         sum = wave_sum(sum);
         const float inv = 1.0f / sum;
         const size_t rbase = ((size_t)z * L + l0 + wv) * n;
         for (int i = lane; i < n; i += 64) {
-            const float p = expf(sr[i] - mx) * inv;
+            const float p = sr[i] * inv;
             a.P1[rbase + i] = p;
             sr[i] = drop_apply(a.d1, p, rbase + i);
         }
@@ -498,15 +509,7 @@ __global__ __launch_bounds__(256) void k_tattn_fwd_a(TAttn a)
     if (part < PARTS) {
         const int per = (n + PARTS - 1) / PARTS, i0 = part * per, i1 = min(n, i0 + per);
         const float *vp = a.qkv + (size_t)(b * n) * 3 * C + 2 * C + h * HD + d;
-        const float *sr = S + lw * n;
-        float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;
-        int i = i0;
-        for (; i + 3 < i1; i += 4) {
-            c0 = fmaf(sr[i], vp[(size_t)i * 3 * C], c0); c1 = fmaf(sr[i + 1], vp[(size_t)(i + 1) * 3 * C], c1);
-            c2 = fmaf(sr[i + 2], vp[(size_t)(i + 2) * 3 * C], c2); c3 = fmaf(sr[i + 3], vp[(size_t)(i + 3) * 3 * C], c3);
-        }
-        for (; i < i1; ++i) c0 = fmaf(sr[i], vp[(size_t)i * 3 * C], c0);
-        red[part * kLT * HD + o] = (c0 + c1) + (c2 + c3);
+        red[part * kLT * HD + o] = strided_dot(S + lw * n, vp, (size_t)3 * C, i0, i1);
     }
     __syncthreads();
     if (part == 0 && l0 + lw < L) {
@@ -514,6 +517,26 @@ __global__ __launch_bounds__(256) void k_tattn_fwd_a(TAttn a)
         if (PARTS == 2) v += red[kLT * HD + o];
         a.PV[((size_t)z * L + l0 + lw) * HD + d] = v;
     }
+}
+
+// sum_i s[i] * g[i * stride] over [i0, i1): sixteen independent requests in flight per step (one dependent request per step
+// made these loops the whole kernel: 345 round trips, r04)
+__device__ __forceinline__ float strided_dot(const float *s, const float *g, size_t stride, int i0, int i1)
+{
+    float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;
+    for (int i = i0; i < i1; i += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = g[(size_t)min(i + u, i1 - 1) * stride];
+#pragma unroll
+        for (int u = 0; u < 16; u += 4) {
+            c0 = fmaf(i + u < i1 ? s[i + u] : 0.0f, v[u], c0);
+            c1 = fmaf(i + u + 1 < i1 ? s[i + u + 1] : 0.0f, v[u + 1], c1);
+            c2 = fmaf(i + u + 2 < i1 ? s[i + u + 2] : 0.0f, v[u + 2], c2);
+            c3 = fmaf(i + u + 3 < i1 ? s[i + u + 3] : 0.0f, v[u + 3], c3);
+        }
+    }
+    return (c0 + c1) + (c2 + c3);
 }
 
 // quad (4 adjacent lanes) reductions
@@ -685,6 +708,7 @@ __global__ __launch_bounds__(256) void k_tattn_bwd_b(TAttn a)
         const int l = l0 + tid / HD, d = tid % HD;
         float pv = 0.0f;
         if (l < L) {
+#pragma unroll 4
             for (int t = 0; t < a.ntile; ++t) {
                 const size_t pi = (((size_t)z * a.ntile + t) * L + l) * HD + d;
                 pv += a.dPVp[pi]; dpt_a += a.dPtp[pi];
@@ -734,15 +758,7 @@ __global__ __launch_bounds__(256) void k_tattn_bwd_b(TAttn a)
     if (part < PARTS) {
         const int per = (n + PARTS - 1) / PARTS, i0 = part * per, i1 = min(n, i0 + per);
         const float *kp = a.qkv + (size_t)(b * n) * 3 * C + C + h * HD + d;
-        const float *sr = S + lw * n;
-        float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;
-        int i = i0;
-        for (; i + 3 < i1; i += 4) {
-            c0 = fmaf(sr[i], kp[(size_t)i * 3 * C], c0); c1 = fmaf(sr[i + 1], kp[(size_t)(i + 1) * 3 * C], c1);
-            c2 = fmaf(sr[i + 2], kp[(size_t)(i + 2) * 3 * C], c2); c3 = fmaf(sr[i + 3], kp[(size_t)(i + 3) * 3 * C], c3);
-        }
-        for (; i < i1; ++i) c0 = fmaf(sr[i], kp[(size_t)i * 3 * C], c0);
-        red[part * kLT * HD + o] = (c0 + c1) + (c2 + c3);
+        red[part * kLT * HD + o] = strided_dot(S + lw * n, kp, (size_t)3 * C, i0, i1);
     }
     __syncthreads();
     if (part == 0 && l0 + lw < L) {

@@ -213,6 +213,7 @@ class ProxyTransformationNormReverse(nn.Module):
         self._slots = None
         self._lanes: Dict[tuple, _Lane] = {}
         self._train_calls = 0
+        self._train_pin = None               # train mode: pinned words + event of the early count read-back, per batch size
         ProxyTransformationNormReverse._instances += 1
         self._instance_salt = ProxyTransformationNormReverse._instances      # dropout masks differ between instances
         self._warned_eval_grad = False
@@ -236,7 +237,7 @@ class ProxyTransformationNormReverse(nn.Module):
     # host caches that hold ctypes pointers / device scratch: never copied or pickled (copy.deepcopy(model),
     # torch.save(model), EMA / SWA copies made after the first forward); a copy rebuilds them on its first call
     _HOST_CACHES = dict(_tensors=None, _slots=None, _lanes=None, _lin_t=None, _wkey=None, _wstruct=None, _prep=None,
-                        _lin=None, _shapes=None, _graph_keepalive=None)
+                        _lin=None, _shapes=None, _graph_keepalive=None, _train_pin=None)
 
     def __getstate__(self):
         state = self.__dict__.copy()

@@ -38,6 +38,7 @@ _F32 = torch.float32
 # test switches: the generic one-launch-per-operator composition stays available (shapes outside the fused kernels' range use it)
 _FUSED_ATTN = os.environ.get("PTX_TRAIN_FUSED_ATTN", "1") != "0"
 _FUSED_BLOCK = os.environ.get("PTX_TRAIN_FUSED_BLOCK", "1") != "0"
+_FUSED_IMG = os.environ.get("PTX_TRAIN_FUSED_IMG", "1") != "0"
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -623,6 +624,60 @@ class _AttnPoolCore(torch.autograd.Function):
         return dtok.view(nimg, T, C), dwq, colsum(dq), dwk, dbk, dwv, dbv, None
 
 
+class _ImgPool(torch.autograd.Function):
+    """channel_mapper + AttentionPool2d up to (not including) c_proj as ONE node on the folded form of csrc/train_img.hip: the
+    pixel tokens, their keys and values are never materialised (only token 0 queries)."""
+
+    @staticmethod
+    def forward(ctx, img, wc, bc, pos, wq, bq, wk, bk, wv, bv, heads):
+        lib = _abi.lib()
+        img = _c(img)
+        nimg, Cin, hw = img.shape
+        C = wc.shape[0]
+        a = _abi.PtxTrainImgPool()
+        a.nimg, a.Cin, a.hw, a.C, a.heads = nimg, Cin, hw, C, heads
+        a.img_dtype = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[img.dtype]
+        params = tuple(_c(t) for t in (wc.reshape(C, Cin), bc, pos, wq, bq, wk, bk, wv, bv))
+        a.img = _p(img)
+        a.wc, a.bc, a.pos, a.wq, a.bq, a.wk, a.bk, a.wv, a.bv = (_p(t) for t in params)
+        s0, s1, s2 = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+        _ck(lib.ptx_train_imgpool_sizes(ctypes.byref(a), ctypes.byref(s0), ctypes.byref(s1), ctypes.byref(s2)), "ptx_train_imgpool_sizes")
+        dev = img.device
+        save = torch.empty((s0.value,), dtype=_F32, device=dev)
+        tmp = torch.empty((s1.value,), dtype=_F32, device=dev)
+        o = torch.empty((nimg, C), dtype=_F32, device=dev)
+        a.o, a.save, a.save_floats, a.tmp, a.tmp_floats = _p(o), _p(save), s0.value, _p(tmp), s1.value
+        _ck(lib.ptx_train_imgpool_fwd(ctypes.byref(a), _st()), "ptx_train_imgpool_fwd")
+        ctx.save_for_backward(img, save, *params)
+        ctx.args, ctx.bwd_floats, ctx.wc_shape = a, s2.value, wc.shape
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        lib = _abi.lib()
+        img, save, *params = ctx.saved_tensors
+        a = ctx.args
+        do = _c(do)
+        dev = do.device
+        numel = [(t.numel() + 63) // 64 * 64 for t in params]
+        flat = torch.empty((sum(numel),), dtype=_F32, device=dev)
+        grads, off = [], 0
+        for t, nn_ in zip(params, numel):
+            grads.append(flat[off: off + t.numel()].view(t.shape)); off += nn_
+        dimg = torch.empty_like(img) if ctx.needs_input_grad[0] else None
+        tmp = torch.empty((ctx.bwd_floats,), dtype=_F32, device=dev)
+        a.dout, a.dimg, a.tmp, a.tmp_floats = _p(do), _p(dimg), _p(tmp), ctx.bwd_floats
+        a.dwc, a.dbc, a.dpos, a.dwq, a.dbq, a.dwk, a.dbk, a.dwv, a.dbv = (_p(g) for g in grads)
+        _ck(lib.ptx_train_imgpool_bwd(ctypes.byref(a), _st()), "ptx_train_imgpool_bwd")
+        grads[0] = grads[0].view(ctx.wc_shape)
+        return (dimg, *grads, None)
+
+
+def _imgpool_ok(img3, C, heads):
+    nimg, Cin, hw = img3.shape
+    return _FUSED_IMG and heads == 8 and hw <= 256 and Cin % 8 == 0 and Cin <= 2048 and C % 64 == 0 and C <= 512 and nimg <= 65535
+
+
 class _AffineApply(torch.autograd.Function):
     """Per-cluster affine + pt_replace + remove_points_by_index (PRE:459-467) through the eval path's compaction
     kernel; backward = ptx_op_affine_bwd."""
@@ -838,6 +893,16 @@ def forward_train(mod, points: List[torch.Tensor], text_feats, text_mask, img_fe
     opos = torch.empty((B, N), **i32)
     counts = torch.empty((B,), **i32)
     _ck(lib.ptx_op_out_positions(_p(tag), B, N, _p(tile_counts), _p(opos), _p(counts), st), "ptx_op_out_positions")
+    # the list lengths of PRE:467 are known here: copy them out now and wait at the very end, so that the host keeps enqueueing
+    # the float half while the index half runs (r04: a blocking read at the end idled the GPU across the forward / backward seam)
+    if getattr(mod, "_train_pin", None) is None:
+        mod._train_pin = {}
+    pin = mod._train_pin.get((B, st))
+    if pin is None:
+        pin = mod._train_pin[(B, st)] = (torch.empty((B,), dtype=torch.int32, pin_memory=True), torch.cuda.Event())
+    pin[1].synchronize()                                         # an earlier call's copy into the same pinned words
+    pin[0].copy_(counts, non_blocking=True)
+    pin[1].record()
     src = torch.empty((B * Mk,), **i32)
     _ck(lib.ptx_op_keep_rows(_p(order), _p(keep), B, M, Mt, Mk, _p(src), st), "ptx_op_keep_rows")
 
@@ -866,9 +931,13 @@ def forward_train(mod, points: List[torch.Tensor], text_feats, text_mask, img_fe
     hw = mod.img_spacial_dim ** 2
     ap = mod.attn_pool2d
     img3 = _c(img_feat).view(B * V, mod.input_dim, hw)
-    tok = _ImgTokens.apply(img3, mod.channel_mapper.weight, mod.channel_mapper.bias, ap.positional_embedding)
-    o = _AttnPoolCore.apply(tok, ap.q_proj.weight, ap.q_proj.bias, ap.k_proj.weight, ap.k_proj.bias, ap.v_proj.weight,
-                            ap.v_proj.bias, mod.num_heads)
+    if _imgpool_ok(img3, C, mod.num_heads):
+        o = _ImgPool.apply(img3, mod.channel_mapper.weight, mod.channel_mapper.bias, ap.positional_embedding, ap.q_proj.weight,
+                           ap.q_proj.bias, ap.k_proj.weight, ap.k_proj.bias, ap.v_proj.weight, ap.v_proj.bias, mod.num_heads)
+    else:
+        tok = _ImgTokens.apply(img3, mod.channel_mapper.weight, mod.channel_mapper.bias, ap.positional_embedding)
+        o = _AttnPoolCore.apply(tok, ap.q_proj.weight, ap.q_proj.bias, ap.k_proj.weight, ap.k_proj.bias, ap.v_proj.weight,
+                                ap.v_proj.bias, mod.num_heads)
     y = _Linear.apply(o, ap.c_proj.weight, ap.c_proj.bias)
     img_proxy = _LayerNorm.apply(y, mod.norm_img.weight, mod.norm_img.bias, mod.norm_img.eps)       # (B*V, C)
     transform = _block(mod, mod.imgformer[-1], mod.img_norm[-1], mod.img_trans, mod.img_trans_norm, pp_i1, pp_i2,
@@ -876,7 +945,8 @@ def forward_train(mod, points: List[torch.Tensor], text_feats, text_mask, img_fe
 
     # ---- submanifold reshape + scatter + drop (PRE:459-467)
     out = _AffineApply.apply(kc_aff, translate, transform, pts, tag, opos, kidx, kcluster, shape, ws)
-    n_keep = counts.cpu().tolist()                                              # the list lengths of PRE:467 (one sync)
+    pin[1].synchronize()
+    n_keep = pin[0].tolist()                                                    # the list lengths of PRE:467
     outs = [out[b, : n_keep[b]] for b in range(B)]
     aux = dict(idx2=idx2, order=order, picks=picks[:, :Kd], keep=keep, kidx=kidx, drop_idx=drop_idx[:, : Kd * K],
                centers=centers, translate=translate, transform=transform, point_proxy=pp, img_proxy=img_proxy,

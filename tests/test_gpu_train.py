@@ -241,15 +241,20 @@ def test_slot_networks_and_image_pool_nodes_against_the_oracle():
         _rel(bn.weight.grad, sdt[prefix + ".mlp.1.weight"].grad.cuda(), 1e-4, prefix + " dgamma")
         _rel(bn.bias.grad, sdt[prefix + ".mlp.1.bias"].grad.cuda(), 1e-4, prefix + " dbeta")
         _rel(bn.running_var, sdt[prefix + ".mlp.1.running_var"].cuda(), 1e-5, prefix + " running_var")
-    # image branch, fp32 and bf16 storage
-    for dt in (torch.float32, torch.bfloat16):
+    # image branch, fp32 and bf16 storage; written out (tokens, keys, values) and on the folded form of csrc/train_img.hip
+    for dt, folded in ((torch.float32, False), (torch.bfloat16, False), (torch.float32, True), (torch.bfloat16, True),
+                       (torch.float16, True)):
         m.zero_grad()
         img = torch.from_numpy(rng.standard_normal((2, 3, 512, 15, 15), dtype=np.float32)).to(dt)
         im = img.cuda().view(6, 512, 225).requires_grad_(True)
         ap = m.attn_pool2d
-        tok = T._ImgTokens.apply(im, m.channel_mapper.weight, m.channel_mapper.bias, ap.positional_embedding)
-        o = T._AttnPoolCore.apply(tok, ap.q_proj.weight, ap.q_proj.bias, ap.k_proj.weight, ap.k_proj.bias,
-                                  ap.v_proj.weight, ap.v_proj.bias, 8)
+        if folded:
+            o = T._ImgPool.apply(im, m.channel_mapper.weight, m.channel_mapper.bias, ap.positional_embedding, ap.q_proj.weight,
+                                 ap.q_proj.bias, ap.k_proj.weight, ap.k_proj.bias, ap.v_proj.weight, ap.v_proj.bias, 8)
+        else:
+            tok = T._ImgTokens.apply(im, m.channel_mapper.weight, m.channel_mapper.bias, ap.positional_embedding)
+            o = T._AttnPoolCore.apply(tok, ap.q_proj.weight, ap.q_proj.bias, ap.k_proj.weight, ap.k_proj.bias,
+                                      ap.v_proj.weight, ap.v_proj.bias, 8)
         y = T._LayerNorm.apply(T._Linear.apply(o, ap.c_proj.weight, ap.c_proj.bias), m.norm_img.weight, m.norm_img.bias, 1e-5)
         gy = _rand(6, 256, seed=41)
         y.backward(gy)
