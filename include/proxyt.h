@@ -439,6 +439,11 @@ int ptx_op_out_positions(const uint32_t *tag, int B, int N, int32_t *tile_counts
 int ptx_op_affine_bwd(const float *dout, const int32_t *opos, const int32_t *kidx, const float *kcluster,
                       const float *kcenter, const float *transform, int B, int N, int Mk, int K, float *dtranslate,
                       float *dtransform, float *dkcenter, void *stream);
+/* the same with one gradient per scene (the module returns a LIST of (n_b,3) tensors, PRE:467): douts [host] = B <= 32 device
+ * pointers, NULL where a scene's output received no gradient */
+int ptx_op_affine_bwd_list(const float *const *douts, const int32_t *opos, const int32_t *kidx, const float *kcluster,
+                           const float *kcenter, const float *transform, int B, int N, int Mk, int K, float *dtranslate,
+                           float *dtransform, float *dkcenter, void *stream);
 /* AttentionPool2d tokens (PRE:155-157): token 0 = mean of the pixel tokens, then + positional embedding; backward of the mean */
 int ptx_op_tokens_finish(float *tok, const float *pos, int nimg, int hw, int C, void *stream);
 int ptx_op_tokens_finish_bwd(float *dtok, int nimg, int hw, int C, void *stream);

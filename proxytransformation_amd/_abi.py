@@ -162,6 +162,7 @@ SIGNATURES.update({
     "ptx_op_rows_scatter": (_I, [_P, _P, _L, _I, _P, _P]),
     "ptx_op_out_positions": (_I, [_P, _I, _I, _P, _P, _P, _P]),
     "ptx_op_affine_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "ptx_op_affine_bwd_list": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "ptx_op_tokens_finish": (_I, [_P, _P, _I, _I, _I, _P]),
     "ptx_op_tokens_finish_bwd": (_I, [_P, _I, _I, _I, _P]),
     "ptx_train_block_sizes": (_I, [C.POINTER(PtxTrainBlock), C.POINTER(_Z), C.POINTER(_Z), C.POINTER(_Z)]),

@@ -228,14 +228,16 @@ __global__ void k_ti_dt0(const float *__restrict__ dS, const float *__restrict__
 }
 
 // dbk[h * hd + d] = scale sum_img q[img][h * hd + d] sig[img][h]  (zero up to rounding: the soft-max gradient sums to zero)
-__global__ void k_ti_dbk(const float *__restrict__ q, const float *__restrict__ sig, int nimg, int C, float scale, float *__restrict__ dbk)
+__global__ __launch_bounds__(256) void k_ti_dbk(const float *__restrict__ q, const float *__restrict__ sig, int nimg, int C, float scale,
+                                                float *__restrict__ dbk)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;      // one wave per column, lanes over the images
     if (c >= C) return;
     const int h = c / (C / 8);
     float s = 0.0f;
-    for (int i = 0; i < nimg; ++i) s = fmaf(q[(size_t)i * C + c], sig[(size_t)i * 8 + h], s);
-    dbk[c] = scale * s;
+    for (int i = lane; i < nimg; i += 64) s = fmaf(q[(size_t)i * C + c], sig[(size_t)i * 8 + h], s);
+    s = wave_sum(s);
+    if (lane == 0) dbk[c] = scale * s;
 }
 
 // dx[img][c][p] = sum_h dS[k][1+p] e'[k][c] + P[k][1+p] Bv[k][c]  +  b0[img][c] / hw;   grid (Cin / 64, nimg), wave: 16 channels
@@ -479,7 +481,7 @@ int ptx_train_imgpool_bwd(const PtxTrainImgPool *ap, void *stream)
     // dq_h = scale wk_h u_h  (the bk_h sum_t dS term is a rounding-level zero and is left out);  dwk_h = scale q_h (x) u_h
     PTX_TRY(bg(Bg{t.u, (long)kTiHeads * C, 1, C, a.wk, 1, C, (long)hd * C, t.dq, C, 1, hd}, nimg, hd, C, kTiHeads, scale, 0, st));
     PTX_TRY(bg(Bg{s.q, 1, C, hd, t.u, (long)kTiHeads * C, 1, C, a.dwk, C, 1, (long)hd * C}, hd, C, nimg, kTiHeads, scale, 0, st));
-    hipLaunchKernelGGL(k_ti_dbk, dim3(cdiv(C, 256)), dim3(256), 0, st, s.q, s.sig, nimg, C, scale, a.dbk);
+    hipLaunchKernelGGL(k_ti_dbk, dim3(cdiv(C, 4)), dim3(256), 0, st, s.q, s.sig, nimg, C, scale, a.dbk);
     PTX_LAUNCHED("k_ti_dbk");
     // token 0
     hipLaunchKernelGGL(k_ti_dt0, dim3(cdiv(nimg * C, 256)), dim3(256), 0, st, dS, P, T, s.sig, w, dg, nimg, C, dt0, dbcv);

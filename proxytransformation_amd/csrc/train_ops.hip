@@ -715,7 +715,8 @@ __global__ void k_keep_rows(const int32_t *__restrict__ order, const int32_t *__
 // slot the gradient of the point it targeted (duplicates included: IndexPutBackward gathers, it does not arbitrate), and
 // points removed afterwards (PRE:467) have no gradient.  One wave per kept cluster:
 //   g_k = dout[opos[idx_k]] (0 if padded / dropped);  dt = sum g_k;  dT = sum g_k (p_k - c)^T;  dc = sum (g_k - T^T g_k)
-__global__ __launch_bounds__(256) void k_affine_bwd(const float *__restrict__ dout, const int32_t *__restrict__ opos,
+struct DoutList { const float *p[32]; };       // per-scene output gradients ((n_b,3) each; null = no gradient); all null: `dout` (B,N,3)
+__global__ __launch_bounds__(256) void k_affine_bwd(const float *__restrict__ dout, DoutList dl, const int32_t *__restrict__ opos,
                                                     const int32_t *__restrict__ idx, const float *__restrict__ cluster,
                                                     const float *__restrict__ kcenter,
                                                     const float *__restrict__ transform, int B, int N, int Mk, int K,
@@ -731,8 +732,9 @@ __global__ __launch_bounds__(256) void k_affine_bwd(const float *__restrict__ do
         const int id = idx[s * K + lane];
         if (id >= 0) {
             const int pos = opos[(size_t)b * N + id];
-            if (pos >= 0) {
-                const float *gp = dout + ((size_t)b * N + pos) * 3;
+            const float *gb = dout ? dout + (size_t)b * N * 3 : dl.p[b];
+            if (pos >= 0 && gb) {
+                const float *gp = gb + (size_t)pos * 3;
                 g[0] = gp[0]; g[1] = gp[1]; g[2] = gp[2];
             }
         }
@@ -1079,8 +1081,24 @@ int ptx_op_affine_bwd(const float *dout, const int32_t *opos, const int32_t *kid
 {
     PTX_REQUIRE(dout && opos && kidx && kcluster && kcenter && transform && dtranslate && dtransform && dkcenter && K <= 64,
                 "ptx_op_affine_bwd: bad arguments");
-    hipLaunchKernelGGL(k_affine_bwd, dim3(cdiv(B * Mk, 4)), dim3(256), 0, static_cast<hipStream_t>(stream), dout, opos, kidx,
+    hipLaunchKernelGGL(k_affine_bwd, dim3(cdiv(B * Mk, 4)), dim3(256), 0, static_cast<hipStream_t>(stream), dout, DoutList{}, opos, kidx,
                        kcluster, kcenter, transform, B, N, Mk, K, dtranslate, dtransform, dkcenter);
+    PTX_LAUNCHED("k_affine_bwd");
+    return PTX_OK;
+}
+
+/* the same with one gradient per scene (the module returns a LIST of (n_b,3) tensors, PRE:467): douts [host] = B device
+ * pointers, NULL where a scene's output received no gradient */
+int ptx_op_affine_bwd_list(const float *const *douts, const int32_t *opos, const int32_t *kidx, const float *kcluster,
+                           const float *kcenter, const float *transform, int B, int N, int Mk, int K, float *dtranslate,
+                           float *dtransform, float *dkcenter, void *stream)
+{
+    PTX_REQUIRE(douts && opos && kidx && kcluster && kcenter && transform && dtranslate && dtransform && dkcenter && K <= 64 &&
+                B >= 1 && B <= 32, "ptx_op_affine_bwd_list: bad arguments");
+    DoutList dl{};
+    for (int b = 0; b < B; ++b) dl.p[b] = douts[b];
+    hipLaunchKernelGGL(k_affine_bwd, dim3(cdiv(B * Mk, 4)), dim3(256), 0, static_cast<hipStream_t>(stream), (const float *)nullptr, dl,
+                       opos, kidx, kcluster, kcenter, transform, B, N, Mk, K, dtranslate, dtransform, dkcenter);
     PTX_LAUNCHED("k_affine_bwd");
     return PTX_OK;
 }

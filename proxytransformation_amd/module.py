@@ -213,6 +213,8 @@ class ProxyTransformationNormReverse(nn.Module):
         self._slots = None
         self._lanes: Dict[tuple, _Lane] = {}
         self._train_calls = 0
+        self._train_checked = None
+        self._train_side = None              # train mode: side stream of the image branch, per device
         self._train_pin = None               # train mode: pinned words + event of the early count read-back, per batch size
         ProxyTransformationNormReverse._instances += 1
         self._instance_salt = ProxyTransformationNormReverse._instances      # dropout masks differ between instances
@@ -237,7 +239,7 @@ class ProxyTransformationNormReverse(nn.Module):
     # host caches that hold ctypes pointers / device scratch: never copied or pickled (copy.deepcopy(model),
     # torch.save(model), EMA / SWA copies made after the first forward); a copy rebuilds them on its first call
     _HOST_CACHES = dict(_tensors=None, _slots=None, _lanes=None, _lin_t=None, _wkey=None, _wstruct=None, _prep=None,
-                        _lin=None, _shapes=None, _graph_keepalive=None, _train_pin=None)
+                        _lin=None, _shapes=None, _graph_keepalive=None, _train_pin=None, _train_side=None)
 
     def __getstate__(self):
         state = self.__dict__.copy()
@@ -299,6 +301,7 @@ class ProxyTransformationNormReverse(nn.Module):
         self._tensors = None
         self._slots = None
         self._wkey = None
+        self._train_checked = None
 
     def _weights_key(self):
         """Per-call change detector over the LIVE parameter / buffer objects: the owning ``_parameters`` /
@@ -671,17 +674,21 @@ class ProxyTransformationNormReverse(nn.Module):
         (B, N, dev), pts, plist, text_feats, mask_u8, img = self._check_inputs(points, text_dict, img_feat)
         if B > _MAX_SCENES_PER_CALL:
             raise RuntimeError(f"train mode takes at most {_MAX_SCENES_PER_CALL} scenes per call (got {B})")
-        for name, t in self.state_dict(keep_vars=True).items():
-            if t.device != dev or (t.is_floating_point() and (t.dtype != torch.float32 or not t.is_contiguous())):
-                raise RuntimeError(f"parameter {name} must be contiguous float32 on {dev}")
+        if self._train_checked != str(dev):
+            # layout of every parameter / buffer: once per (device, storage generation) -- invalidate_weights() (load_state_dict,
+            # .to(), train() / eval()) asks for it again; walking the state_dict on every step cost 0.1 ms
+            for name, t in self.state_dict(keep_vars=True).items():
+                if t.device != dev or (t.is_floating_point() and (t.dtype != torch.float32 or not t.is_contiguous())):
+                    raise RuntimeError(f"parameter {name} must be contiguous float32 on {dev}")
+            for name, bn in self._batch_norms():
+                if type(bn) not in (nn.BatchNorm1d, nn.BatchNorm2d):
+                    raise NotImplementedError(f"{name} is a {type(bn).__name__}: the HIP train path computes local batch "
+                                              "statistics (the reference trains with plain DDP, no SyncBatchNorm)")
+                if bn.momentum is None:
+                    raise NotImplementedError(f"{name}.momentum=None (cumulative moving average) is not implemented")
+            self._train_checked = str(dev)
         if dev.index is not None and dev.index != torch.cuda.current_device():
             raise RuntimeError(f"inputs are on {dev} but the current device is cuda:{torch.cuda.current_device()}")
-        for name, bn in self._batch_norms():
-            if type(bn) not in (nn.BatchNorm1d, nn.BatchNorm2d):
-                raise NotImplementedError(f"{name} is a {type(bn).__name__}: the HIP train path computes local batch "
-                                          "statistics (the reference trains with plain DDP, no SyncBatchNorm)")
-            if bn.momentum is None:
-                raise NotImplementedError(f"{name}.momentum=None (cumulative moving average) is not implemented")
         shape = self._shape(B, N, text_feats.shape[1], img.shape[1], _IMG_DTYPES[img.dtype])
         tstream = torch.cuda.current_stream(dev)
         lane = self._lane(dev, tstream)
@@ -691,9 +698,13 @@ class ProxyTransformationNormReverse(nn.Module):
         tf, im = text_feats, img
         res = train.forward_train(self, list(points), tf, mask_u8, im, shape, ws, self._order_override)
         # the running statistics were updated through raw pointers: tell torch (and _weights_key) that they changed
-        for _, bn in self._batch_norms():
-            bn.running_mean.add_(0)
-            bn.running_var.add_(0)
+        bns = [bn for _, bn in self._batch_norms()]
+        for bn in bns:                                     # no kernel: only the version counters move
+            torch.autograd.graph.increment_version(bn.running_mean)
+            torch.autograd.graph.increment_version(bn.running_var)
+        tracked = [bn.num_batches_tracked for bn in bns if bn.num_batches_tracked is not None]
+        if tracked:
+            torch._foreach_add_(tracked, 1)                # one launch for the four counters
         return res
 
     def uses_stream_gates(self, stream=None) -> bool:

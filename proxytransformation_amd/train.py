@@ -39,6 +39,18 @@ _F32 = torch.float32
 _FUSED_ATTN = os.environ.get("PTX_TRAIN_FUSED_ATTN", "1") != "0"
 _FUSED_BLOCK = os.environ.get("PTX_TRAIN_FUSED_BLOCK", "1") != "0"
 _FUSED_IMG = os.environ.get("PTX_TRAIN_FUSED_IMG", "1") != "0"
+_SIDE_STREAM = os.environ.get("PTX_TRAIN_SIDE_STREAM", "1") != "0"
+
+
+def _side_stream(mod, dev):
+    """The module's side stream for the image branch of the training step (one per device)."""
+    cache = getattr(mod, "_train_side", None)
+    if cache is None:
+        cache = mod._train_side = {}
+    st = cache.get(str(dev))
+    if st is None:
+        st = cache[str(dev)] = torch.cuda.Stream(device=dev)
+    return st
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -680,10 +692,12 @@ def _imgpool_ok(img3, C, heads):
 
 class _AffineApply(torch.autograd.Function):
     """Per-cluster affine + pt_replace + remove_points_by_index (PRE:459-467) through the eval path's compaction
-    kernel; backward = ptx_op_affine_bwd."""
+    kernel; returns the per-scene outputs themselves (slices of one buffer), so that the backward takes the B gradients
+    as they come instead of autograd scattering each into a zero-filled (B,N,3) tensor first (r04: 30 launches and 0.4 ms
+    of host time per step); backward = ptx_op_affine_bwd_list."""
 
     @staticmethod
-    def forward(ctx, kcenter, translate, transform, pts, tag, opos, kidx, kcluster, shape, ws):
+    def forward(ctx, kcenter, translate, transform, pts, tag, opos, kidx, kcluster, shape, ws, n_keep):
         lib = _abi.lib()
         B, N = pts.shape[0], pts.shape[1]
         out = torch.zeros((B, N, 3), dtype=_F32, device=pts.device)
@@ -693,20 +707,21 @@ class _AffineApply(torch.autograd.Function):
                                    _p(out), _p(counts), _p(ws), ws.numel(), _st()), "ptx_affine_compact")
         ctx.save_for_backward(opos, kidx, kcluster, kcenter, transform)
         ctx.dims = (B, N, shape.Mk, shape.K)
-        return out
+        return tuple(out[b, : n_keep[b]] for b in range(B))
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, *douts):
         opos, kidx, kcluster, kcenter, transform = ctx.saved_tensors
         B, N, Mk, K = ctx.dims
-        dout = _c(dout)
-        dev = dout.device
+        douts = [None if g is None else _c(g) for g in douts]
+        dev = kcenter.device
         dt = torch.empty((B * Mk, 3), dtype=_F32, device=dev)
         dT = torch.empty((B * Mk, 9), dtype=_F32, device=dev)
         dc = torch.empty((B * Mk, 3), dtype=_F32, device=dev)
-        _ck(_abi.lib().ptx_op_affine_bwd(_p(dout), _p(opos), _p(kidx), _p(kcluster), _p(kcenter), _p(transform), B, N, Mk, K,
-                                         _p(dt), _p(dT), _p(dc), _st()), "ptx_op_affine_bwd")
-        return dc, dt, dT, None, None, None, None, None, None, None
+        ptrs = (ctypes.c_void_p * B)(*[_p(g) for g in douts])
+        _ck(_abi.lib().ptx_op_affine_bwd_list(ptrs, _p(opos), _p(kidx), _p(kcluster), _p(kcenter), _p(transform), B, N, Mk, K,
+                                              _p(dt), _p(dT), _p(dc), _st()), "ptx_op_affine_bwd_list")
+        return dc, dt, dT, None, None, None, None, None, None, None, None
 
 
 # --------------------------------------------------------------------------- the train-mode forward
@@ -802,8 +817,6 @@ def _block(mod, blk, out_norm, head, head_bn, xa, xb, proxy2d, mask_u8, B, n, L,
                               a.proxy_proj.weight, a.proxy_proj.bias, a.proj.weight, a.proj.bias, blk.norm2.weight, blk.norm2.bias,
                               blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias, out_norm.weight,
                               out_norm.bias, head.weight, head.bias, head_bn.weight, head_bn.bias)
-        if head_bn.num_batches_tracked is not None:
-            head_bn.num_batches_tracked.add_(1)
         return t
     if xa is xb:
         xa, xb = fork(xa, 2)
@@ -831,8 +844,6 @@ def _block(mod, blk, out_norm, head, head_bn, xa, xb, proxy2d, mask_u8, B, n, L,
     t = _Linear.apply(g, head.weight, head.bias)
     t = _BatchNormRows.apply(t, head_bn.weight, head_bn.bias, head_bn.running_mean, head_bn.running_var, head_bn.eps,
                              head_bn.momentum, False)
-    if head_bn.num_batches_tracked is not None:
-        head_bn.num_batches_tracked.add_(1)
     return t
 
 
@@ -850,6 +861,30 @@ def forward_train(mod, points: List[torch.Tensor], text_feats, text_mask, img_fe
     mod._train_calls += 1
     seeds = site_seeds(torch.initial_seed(), mod._train_calls, mod._instance_salt)
 
+    # ---- image branch (PRE:449-455), on a side stream: it depends on nothing of the index half, whose farthest point sampling
+    # keeps one work-group per scene busy for ~0.2 ms; autograd runs each node's backward on the stream of its forward, so the
+    # backward of this chain overlaps the text block's in the same way
+    V = img_feat.shape[1]
+    hw = mod.img_spacial_dim ** 2
+    ap = mod.attn_pool2d
+    img3 = _c(img_feat).view(B * V, mod.input_dim, hw)
+    main = torch.cuda.current_stream(dev)
+    side = _side_stream(mod, dev) if _SIDE_STREAM else None
+    if side is not None:
+        side.wait_stream(main)
+    with torch.cuda.stream(side if side is not None else main):
+        if _imgpool_ok(img3, C, mod.num_heads):
+            o = _ImgPool.apply(img3, mod.channel_mapper.weight, mod.channel_mapper.bias, ap.positional_embedding, ap.q_proj.weight,
+                               ap.q_proj.bias, ap.k_proj.weight, ap.k_proj.bias, ap.v_proj.weight, ap.v_proj.bias, mod.num_heads)
+        else:
+            tok = _ImgTokens.apply(img3, mod.channel_mapper.weight, mod.channel_mapper.bias, ap.positional_embedding)
+            o = _AttnPoolCore.apply(tok, ap.q_proj.weight, ap.q_proj.bias, ap.k_proj.weight, ap.k_proj.bias, ap.v_proj.weight,
+                                    ap.v_proj.bias, mod.num_heads)
+        y = _Linear.apply(o, ap.c_proj.weight, ap.c_proj.bias)
+        img_proxy = _LayerNorm.apply(y, mod.norm_img.weight, mod.norm_img.bias, mod.norm_img.eps)       # (B*V, C)
+    if side is not None:
+        img_proxy.record_stream(main)
+
     # ---- index half, part 1: grid centres + ball query #1 (PRE:55-56)
     minmax = torch.empty((B, 2, 3), dtype=_F32, device=dev)
     c0 = torch.empty((B, M, 3), dtype=_F32, device=dev)
@@ -866,7 +901,6 @@ def forward_train(mod, points: List[torch.Tensor], text_feats, text_mask, img_fe
     bn = off.mlp[1]
     pooled = _SlotNet.apply(c0.view(B * M, 3), cl1, off.mlp[0].weight, off.mlp[0].bias, bn.weight, bn.bias,
                             bn.running_mean, bn.running_var, bn.eps, bn.momentum, False)
-    bn.num_batches_tracked.add_(1)
     centers = _OffsetHead.apply(pooled, off.channel_mapper.weight, c0, minmax, M, 4.0)       # (B*M,3)
 
     # ---- index half, part 2: ball query #2, selection, tags, output positions (PRE:65, 352-420, 478-523)
@@ -913,7 +947,6 @@ def forward_train(mod, points: List[torch.Tensor], text_feats, text_mask, img_fe
     ebn = enc.mlp[1]
     pp = _SlotNet.apply(kc_enc, kcluster, enc.mlp[0].weight, enc.mlp[0].bias, ebn.weight, ebn.bias, ebn.running_mean,
                         ebn.running_var, ebn.eps, ebn.momentum, True)            # (B*Mk, C)
-    ebn.num_batches_tracked.add_(1)
     if _FUSED_BLOCK:                      # the fused block node sums its two uses of the point proxies itself
         pp_t1, pp_i1 = fork(pp, 2)
         pp_t2, pp_i2 = pp_t1, pp_i1
@@ -926,28 +959,15 @@ def forward_train(mod, points: List[torch.Tensor], text_feats, text_mask, img_fe
     translate = _block(mod, mod.textformer[-1], mod.text_norm[-1], mod.text_trans, mod.text_trans_norm, pp_t1, pp_t2,
                        tf2, text_mask, B, Mk, L, seeds[0])
 
-    # ---- image branch (PRE:449-455)
-    V = img_feat.shape[1]
-    hw = mod.img_spacial_dim ** 2
-    ap = mod.attn_pool2d
-    img3 = _c(img_feat).view(B * V, mod.input_dim, hw)
-    if _imgpool_ok(img3, C, mod.num_heads):
-        o = _ImgPool.apply(img3, mod.channel_mapper.weight, mod.channel_mapper.bias, ap.positional_embedding, ap.q_proj.weight,
-                           ap.q_proj.bias, ap.k_proj.weight, ap.k_proj.bias, ap.v_proj.weight, ap.v_proj.bias, mod.num_heads)
-    else:
-        tok = _ImgTokens.apply(img3, mod.channel_mapper.weight, mod.channel_mapper.bias, ap.positional_embedding)
-        o = _AttnPoolCore.apply(tok, ap.q_proj.weight, ap.q_proj.bias, ap.k_proj.weight, ap.k_proj.bias, ap.v_proj.weight,
-                                ap.v_proj.bias, mod.num_heads)
-    y = _Linear.apply(o, ap.c_proj.weight, ap.c_proj.bias)
-    img_proxy = _LayerNorm.apply(y, mod.norm_img.weight, mod.norm_img.bias, mod.norm_img.eps)       # (B*V, C)
+    if side is not None:
+        main.wait_stream(side)
     transform = _block(mod, mod.imgformer[-1], mod.img_norm[-1], mod.img_trans, mod.img_trans_norm, pp_i1, pp_i2,
                        img_proxy, None, B, Mk, V, seeds[1])
 
     # ---- submanifold reshape + scatter + drop (PRE:459-467)
-    out = _AffineApply.apply(kc_aff, translate, transform, pts, tag, opos, kidx, kcluster, shape, ws)
     pin[1].synchronize()
     n_keep = pin[0].tolist()                                                    # the list lengths of PRE:467
-    outs = [out[b, : n_keep[b]] for b in range(B)]
+    outs = list(_AffineApply.apply(kc_aff, translate, transform, pts, tag, opos, kidx, kcluster, shape, ws, n_keep))
     aux = dict(idx2=idx2, order=order, picks=picks[:, :Kd], keep=keep, kidx=kidx, drop_idx=drop_idx[:, : Kd * K],
                centers=centers, translate=translate, transform=transform, point_proxy=pp, img_proxy=img_proxy,
                kcenter=kcenter, opos=opos)
