@@ -40,6 +40,17 @@ _FUSED_ATTN = os.environ.get("PTX_TRAIN_FUSED_ATTN", "1") != "0"
 _FUSED_BLOCK = os.environ.get("PTX_TRAIN_FUSED_BLOCK", "1") != "0"
 _FUSED_IMG = os.environ.get("PTX_TRAIN_FUSED_IMG", "1") != "0"
 _SIDE_STREAM = os.environ.get("PTX_TRAIN_SIDE_STREAM", "1") != "0"
+_IMG_POS = int(os.environ.get("PTX_TRAIN_IMG_POS", "1"))     # where the image branch is enqueued: 0 first, 1 after the selection,
+                                                              # 2 before the text block, 3 after it
+
+
+_TICKS = None          # scratch/train_hostprof3.py: list of (label, perf_counter) of the last forward
+
+
+def _tick(label):
+    if _TICKS is not None:
+        import time
+        _TICKS.append((label, time.perf_counter()))
 
 
 def _side_stream(mod, dev):
@@ -853,6 +864,7 @@ def forward_train(mod, points: List[torch.Tensor], text_feats, text_mask, img_fe
     lib = _abi.lib()
     dev = points[0].device
     st = _st()
+    _tick("enter")
     B, N = len(points), points[0].shape[0]
     M, K, Mt, Mk, C = mod.num_cluster, mod.num_sub, shape.Mt, shape.Mk, mod.embed_dim
     Kd = Mt - Mk
@@ -861,30 +873,38 @@ def forward_train(mod, points: List[torch.Tensor], text_feats, text_mask, img_fe
     mod._train_calls += 1
     seeds = site_seeds(torch.initial_seed(), mod._train_calls, mod._instance_salt)
 
-    # ---- image branch (PRE:449-455), on a side stream: it depends on nothing of the index half, whose farthest point sampling
-    # keeps one work-group per scene busy for ~0.2 ms; autograd runs each node's backward on the stream of its forward, so the
-    # backward of this chain overlaps the text block's in the same way
     V = img_feat.shape[1]
-    hw = mod.img_spacial_dim ** 2
-    ap = mod.attn_pool2d
-    img3 = _c(img_feat).view(B * V, mod.input_dim, hw)
-    main = torch.cuda.current_stream(dev)
-    side = _side_stream(mod, dev) if _SIDE_STREAM else None
-    if side is not None:
-        side.wait_stream(main)
-    with torch.cuda.stream(side if side is not None else main):
-        if _imgpool_ok(img3, C, mod.num_heads):
-            o = _ImgPool.apply(img3, mod.channel_mapper.weight, mod.channel_mapper.bias, ap.positional_embedding, ap.q_proj.weight,
-                               ap.q_proj.bias, ap.k_proj.weight, ap.k_proj.bias, ap.v_proj.weight, ap.v_proj.bias, mod.num_heads)
-        else:
-            tok = _ImgTokens.apply(img3, mod.channel_mapper.weight, mod.channel_mapper.bias, ap.positional_embedding)
-            o = _AttnPoolCore.apply(tok, ap.q_proj.weight, ap.q_proj.bias, ap.k_proj.weight, ap.k_proj.bias, ap.v_proj.weight,
-                                    ap.v_proj.bias, mod.num_heads)
-        y = _Linear.apply(o, ap.c_proj.weight, ap.c_proj.bias)
-        img_proxy = _LayerNorm.apply(y, mod.norm_img.weight, mod.norm_img.bias, mod.norm_img.eps)       # (B*V, C)
-    if side is not None:
-        img_proxy.record_stream(main)
 
+    def _image_branch():
+        # ---- image branch (PRE:449-455), on a side stream: it depends on nothing before it, and the host is ahead of the GPU here
+        # (farthest point sampling keeps one work-group per scene busy for ~0.2 ms), so it overlaps the index half and the text
+        # block.  Autograd runs a node's backward on the stream of its forward and picks the most recently created ready node
+        # first: created HERE -- after the text block -- this chain's backward is enqueued right after the image block's and
+        # overlaps the text block's backward (created at the top of the forward it ran last, alone, for 0.5 ms)
+        V = img_feat.shape[1]
+        hw = mod.img_spacial_dim ** 2
+        ap = mod.attn_pool2d
+        img3 = _c(img_feat).view(B * V, mod.input_dim, hw)
+        main = torch.cuda.current_stream(dev)
+        side = _side_stream(mod, dev) if _SIDE_STREAM else None
+        if side is not None:
+            side.wait_stream(main)
+        with torch.cuda.stream(side if side is not None else main):
+            if _imgpool_ok(img3, C, mod.num_heads):
+                o = _ImgPool.apply(img3, mod.channel_mapper.weight, mod.channel_mapper.bias, ap.positional_embedding, ap.q_proj.weight,
+                                   ap.q_proj.bias, ap.k_proj.weight, ap.k_proj.bias, ap.v_proj.weight, ap.v_proj.bias, mod.num_heads)
+            else:
+                tok = _ImgTokens.apply(img3, mod.channel_mapper.weight, mod.channel_mapper.bias, ap.positional_embedding)
+                o = _AttnPoolCore.apply(tok, ap.q_proj.weight, ap.q_proj.bias, ap.k_proj.weight, ap.k_proj.bias, ap.v_proj.weight,
+                                        ap.v_proj.bias, mod.num_heads)
+            y = _Linear.apply(o, ap.c_proj.weight, ap.c_proj.bias)
+            img_proxy = _LayerNorm.apply(y, mod.norm_img.weight, mod.norm_img.bias, mod.norm_img.eps)       # (B*V, C)
+        if side is not None:
+            img_proxy.record_stream(main)
+        return img_proxy, side, main
+
+    if _IMG_POS == 0:
+        img_proxy, side, main = _image_branch()
     # ---- index half, part 1: grid centres + ball query #1 (PRE:55-56)
     minmax = torch.empty((B, 2, 3), dtype=_F32, device=dev)
     c0 = torch.empty((B, M, 3), dtype=_F32, device=dev)
@@ -896,6 +916,7 @@ def forward_train(mod, points: List[torch.Tensor], text_feats, text_mask, img_fe
     cl1 = torch.empty((B, M, K, 3), dtype=_F32, device=dev)
     _ck(lib.ptx_ball_query(_p(c0), _p(pts), B, M, N, K, 3.0, _p(idx1), _p(cl1), None, st), "ptx_ball_query")
 
+    _tick("index1")
     # ---- offset network (PRE:58-62)
     off = mod.get_deformable_cluster.get_offsets
     bn = off.mlp[1]
@@ -903,6 +924,7 @@ def forward_train(mod, points: List[torch.Tensor], text_feats, text_mask, img_fe
                             bn.running_mean, bn.running_var, bn.eps, bn.momentum, False)
     centers = _OffsetHead.apply(pooled, off.channel_mapper.weight, c0, minmax, M, 4.0)       # (B*M,3)
 
+    _tick("offset_net")
     # ---- index half, part 2: ball query #2, selection, tags, output positions (PRE:65, 352-420, 478-523)
     cdet = centers.detach()
     if mod._centers_override is not None:
@@ -922,6 +944,8 @@ def forward_train(mod, points: List[torch.Tensor], text_feats, text_mask, img_fe
     oo = None if order_override is None else order_override.to(device=dev, dtype=torch.int32).contiguous()
     _ck(lib.ptx_select_clusters(ctypes.byref(shape), _p(idx2), _p(cdet), _p(cl2), _p(pad), _p(oo), _p(order), _p(picks),
                                 _p(keep), _p(kcenter_i), _p(kcluster), _p(kidx), _p(drop_idx), _p(tag), st), "ptx_select_clusters")
+    if _IMG_POS == 1:
+        img_proxy, side, main = _image_branch()
     ntiles = (N + 2047) // 2048
     tile_counts = torch.empty((B * ntiles,), **i32)
     opos = torch.empty((B, N), **i32)
@@ -940,6 +964,7 @@ def forward_train(mod, points: List[torch.Tensor], text_feats, text_mask, img_fe
     src = torch.empty((B * Mk,), **i32)
     _ck(lib.ptx_op_keep_rows(_p(order), _p(keep), B, M, Mt, Mk, _p(src), st), "ptx_op_keep_rows")
 
+    _tick("index2")
     # ---- float half: kept centres, point proxies (PRE:437)
     kcenter = _GatherRows.apply(centers, src)                                    # (B*Mk,3), differentiable
     kc_enc, kc_aff = fork(kcenter, 2)
@@ -953,21 +978,30 @@ def forward_train(mod, points: List[torch.Tensor], text_feats, text_mask, img_fe
     else:
         pp_t1, pp_t2, pp_i1, pp_i2 = fork(pp, 4)
 
+    _tick("encoder")
+    if _IMG_POS == 2:
+        img_proxy, side, main = _image_branch()
     # ---- text branch (PRE:440-446)
     L = text_feats.shape[1]
     tf2 = _c(text_feats.to(_F32)).view(B * L, C)
     translate = _block(mod, mod.textformer[-1], mod.text_norm[-1], mod.text_trans, mod.text_trans_norm, pp_t1, pp_t2,
                        tf2, text_mask, B, Mk, L, seeds[0])
 
+    _tick("text_block")
+    if _IMG_POS == 3:
+        img_proxy, side, main = _image_branch()
+    _tick("img_branch")
     if side is not None:
         main.wait_stream(side)
     transform = _block(mod, mod.imgformer[-1], mod.img_norm[-1], mod.img_trans, mod.img_trans_norm, pp_i1, pp_i2,
                        img_proxy, None, B, Mk, V, seeds[1])
 
+    _tick("img_block")
     # ---- submanifold reshape + scatter + drop (PRE:459-467)
     pin[1].synchronize()
     n_keep = pin[0].tolist()                                                    # the list lengths of PRE:467
     outs = list(_AffineApply.apply(kc_aff, translate, transform, pts, tag, opos, kidx, kcluster, shape, ws, n_keep))
+    _tick("affine")
     aux = dict(idx2=idx2, order=order, picks=picks[:, :Kd], keep=keep, kidx=kidx, drop_idx=drop_idx[:, : Kd * K],
                centers=centers, translate=translate, transform=transform, point_proxy=pp, img_proxy=img_proxy,
                kcenter=kcenter, opos=opos)

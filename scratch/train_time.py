@@ -30,10 +30,11 @@ def step():
     torch.autograd.backward(outs, _gos[key])
 for _ in range(3): step()
 torch.cuda.synchronize(); t0 = time.perf_counter()
-n = 10
+n = 30
 for _ in range(n): step()
 torch.cuda.synchronize()
 print(f"train step (fwd+bwd) B=6 N=100k gs=12 V=20: {1e3*(time.perf_counter()-t0)/n:.2f} ms")
+if os.environ.get("ONLY_STEP") == "1": sys.exit(0)
 m.eval()
 with torch.no_grad():
     for _ in range(3): m(*args)
