@@ -11,6 +11,8 @@
 // Per-channel sums run over every slot of the batch: each lane accumulates in double, waves are combined in a fixed
 // order (work-group partials, then one finalising work-group): deterministic, and as accurate as the column reductions
 // they replace.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace ptx {
@@ -147,6 +149,82 @@ __global__ __launch_bounds__(256) void k_sn_finish(const double *__restrict__ pa
     const int i = blockIdx.x * 16 + (threadIdx.x & 15);
     const double s = sn_finish_sum(part, nblocks, width, i);
     if ((threadIdx.x >> 4) == 0 && i < width) out[i] = (float)(s * (double)scale);
+}
+
+// Batch statistics of the convolution's output WITHOUT evaluating it: h_c = w_c . x + b_c is linear in the six slot inputs, so
+//   mean_c = w_c . mu + b_c,   var_c = w_c^T Cov w_c      with mu = E[x] (6), Cov = E[x x^T] - mu mu^T (6 x 6) over all slots
+// (padded slots and their zero inputs included, as BatchNorm2d sees them).  One pass over the 24-byte slots accumulating the
+// 6 + 21 moments in double replaces the two passes that recomputed all C channels of every slot (r04: 2 x 30 us + 2 x 15 us
+// and four finishing launches per step); k_sn_moments_finish turns them into mean / rstd and updates the running statistics.
+constexpr int kSnMom = 27;
+__global__ __launch_bounds__(256) void k_sn_moments(SnArgs a)
+{
+    __shared__ double red[4][kSnMom];
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    const int gw = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);
+    double acc[kSnMom];
+#pragma unroll
+    for (int i = 0; i < kSnMom; ++i) acc[i] = 0.0;
+    for (long cl = gw; cl < a.nclus; cl += (long)gridDim.x * 4) {
+        float x[6];
+        sn_slot(a, cl, lane, x);
+        int t = 6;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            acc[i] += (double)x[i];
+#pragma unroll
+            for (int j = i; j < 6; ++j) { acc[t] += (double)x[i] * (double)x[j]; ++t; }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < kSnMom; ++i) {
+        double v = acc[i];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) red[wv][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kSnMom) a.part[(size_t)blockIdx.x * kSnMom + threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+__global__ __launch_bounds__(512) void k_sn_moments_finish(const double *__restrict__ part, int nblocks, const float *__restrict__ conv_w,
+                                                           const float *__restrict__ conv_b, int C, double total, float eps, float momentum,
+                                                           float *__restrict__ mean_rstd, float *__restrict__ run_mean, float *__restrict__ run_var)
+{
+    __shared__ double mom[kSnMom];
+    __shared__ double red[16][32];
+    {   // 16 interleaved slices of the work-group partials per moment, combined in slice order
+        const int i = threadIdx.x & 31, sl = threadIdx.x >> 5;
+        double t = 0.0;
+        if (i < kSnMom)
+            for (int b = sl; b < nblocks; b += 16) t += part[(size_t)b * kSnMom + i];
+        red[sl][i] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < kSnMom) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += red[q][threadIdx.x];
+        mom[threadIdx.x] = t / total;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 512) {
+        double w[6], mean = (double)conv_b[c], var = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { w[i] = (double)conv_w[c * 6 + i]; mean += w[i] * mom[i]; }
+        int t = 6;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = i; j < 6; ++j) { const double cov = mom[t] - mom[i] * mom[j]; var += (i == j ? 1.0 : 2.0) * w[i] * w[j] * cov; ++t; }
+        const float vf = var > 0.0 ? (float)var : 0.0f;                   // biased: what normalises (PRE:74, 114)
+        mean_rstd[c] = (float)mean;
+        mean_rstd[C + c] = 1.0f / sqrtf(vf + eps);
+        if (run_mean) {
+            const float unb = total > 1.0 ? (float)(var * total / (total - 1.0)) : vf;
+            run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * (float)mean;
+            run_var[c] = (1.0f - momentum) * run_var[c] + momentum * unb;
+        }
+    }
 }
 
 // y = relu(bn(h)); pooled over the K slots (mean, or max with the FIRST arg-max like torch.max)
@@ -341,17 +419,26 @@ int ptx_op_slotnet_fwd(const float *center, const float *cluster, long nclus, in
     a.center = center; a.cluster = cluster; a.nclus = nclus; a.K = K; a.C = C; a.conv_w = conv_w; a.conv_b = conv_b;
     a.bn_w = bn_w; a.bn_b = bn_b; a.mean_rstd = mean_rstd; a.out = out; a.arg_out = arg; a.part = static_cast<double *>(scratch);
     a.maxpool = maxpool; a.inv_total = 1.0f / (float)((double)nclus * K);
-    const size_t lds1 = (size_t)4 * C * sizeof(double);
-    float *mean = stat_tmp, *sq = stat_tmp + C;             // (2,C): batch mean, centred sum of squares
-    if (C == 256) hipLaunchKernelGGL((k_sn_stats<4, 0>), dim3(kSnBlocks), dim3(256), lds1, st, a);
-    else          hipLaunchKernelGGL((k_sn_stats<8, 0>), dim3(kSnBlocks), dim3(256), lds1, st, a);
-    hipLaunchKernelGGL(k_sn_finish, dim3(cdiv(C, 16)), dim3(256), 0, st, a.part, kSnBlocks, C, a.inv_total, mean);
-    a.mean_in = mean;
-    if (C == 256) hipLaunchKernelGGL((k_sn_stats<4, 1>), dim3(kSnBlocks), dim3(256), lds1, st, a);
-    else          hipLaunchKernelGGL((k_sn_stats<8, 1>), dim3(kSnBlocks), dim3(256), lds1, st, a);
-    hipLaunchKernelGGL(k_sn_finish, dim3(cdiv(C, 16)), dim3(256), 0, st, a.part, kSnBlocks, C, 1.0f, sq);
-    PTX_LAUNCHED("k_sn_stats");
-    PTX_TRY(ptx_op_bn_stats(mean, sq, C, nclus * K, eps, momentum, mean_rstd, run_mean, run_var, stream));
+    static const bool two_pass = getenv("PTX_SN_TWO_PASS") != nullptr;      // the r03 form: both statistics from the C channels
+    if (!two_pass) {
+        (void)stat_tmp;
+        hipLaunchKernelGGL(k_sn_moments, dim3(kSnBlocks), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_sn_moments_finish, dim3(1), dim3(512), 0, st, a.part, kSnBlocks, conv_w, conv_b, C, (double)nclus * K, eps,
+                           momentum, mean_rstd, run_mean, run_var);
+        PTX_LAUNCHED("k_sn_moments");
+    } else {
+        const size_t lds1 = (size_t)4 * C * sizeof(double);
+        float *mean = stat_tmp, *sq = stat_tmp + C;             // (2,C): batch mean, centred sum of squares
+        if (C == 256) hipLaunchKernelGGL((k_sn_stats<4, 0>), dim3(kSnBlocks), dim3(256), lds1, st, a);
+        else          hipLaunchKernelGGL((k_sn_stats<8, 0>), dim3(kSnBlocks), dim3(256), lds1, st, a);
+        hipLaunchKernelGGL(k_sn_finish, dim3(cdiv(C, 16)), dim3(256), 0, st, a.part, kSnBlocks, C, a.inv_total, mean);
+        a.mean_in = mean;
+        if (C == 256) hipLaunchKernelGGL((k_sn_stats<4, 1>), dim3(kSnBlocks), dim3(256), lds1, st, a);
+        else          hipLaunchKernelGGL((k_sn_stats<8, 1>), dim3(kSnBlocks), dim3(256), lds1, st, a);
+        hipLaunchKernelGGL(k_sn_finish, dim3(cdiv(C, 16)), dim3(256), 0, st, a.part, kSnBlocks, C, 1.0f, sq);
+        PTX_LAUNCHED("k_sn_stats");
+        PTX_TRY(ptx_op_bn_stats(mean, sq, C, nclus * K, eps, momentum, mean_rstd, run_mean, run_var, stream));
+    }
     if (C == 256) hipLaunchKernelGGL(k_sn_apply<4>, dim3((unsigned)((nclus + 3) / 4)), dim3(256), 0, st, a);
     else          hipLaunchKernelGGL(k_sn_apply<8>, dim3((unsigned)((nclus + 3) / 4)), dim3(256), 0, st, a);
     PTX_LAUNCHED("k_sn_apply");

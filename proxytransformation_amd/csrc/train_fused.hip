@@ -114,105 +114,125 @@ __global__ __launch_bounds__(256) void k_t_gelu_drop(const float *__restrict__ x
     }
 }
 
-// ------------------------------------------------------------------------------ BatchNorm1d over (R, nout <= 16), one work-group
-// (the head's output is 3 or 9 columns wide: six launches of the general column-sum machinery for 37 k values before)
-constexpr int kBnMaxC = 16;
+// ------------------------------------------------------------------------------ BatchNorm1d over (R, nout <= 9 columns)
+// (the head's output is 3 or 9 columns wide: six launches of the general column-sum machinery for 37 k values in r03; one
+//  1024-thread work-group walking them three times took 25-40 us, r04).  Two launches of kBnParts work-groups: per-part sums
+//  in double, then every work-group adds the parts in part order and normalises its share of the rows.
+constexpr int kBnMaxC = 9;      // = kHeadMax
+constexpr int kBnParts = 8;
 __device__ __forceinline__ double wave_sum_d(double v)
 {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
-// block sum of per-thread doubles acc[0..nc) over 1024 threads -> every thread reads tot[j]
-__device__ __forceinline__ void block_sum_d(double (&acc)[kBnMaxC], int nc, double (*red)[kBnMaxC], double *tot)
+// part[(blockIdx.x * 2 + k) * kBnMaxC + j] = sum over this work-group's elements of column j of f_k:
+//   MODE 0: f_0 = x, f_1 = x^2        MODE 1: f_0 = dy, f_1 = dy * xhat (mr = mean, rstd)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_t_bn_part(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ mr,
+                                                   int R, int nc, double *__restrict__ part)
 {
+    __shared__ double red[4][2][kBnMaxC];
+    const long n = (long)R * nc, per = (n + gridDim.x - 1) / gridDim.x, i0 = blockIdx.x * per, i1 = min(n, i0 + per);
+    double a0[kBnMaxC], a1[kBnMaxC];
+#pragma unroll
+    for (int j = 0; j < kBnMaxC; ++j) { a0[j] = 0.0; a1[j] = 0.0; }
+    for (long i = i0 + threadIdx.x; i < i1; i += 256) {
+        const int c = (int)(i % nc);
+        double f0, f1;
+        if (MODE == 0) { f0 = (double)x[i]; f1 = f0 * f0; }
+        else { const float g = dy[i]; f0 = (double)g; f1 = (double)(g * ((x[i] - mr[c]) * mr[nc + c])); }
+#pragma unroll
+        for (int j = 0; j < kBnMaxC; ++j) if (j == c) { a0[j] += f0; a1[j] += f1; }
+    }
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int j = 0; j < nc; ++j) {
-        const double s = wave_sum_d(acc[j]);
-        if (lane == 0) red[wv][j] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x < nc) {
-        double t = 0.0;
-        for (int w = 0; w < 16; ++w) t += red[w][threadIdx.x];
-        tot[threadIdx.x] = t;
-    }
-    __syncthreads();
-}
-__global__ __launch_bounds__(1024) void k_t_bn_small_fwd(const float *__restrict__ x, int R, int nc, const float *__restrict__ w,
-                                                         const float *__restrict__ b, float eps, float momentum,
-                                                         float *__restrict__ run_mean, float *__restrict__ run_var,
-                                                         float *__restrict__ y, float *__restrict__ mr)
-{
-    __shared__ double red[16][kBnMaxC];
-    __shared__ double tot[kBnMaxC];
-    __shared__ float s_mean[kBnMaxC], s_rstd[kBnMaxC];
-    double acc[kBnMaxC];
-    for (int j = 0; j < kBnMaxC; ++j) acc[j] = 0.0;
-    for (int r = threadIdx.x; r < R; r += 1024)
-        for (int j = 0; j < nc; ++j) acc[j] += (double)x[(size_t)r * nc + j];
-    block_sum_d(acc, nc, red, tot);
-    if (threadIdx.x < nc) s_mean[threadIdx.x] = (float)(tot[threadIdx.x] / (double)R);     // colsum(x, scale = 1 / R)
-    __syncthreads();
-    for (int j = 0; j < kBnMaxC; ++j) acc[j] = 0.0;
-    for (int r = threadIdx.x; r < R; r += 1024)
-        for (int j = 0; j < nc; ++j) { const double d = (double)x[(size_t)r * nc + j] - (double)s_mean[j]; acc[j] += d * d; }
-    block_sum_d(acc, nc, red, tot);
-    if (threadIdx.x < nc) {
-        const int c = threadIdx.x;
-        const float mean = s_mean[c];
-        const float var = (float)tot[c] / (float)R;                     // biased: what normalises (PRE:329-330)
-        const float rstd = 1.0f / sqrtf(var + eps);
-        s_rstd[c] = rstd; mr[c] = mean; mr[nc + c] = rstd;
-        if (run_mean) {
-            const float unb = R > 1 ? var * (float)R / (float)(R - 1) : var;
-            run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * mean;
-            run_var[c] = (1.0f - momentum) * run_var[c] + momentum * unb;
+#pragma unroll
+    for (int j = 0; j < kBnMaxC; ++j) {
+        if (j < nc) {
+            const double s0 = wave_sum_d(a0[j]), s1 = wave_sum_d(a1[j]);
+            if (lane == 0) { red[wv][0][j] = s0; red[wv][1][j] = s1; }
         }
     }
     __syncthreads();
-    for (long i = threadIdx.x; i < (long)R * nc; i += 1024) {
+    if (threadIdx.x < 2 * kBnMaxC) {
+        const int k = threadIdx.x / kBnMaxC, j = threadIdx.x % kBnMaxC;
+        part[((size_t)blockIdx.x * 2 + k) * kBnMaxC + j] = j < nc ? ((red[0][k][j] + red[1][k][j]) + red[2][k][j]) + red[3][k][j] : 0.0;
+    }
+}
+// forward: mean / biased variance from the parts (sum x^2 - R mean^2 in double: fp32 data leave 29 digits of headroom),
+// running statistics (work-group 0), y = (x - mean) rstd w + b
+__global__ __launch_bounds__(256) void k_t_bn_small_fwd(const float *__restrict__ x, const double *__restrict__ part, int nparts, int R,
+                                                        int nc, const float *__restrict__ w, const float *__restrict__ b, float eps,
+                                                        float momentum, float *__restrict__ run_mean, float *__restrict__ run_var,
+                                                        float *__restrict__ y, float *__restrict__ mr)
+{
+    __shared__ float s_mean[kBnMaxC], s_rstd[kBnMaxC];
+    if (threadIdx.x < nc) {
+        const int c = threadIdx.x;
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+        for (int p = 0; p < nparts; ++p) { s0 += part[((size_t)p * 2) * kBnMaxC + c]; s1 += part[((size_t)p * 2 + 1) * kBnMaxC + c]; }
+        const double mean = s0 / (double)R;
+        double var = s1 / (double)R - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = 1.0f / sqrtf((float)var + eps);
+        s_mean[c] = (float)mean; s_rstd[c] = rstd;
+        if (blockIdx.x == 0) {
+            mr[c] = (float)mean; mr[nc + c] = rstd;
+            if (run_mean) {
+                const float unb = R > 1 ? (float)(var * (double)R / (double)(R - 1)) : (float)var;
+                run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * (float)mean;
+                run_var[c] = (1.0f - momentum) * run_var[c] + momentum * unb;
+            }
+        }
+    }
+    __syncthreads();
+    const long n = (long)R * nc;
+    for (long i = blockIdx.x * 256l + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const int c = (int)(i % nc);
         y[i] = (x[i] - s_mean[c]) * s_rstd[c] * w[c] + b[c];
     }
 }
-// dbeta = sum dy, dgamma = sum dy xhat, dx = w rstd (dy - dbeta / R - xhat dgamma / R);  dbias = sum dx (the bias gradient of
-// the Linear in front: zero up to rounding, evaluated like the reference evaluates it)
-__global__ __launch_bounds__(1024) void k_t_bn_small_bwd(const float *__restrict__ x, const float *__restrict__ mr,
-                                                         const float *__restrict__ w, const float *__restrict__ dy, int R, int nc,
-                                                         float *__restrict__ dx, float *__restrict__ dgamma,
-                                                         float *__restrict__ dbeta, float *__restrict__ dbias)
+// backward: dbeta = sum dy, dgamma = sum dy xhat (from the parts), dx = w rstd (dy - dbeta / R - xhat dgamma / R); the column
+// sums of dx (the bias gradient of the Linear in front: zero up to rounding, evaluated like the reference evaluates it) leave
+// as one partial per work-group for the block's final fixed-order pass
+__global__ __launch_bounds__(256) void k_t_bn_small_bwd(const float *__restrict__ x, const float *__restrict__ mr,
+                                                        const float *__restrict__ w, const float *__restrict__ dy,
+                                                        const double *__restrict__ part, int nparts, int R, int nc,
+                                                        float *__restrict__ dx, float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                        float *__restrict__ dxpart)
 {
-    __shared__ double red[16][kBnMaxC];
-    __shared__ double tot[kBnMaxC];
     __shared__ float s_db[kBnMaxC], s_dg[kBnMaxC];
-    double acc[kBnMaxC];
-    for (int j = 0; j < kBnMaxC; ++j) acc[j] = 0.0;
-    for (int r = threadIdx.x; r < R; r += 1024)
-        for (int j = 0; j < nc; ++j) acc[j] += (double)dy[(size_t)r * nc + j];
-    block_sum_d(acc, nc, red, tot);
-    if (threadIdx.x < nc) { s_db[threadIdx.x] = (float)tot[threadIdx.x]; dbeta[threadIdx.x] = (float)tot[threadIdx.x]; }
-    __syncthreads();
-    for (int j = 0; j < kBnMaxC; ++j) acc[j] = 0.0;
-    for (int r = threadIdx.x; r < R; r += 1024)
-        for (int j = 0; j < nc; ++j) {
-            const size_t i = (size_t)r * nc + j;
-            acc[j] += (double)(dy[i] * ((x[i] - mr[j]) * mr[nc + j]));
-        }
-    block_sum_d(acc, nc, red, tot);
-    if (threadIdx.x < nc) { s_dg[threadIdx.x] = (float)tot[threadIdx.x]; dgamma[threadIdx.x] = (float)tot[threadIdx.x]; }
+    __shared__ float red[4][kBnMaxC];
+    if (threadIdx.x < nc) {
+        const int c = threadIdx.x;
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+        for (int p = 0; p < nparts; ++p) { s0 += part[((size_t)p * 2) * kBnMaxC + c]; s1 += part[((size_t)p * 2 + 1) * kBnMaxC + c]; }
+        s_db[c] = (float)s0; s_dg[c] = (float)s1;
+        if (blockIdx.x == 0) { dbeta[c] = (float)s0; dgamma[c] = (float)s1; }
+    }
     __syncthreads();
     const float invR = 1.0f / (float)R;
-    for (int j = 0; j < kBnMaxC; ++j) acc[j] = 0.0;
-    for (int r = threadIdx.x; r < R; r += 1024)
-        for (int j = 0; j < nc; ++j) {
-            const size_t i = (size_t)r * nc + j;
-            const float xh = (x[i] - mr[j]) * mr[nc + j];
-            const float v = w[j] * mr[nc + j] * (dy[i] - s_db[j] * invR - xh * s_dg[j] * invR);
-            dx[i] = v; acc[j] += (double)v;
-        }
-    block_sum_d(acc, nc, red, tot);
-    if (dbias && threadIdx.x < nc) dbias[threadIdx.x] = (float)tot[threadIdx.x];
+    const long n = (long)R * nc, per = (n + gridDim.x - 1) / gridDim.x, i0 = blockIdx.x * per, i1 = min(n, i0 + per);
+    float acc[kBnMaxC];
+#pragma unroll
+    for (int j = 0; j < kBnMaxC; ++j) acc[j] = 0.0f;
+    for (long i = i0 + threadIdx.x; i < i1; i += 256) {
+        const int c = (int)(i % nc);
+        const float xh = (x[i] - mr[c]) * mr[nc + c];
+        const float v = w[c] * mr[nc + c] * (dy[i] - s_db[c] * invR - xh * s_dg[c] * invR);
+        dx[i] = v;
+#pragma unroll
+        for (int j = 0; j < kBnMaxC; ++j) if (j == c) acc[j] += v;
+    }
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int j = 0; j < kBnMaxC; ++j) {
+        if (j < nc) { const float sv = wave_sum(acc[j]); if (lane == 0) red[wv][j] = sv; }
+    }
+    __syncthreads();
+    if (threadIdx.x < nc) dxpart[(size_t)blockIdx.x * nc + threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------ backward row kernels with column partials
@@ -433,6 +453,46 @@ struct FinList {
         if (J.n == 0) return PTX_OK;
         hipLaunchKernelGGL(k_t_finalize, dim3(blocks), dim3(256), 0, st, J);
         PTX_LAUNCHED("k_t_finalize");
+        return PTX_OK;
+    }
+};
+
+// ------------------------------------------------------------------------------ weight transposes of one block, one launch
+// out (cols, rows) = in (rows, cols)^T for up to six matrices: the input gradients run as NT products against w^T
+struct TrJob { const float *in; float *out; int rows, cols, tiles_x; };
+struct TrJobs { TrJob j[6]; int blk0[7]; int n; };
+__global__ __launch_bounds__(256) void k_t_transposes(TrJobs J)
+{
+    __shared__ float tile[32][33];
+    int k = 0;
+    while (k + 1 < J.n && (int)blockIdx.x >= J.blk0[k + 1]) ++k;
+    const TrJob jb = J.j[k];
+    const int b = (int)blockIdx.x - J.blk0[k], r0 = (b / jb.tiles_x) * 32, c0 = (b % jb.tiles_x) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = r0 + ty + 8 * r, col = c0 + tx;
+        tile[ty + 8 * r][tx] = (row < jb.rows && col < jb.cols) ? jb.in[(size_t)row * jb.cols + col] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int col = c0 + ty + 8 * r, row = r0 + tx;
+        if (col < jb.cols && row < jb.rows) jb.out[(size_t)col * jb.rows + row] = tile[tx][ty + 8 * r];
+    }
+}
+struct TrList {
+    TrJobs J; int blocks;
+    TrList() { J.n = 0; blocks = 0; J.blk0[0] = 0; }
+    void add(const float *in, float *out, int rows, int cols)
+    {
+        J.j[J.n] = TrJob{in, out, rows, cols, cdiv(cols, 32)};
+        blocks += cdiv(rows, 32) * cdiv(cols, 32); J.n += 1; J.blk0[J.n] = blocks;
+    }
+    int launch(hipStream_t st)
+    {
+        hipLaunchKernelGGL(k_t_transposes, dim3(blocks), dim3(256), 0, st, J);
+        PTX_LAUNCHED("k_t_transposes");
         return PTX_OK;
     }
 };
@@ -917,8 +977,8 @@ static int dw_ksplit(int M, int N, int K)
     return 1;
 }
 struct BwdBufs {
-    float *dtpre, *dg, *dx2, *dh2, *dhact, *dhpre, *dhln, *dx1, *dob, *dO, *dqkv, *dpt, *dxln, *attn, *wT, *dtab;
-    float *p_head, *p_ln3, *p_gelu, *p_ln2, *p_qkv, *p_ln1, *p_w[6];
+    float *dtpre, *dg, *dx2, *dh2, *dhact, *dhpre, *dhln, *dx1, *dob, *dO, *dqkv, *dpt, *dxln, *attn, *wT[5], *dtab;
+    float *p_head, *p_ln3, *p_gelu, *p_ln2, *p_qkv, *p_ln1, *p_bn, *p_w[6];
     int ks[6];
     size_t total;
 };
@@ -932,9 +992,11 @@ static void block_bwd_layout(const PtxTrainBlock &a, float *base, BwdBufs &t)
     t.dhpre = c.take(R * H); t.dhln = c.take(R * C); t.dx1 = c.take(R * C); t.dob = c.take(R * C); t.dO = c.take(R * C);
     t.dqkv = c.take(R * 3 * C); t.dpt = c.take(BL * C); t.dxln = c.take(R * C);
     t.attn = c.take(tattn_ok(a.B, a.n, a.L, a.heads, a.C) ? tattn_tmp_floats(a.B, a.n, a.L, a.heads, a.C) : 64);
-    t.wT = c.take(C * H); t.dtab = c.take((size_t)a.n * C);
+    t.wT[0] = c.take(3 * C * C); t.wT[1] = c.take(C * C); t.wT[2] = c.take(C * C); t.wT[3] = c.take(C * H); t.wT[4] = c.take(C * H);
+    t.dtab = c.take((size_t)a.n * C);      // wT: qkv, proxy_proj, proj, fc1, fc2
     t.p_head = c.take(chunks * a.nout * C); t.p_ln3 = c.take(chunks * 3 * C); t.p_gelu = c.take(chunks * H);
     t.p_ln2 = c.take(chunks * 3 * C); t.p_qkv = c.take(chunks * 3 * C); t.p_ln1 = c.take(chunks * 2 * C);
+    t.p_bn = c.take((size_t)kBnParts * kBnMaxC);
     const int Ms[5] = {3 * a.C, a.C, a.C, a.H, a.C}, Ns[5] = {a.C, a.C, a.C, a.C, a.H};
     const int Ks[5] = {(int)R, (int)BL, (int)R, (int)R, (int)R};
     for (int i = 0; i < 5; ++i) {
@@ -970,9 +1032,8 @@ static int nt_gemm(const float *x, const float *w, const float *bias, float *y, 
     return launch_gemm(g, st);
 }
 // dx (rows, n_in) = dy (rows, n_out) @ w (n_out, n_in): NT against the transposed weight
-static int dx_gemm(const float *dy, const float *w, float *wT, float *dx, int rows, int n_out, int n_in, hipStream_t st)
+static int dx_gemm(const float *dy, const float *wT, float *dx, int rows, int n_out, int n_in, hipStream_t st)
 {
-    PTX_TRY(ptx_op_transpose(w, n_out, n_in, wT, st));
     return nt_gemm(dy, wT, nullptr, dx, rows, n_in, n_out, st);
 }
 // dw (n_out, n_in) = dy^T x over `rows`; K-sliced partials go to the finalize list
@@ -1055,8 +1116,12 @@ int ptx_train_block_fwd(const PtxTrainBlock *ap, void *stream)
         PTX_LAUNCHED("k_t_ln_fwd");
     }
     PTX_TRY(nt_gemm(s.g, P[PTX_TB_HEAD_W], P[PTX_TB_HEAD_B], s.tpre, R, a.nout, C, st));
-    hipLaunchKernelGGL(k_t_bn_small_fwd, dim3(1), dim3(1024), 0, st, s.tpre, R, a.nout, P[PTX_TB_BN_W], P[PTX_TB_BN_B], a.bn_eps,
-                       a.bn_momentum, a.bn_run_mean, a.bn_run_var, a.out, s.mr);
+    {
+        double *bnp = reinterpret_cast<double *>(h2);            // 2 * kBnParts * kBnMaxC doubles of the free scratch rows
+        hipLaunchKernelGGL(k_t_bn_part<0>, dim3(kBnParts), dim3(256), 0, st, s.tpre, (const float *)nullptr, (const float *)nullptr, R, a.nout, bnp);
+        hipLaunchKernelGGL(k_t_bn_small_fwd, dim3(kBnParts), dim3(256), 0, st, s.tpre, bnp, kBnParts, R, a.nout, P[PTX_TB_BN_W],
+                           P[PTX_TB_BN_B], a.bn_eps, a.bn_momentum, a.bn_run_mean, a.bn_run_var, a.out, s.mr);
+    }
     PTX_LAUNCHED("k_t_bn_small_fwd");
     return PTX_OK;
 }
@@ -1076,9 +1141,20 @@ int ptx_train_block_bwd(const PtxTrainBlock *ap, void *stream)
     for (int i = 0; i < PTX_TB_NPARAM; ++i) PTX_REQUIRE(G[i] || P[i] == nullptr, "ptx_train_block_bwd: gradient buffer %d is null", i);
     const Drop1 none = make_drop(0.0f, 0);
     FinList fin;
+    {
+        TrList tr;
+        tr.add(P[PTX_TB_QKV_W], t.wT[0], 3 * C, C); tr.add(P[PTX_TB_PP_W], t.wT[1], C, C); tr.add(P[PTX_TB_PROJ_W], t.wT[2], C, C);
+        tr.add(P[PTX_TB_FC1_W], t.wT[3], H, C); tr.add(P[PTX_TB_FC2_W], t.wT[4], C, H);
+        PTX_TRY(tr.launch(st));
+    }
     // BatchNorm1d + Linear head
-    hipLaunchKernelGGL(k_t_bn_small_bwd, dim3(1), dim3(1024), 0, st, s.tpre, s.mr, P[PTX_TB_BN_W], a.dout, R, a.nout, t.dtpre,
-                       G[PTX_TB_BN_W], G[PTX_TB_BN_B], G[PTX_TB_HEAD_B]);
+    {
+        double *bnp = reinterpret_cast<double *>(t.dg);          // free until k_t_head_bwd writes it
+        hipLaunchKernelGGL(k_t_bn_part<1>, dim3(kBnParts), dim3(256), 0, st, s.tpre, a.dout, s.mr, R, a.nout, bnp);
+        hipLaunchKernelGGL(k_t_bn_small_bwd, dim3(kBnParts), dim3(256), 0, st, s.tpre, s.mr, P[PTX_TB_BN_W], a.dout, bnp, kBnParts, R,
+                           a.nout, t.dtpre, G[PTX_TB_BN_W], G[PTX_TB_BN_B], t.p_bn);
+        fin.add(t.p_bn, G[PTX_TB_HEAD_B], kBnParts, a.nout, a.nout);
+    }
     PTX_LAUNCHED("k_t_bn_small_bwd");
     {
         const size_t lds = ((size_t)4 * a.nout * C + (size_t)a.nout * C) * 4;
@@ -1098,7 +1174,7 @@ int ptx_train_block_bwd(const PtxTrainBlock *ap, void *stream)
         fin.add(t.p_ln3 + 2 * C, G[PTX_TB_FC2_B], chunks, C, 3l * C);
     }
     // fc2
-    PTX_TRY(dx_gemm(t.dh2, P[PTX_TB_FC2_W], t.wT, t.dhact, R, C, H, st));
+    PTX_TRY(dx_gemm(t.dh2, t.wT[4], t.dhact, R, C, H, st));
     PTX_TRY(dw_gemm(t.dh2, s.hact, G[PTX_TB_FC2_W], R, C, H, t.ks[4], t.p_w[4], fin, st));
     // GELU + Dropout
     hipLaunchKernelGGL(k_t_gelu_bwd, dim3(chunks), dim3(256), (size_t)4 * H * 4, st, s.hpre, t.dhact, make_drop(a.p_drop, a.seed[3]), R, H,
@@ -1106,7 +1182,7 @@ int ptx_train_block_bwd(const PtxTrainBlock *ap, void *stream)
     PTX_LAUNCHED("k_t_gelu_bwd");
     fin.add(t.p_gelu, G[PTX_TB_FC1_B], chunks, H, H);
     // fc1
-    PTX_TRY(dx_gemm(t.dhpre, P[PTX_TB_FC1_W], t.wT, t.dhln, R, H, C, st));
+    PTX_TRY(dx_gemm(t.dhpre, t.wT[3], t.dhln, R, H, C, st));
     PTX_TRY(dw_gemm(t.dhpre, s.hln, G[PTX_TB_FC1_W], R, H, C, t.ks[3], t.p_w[3], fin, st));
     // norm2 + residual; dob = gradient of proj's output
     {
@@ -1119,7 +1195,7 @@ int ptx_train_block_bwd(const PtxTrainBlock *ap, void *stream)
         fin.add(t.p_ln2 + 2 * C, G[PTX_TB_PROJ_B], chunks, C, 3l * C);
     }
     // proj
-    PTX_TRY(dx_gemm(t.dob, P[PTX_TB_PROJ_W], t.wT, t.dO, R, C, C, st));
+    PTX_TRY(dx_gemm(t.dob, t.wT[2], t.dO, R, C, C, st));
     PTX_TRY(dw_gemm(t.dob, s.O, G[PTX_TB_PROJ_W], R, C, C, t.ks[2], t.p_w[2], fin, st));
     // proxy attention
     {
@@ -1129,7 +1205,7 @@ int ptx_train_block_bwd(const PtxTrainBlock *ap, void *stream)
         PTX_TRY(tattn_bwd(ta, st));
     }
     // proxy_proj
-    PTX_TRY(dx_gemm(t.dpt, P[PTX_TB_PP_W], t.wT, a.dproxy, BL, C, C, st));
+    PTX_TRY(dx_gemm(t.dpt, t.wT[1], a.dproxy, BL, C, C, st));
     PTX_TRY(dw_gemm(t.dpt, a.proxy, G[PTX_TB_PP_W], BL, C, C, t.ks[1], t.p_w[1], fin, st));
     fin.add(t.dpt, G[PTX_TB_PP_B], BL, C, C);
     // qkv
@@ -1138,7 +1214,7 @@ int ptx_train_block_bwd(const PtxTrainBlock *ap, void *stream)
         PTX_LAUNCHED("k_t_colpart");
         fin.add(t.p_qkv, G[PTX_TB_QKV_B], chunks, 3l * C, 3l * C);
     }
-    PTX_TRY(dx_gemm(t.dqkv, P[PTX_TB_QKV_W], t.wT, t.dxln, R, 3 * C, C, st));
+    PTX_TRY(dx_gemm(t.dqkv, t.wT[0], t.dxln, R, 3 * C, C, st));
     PTX_TRY(dw_gemm(t.dqkv, s.xln, G[PTX_TB_QKV_W], R, 3 * C, C, t.ks[0], t.p_w[0], fin, st));
     // norm1 + residual -> dx;  slot-bias table gradient = sum over the scenes of dxln
     {

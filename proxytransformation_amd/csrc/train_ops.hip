@@ -644,8 +644,9 @@ __global__ void k_slotbias_fwd(const float *pb, const float *pc, const float *pr
     const float v = ly0 * (lx0 * p[y0 * 4 + x0] + lx1 * p[y0 * 4 + x1]) + ly1 * (lx0 * p[y1 * 4 + x0] + lx1 * p[y1 * 4 + x1]);
     out[i] = v + (pc[(size_t)j * s + y] + pr[(size_t)j * s + x]);
 }
-// one wave per kept slot j: the C table gradients of the slot are staged in LDS, then lane o computes output o
-// (16 taps of pb, s entries of pc, s entries of pr; s <= 23) by walking them in a fixed order
+// one wave per kept slot j: the C table gradients of the slot are staged in LDS; the 16 taps of pb are dealt to 16 x 4 lanes
+// (four interleaved quarters of the grid per tap, combined across the quad in lane order), then lanes 0 .. 2 s - 1 sum the rows
+// (pc) and the columns (pr).  (r04: one lane per tap walked all C entries with four compares each -- 32 us per call)
 __global__ __launch_bounds__(256) void k_slotbias_bwd(const float *dtab, int Mk, int s, int C, float *dpb, float *dpc, float *dpr)
 {
     __shared__ float g[4][512];
@@ -655,29 +656,30 @@ __global__ __launch_bounds__(256) void k_slotbias_bwd(const float *dtab, int Mk,
     for (int i = lane; i < C; i += 64) g[wv][i] = dtab[(size_t)j * C + i];
     // same wave: LDS accesses complete in order
     const float *gj = g[wv];
-    if (lane < 16) {                       // pb tap (ty, tx) = (lane / 4, lane % 4)
-        const int ty = lane >> 2, tx = lane & 3;
+    {
+        const int tap = lane >> 2, part = lane & 3, ty = tap >> 2, tx = tap & 3;
         float acc = 0.0f;
-        for (int yx = 0; yx < C; ++yx) {
+        for (int yx = part; yx < C; yx += 4) {
             const int y = yx / s, x = yx - y * s;
             int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
             bilin_taps(y, x, s, y0, y1, x0, x1, ly0, ly1, lx0, lx1);
-            float wy = 0.0f, wx = 0.0f;
-            if (y0 == ty) wy += ly0;
-            if (y1 == ty) wy += ly1;
-            if (x0 == tx) wx += lx0;
-            if (x1 == tx) wx += lx1;
+            const float wy = (y0 == ty ? ly0 : 0.0f) + (y1 == ty ? ly1 : 0.0f);
+            const float wx = (x0 == tx ? lx0 : 0.0f) + (x1 == tx ? lx1 : 0.0f);
             acc = fmaf(gj[yx], wy * wx, acc);
         }
-        dpb[(size_t)j * 16 + lane] = acc;
-    } else if (lane < 16 + s) {            // pc[y]: sum over the row
-        const int y = lane - 16;
+        const float a1 = __shfl_xor(acc, 1);
+        acc = (lane & 1) ? a1 + acc : acc + a1;
+        const float a2 = __shfl_xor(acc, 2);
+        acc = (lane & 2) ? a2 + acc : acc + a2;
+        if (part == 0) dpb[(size_t)j * 16 + tap] = acc;
+    }
+    if (lane < s) {                        // pc[y]: sum over the row
+        const int y = lane;
         float acc = 0.0f;
         for (int x = 0; x < s; ++x) { const int yx = y * s + x; if (yx < C) acc += gj[yx]; }
         dpc[(size_t)j * s + y] = acc;
-    }
-    if (lane >= 40 && lane < 40 + s) {     // pr[x]: sum over the column
-        const int x = lane - 40;
+    } else if (lane >= 32 && lane < 32 + s) {     // pr[x]: sum over the column
+        const int x = lane - 32;
         float acc = 0.0f;
         for (int y = 0; y * s + x < C; ++y) acc += gj[y * s + x];
         dpr[(size_t)j * s + x] = acc;
