@@ -685,6 +685,8 @@ int launch_gemm(const GemmBatch &gb_in, hipStream_t st, int compute_dtype)
         else if (nkg == 2) hipLaunchKernelGGL((k_gemm64x<2, 1>), grid, dim3(256), 0, st, gb);
         else if (nkg == 4) hipLaunchKernelGGL((k_gemm64x<4, 1>), grid, dim3(256), 0, st, gb);
         else if (nkg == 8) hipLaunchKernelGGL((k_gemm64x<8, 1>), grid, dim3(256), 0, st, gb);
+        else if (nkg == 6) hipLaunchKernelGGL((k_gemm64x<2, 3>), grid, dim3(256), 0, st, gb);        // K = 3 C: the qkv input gradient (train)
+        else if (nkg == 12) hipLaunchKernelGGL((k_gemm64x<4, 3>), grid, dim3(256), 0, st, gb);
         else if (nkg == 16) hipLaunchKernelGGL((k_gemm64x<8, 2>), grid, dim3(256), 0, st, gb);       // embed_dim 512: hidden = 2048
         else if (nkg == 32) hipLaunchKernelGGL((k_gemm64x<8, 4>), grid, dim3(256), 0, st, gb);
         else hipLaunchKernelGGL(k_gemm64, grid, dim3(256), 0, st, gb);      // fp32 matrix instruction, any K
