@@ -19,6 +19,7 @@
 #include <cstring>
 
 #include "common.h"
+#include "split3.h"
 
 namespace ptx {
 
@@ -456,6 +457,119 @@ struct FinList {
         return PTX_OK;
     }
 };
+
+// ------------------------------------------------------------------------------ weight gradients: grouped TN products, K in slices
+// C[m][n] = sum_k A[k][m] B[k][n] for A (K, M) = the rows' output gradients and B (K, N) = the rows' inputs, both row-major: the
+// contraction runs over the ROWS (K = B * n tokens), the result is a small (M, N) weight.  All weight gradients of a block
+// in ONE launch; every 64 x 64 tile is cut into `ks` slices of K whose partial products land c_sk floats apart and are summed in
+// slice order by k_t_finalize.  Operands are split into three bf16 parts on the way into LDS (split3.h: six matrix-core
+// products per 16 k, fp32-equivalent) -- the generic strided kernel did this on the fp32 matrix instruction at 1/16 of the bf16
+// rate with scalar requests (r04: 2 x 156 us per step).  A lane requests eight consecutive k of ONE column m (coalesced along m
+// across the wave), which is exactly the eight-k fragment the 32 x 32 x 16 instruction wants: split in registers, one 16-byte
+// LDS write per part, same swizzled row layout as k_gemm64x.
+struct TnProb { const float *A, *B; float *C; int M, N, K, ks; long c_sk; int tiles_n, tiles; };
+struct TnBatch { TnProb p[6]; int blk0[7]; int n; };
+__global__ __launch_bounds__(256) void k_t_tn_gemm(TnBatch tb)
+{
+    constexpr int kPlane = 64 * XROW, kBuf = 6 * kPlane;        // [A1 A2 A3 B1 B2 B3], 64 rows x 32 k each
+    __shared__ __attribute__((aligned(16))) char smem[2 * kBuf];
+    int pi = 0;
+    while (pi + 1 < tb.n && (int)blockIdx.x >= tb.blk0[pi + 1]) ++pi;
+    const TnProb pr = tb.p[pi];
+    const int b = (int)blockIdx.x - tb.blk0[pi], slice = b / pr.tiles, tile = b - slice * pr.tiles;
+    const int m0 = (tile / pr.tiles_n) * 64, n0 = (tile % pr.tiles_n) * 64;
+    const int kper = ((pr.K + pr.ks - 1) / pr.ks + 31) / 32 * 32, kbeg = slice * kper, kend = min(pr.K, kbeg + kper);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 1, wc = wid & 1, li = lane & 31, hh = lane >> 5;
+    const int sm_ = tid & 63, koct = tid >> 6;                  // staging: column sm_ of both tiles, k octet koct of the step
+    const float *Ap = pr.A + min(m0 + sm_, pr.M - 1), *Bp = pr.B + min(n0 + sm_, pr.N - 1);
+    const bool aok = m0 + sm_ < pr.M, bok = n0 + sm_ < pr.N;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    float xa[8], xb[8];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = min(k0 + koct * 8 + u, pr.K - 1);
+            xa[u] = Ap[(size_t)k * pr.M]; xb[u] = Bp[(size_t)k * pr.N];
+        }
+    };
+    auto stash = [&](int k0, int buf) {
+        float ya[8], yb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool kin = k0 + koct * 8 + u < kend;
+            ya[u] = (aok && kin) ? xa[u] : 0.0f; yb[u] = (bok && kin) ? xb[u] : 0.0f;
+        }
+        u32x4 fa[3], fb[3];
+        frag_parts<3>(ya, fa); frag_parts<3>(yb, fb);
+        char *d = smem + buf * kBuf + sm_ * XROW + xswz(sm_, koct);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            *reinterpret_cast<u32x4 *>(d + q * kPlane) = fa[q];
+            *reinterpret_cast<u32x4 *>(d + (3 + q) * kPlane) = fb[q];
+        }
+    };
+    if (kbeg < kend) {
+        fetch(kbeg);
+        stash(kbeg, 0);
+        __syncthreads();
+        int buf = 0;
+        for (int k0 = kbeg; k0 < kend; k0 += 32) {
+            const bool more = k0 + 32 < kend;
+            if (more) fetch(k0 + 32);
+            const char *A_ = smem + buf * kBuf + (wr * 32 + li) * XROW;
+            const char *B_ = smem + buf * kBuf + 3 * kPlane + (wc * 32 + li) * XROW;
+#pragma unroll
+            for (int kg = 0; kg < 2; ++kg) {
+                const int o_ = xswz(li, kg * 2 + hh);
+                u32x4 fa[3], fb[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    fa[q] = *reinterpret_cast<const u32x4 *>(A_ + o_ + q * kPlane);
+                    fb[q] = *reinterpret_cast<const u32x4 *>(B_ + o_ + q * kPlane);
+                }
+                acc = mfma_parts<3>(fa, fb, acc);
+            }
+            if (more) stash(k0 + 32, 1 - buf);
+            __syncthreads();
+            buf = 1 - buf;
+        }
+    }
+    float *Cs = pr.C + (size_t)slice * pr.c_sk;
+    const int n = n0 + wc * 32 + li;
+    if (n < pr.N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (m < pr.M) Cs[(size_t)m * pr.N + n] = acc[r];
+        }
+    }
+}
+struct TnList {
+    TnBatch tb; int blocks;
+    TnList() { tb.n = 0; blocks = 0; tb.blk0[0] = 0; }
+    void add(const float *A, const float *B, float *C, int M, int N, int K, int ks, long c_sk)
+    {
+        TnProb &p = tb.p[tb.n];
+        p = TnProb{A, B, C, M, N, K, ks, c_sk, cdiv(N, 64), cdiv(M, 64) * cdiv(N, 64)};
+        blocks += p.tiles * ks; tb.n += 1; tb.blk0[tb.n] = blocks;
+    }
+    int launch(hipStream_t st)
+    {
+        if (tb.n == 0) return PTX_OK;
+        hipLaunchKernelGGL(k_t_tn_gemm, dim3(blocks), dim3(256), 0, st, tb);
+        PTX_LAUNCHED("k_t_tn_gemm");
+        return PTX_OK;
+    }
+};
+static int tn_ksplit(int M, int N, int K)
+{
+    const int tiles = cdiv(M, 64) * cdiv(N, 64);
+    int ks = 2048 / tiles, kb = K / 128;
+    if (ks > kb) ks = kb;
+    return ks < 1 ? 1 : (ks > 64 ? 64 : ks);
+}
 
 // ------------------------------------------------------------------------------ weight transposes of one block, one launch
 // out (cols, rows) = in (rows, cols)^T for up to six matrices: the input gradients run as NT products against w^T
@@ -964,18 +1078,6 @@ static void block_save_layout(const PtxTrainBlock &a, float *base, BlockBufs &s)
     s.mr = c.take(2 * kBnMaxC);
     s.save_total = c.off;
 }
-static int dw_ksplit(int M, int N, int K)
-{
-    // train.mm: a long contraction into a small result -- slices of K across the chip, summed in slice order
-    const int tiles = cdiv(M, 64) * cdiv(N, 64);
-    if (K >= 1024 && tiles < 512) {
-        int ks = 2048 / tiles; if (ks < 2) ks = 2;
-        int kb = K / 256; if (kb < 2) kb = 2;
-        ks = ks < kb ? ks : kb;
-        return ks > 256 ? 256 : ks;
-    }
-    return 1;
-}
 struct BwdBufs {
     float *dtpre, *dg, *dx2, *dh2, *dhact, *dhpre, *dhln, *dx1, *dob, *dO, *dqkv, *dpt, *dxln, *attn, *wT[5], *dtab;
     float *p_head, *p_ln3, *p_gelu, *p_ln2, *p_qkv, *p_ln1, *p_bn, *p_w[6];
@@ -1000,7 +1102,7 @@ static void block_bwd_layout(const PtxTrainBlock &a, float *base, BwdBufs &t)
     const int Ms[5] = {3 * a.C, a.C, a.C, a.H, a.C}, Ns[5] = {a.C, a.C, a.C, a.C, a.H};
     const int Ks[5] = {(int)R, (int)BL, (int)R, (int)R, (int)R};
     for (int i = 0; i < 5; ++i) {
-        t.ks[i] = dw_ksplit(Ms[i], Ns[i], Ks[i]);
+        t.ks[i] = tn_ksplit(Ms[i], Ns[i], Ks[i]);
         t.p_w[i] = t.ks[i] > 1 ? c.take((size_t)t.ks[i] * Ms[i] * Ns[i]) : nullptr;
     }
     t.total = c.off;
@@ -1036,17 +1138,15 @@ static int dx_gemm(const float *dy, const float *wT, float *dx, int rows, int n_
 {
     return nt_gemm(dy, wT, nullptr, dx, rows, n_in, n_out, st);
 }
-// dw (n_out, n_in) = dy^T x over `rows`; K-sliced partials go to the finalize list
-static int dw_gemm(const float *dy, const float *x, float *dw, int rows, int n_out, int n_in, int ks, float *part, FinList &fin,
-                   hipStream_t st)
+// dw (n_out, n_in) = dy^T x over `rows`: a problem of the block's grouped TN launch; K-sliced partials go to the finalize list
+static int dw_add(TnList &tn, FinList &fin, const float *dy, const float *x, float *dw, int rows, int n_out, int n_in, int ks, float *part)
 {
+    PTX_REQUIRE(tn.tb.n < 6, "ptx_train_block_bwd: too many weight-gradient products");
     if (ks > 1) {
-        PTX_TRY(ptx_op_gemm(dy, x, part, n_out, n_in, rows, 1, n_out, n_in, 1, n_in, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1.0f, 0, ks,
-                            (long)n_out * n_in, st));
+        tn.add(dy, x, part, n_out, n_in, rows, ks, (long)n_out * n_in);
         PTX_REQUIRE(fin.add(part, dw, ks, (long)n_out * n_in, (long)n_out * n_in), "ptx_train_block_bwd: job table full");
-        return PTX_OK;
-    }
-    return ptx_op_gemm(dy, x, dw, n_out, n_in, rows, 1, n_out, n_in, 1, n_in, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1.0f, 0, 1, 0, st);
+    } else tn.add(dy, x, dw, n_out, n_in, rows, 1, 0);
+    return PTX_OK;
 }
 
 }  // namespace ptx
@@ -1141,6 +1241,7 @@ int ptx_train_block_bwd(const PtxTrainBlock *ap, void *stream)
     for (int i = 0; i < PTX_TB_NPARAM; ++i) PTX_REQUIRE(G[i] || P[i] == nullptr, "ptx_train_block_bwd: gradient buffer %d is null", i);
     const Drop1 none = make_drop(0.0f, 0);
     FinList fin;
+    TnList tn;
     {
         TrList tr;
         tr.add(P[PTX_TB_QKV_W], t.wT[0], 3 * C, C); tr.add(P[PTX_TB_PP_W], t.wT[1], C, C); tr.add(P[PTX_TB_PROJ_W], t.wT[2], C, C);
@@ -1175,7 +1276,7 @@ int ptx_train_block_bwd(const PtxTrainBlock *ap, void *stream)
     }
     // fc2
     PTX_TRY(dx_gemm(t.dh2, t.wT[4], t.dhact, R, C, H, st));
-    PTX_TRY(dw_gemm(t.dh2, s.hact, G[PTX_TB_FC2_W], R, C, H, t.ks[4], t.p_w[4], fin, st));
+    PTX_TRY(dw_add(tn, fin, t.dh2, s.hact, G[PTX_TB_FC2_W], R, C, H, t.ks[4], t.p_w[4]));
     // GELU + Dropout
     hipLaunchKernelGGL(k_t_gelu_bwd, dim3(chunks), dim3(256), (size_t)4 * H * 4, st, s.hpre, t.dhact, make_drop(a.p_drop, a.seed[3]), R, H,
                        t.dhpre, t.p_gelu);
@@ -1183,7 +1284,7 @@ int ptx_train_block_bwd(const PtxTrainBlock *ap, void *stream)
     fin.add(t.p_gelu, G[PTX_TB_FC1_B], chunks, H, H);
     // fc1
     PTX_TRY(dx_gemm(t.dhpre, t.wT[3], t.dhln, R, H, C, st));
-    PTX_TRY(dw_gemm(t.dhpre, s.hln, G[PTX_TB_FC1_W], R, H, C, t.ks[3], t.p_w[3], fin, st));
+    PTX_TRY(dw_add(tn, fin, t.dhpre, s.hln, G[PTX_TB_FC1_W], R, H, C, t.ks[3], t.p_w[3]));
     // norm2 + residual; dob = gradient of proj's output
     {
         LnBwdArgs g{s.x1, s.stats2, P[PTX_TB_LN2_W], t.dhln, t.dx2, make_drop(a.p_drop, a.seed[1]), make_drop(a.p_path, a.seed[2]), a.n,
@@ -1196,7 +1297,7 @@ int ptx_train_block_bwd(const PtxTrainBlock *ap, void *stream)
     }
     // proj
     PTX_TRY(dx_gemm(t.dob, t.wT[2], t.dO, R, C, C, st));
-    PTX_TRY(dw_gemm(t.dob, s.O, G[PTX_TB_PROJ_W], R, C, C, t.ks[2], t.p_w[2], fin, st));
+    PTX_TRY(dw_add(tn, fin, t.dob, s.O, G[PTX_TB_PROJ_W], R, C, C, t.ks[2], t.p_w[2]));
     // proxy attention
     {
         TAttn ta = tattn_args(s.qkv, s.pt, a.mask, a.B, a.n, a.L, a.heads, C, a.p_attn, a.seed[0]);
@@ -1206,7 +1307,7 @@ int ptx_train_block_bwd(const PtxTrainBlock *ap, void *stream)
     }
     // proxy_proj
     PTX_TRY(dx_gemm(t.dpt, t.wT[1], a.dproxy, BL, C, C, st));
-    PTX_TRY(dw_gemm(t.dpt, a.proxy, G[PTX_TB_PP_W], BL, C, C, t.ks[1], t.p_w[1], fin, st));
+    PTX_TRY(dw_add(tn, fin, t.dpt, a.proxy, G[PTX_TB_PP_W], BL, C, C, t.ks[1], t.p_w[1]));
     fin.add(t.dpt, G[PTX_TB_PP_B], BL, C, C);
     // qkv
     if (P[PTX_TB_QKV_B]) {
@@ -1215,7 +1316,7 @@ int ptx_train_block_bwd(const PtxTrainBlock *ap, void *stream)
         fin.add(t.p_qkv, G[PTX_TB_QKV_B], chunks, 3l * C, 3l * C);
     }
     PTX_TRY(dx_gemm(t.dqkv, t.wT[0], t.dxln, R, 3 * C, C, st));
-    PTX_TRY(dw_gemm(t.dqkv, s.xln, G[PTX_TB_QKV_W], R, 3 * C, C, t.ks[0], t.p_w[0], fin, st));
+    PTX_TRY(dw_add(tn, fin, t.dqkv, s.xln, G[PTX_TB_QKV_W], R, 3 * C, C, t.ks[0], t.p_w[0]));
     // norm1 + residual -> dx;  slot-bias table gradient = sum over the scenes of dxln
     {
         LnBwdArgs g{a.x, s.stats1, P[PTX_TB_LN1_W], t.dxln, t.dx1, none, none, a.n, R, C, a.dx, nullptr, t.p_ln1};
@@ -1225,6 +1326,7 @@ int ptx_train_block_bwd(const PtxTrainBlock *ap, void *stream)
         fin.add(t.p_ln1 + C, G[PTX_TB_LN1_B], chunks, C, 2l * C);
     }
     fin.add(t.dxln, t.dtab, a.B, (long)a.n * C, (long)a.n * C);
+    PTX_TRY(tn.launch(st));                                  // every weight gradient of the block
     PTX_TRY(fin.launch(st));
     PTX_TRY(ptx_op_slotbias_bwd(t.dtab, a.n, a.s, C, G[PTX_TB_PB], G[PTX_TB_PC], G[PTX_TB_PR], st));
     return PTX_OK;
