@@ -214,6 +214,7 @@ class ProxyTransformationNormReverse(nn.Module):
         self._lanes: Dict[tuple, _Lane] = {}
         self._train_calls = 0
         self._train_checked = None
+        self._train_live = None              # train mode: the parameters that receive a gradient (one-node step)
         self._train_side = None              # train mode: side stream of the image branch, per device
         self._train_pin = None               # train mode: pinned words + event of the early count read-back, per batch size
         ProxyTransformationNormReverse._instances += 1
@@ -239,7 +240,7 @@ class ProxyTransformationNormReverse(nn.Module):
     # host caches that hold ctypes pointers / device scratch: never copied or pickled (copy.deepcopy(model),
     # torch.save(model), EMA / SWA copies made after the first forward); a copy rebuilds them on its first call
     _HOST_CACHES = dict(_tensors=None, _slots=None, _lanes=None, _lin_t=None, _wkey=None, _wstruct=None, _prep=None,
-                        _lin=None, _shapes=None, _graph_keepalive=None, _train_pin=None, _train_side=None)
+                        _lin=None, _shapes=None, _graph_keepalive=None, _train_pin=None, _train_side=None, _train_live=None)
 
     def __getstate__(self):
         state = self.__dict__.copy()
@@ -675,6 +676,7 @@ class ProxyTransformationNormReverse(nn.Module):
         if B > _MAX_SCENES_PER_CALL:
             raise RuntimeError(f"train mode takes at most {_MAX_SCENES_PER_CALL} scenes per call (got {B})")
         if self._train_checked != str(dev):
+            self._train_live = None
             # layout of every parameter / buffer: once per (device, storage generation) -- invalidate_weights() (load_state_dict,
             # .to(), train() / eval()) asks for it again; walking the state_dict on every step cost 0.1 ms
             for name, t in self.state_dict(keep_vars=True).items():

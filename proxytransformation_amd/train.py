@@ -40,6 +40,7 @@ _FUSED_ATTN = os.environ.get("PTX_TRAIN_FUSED_ATTN", "1") != "0"
 _FUSED_BLOCK = os.environ.get("PTX_TRAIN_FUSED_BLOCK", "1") != "0"
 _FUSED_IMG = os.environ.get("PTX_TRAIN_FUSED_IMG", "1") != "0"
 _SIDE_STREAM = os.environ.get("PTX_TRAIN_SIDE_STREAM", "1") != "0"
+_ONE_NODE = os.environ.get("PTX_TRAIN_ONE_NODE", "1") != "0"
 _IMG_POS = int(os.environ.get("PTX_TRAIN_IMG_POS", "1"))     # where the image branch is enqueued: 0 first, 1 after the selection,
                                                               # 2 before the text block, 3 after it
 
@@ -697,7 +698,7 @@ class _ImgPool(torch.autograd.Function):
 
 
 def _imgpool_ok(img3, C, heads):
-    nimg, Cin, hw = img3.shape
+    nimg, Cin, hw = img3 if isinstance(img3, tuple) else img3.shape
     return _FUSED_IMG and heads == 8 and hw <= 256 and Cin % 8 == 0 and Cin <= 2048 and C % 64 == 0 and C <= 512 and nimg <= 65535
 
 
@@ -815,20 +816,26 @@ def _block_fused_ok(mod, blk, head, n, L):
             and mod.embed_dim <= 512 and blk.mlp.fc1.weight.shape[0] <= 2048)
 
 
+def _block_cfg(mod, blk, out_norm, head, head_bn, B, n, L, seeds):
+    """(cfg tuple, parameters in PTX_TB_* order) of one fused block call."""
+    a = blk.attn
+    cfg = (B, n, L, mod.embed_dim, blk.mlp.fc1.weight.shape[0], mod.num_heads, a.pc_bias.shape[2], head.weight.shape[0],
+           blk.norm1.eps, blk.norm2.eps, out_norm.eps, head_bn.eps, head_bn.momentum, float(mod.attn_drop_rate),
+           float(mod.drop_rate), float(mod._dpr_last(blk)), tuple(seeds))
+    params = (blk.norm1.weight, blk.norm1.bias, a.pb_bias, a.pc_bias, a.pr_bias, a.qkv.weight, a.qkv.bias, a.proxy_proj.weight,
+              a.proxy_proj.bias, a.proj.weight, a.proj.bias, blk.norm2.weight, blk.norm2.bias, blk.mlp.fc1.weight, blk.mlp.fc1.bias,
+              blk.mlp.fc2.weight, blk.mlp.fc2.bias, out_norm.weight, out_norm.bias, head.weight, head.bias, head_bn.weight,
+              head_bn.bias)
+    return cfg, params
+
+
 def _block(mod, blk, out_norm, head, head_bn, xa, xb, proxy2d, mask_u8, B, n, L, seeds):
     """One ProxyBlock in train mode (PRE:273-276) + trailing LayerNorm + Linear head + BatchNorm1d (PRE:441-446)."""
     C, heads = mod.embed_dim, mod.num_heads
     a = blk.attn
     if xa is xb and _block_fused_ok(mod, blk, head, n, L):
-        cfg = (B, n, L, C, blk.mlp.fc1.weight.shape[0], heads, a.pc_bias.shape[2], head.weight.shape[0], blk.norm1.eps,
-               blk.norm2.eps, out_norm.eps, head_bn.eps, head_bn.momentum, float(mod.attn_drop_rate), float(mod.drop_rate),
-               float(mod._dpr_last(blk)), tuple(seeds))
-        t = _BlockFused.apply(xa, proxy2d, mask_u8, cfg, head_bn.running_mean, head_bn.running_var,
-                              blk.norm1.weight, blk.norm1.bias, a.pb_bias, a.pc_bias, a.pr_bias, a.qkv.weight, a.qkv.bias,
-                              a.proxy_proj.weight, a.proxy_proj.bias, a.proj.weight, a.proj.bias, blk.norm2.weight, blk.norm2.bias,
-                              blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias, out_norm.weight,
-                              out_norm.bias, head.weight, head.bias, head_bn.weight, head_bn.bias)
-        return t
+        cfg, params = _block_cfg(mod, blk, out_norm, head, head_bn, B, n, L, seeds)
+        return _BlockFused.apply(xa, proxy2d, mask_u8, cfg, head_bn.running_mean, head_bn.running_var, *params)
     if xa is xb:
         xa, xb = fork(xa, 2)
     s = a.pc_bias.shape[2]
@@ -869,9 +876,15 @@ def forward_train(mod, points: List[torch.Tensor], text_feats, text_mask, img_fe
     M, K, Mt, Mk, C = mod.num_cluster, mod.num_sub, shape.Mt, shape.Mk, mod.embed_dim
     Kd = Mt - Mk
     i32 = dict(dtype=torch.int32, device=dev)
-    pts = torch.stack([p.detach().to(_F32) for p in points]).contiguous()          # PRE:426-427
     mod._train_calls += 1
     seeds = site_seeds(torch.initial_seed(), mod._train_calls, mod._instance_salt)
+    if _one_node_ok(mod, (B * img_feat.shape[1], mod.input_dim, mod.img_spacial_dim ** 2), Mk, text_feats.shape[1], img_feat.shape[1]):
+        st8 = dict(args=(mod, points, text_mask, shape, ws, order_override), seeds=seeds)
+        if getattr(mod, "_train_live", None) is None:
+            mod._train_live = live_params(mod)              # dropped with the layout check (module.invalidate_weights)
+        outs = _TrainStep.apply(st8, text_feats, img_feat, *mod._train_live)
+        return list(outs), st8["aux"]
+    pts = torch.stack([p.detach().to(_F32) for p in points]).contiguous()          # PRE:426-427
 
     V = img_feat.shape[1]
 
@@ -1006,3 +1019,212 @@ def forward_train(mod, points: List[torch.Tensor], text_feats, text_mask, img_fe
                centers=centers, translate=translate, transform=transform, point_proxy=pp, img_proxy=img_proxy,
                kcenter=kcenter, opos=opos)
     return outs, aux
+
+
+# --------------------------------------------------------------------------- the whole float half as ONE autograd node
+# r04: with every stage fused the step was host-bound again, and a third of the host time was autograd itself: ~12 custom
+# Function.apply calls forward, as many engine callbacks backward, ~60 AccumulateGrad hand-overs, stream bookkeeping per node.
+# The graph of this path is static, so the training forward below runs the SAME node bodies (their static forward / backward
+# methods, on a plain context object) in program order inside one Function, and its backward walks them in reverse with the
+# gradient sums written out.  The per-operator nodes above remain the unit-tested building blocks and the fallback for shapes
+# outside the fused kernels' range.
+class _Ctx:
+    """What a node body expects of its ``ctx``."""
+
+    def __init__(self, needs=()):
+        self.needs_input_grad = needs
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+
+def _one_node_ok(mod, img3, n, L, V):
+    return (_ONE_NODE and _imgpool_ok(img3, mod.embed_dim, mod.num_heads) and
+            _block_fused_ok(mod, mod.textformer[-1], mod.text_trans, n, L) and _block_fused_ok(mod, mod.imgformer[-1], mod.img_trans, n, V))
+
+
+class _TrainStep(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, st8, text_feats, img_feat, *params):
+        mod, points, text_mask, shape, ws, order_override = st8["args"]
+        lib = _abi.lib()
+        dev = points[0].device
+        st = _st()
+        B, N = len(points), points[0].shape[0]
+        M, K, Mt, Mk, C = mod.num_cluster, mod.num_sub, shape.Mt, shape.Mk, mod.embed_dim
+        Kd = Mt - Mk
+        i32 = dict(dtype=torch.int32, device=dev)
+        pts = torch.stack([p.detach().to(_F32) for p in points]).contiguous()          # PRE:426-427
+        seeds = st8["seeds"]
+        T = {}                                                        # the tape: one context per node body
+        # ---- index half, part 1 + offset network (PRE:55-62)
+        minmax = torch.empty((B, 2, 3), dtype=_F32, device=dev)
+        c0 = torch.empty((B, M, 3), dtype=_F32, device=dev)
+        lin = mod._train_lin(dev)
+        enc_scratch = torch.empty((max(B * 6, 64),), **i32)
+        _ck(lib.ptx_grid_centers(_p(pts), B, N, _p(lin), mod.grid_size, 4.0, _p(minmax), _p(c0), _p(enc_scratch),
+                                 enc_scratch.numel() * 4, st), "ptx_grid_centers")
+        idx1 = torch.empty((B, M, K), **i32)
+        cl1 = torch.empty((B, M, K, 3), dtype=_F32, device=dev)
+        _ck(lib.ptx_ball_query(_p(c0), _p(pts), B, M, N, K, 3.0, _p(idx1), _p(cl1), None, st), "ptx_ball_query")
+        off = mod.get_deformable_cluster.get_offsets
+        bn = off.mlp[1]
+        T["off"] = _Ctx((False,) * 11)
+        pooled = _SlotNet.forward(T["off"], c0.view(B * M, 3), cl1, off.mlp[0].weight, off.mlp[0].bias, bn.weight, bn.bias,
+                                  bn.running_mean, bn.running_var, bn.eps, bn.momentum, False)
+        T["oh"] = _Ctx()
+        centers = _OffsetHead.forward(T["oh"], pooled, off.channel_mapper.weight, c0, minmax, M, 4.0)
+        # ---- index half, part 2 (PRE:65, 352-420, 478-523)
+        cdet = centers
+        if mod._centers_override is not None:
+            cdet = mod._centers_override.to(device=dev, dtype=_F32).reshape(B * M, 3).contiguous()
+        idx2 = torch.empty((B, M, K), **i32)
+        cl2 = torch.empty((B, M, K, 3), dtype=_F32, device=dev)
+        pad = torch.empty((B, M), **i32)
+        _ck(lib.ptx_ball_query(_p(cdet), _p(pts), B, M, N, K, 3.0, _p(idx2), _p(cl2), _p(pad), st), "ptx_ball_query")
+        order = torch.empty((B, Mt), **i32)
+        picks = torch.empty((B, max(Kd, 1)), **i32)
+        keep = torch.empty((B, Mk), **i32)
+        kcenter_i = torch.empty((B, Mk, 3), dtype=_F32, device=dev)
+        kcluster = torch.empty((B, Mk, K, 3), dtype=_F32, device=dev)
+        kidx = torch.empty((B, Mk, K), **i32)
+        drop_idx = torch.empty((B, max(Kd, 1) * K), **i32)
+        tag = torch.zeros((B, N), **i32)
+        oo = None if order_override is None else order_override.to(device=dev, dtype=torch.int32).contiguous()
+        _ck(lib.ptx_select_clusters(ctypes.byref(shape), _p(idx2), _p(cdet), _p(cl2), _p(pad), _p(oo), _p(order), _p(picks),
+                                    _p(keep), _p(kcenter_i), _p(kcluster), _p(kidx), _p(drop_idx), _p(tag), st), "ptx_select_clusters")
+        # ---- image branch on the side stream, beside the selection (PRE:449-450)
+        V = img_feat.shape[1]
+        hw = mod.img_spacial_dim ** 2
+        ap = mod.attn_pool2d
+        img3 = _c(img_feat).view(B * V, mod.input_dim, hw)
+        main = torch.cuda.current_stream(dev)
+        side = _side_stream(mod, dev) if _SIDE_STREAM else None
+        if side is not None:
+            side.wait_stream(main)
+        with torch.cuda.stream(side if side is not None else main):
+            T["ip"] = _Ctx((ctx.needs_input_grad[2],))
+            o = _ImgPool.forward(T["ip"], img3, mod.channel_mapper.weight, mod.channel_mapper.bias, ap.positional_embedding,
+                                 ap.q_proj.weight, ap.q_proj.bias, ap.k_proj.weight, ap.k_proj.bias, ap.v_proj.weight, ap.v_proj.bias,
+                                 mod.num_heads)
+            T["cp"] = _Ctx((True, True, True))
+            y = _Linear.forward(T["cp"], o, ap.c_proj.weight, ap.c_proj.bias)
+            T["ni"] = _Ctx()
+            img_proxy = _LayerNorm.forward(T["ni"], y, mod.norm_img.weight, mod.norm_img.bias, mod.norm_img.eps)
+        # ---- output positions; the list lengths of PRE:467 are copied out now and awaited at the very end
+        ntiles = (N + 2047) // 2048
+        tile_counts = torch.empty((B * ntiles,), **i32)
+        opos = torch.empty((B, N), **i32)
+        counts = torch.empty((B,), **i32)
+        _ck(lib.ptx_op_out_positions(_p(tag), B, N, _p(tile_counts), _p(opos), _p(counts), st), "ptx_op_out_positions")
+        if getattr(mod, "_train_pin", None) is None:
+            mod._train_pin = {}
+        pin = mod._train_pin.get((B, st))
+        if pin is None:
+            pin = mod._train_pin[(B, st)] = (torch.empty((B,), dtype=torch.int32, pin_memory=True), torch.cuda.Event())
+        pin[1].synchronize()
+        pin[0].copy_(counts, non_blocking=True)
+        pin[1].record()
+        src = torch.empty((B * Mk,), **i32)
+        _ck(lib.ptx_op_keep_rows(_p(order), _p(keep), B, M, Mt, Mk, _p(src), st), "ptx_op_keep_rows")
+        # ---- float half (PRE:437-455)
+        T["g"] = _Ctx()
+        kcenter = _GatherRows.forward(T["g"], centers, src)
+        enc = mod.simple_encoder
+        ebn = enc.mlp[1]
+        T["enc"] = _Ctx((True,) + (False,) * 10)
+        pp = _SlotNet.forward(T["enc"], kcenter, kcluster, enc.mlp[0].weight, enc.mlp[0].bias, ebn.weight, ebn.bias, ebn.running_mean,
+                              ebn.running_var, ebn.eps, ebn.momentum, True)
+        L = text_feats.shape[1]
+        tf2 = _c(text_feats.to(_F32)).view(B * L, C)
+        cfg_t, par_t = _block_cfg(mod, mod.textformer[-1], mod.text_norm[-1], mod.text_trans, mod.text_trans_norm, B, Mk, L, seeds[0])
+        T["tb"] = _Ctx()
+        translate = _BlockFused.forward(T["tb"], pp, tf2, text_mask, cfg_t, mod.text_trans_norm.running_mean,
+                                        mod.text_trans_norm.running_var, *par_t)
+        if side is not None:
+            img_proxy.record_stream(main)
+            main.wait_stream(side)
+        cfg_i, par_i = _block_cfg(mod, mod.imgformer[-1], mod.img_norm[-1], mod.img_trans, mod.img_trans_norm, B, Mk, V, seeds[1])
+        T["ib"] = _Ctx()
+        transform = _BlockFused.forward(T["ib"], pp, img_proxy, None, cfg_i, mod.img_trans_norm.running_mean,
+                                        mod.img_trans_norm.running_var, *par_i)
+        # ---- submanifold reshape + scatter + drop (PRE:459-467)
+        pin[1].synchronize()
+        n_keep = pin[0].tolist()
+        T["aff"] = _Ctx()
+        outs = _AffineApply.forward(T["aff"], kcenter, translate, transform, pts, tag, opos, kidx, kcluster, shape, ws, n_keep)
+        st8["aux"] = dict(idx2=idx2, order=order, picks=picks[:, :Kd], keep=keep, kidx=kidx, drop_idx=drop_idx[:, : Kd * K],
+                          centers=centers, translate=translate, transform=transform, point_proxy=pp, img_proxy=img_proxy,
+                          kcenter=kcenter, opos=opos)
+        ctx.tape = T
+        ctx.streams = (main, side)
+        ctx.meta = (text_feats.shape, text_feats.dtype, img_feat.shape, [id(p) for p in params],
+                    dict(off=(off.mlp[0].weight, off.mlp[0].bias, bn.weight, bn.bias), oh=off.channel_mapper.weight,
+                         enc=(enc.mlp[0].weight, enc.mlp[0].bias, ebn.weight, ebn.bias), tb=par_t, ib=par_i,
+                         ip=(mod.channel_mapper.weight, mod.channel_mapper.bias, ap.positional_embedding, ap.q_proj.weight,
+                             ap.q_proj.bias, ap.k_proj.weight, ap.k_proj.bias, ap.v_proj.weight, ap.v_proj.bias),
+                         cp=(ap.c_proj.weight, ap.c_proj.bias), ni=(mod.norm_img.weight, mod.norm_img.bias)))
+        return outs
+
+    @staticmethod
+    def backward(ctx, *douts):
+        T = ctx.tape
+        main, side = ctx.streams
+        tf_shape, tf_dtype, img_shape, pids, P = ctx.meta
+        G = {}                                               # id(parameter) -> gradient
+
+        def put(params, grads):
+            for p_, g_ in zip(params, grads):
+                if p_ is not None and g_ is not None:
+                    G[id(p_)] = g_
+
+        dkc_aff, dtranslate, dtransform = _AffineApply.backward(T["aff"], *douts)[:3]
+        r = _BlockFused.backward(T["ib"], dtransform)
+        dpp_i, dproxy_i = r[0], r[1]
+        put(P["ib"], r[6:])
+        # image branch on its side stream, overlapping the text block's backward below
+        if side is not None:
+            dproxy_i.record_stream(side)
+            side.wait_stream(main)
+        with torch.cuda.stream(side if side is not None else main):
+            r = _LayerNorm.backward(T["ni"], dproxy_i)
+            put(P["ni"], r[1:3])
+            r2 = _Linear.backward(T["cp"], r[0])
+            put(P["cp"], r2[1:3])
+            r3 = _ImgPool.backward(T["ip"], r2[0])
+            put(P["ip"], r3[1:10])
+            dimg = r3[0]
+            side_grads = [g for g in (list(r[1:3]) + list(r2[1:3]) + list(r3[:10])) if g is not None]
+        r = _BlockFused.backward(T["tb"], dtranslate)
+        dpp_t, dtf2 = r[0], r[1]
+        put(P["tb"], r[6:])
+        dpp = add_(dpp_t, dpp_i)
+        r = _SlotNet.backward(T["enc"], dpp)
+        put(P["enc"], r[2:6])
+        dkcenter = add_(r[0], _c(dkc_aff))
+        dcenters = _GatherRows.backward(T["g"], dkcenter)[0]
+        r = _OffsetHead.backward(T["oh"], dcenters)
+        G[id(P["oh"])] = r[1]
+        r = _SlotNet.backward(T["off"], r[0])
+        put(P["off"], r[2:6])
+        if side is not None:
+            for g in side_grads:
+                g.record_stream(main)
+            main.wait_stream(side)
+        dtext = dtf2.view(tf_shape).to(tf_dtype) if ctx.needs_input_grad[1] else None
+        dimg = dimg.view(img_shape) if (dimg is not None and ctx.needs_input_grad[2]) else None
+        return (None, dtext, dimg, *[G.get(i) for i in pids])
+
+
+def live_params(mod):
+    """The parameters that receive a gradient (the last block of each list and everything outside the block lists: SURVEY H8)."""
+    off, enc, ap = mod.get_deformable_cluster.get_offsets, mod.simple_encoder, mod.attn_pool2d
+    mods = [off, enc, mod.channel_mapper, ap, mod.norm_img, mod.textformer[-1], mod.text_norm[-1], mod.text_trans, mod.text_trans_norm,
+            mod.imgformer[-1], mod.img_norm[-1], mod.img_trans, mod.img_trans_norm]
+    out, seen = [], set()
+    for m_ in mods:
+        for p_ in m_.parameters():
+            if id(p_) not in seen:
+                seen.add(id(p_)); out.append(p_)
+    return out
