@@ -683,11 +683,7 @@ class _ImgPool(torch.autograd.Function):
         a = ctx.args
         do = _c(do)
         dev = do.device
-        numel = [(t.numel() + 63) // 64 * 64 for t in params]
-        flat = torch.empty((sum(numel),), dtype=_F32, device=dev)
-        grads, off = [], 0
-        for t, nn_ in zip(params, numel):
-            grads.append(flat[off: off + t.numel()].view(t.shape)); off += nn_
+        grads = _flat_grads(params, dev)
         dimg = torch.empty_like(img) if ctx.needs_input_grad[0] else None
         tmp = torch.empty((ctx.bwd_floats,), dtype=_F32, device=dev)
         a.dout, a.dimg, a.tmp, a.tmp_floats = _p(do), _p(dimg), _p(tmp), ctx.bwd_floats
@@ -749,6 +745,33 @@ def site_seeds(torch_seed: int, call: int, salt: int = 0):
     return [[base + _SITES_PER_BLOCK * b + (0 if i == 0 else i + 1) for i in range(6)] for b in range(2)]
 
 
+def _flat_grads(params, dev, slots=None):
+    """One allocation for the gradients of ``params`` (None entries stay None): a tuple of tensors shaped like the parameters,
+    each starting on a 256-byte boundary; ``slots[i]`` (a ctypes pointer array) receives the addresses.  One split + one view per
+    multi-dimensional parameter instead of a slice and a view each (r04: 110 tensor operations per step for two blocks)."""
+    sizes = [0 if t is None else (t.numel() + 63) // 64 * 64 for t in params]
+    flat = torch.empty((sum(sizes),), dtype=_F32, device=dev)
+    base = flat.data_ptr()
+    parts = flat.split_with_sizes(sizes)
+    grads, off = [], 0
+    for i, t in enumerate(params):
+        if t is None:
+            grads.append(None)
+            if slots is not None:
+                slots[i] = None
+            continue
+        g, n = parts[i], t.numel()
+        if sizes[i] != n:
+            g = g[:n]
+        if t.dim() != 1:
+            g = g.view(t.shape)
+        grads.append(g)
+        if slots is not None:
+            slots[i] = base + 4 * off
+        off += sizes[i]
+    return grads
+
+
 class _BlockFused(torch.autograd.Function):
     """ProxyBlock + trailing LayerNorm + Linear head + BatchNorm1d as ONE node: forward and backward are one C call each
     (ptx_train_block_fwd / _bwd, csrc/train_fused.hip) that enqueue every kernel of the chain from C++."""
@@ -794,15 +817,7 @@ class _BlockFused(torch.autograd.Function):
         a = ctx.args
         dout = _c(dout)
         dev = dout.device
-        numel = [0 if t is None else (t.numel() + 63) // 64 * 64 for t in params]
-        flat = torch.empty((sum(numel),), dtype=_F32, device=dev)           # every parameter gradient, one allocation
-        grads, off = [], 0
-        for i, t in enumerate(params):
-            if t is None:
-                grads.append(None); a.grad[i] = None
-            else:
-                g = flat[off: off + t.numel()].view(t.shape)
-                grads.append(g); a.grad[i] = _p(g); off += numel[i]
+        grads = _flat_grads(params, dev, a.grad)                            # every parameter gradient, one allocation
         dx, dproxy = torch.empty_like(x), torch.empty_like(proxy)
         tmp = torch.empty((ctx.bwd_floats,), dtype=_F32, device=dev)
         a.dout, a.dx, a.dproxy, a.tmp, a.tmp_floats = _p(dout), _p(dx), _p(dproxy), _p(tmp), ctx.bwd_floats

@@ -13,10 +13,13 @@ dev = torch.device("cuda:0")
 args = ([torch.from_numpy(p).to(dev) for p in pts], {"text_feats": torch.from_numpy(text).to(dev).requires_grad_(True),
         "text_token_mask": torch.from_numpy(mask).to(dev)}, torch.from_numpy(img).to(dev).requires_grad_(True))
 leaves = list(m.parameters()) + [args[1]["text_feats"], args[2]]
+gos = None
 def step():
+    global gos
     for t in leaves: t.grad = None
     outs = m(*args)
-    sum(o.sum() for o in outs).backward()
+    if gos is None: gos = [torch.ones_like(o) for o in outs]
+    torch.autograd.backward(outs, gos)
 torch.autograd.set_multithreading_enabled(False)
 for _ in range(3): step()
 torch.cuda.synchronize()
@@ -30,14 +33,13 @@ for _ in range(n):
     t1 = time.perf_counter()
     outs = m(*args)
     t2 = time.perf_counter()
-    loss = sum(o.sum() for o in outs)
     t3 = time.perf_counter()
-    loss.backward()
+    torch.autograd.backward(outs, gos)
     t4 = time.perf_counter()
     acc["zero"] += t1 - t0; acc["fwd"] += t2 - t1; acc["loss"] += t3 - t2; acc["bwd"] += t4 - t3
 print({k: round(1e3 * v / n, 3) for k, v in acc.items()}, "ms per step (host, GPU idle at entry)")
 pr = cProfile.Profile(); pr.enable()
-for _ in range(5): step()
+for _ in range(100): step()
 torch.cuda.synchronize()
 pr.disable()
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(45); print(s.getvalue()[:9000])
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(40); print(s.getvalue()[:9000])
