@@ -157,7 +157,7 @@ def work_model(cfg, B, dt_bytes):
     return byts, flops
 
 
-def train_step_ms(device, steps=8):
+def train_step_ms(device, steps=20):
     """One training step (train-mode forward + backward through every live parameter, text_feats and img_feat) at the
     reference's training shape -- CFG:41, 108, 145: 6 scenes per GPU, 100k points, gs = 12, 3 + 3 blocks, 20 views."""
     from proxytransformation_amd.synth import PreshapeConfig
@@ -173,21 +173,35 @@ def train_step_ms(device, steps=8):
 
     leaves = list(mod.parameters()) + [args[1]["text_feats"], args[2]]
 
-    def step():
+    gos = {}
+
+    def step(scalar_loss=False):
         for t in leaves:                # optimizer.zero_grad(set_to_none=True): gradients are written, not accumulated
             t.grad = None
         outs = mod(*args)
-        sum(o.sum() for o in outs).backward()
-    for _ in range(3):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    return dict(ms=round(1e3 * (time.perf_counter() - t0) / steps, 3), steps=steps,
+        if scalar_loss:                 # a loss built from the outputs: six reductions + their backward on top of the neck's own work
+            sum(o.sum() for o in outs).backward()
+            return
+        # the neck sits in the middle of the detector: the gradients of its outputs ARRIVE from the stages behind it
+        key = tuple(o.shape[0] for o in outs)
+        if key not in gos:
+            gos[key] = [torch.ones_like(o) for o in outs]
+        torch.autograd.backward(outs, gos[key])
+
+    def timed(scalar_loss):
+        for _ in range(3):
+            step(scalar_loss)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(scalar_loss)
+        torch.cuda.synchronize()
+        return round(1e3 * (time.perf_counter() - t0) / steps, 3)
+    ms = timed(False)
+    return dict(ms=ms, ms_with_scalar_loss=timed(True), steps=steps,
                 shape="6 scenes x 100k points, gs=12 -> 691 kept clusters, L=20, V=20 fp32 features, 3+3 blocks (CFG:41,108,145); "
-                      "drop rates 0.2; forward + backward")
+                      "drop rates 0.2; forward + backward, output gradients handed in (ms) / a scalar loss built from the "
+                      "outputs (ms_with_scalar_loss)")
 
 
 def cpu_baseline(cfg, sd, n_scenes):
