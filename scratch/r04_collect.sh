@@ -8,5 +8,6 @@ cp $O/r04_timeline_bf16.txt $P/r04_final_timeline_bf16.txt; cp $O/r04_timeline_f
 for n in b1 b32 cfg1 cfg4 cfg4_b6 cfg5 cfg5_b16 driver_args; do cp $F/bench_$n.json $P/r04_final_bench_$n.json; done
 cp $F/r04_timeline_cfg4_b6.txt $P/r04_final_timeline_cfg4_b6.txt
 grep -v amdgpu.ids $F/vox_time.txt > $P/r04_final_vox_time.txt; grep -v amdgpu.ids $F/ingest_time.txt > $P/r04_final_ingest_time.txt
-cp $F/train_kernel_stats.csv $P/r04_train_kernel_stats.csv; grep -v amdgpu.ids $F/train_time.txt > $P/r04_train_time.txt
+T=gpurun_out/r04train
+cp $T/r04_train_kernel_stats.csv $T/r04_train_step_trace.txt $P/; grep -v amdgpu.ids $T/r04_train_time.txt > $P/r04_train_time.txt
 ls -la $P | grep r04 | wc -l

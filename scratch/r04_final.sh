@@ -13,6 +13,5 @@ python scratch/vox_time.py > $F/vox_time.txt 2>&1
 python scratch/ingest_time.py 4 > $F/ingest_time.txt 2>&1
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $F/vox -o v -- python $R/scratch/vox_time.py > /dev/null 2>&1 )
 grep -i "vox\|fillBuffer" $(find $F/vox -name "*kernel_stats.csv" | head -1) | cut -c1-160 >> $F/vox_time.txt
-bash scratch/train_prof.sh r04_train > $F/train_prof.log 2>&1
-cp $R/gpurun_out/r04_train/train_kernel_stats.csv $F/ 2>/dev/null; cp $R/gpurun_out/r04_train/time.txt $F/train_time.txt 2>/dev/null
+bash scratch/r04_train_final.sh > $F/train_final.log 2>&1          # -> gpurun_out/r04train/r04_train_{time.txt,kernel_stats.csv,step_trace.txt}
 ls $O $F
