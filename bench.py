@@ -198,7 +198,11 @@ def train_step_ms(device, steps=20):
         torch.cuda.synchronize()
         return round(1e3 * (time.perf_counter() - t0) / steps, 3)
     ms = timed(False)
-    return dict(ms=ms, ms_with_scalar_loss=timed(True), steps=steps,
+    ms_loss = timed(True)
+    mod.compute_dtype = "bf16"          # opt-in: the blocks' Linear layers and their gradients on plain bf16 operands (what --amp gives them)
+    ms_bf16 = timed(False)
+    mod.compute_dtype = "fp32"
+    return dict(ms=ms, ms_with_scalar_loss=ms_loss, ms_bf16_compute=ms_bf16, steps=steps,
                 shape="6 scenes x 100k points, gs=12 -> 691 kept clusters, L=20, V=20 fp32 features, 3+3 blocks (CFG:41,108,145); "
                       "drop rates 0.2; forward + backward, output gradients handed in (ms) / a scalar loss built from the "
                       "outputs (ms_with_scalar_loss)")

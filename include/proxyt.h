@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PTX_ABI_VERSION 8
+#define PTX_ABI_VERSION 9
 
 #define PTX_OK          0
 #define PTX_EINVAL     -1   /* bad shape / null pointer / unsupported size */
@@ -465,6 +465,8 @@ enum { PTX_TB_LN1_W = 0, PTX_TB_LN1_B, PTX_TB_PB, PTX_TB_PC, PTX_TB_PR, PTX_TB_Q
        PTX_TB_FC2_B, PTX_TB_LN3_W, PTX_TB_LN3_B, PTX_TB_HEAD_W, PTX_TB_HEAD_B, PTX_TB_BN_W, PTX_TB_BN_B, PTX_TB_NPARAM };
 typedef struct {
     int32_t B, n, L, C, H, heads, s, nout;     /* s: bias grid side (pc / pr), nout: head width (3 / 9) */
+    int32_t compute_dtype;                     /* 0: fp32-equivalent products (three-way bf16 split); 1: plain bf16 operands, fp32 accumulation, for the
+                                                  five Linear layers of the block and their gradients (what autocast gives them under --amp) */
     float eps1, eps2, eps3, bn_eps, bn_momentum;
     float p_attn, p_drop, p_path;
     uint64_t seed[6];

@@ -13,7 +13,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libproxyt_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 c_float_p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 
@@ -65,7 +65,7 @@ TB_PARAMS = ("ln1_w", "ln1_b", "pb", "pc", "pr", "qkv_w", "qkv_b", "pp_w", "pp_b
 
 
 class PtxTrainBlock(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("B", "n", "L", "C", "H", "heads", "s", "nout")] + \
+    _fields_ = [(n, C.c_int32) for n in ("B", "n", "L", "C", "H", "heads", "s", "nout", "compute_dtype")] + \
                [(n, C.c_float) for n in ("eps1", "eps2", "eps3", "bn_eps", "bn_momentum", "p_attn", "p_drop", "p_path")] + \
                [("seed", C.c_uint64 * 6), ("x", C.c_void_p), ("proxy", C.c_void_p), ("mask", C.c_void_p),
                 ("param", C.c_void_p * len(TB_PARAMS)), ("bn_run_mean", C.c_void_p), ("bn_run_var", C.c_void_p),

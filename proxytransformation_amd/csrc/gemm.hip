@@ -669,6 +669,7 @@ int launch_gemm(const GemmBatch &gb_in, hipStream_t st, int compute_dtype)
         else if (nkg == 2) hipLaunchKernelGGL((k_gemm64x<2, 1, 1>), grid, dim3(256), 0, st, gb);
         else if (nkg == 4) hipLaunchKernelGGL((k_gemm64x<4, 1, 1>), grid, dim3(256), 0, st, gb);
         else if (nkg == 8) hipLaunchKernelGGL((k_gemm64x<8, 1, 1>), grid, dim3(256), 0, st, gb);
+        else if (nkg == 6) hipLaunchKernelGGL((k_gemm64x<2, 3, 1>), grid, dim3(256), 0, st, gb);     // K = 3 C (train: qkv input gradient)
         else { set_error("gemm: K=%d in bf16 mode", kmin); return PTX_EINVAL; }
         PTX_LAUNCHED("k_gemm64x<bf16>");
         return PTX_OK;

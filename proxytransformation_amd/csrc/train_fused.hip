@@ -469,6 +469,7 @@ struct FinList {
 // LDS write per part, same swizzled row layout as k_gemm64x.
 struct TnProb { const float *A, *B; float *C; int M, N, K, ks; long c_sk; int tiles_n, tiles; };
 struct TnBatch { TnProb p[6]; int blk0[7]; int n; };
+template <int NP>     // 3: split operands (fp32-equivalent); 1: plain bf16 operands (compute_dtype 1)
 __global__ __launch_bounds__(256) void k_t_tn_gemm(TnBatch tb)
 {
     constexpr int kPlane = 64 * XROW, kBuf = 6 * kPlane;        // [A1 A2 A3 B1 B2 B3], 64 rows x 32 k each
@@ -502,10 +503,10 @@ __global__ __launch_bounds__(256) void k_t_tn_gemm(TnBatch tb)
             ya[u] = (aok && kin) ? xa[u] : 0.0f; yb[u] = (bok && kin) ? xb[u] : 0.0f;
         }
         u32x4 fa[3], fb[3];
-        frag_parts<3>(ya, fa); frag_parts<3>(yb, fb);
+        frag_parts<NP>(ya, fa); frag_parts<NP>(yb, fb);
         char *d = smem + buf * kBuf + sm_ * XROW + xswz(sm_, koct);
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < NP; ++q) {
             *reinterpret_cast<u32x4 *>(d + q * kPlane) = fa[q];
             *reinterpret_cast<u32x4 *>(d + (3 + q) * kPlane) = fb[q];
         }
@@ -525,11 +526,11 @@ __global__ __launch_bounds__(256) void k_t_tn_gemm(TnBatch tb)
                 const int o_ = xswz(li, kg * 2 + hh);
                 u32x4 fa[3], fb[3];
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
+                for (int q = 0; q < NP; ++q) {
                     fa[q] = *reinterpret_cast<const u32x4 *>(A_ + o_ + q * kPlane);
                     fb[q] = *reinterpret_cast<const u32x4 *>(B_ + o_ + q * kPlane);
                 }
-                acc = mfma_parts<3>(fa, fb, acc);
+                acc = mfma_parts<NP>(fa, fb, acc);
             }
             if (more) stash(k0 + 32, 1 - buf);
             __syncthreads();
@@ -555,10 +556,11 @@ struct TnList {
         p = TnProb{A, B, C, M, N, K, ks, c_sk, cdiv(N, 64), cdiv(M, 64) * cdiv(N, 64)};
         blocks += p.tiles * ks; tb.n += 1; tb.blk0[tb.n] = blocks;
     }
-    int launch(hipStream_t st)
+    int launch(hipStream_t st, int compute_dtype)
     {
         if (tb.n == 0) return PTX_OK;
-        hipLaunchKernelGGL(k_t_tn_gemm, dim3(blocks), dim3(256), 0, st, tb);
+        if (compute_dtype == 1) hipLaunchKernelGGL(k_t_tn_gemm<1>, dim3(blocks), dim3(256), 0, st, tb);
+        else hipLaunchKernelGGL(k_t_tn_gemm<3>, dim3(blocks), dim3(256), 0, st, tb);
         PTX_LAUNCHED("k_t_tn_gemm");
         return PTX_OK;
     }
@@ -1120,6 +1122,7 @@ static int block_check(const PtxTrainBlock *a, bool bwd)
     PTX_REQUIRE(a->x && a->proxy && a->save && a->tmp, "ptx_train_block: null buffer");
     for (int i = 0; i < PTX_TB_NPARAM; ++i)
         PTX_REQUIRE(a->param[i] || i == PTX_TB_QKV_B, "ptx_train_block: parameter %d is null", i);
+    PTX_REQUIRE(a->compute_dtype == 0 || a->compute_dtype == 1, "ptx_train_block: compute_dtype=%d", a->compute_dtype);
     PTX_REQUIRE(a->p_attn >= 0.f && a->p_attn < 1.f && a->p_drop >= 0.f && a->p_drop < 1.f && a->p_path >= 0.f && a->p_path < 1.f,
                 "ptx_train_block: drop rates");
     if (bwd) PTX_REQUIRE(a->dout && a->dx && a->dproxy, "ptx_train_block_bwd: null gradient buffer");
@@ -1127,16 +1130,16 @@ static int block_check(const PtxTrainBlock *a, bool bwd)
     return PTX_OK;
 }
 
-static int nt_gemm(const float *x, const float *w, const float *bias, float *y, int rows, int n_out, int n_in, hipStream_t st)
+static int nt_gemm(const float *x, const float *w, const float *bias, float *y, int rows, int n_out, int n_in, hipStream_t st, int cdt = 0)
 {
     GemmBatch g{}; g.n = 1;
     g.p[0] = GemmProb{x, w, y, bias, nullptr, nullptr, nullptr, rows, n_out, n_in, n_in, n_in, n_out, n_out, 0, 0, EPI_NONE};
-    return launch_gemm(g, st);
+    return launch_gemm(g, st, cdt);
 }
 // dx (rows, n_in) = dy (rows, n_out) @ w (n_out, n_in): NT against the transposed weight
-static int dx_gemm(const float *dy, const float *wT, float *dx, int rows, int n_out, int n_in, hipStream_t st)
+static int dx_gemm(const float *dy, const float *wT, float *dx, int rows, int n_out, int n_in, hipStream_t st, int cdt)
 {
-    return nt_gemm(dy, wT, nullptr, dx, rows, n_in, n_out, st);
+    return nt_gemm(dy, wT, nullptr, dx, rows, n_in, n_out, st, cdt);
 }
 // dw (n_out, n_in) = dy^T x over `rows`: a problem of the block's grouped TN launch; K-sliced partials go to the finalize list
 static int dw_add(TnList &tn, FinList &fin, const float *dy, const float *x, float *dw, int rows, int n_out, int n_in, int ks, float *part)
@@ -1187,28 +1190,28 @@ int ptx_train_block_fwd(const PtxTrainBlock *ap, void *stream)
         hipLaunchKernelGGL(k_t_ln_fwd, dim3(cdiv(R, 4)), dim3(256), 0, st, g);
         PTX_LAUNCHED("k_t_ln_fwd");
     }
-    PTX_TRY(nt_gemm(s.xln, P[PTX_TB_QKV_W], P[PTX_TB_QKV_B], s.qkv, R, 3 * C, C, st));
-    PTX_TRY(nt_gemm(a.proxy, P[PTX_TB_PP_W], P[PTX_TB_PP_B], s.pt, BL, C, C, st));
+    PTX_TRY(nt_gemm(s.xln, P[PTX_TB_QKV_W], P[PTX_TB_QKV_B], s.qkv, R, 3 * C, C, st, a.compute_dtype));
+    PTX_TRY(nt_gemm(a.proxy, P[PTX_TB_PP_W], P[PTX_TB_PP_B], s.pt, BL, C, C, st, a.compute_dtype));
     {
         TAttn t = tattn_args(s.qkv, s.pt, a.mask, a.B, a.n, a.L, a.heads, C, a.p_attn, a.seed[0]);
         t.P1 = s.P1; t.PV = s.PV; t.P2 = s.P2; t.O = s.O;
         PTX_TRY(tattn_fwd(t, st));
     }
-    PTX_TRY(nt_gemm(s.O, P[PTX_TB_PROJ_W], P[PTX_TB_PROJ_B], o, R, C, C, st));
+    PTX_TRY(nt_gemm(s.O, P[PTX_TB_PROJ_W], P[PTX_TB_PROJ_B], o, R, C, C, st, a.compute_dtype));
     {   // x1 = x + DropPath(Dropout(o)); hln = norm2(x1)
         LnFwdArgs g{a.x, o, make_drop(a.p_drop, a.seed[1]), make_drop(a.p_path, a.seed[2]), a.n, P[PTX_TB_LN2_W], P[PTX_TB_LN2_B],
                     nullptr, 1, R, C, a.eps2, s.x1, s.hln, s.stats2};
         hipLaunchKernelGGL(k_t_ln_fwd, dim3(cdiv(R, 4)), dim3(256), 0, st, g);
         PTX_LAUNCHED("k_t_ln_fwd");
     }
-    PTX_TRY(nt_gemm(s.hln, P[PTX_TB_FC1_W], P[PTX_TB_FC1_B], s.hpre, R, H, C, st));
+    PTX_TRY(nt_gemm(s.hln, P[PTX_TB_FC1_W], P[PTX_TB_FC1_B], s.hpre, R, H, C, st, a.compute_dtype));
     {
         const long n4 = (long)R * H / 4;
         hipLaunchKernelGGL(k_t_gelu_drop, dim3((unsigned)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256)), dim3(256), 0, st, s.hpre, n4,
                            make_drop(a.p_drop, a.seed[3]), s.hact);
         PTX_LAUNCHED("k_t_gelu_drop");
     }
-    PTX_TRY(nt_gemm(s.hact, P[PTX_TB_FC2_W], P[PTX_TB_FC2_B], h2, R, C, H, st));
+    PTX_TRY(nt_gemm(s.hact, P[PTX_TB_FC2_W], P[PTX_TB_FC2_B], h2, R, C, H, st, a.compute_dtype));
     {   // x2 = x1 + DropPath(Dropout(h2)); g = trailing LayerNorm(x2)
         LnFwdArgs g{s.x1, h2, make_drop(a.p_drop, a.seed[4]), make_drop(a.p_path, a.seed[5]), a.n, P[PTX_TB_LN3_W], P[PTX_TB_LN3_B],
                     nullptr, 1, R, C, a.eps3, s.x2, s.g, s.stats3};
@@ -1275,7 +1278,7 @@ int ptx_train_block_bwd(const PtxTrainBlock *ap, void *stream)
         fin.add(t.p_ln3 + 2 * C, G[PTX_TB_FC2_B], chunks, C, 3l * C);
     }
     // fc2
-    PTX_TRY(dx_gemm(t.dh2, t.wT[4], t.dhact, R, C, H, st));
+    PTX_TRY(dx_gemm(t.dh2, t.wT[4], t.dhact, R, C, H, st, a.compute_dtype));
     PTX_TRY(dw_add(tn, fin, t.dh2, s.hact, G[PTX_TB_FC2_W], R, C, H, t.ks[4], t.p_w[4]));
     // GELU + Dropout
     hipLaunchKernelGGL(k_t_gelu_bwd, dim3(chunks), dim3(256), (size_t)4 * H * 4, st, s.hpre, t.dhact, make_drop(a.p_drop, a.seed[3]), R, H,
@@ -1283,7 +1286,7 @@ int ptx_train_block_bwd(const PtxTrainBlock *ap, void *stream)
     PTX_LAUNCHED("k_t_gelu_bwd");
     fin.add(t.p_gelu, G[PTX_TB_FC1_B], chunks, H, H);
     // fc1
-    PTX_TRY(dx_gemm(t.dhpre, t.wT[3], t.dhln, R, H, C, st));
+    PTX_TRY(dx_gemm(t.dhpre, t.wT[3], t.dhln, R, H, C, st, a.compute_dtype));
     PTX_TRY(dw_add(tn, fin, t.dhpre, s.hln, G[PTX_TB_FC1_W], R, H, C, t.ks[3], t.p_w[3]));
     // norm2 + residual; dob = gradient of proj's output
     {
@@ -1296,7 +1299,7 @@ int ptx_train_block_bwd(const PtxTrainBlock *ap, void *stream)
         fin.add(t.p_ln2 + 2 * C, G[PTX_TB_PROJ_B], chunks, C, 3l * C);
     }
     // proj
-    PTX_TRY(dx_gemm(t.dob, t.wT[2], t.dO, R, C, C, st));
+    PTX_TRY(dx_gemm(t.dob, t.wT[2], t.dO, R, C, C, st, a.compute_dtype));
     PTX_TRY(dw_add(tn, fin, t.dob, s.O, G[PTX_TB_PROJ_W], R, C, C, t.ks[2], t.p_w[2]));
     // proxy attention
     {
@@ -1306,7 +1309,7 @@ int ptx_train_block_bwd(const PtxTrainBlock *ap, void *stream)
         PTX_TRY(tattn_bwd(ta, st));
     }
     // proxy_proj
-    PTX_TRY(dx_gemm(t.dpt, t.wT[1], a.dproxy, BL, C, C, st));
+    PTX_TRY(dx_gemm(t.dpt, t.wT[1], a.dproxy, BL, C, C, st, a.compute_dtype));
     PTX_TRY(dw_add(tn, fin, t.dpt, a.proxy, G[PTX_TB_PP_W], BL, C, C, t.ks[1], t.p_w[1]));
     fin.add(t.dpt, G[PTX_TB_PP_B], BL, C, C);
     // qkv
@@ -1315,7 +1318,7 @@ int ptx_train_block_bwd(const PtxTrainBlock *ap, void *stream)
         PTX_LAUNCHED("k_t_colpart");
         fin.add(t.p_qkv, G[PTX_TB_QKV_B], chunks, 3l * C, 3l * C);
     }
-    PTX_TRY(dx_gemm(t.dqkv, t.wT[0], t.dxln, R, 3 * C, C, st));
+    PTX_TRY(dx_gemm(t.dqkv, t.wT[0], t.dxln, R, 3 * C, C, st, a.compute_dtype));
     PTX_TRY(dw_add(tn, fin, t.dqkv, s.xln, G[PTX_TB_QKV_W], R, 3 * C, C, t.ks[0], t.p_w[0]));
     // norm1 + residual -> dx;  slot-bias table gradient = sum over the scenes of dxln
     {
@@ -1326,7 +1329,7 @@ int ptx_train_block_bwd(const PtxTrainBlock *ap, void *stream)
         fin.add(t.p_ln1 + C, G[PTX_TB_LN1_B], chunks, C, 2l * C);
     }
     fin.add(t.dxln, t.dtab, a.B, (long)a.n * C, (long)a.n * C);
-    PTX_TRY(tn.launch(st));                                  // every weight gradient of the block
+    PTX_TRY(tn.launch(st, a.compute_dtype));                                  // every weight gradient of the block
     PTX_TRY(fin.launch(st));
     PTX_TRY(ptx_op_slotbias_bwd(t.dtab, a.n, a.s, C, G[PTX_TB_PB], G[PTX_TB_PC], G[PTX_TB_PR], st));
     return PTX_OK;

@@ -782,7 +782,8 @@ class _BlockFused(torch.autograd.Function):
         x, proxy = _c(x), _c(proxy)
         a = _abi.PtxTrainBlock()
         (a.B, a.n, a.L, a.C, a.H, a.heads, a.s, a.nout, a.eps1, a.eps2, a.eps3, a.bn_eps, a.bn_momentum, a.p_attn, a.p_drop,
-         a.p_path, seeds) = cfg
+         a.p_path, seeds) = cfg[:17]
+        a.compute_dtype = cfg[17] if len(cfg) > 17 else 0
         for i, sd in enumerate(seeds):
             a.seed[i] = sd & 0xFFFFFFFFFFFFFFFF
         a.x, a.proxy, a.mask = _p(x), _p(proxy), _p(mask)
@@ -836,7 +837,7 @@ def _block_cfg(mod, blk, out_norm, head, head_bn, B, n, L, seeds):
     a = blk.attn
     cfg = (B, n, L, mod.embed_dim, blk.mlp.fc1.weight.shape[0], mod.num_heads, a.pc_bias.shape[2], head.weight.shape[0],
            blk.norm1.eps, blk.norm2.eps, out_norm.eps, head_bn.eps, head_bn.momentum, float(mod.attn_drop_rate),
-           float(mod.drop_rate), float(mod._dpr_last(blk)), tuple(seeds))
+           float(mod.drop_rate), float(mod._dpr_last(blk)), tuple(seeds), 1 if getattr(mod, "compute_dtype", "fp32") == "bf16" else 0)
     params = (blk.norm1.weight, blk.norm1.bias, a.pb_bias, a.pc_bias, a.pr_bias, a.qkv.weight, a.qkv.bias, a.proxy_proj.weight,
               a.proxy_proj.bias, a.proj.weight, a.proj.bias, blk.norm2.weight, blk.norm2.bias, blk.mlp.fc1.weight, blk.mlp.fc1.bias,
               blk.mlp.fc2.weight, blk.mlp.fc2.bias, out_norm.weight, out_norm.bias, head.weight, head.bias, head_bn.weight,
