@@ -81,8 +81,12 @@ __device__ __forceinline__ void mlp_wait4(mlp_f4 &a, mlp_f4 &b, mlp_f4 &c, mlp_f
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) :: "memory");
 }
 
-template <int NP>       // 3: split operands (fp32-equivalent); 1: plain bf16 operands = the first plane only (compute_dtype = 1)
-__global__ __launch_bounds__(kMlpWaves * 64) void k_mlp(MlpBatch mb)
+// LITE (calls with more work-groups than CUs: the shipped configuration at its training batch is 1 040): the H planes take the
+// place of the x1 planes (one more barrier) and the weight fragments are requested four steps ahead instead of eight, so that TWO
+// work-groups fit a CU (49 KB of LDS, <= 128 registers) and hide each other's round trips; with one work-group per CU -- the
+// benchmark shape -- the deeper prefetch is what hides them (r03 stamps) and LITE is off.
+template <int NP, bool LITE>       // NP 3: split operands (fp32-equivalent); 1: plain bf16 operands = the first plane only (compute_dtype = 1)
+__global__ __launch_bounds__(kMlpWaves * 64) __attribute__((amdgpu_waves_per_eu(LITE ? 4 : 1, LITE ? 4 : 4))) void k_mlp(MlpBatch mb)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const MlpProb p = mb.p[blockIdx.z];
@@ -90,8 +94,8 @@ __global__ __launch_bounds__(kMlpWaves * 64) void k_mlp(MlpBatch mb)
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, hh = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int C = 256, R = p.R;
-    char *Xp = smem, *Hp = smem + 3 * kMlpPlane;
-    float *s_mu = reinterpret_cast<float *>(smem + 6 * kMlpPlane), *s_rs = s_mu + 32;
+    char *Xp = smem, *Hp = LITE ? smem : smem + 3 * kMlpPlane;
+    float *s_mu = reinterpret_cast<float *>(smem + (LITE ? 3 : 6) * kMlpPlane), *s_rs = s_mu + 32;
 
     // ---- requests first: the x1 tile, the LayerNorm partials of its rows, the column terms, the first weight fragments
     float4 xv[4];
@@ -114,7 +118,7 @@ __global__ __launch_bounds__(kMlpWaves * 64) void k_mlp(MlpBatch mb)
 #pragma unroll
         for (int q = 0; q < NP; ++q) b[q] = W[mlp_w_piece(t, steps, step, q, hh, li)];
     };
-    constexpr int kAhead = 8;                                       // weight fragments requested this many k steps ahead (r03
+    constexpr int kAhead = LITE ? 4 : 8;                            // weight fragments requested this many k steps ahead (r03
                                                                     // stamps: with 4 a phase was 10 k cycles for 3 k of MFMA time)
     u32x4 bq[kAhead][3];
 #pragma unroll
@@ -164,6 +168,7 @@ __global__ __launch_bounds__(kMlpWaves * 64) void k_mlp(MlpBatch mb)
             const int row = mlp_acc_row(r, hh);
             h[r] = gelu_erf(fmaf(s_rs[row], fmaf(-s_mu[row], s_j, acc[r]), c_j));
         }
+        if (LITE) __syncthreads();                                  // every wave is done reading the x1 planes H overwrites
         // column j of H is k = 32 wv + li of phase 2: step 2 wv + (li >> 4), half (li >> 3) & 1, position li & 7
         const int step = 2 * wv + (li >> 4), h2 = (li >> 3) & 1, pos = (li & 7) * 2;
 #pragma unroll
@@ -228,19 +233,22 @@ __global__ __launch_bounds__(kMlpWaves * 64) void k_mlp(MlpBatch mb)
     }
     // (every partial, residual and bias request of the four rows of this wave goes out before the first is used: as a loop
     //  over the rows the merge was four round trips to memory in sequence, 10 k of the last slice's 46 k cycles)
-    mlp_f4 v[4][4];
-    float4 xr[4];
+    constexpr int RB = LITE ? 2 : 4;                               // rows of this wave in flight at once (LITE: register budget)
     const float4 b = *reinterpret_cast<const float4 *>(p.b2 + 4 * lane);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = wv + 8 * i, c4 = 4 * lane;
+    for (int i0 = 0; i0 < 4; i0 += RB) {
+    mlp_f4 v[RB][4];
+    float4 xr[RB];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) v[i][s] = mlp_ld4_agent(gp + (size_t)min(s, nsl - 1) * (kMlpRows * 256) + row * 256 + c4);
-        xr[i] = *reinterpret_cast<const float4 *>(p.x1 + (size_t)min(row0 + row, R - 1) * C + c4);
+    for (int ii = 0; ii < RB; ++ii) {
+        const int row = wv + 8 * (i0 + ii), c4 = 4 * lane;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) v[ii][s] = mlp_ld4_agent(gp + (size_t)min(s, nsl - 1) * (kMlpRows * 256) + row * 256 + c4);
+        xr[ii] = *reinterpret_cast<const float4 *>(p.x1 + (size_t)min(row0 + row, R - 1) * C + c4);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = wv + 8 * i, c4 = 4 * lane;
+    for (int ii = 0; ii < RB; ++ii) {
+        const int i = ii, row = wv + 8 * (i0 + ii), c4 = 4 * lane;
         mlp_wait4(v[i][0], v[i][1], v[i][2], v[i][3]);
         const float4 x = xr[i];
         mlp_f4 sum = v[i][0];
@@ -270,14 +278,17 @@ __global__ __launch_bounds__(kMlpWaves * 64) void k_mlp(MlpBatch mb)
         }
         if (lane < p.nout) p.head_out[(size_t)(row0 + row) * p.nout + lane] = fmaf(mine + hbias, bn_a, bn_b);     // eval BatchNorm1d
     }
+    }
 }
 
 bool mlp_fused_supported(int C, int hidden, int R, int compute_dtype)
 {
     static const int env = getenv("PTX_MLP_FUSED") ? atoi(getenv("PTX_MLP_FUSED")) : 1;
-    // up to ~6000 rows: measured r03 -- 4146 rows (the shipped configuration at 6 scenes) +4.5 % over the two GEMM launches,
-    // 4096 rows (cfg2 at 16 scenes) +0.7 %, 8192 rows (32 scenes) -3 %: there the 64 x 64-tile GEMMs run at 0.57 of their peak
-    static const int rmax = getenv("PTX_MLP_RMAX") ? atoi(getenv("PTX_MLP_RMAX")) : 6144;
+    // r03 (one work-group per CU): 4146 rows (the shipped configuration at 6 scenes) +4.5 % over the two GEMM launches, 4096 rows
+    // (cfg2 at 16 scenes) +0.7 %, 8192 rows (32 scenes) -3 %.  r04, with two work-groups per CU where there are more than 768 of
+    // them (LITE): cfg2 at 16 scenes +3.8 % on top, at 32 scenes 26.2k vs 25.5k scenes/s for the two launches
+    // (profiles/r04_mlp_lite_ab.txt) -- the fused form now covers every batch up to 36 scenes per call
+    static const int rmax = getenv("PTX_MLP_RMAX") ? atoi(getenv("PTX_MLP_RMAX")) : 9216;
     return env != 0 && (compute_dtype == 0 || compute_dtype == 1) && C == 256 && hidden == 1024 && R >= 1 && R <= rmax;
 }
 
@@ -295,13 +306,17 @@ int launch_mlp(const MlpBatch &mb, hipStream_t st)
         rmax = p.R;
     }
     const dim3 grid(cdiv(rmax, kMlpRows), 4, mb.n), block(kMlpWaves * 64);
-    if (mb.compute_dtype == 1) {
-        PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp<1>), hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
-        hipLaunchKernelGGL(k_mlp<1>, grid, block, kMlpLds, st, mb);
-    } else {
-        PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp<3>), hipFuncAttributeMaxDynamicSharedMemorySize, kMlpLds));
-        hipLaunchKernelGGL(k_mlp<3>, grid, block, kMlpLds, st, mb);
-    }
+    static const int lite_env = getenv("PTX_MLP_LITE") ? atoi(getenv("PTX_MLP_LITE")) : -1;
+    const bool lite = lite_env >= 0 ? lite_env != 0 : (long)grid.x * grid.y * grid.z > 768;     // r04 A/B: 512 work-groups -0.4 %, 1024 +3.8 %
+    constexpr int kLiteLds = 3 * kMlpPlane + 2 * 32 * 4;
+#define PTX_MLP_LAUNCH(NP_, LITE_, LDS_)                                                                                           \
+    do {                                                                                                                         \
+        PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mlp<NP_, LITE_>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_)); \
+        hipLaunchKernelGGL((k_mlp<NP_, LITE_>), grid, block, LDS_, st, mb);                                                      \
+    } while (0)
+    if (mb.compute_dtype == 1) { if (lite) PTX_MLP_LAUNCH(1, true, kLiteLds); else PTX_MLP_LAUNCH(1, false, kMlpLds); }
+    else { if (lite) PTX_MLP_LAUNCH(3, true, kLiteLds); else PTX_MLP_LAUNCH(3, false, kMlpLds); }
+#undef PTX_MLP_LAUNCH
     PTX_LAUNCHED("k_mlp");
     return PTX_OK;
 }
