@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PTX_ABI_VERSION 9
+#define PTX_ABI_VERSION 10
 
 #define PTX_OK          0
 #define PTX_EINVAL     -1   /* bad shape / null pointer / unsupported size */
@@ -483,6 +483,7 @@ typedef struct {
     float *dx;                                 /* (R, C) */
     float *dproxy;                             /* (B*L, C) */
     float *grad[PTX_TB_NPARAM];                /* shaped like param[] */
+    const float *dx_add;                       /* optional (R, C): added into dx (the other block's gradient of the same point proxies) */
 } PtxTrainBlock;
 int ptx_train_block_sizes(const PtxTrainBlock *a, size_t *save_floats, size_t *tmp_fwd_floats, size_t *tmp_bwd_floats);
 int ptx_train_block_fwd(const PtxTrainBlock *a, void *stream);
@@ -496,6 +497,13 @@ int ptx_train_attn_fwd(const float *qkv, const float *pt, const uint8_t *mask, i
 int ptx_train_attn_bwd(const float *qkv, const float *pt, const uint8_t *mask, int B, int n, int L, int heads, int C,
                        float p_drop, uint64_t seed, const float *P1, const float *PV, const float *P2, const float *dO,
                        float *dqkv, float *dpt, float *tmp, size_t tmp_floats, void *stream);
+
+/* backward of a narrow Linear without bias, y (R, nout <= 9) = x (R, C) w^T (the offset network's channel_mapper, PRE:75; the
+ * blocks' heads use the same kernel inside ptx_train_block_bwd): dx = (dt * coef) w, dw = (dt * coef)^T x; coef (R, nout) or NULL;
+ * tmp: ptx_op_head_bwd_tmp_floats() floats (per-chunk partials of dw, summed in chunk order) */
+size_t ptx_op_head_bwd_tmp_floats(int R, int C, int nout);
+int ptx_op_head_bwd(const float *dt, const float *coef, const float *x, const float *w, int R, int C, int nout, float *dx, float *dw,
+                    float *tmp, size_t tmp_floats, void *stream);
 
 /* ---- AttentionPool2d in train mode without materialised pixel tokens (csrc/train_img.hip; PRE:144-177, 338)
  * img (nimg, Cin, hw) in its storage type (img_dtype 0 fp32 / 1 bf16 / 2 fp16) -> o (nimg, C), the attention output of the
@@ -515,6 +523,12 @@ typedef struct {
     const float *dout;                         /* backward: (nimg, C) */
     void *dimg;                                /* (nimg, Cin, hw) in img's storage type, or NULL */
     float *dwc, *dbc, *dpos, *dwq, *dbq, *dwk, *dbk, *dwv, *dbv;
+    /* optional tail (cw != NULL): proxy = LayerNorm(o cw^T + cb) -- c_proj and norm_img (PRE:177, 450) in the same two calls; the
+     * forward then writes `proxy` (nimg, C) (o may be NULL: it lives in `save`), the backward takes `dproxy` instead of dout */
+    const float *cw, *cb, *lnw, *lnb; float ln_eps;
+    float *proxy;
+    const float *dproxy;
+    float *dcw, *dcb, *dlnw, *dlnb;
 } PtxTrainImgPool;
 int ptx_train_imgpool_sizes(const PtxTrainImgPool *a, size_t *save_floats, size_t *tmp_fwd_floats, size_t *tmp_bwd_floats);
 int ptx_train_imgpool_fwd(const PtxTrainImgPool *a, void *stream);

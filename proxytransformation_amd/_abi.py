@@ -13,7 +13,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libproxyt_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 c_float_p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 
@@ -71,14 +71,16 @@ class PtxTrainBlock(C.Structure):
                 ("param", C.c_void_p * len(TB_PARAMS)), ("bn_run_mean", C.c_void_p), ("bn_run_var", C.c_void_p),
                 ("out", C.c_void_p), ("save", C.c_void_p), ("save_floats", C.c_size_t), ("tmp", C.c_void_p),
                 ("tmp_floats", C.c_size_t), ("dout", C.c_void_p), ("dx", C.c_void_p), ("dproxy", C.c_void_p),
-                ("grad", C.c_void_p * len(TB_PARAMS))]
+                ("grad", C.c_void_p * len(TB_PARAMS)), ("dx_add", C.c_void_p)]
 
 
 class PtxTrainImgPool(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("nimg", "Cin", "hw", "C", "heads", "img_dtype")] + \
                [(n, C.c_void_p) for n in ("img", "wc", "bc", "pos", "wq", "bq", "wk", "bk", "wv", "bv", "o", "save")] + \
                [("save_floats", C.c_size_t), ("tmp", C.c_void_p), ("tmp_floats", C.c_size_t)] + \
-               [(n, C.c_void_p) for n in ("dout", "dimg", "dwc", "dbc", "dpos", "dwq", "dbq", "dwk", "dbk", "dwv", "dbv")]
+               [(n, C.c_void_p) for n in ("dout", "dimg", "dwc", "dbc", "dpos", "dwq", "dbq", "dwk", "dbk", "dwv", "dbv")] + \
+               [(n, C.c_void_p) for n in ("cw", "cb", "lnw", "lnb")] + [("ln_eps", C.c_float)] + \
+               [(n, C.c_void_p) for n in ("proxy", "dproxy", "dcw", "dcb", "dlnw", "dlnb")]
 
 
 class PtxForwardOpts(C.Structure):
@@ -171,6 +173,8 @@ SIGNATURES.update({
     "ptx_train_imgpool_sizes": (_I, [C.POINTER(PtxTrainImgPool), C.POINTER(_Z), C.POINTER(_Z), C.POINTER(_Z)]),
     "ptx_train_imgpool_fwd": (_I, [C.POINTER(PtxTrainImgPool), _P]),
     "ptx_train_imgpool_bwd": (_I, [C.POINTER(PtxTrainImgPool), _P]),
+    "ptx_op_head_bwd_tmp_floats": (_Z, [_I, _I, _I]),
+    "ptx_op_head_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _Z, _P]),
     "ptx_train_attn_tmp_floats": (_Z, [_I, _I, _I, _I, _I]),
     "ptx_train_attn_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _U64, _P, _P, _P, _P, _P]),
     "ptx_train_attn_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _U64, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),

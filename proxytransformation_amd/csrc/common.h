@@ -415,6 +415,11 @@ int launch_tags(const PtxShape &s, const int32_t *idx, const int32_t *order, con
 int launch_select_slots(const PtxShape &s, const int32_t *idx, const float *cluster, const int32_t *order,
                         const int32_t *picks, const int32_t *keep, float *kcluster, int32_t *kidx,
                         int32_t *drop_idx, uint32_t *tag, hipStream_t st);
+// train_fused.hip: LayerNorm rows of the training path for other translation units (the folded attention pool's c_proj + norm_img tail)
+int launch_t_ln_fwd(const float *x, const float *w, const float *b, int R, int C, float eps, float *y, float *stats, hipStream_t st);
+int t_ln_chunks(int R);                                  // row chunks of launch_t_ln_bwd's column partials
+// dx = LayerNorm backward of dy; part[(chunk * 2 + k) * C + c]: k = 0 the chunk's sum of dy * xhat (dgamma), k = 1 of dy (dbeta)
+int launch_t_ln_bwd(const float *x, const float *stats, const float *w, const float *dy, int R, int C, float *dx, float *part, hipStream_t st);
 int launch_tile_count(const uint32_t *tag, int B, int N, int32_t *tile_counts, int32_t *counts, int32_t *scene_acc,
                       hipStream_t st);
 int launch_affine(const PtxShape &s, const ScenePts &points, uint32_t *tag, const float *kcenter,

@@ -261,6 +261,7 @@ __device__ __forceinline__ void chunk_partials(float (&acc)[NS][MQ], int nq, int
 struct LnBwdArgs {
     const float *x, *stats, *w, *dy, *dres; Drop1 d1, d2; int rows_per_scene; int R, C;
     float *dx, *dd; float *part;      // part: [chunks][2 or 3][C]
+    const float *dres2;               // a second gradient of the same rows to add (the other block's use of the point proxies)
 };
 template <bool DD>
 __global__ __launch_bounds__(256) void k_t_ln_bwd(LnBwdArgs g)
@@ -297,6 +298,7 @@ __global__ __launch_bounds__(256) void k_t_ln_bwd(LnBwdArgs g)
             if (q < nq) {
                 float v = rstd * (gg[q] - s1 - xh[q] * s2);
                 if (g.dres) v = g.dres[base + c] + v;
+                if (g.dres2) v = v + g.dres2[base + c];
                 g.dx[base + c] = v;
                 acc[0][q] += dyv[q] * xh[q];
                 acc[1][q] += dyv[q];
@@ -358,9 +360,9 @@ __global__ __launch_bounds__(256) void k_t_colpart(const float *__restrict__ x, 
 
 // Linear head backward (nout <= 9 columns): dg[r][c] = sum_j dt[r][j] W[j][c];  partial dW[j][c] = sum_r dt[r][j] g[r][c]
 constexpr int kHeadMax = 9;
-__global__ __launch_bounds__(256) void k_t_head_bwd(const float *__restrict__ dt, const float *__restrict__ gin,
-                                                    const float *__restrict__ W, int R, int C, int nout, float *__restrict__ dg,
-                                                    float *__restrict__ part)
+__global__ __launch_bounds__(256) void k_t_head_bwd(const float *__restrict__ dt, const float *__restrict__ coef,
+                                                    const float *__restrict__ gin, const float *__restrict__ W, int R, int C, int nout,
+                                                    float *__restrict__ dg, float *__restrict__ part)
 {
     extern __shared__ float red[];               // [4][nout][C] for the partials; W staged behind it
     float *Ws = red + 4 * nout * C;
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(256) void k_t_head_bwd(const float *__restrict__ dt
         if (row >= R) break;
         float t[kHeadMax];
 #pragma unroll
-        for (int j = 0; j < kHeadMax; ++j) t[j] = j < nout ? dt[(size_t)row * nout + j] : 0.0f;
+        for (int j = 0; j < kHeadMax; ++j) t[j] = j < nout ? dt[(size_t)row * nout + j] * (coef ? coef[(size_t)row * nout + j] : 1.0f) : 0.0f;
 #pragma unroll
         for (int q = 0; q < kMaxQ; ++q) {
             if (q < nq) {
@@ -1059,6 +1061,26 @@ static void tattn_carve(TAttn &a, float *tmp)
 static int tattn_fwd(const TAttn &a, hipStream_t st) { return a.C / a.heads == 32 ? tattn_fwd_t<32>(a, st) : tattn_fwd_t<64>(a, st); }
 static int tattn_bwd(const TAttn &a, hipStream_t st) { return a.C / a.heads == 32 ? tattn_bwd_t<32>(a, st) : tattn_bwd_t<64>(a, st); }
 
+int launch_t_ln_fwd(const float *x, const float *w, const float *b, int R, int C, float eps, float *y, float *stats, hipStream_t st)
+{
+    PTX_REQUIRE(x && w && b && y && stats && R >= 1 && C % 64 == 0 && C <= 64 * kMaxQ, "layernorm rows: bad arguments (C=%d)", C);
+    const Drop1 none = make_drop(0.0f, 0);
+    LnFwdArgs g{x, nullptr, none, none, 1, w, b, nullptr, 1, R, C, eps, nullptr, y, stats};
+    hipLaunchKernelGGL(k_t_ln_fwd, dim3(cdiv(R, 4)), dim3(256), 0, st, g);
+    PTX_LAUNCHED("k_t_ln_fwd");
+    return PTX_OK;
+}
+int t_ln_chunks(int R) { return cdiv(R, kRowsPerChunk); }
+int launch_t_ln_bwd(const float *x, const float *stats, const float *w, const float *dy, int R, int C, float *dx, float *part, hipStream_t st)
+{
+    PTX_REQUIRE(x && stats && w && dy && dx && part && R >= 1 && C % 64 == 0 && C <= 64 * kMaxQ, "layernorm rows backward: bad arguments");
+    const Drop1 none = make_drop(0.0f, 0);
+    LnBwdArgs g{x, stats, w, dy, nullptr, none, none, 1, R, C, dx, nullptr, part};
+    hipLaunchKernelGGL(k_t_ln_bwd<false>, dim3(cdiv(R, kRowsPerChunk)), dim3(256), (size_t)4 * 2 * C * 4, st, g);
+    PTX_LAUNCHED("k_t_ln_bwd");
+    return PTX_OK;
+}
+
 // ------------------------------------------------------------------------------ the block: buffers
 struct BlockBufs {
     // saved by the forward
@@ -1263,7 +1285,7 @@ int ptx_train_block_bwd(const PtxTrainBlock *ap, void *stream)
     {
         const size_t lds = ((size_t)4 * a.nout * C + (size_t)a.nout * C) * 4;
         PTX_TRY(set_lds<0>(reinterpret_cast<const void *>(&k_t_head_bwd), lds));
-        hipLaunchKernelGGL(k_t_head_bwd, dim3(chunks), dim3(256), lds, st, t.dtpre, s.g, P[PTX_TB_HEAD_W], R, C, a.nout, t.dg, t.p_head);
+        hipLaunchKernelGGL(k_t_head_bwd, dim3(chunks), dim3(256), lds, st, t.dtpre, (const float *)nullptr, s.g, P[PTX_TB_HEAD_W], R, C, a.nout, t.dg, t.p_head);
         PTX_LAUNCHED("k_t_head_bwd");
         fin.add(t.p_head, G[PTX_TB_HEAD_W], chunks, (long)a.nout * C, (long)a.nout * C);
     }
@@ -1322,7 +1344,7 @@ int ptx_train_block_bwd(const PtxTrainBlock *ap, void *stream)
     PTX_TRY(dw_add(tn, fin, t.dqkv, s.xln, G[PTX_TB_QKV_W], R, 3 * C, C, t.ks[0], t.p_w[0]));
     // norm1 + residual -> dx;  slot-bias table gradient = sum over the scenes of dxln
     {
-        LnBwdArgs g{a.x, s.stats1, P[PTX_TB_LN1_W], t.dxln, t.dx1, none, none, a.n, R, C, a.dx, nullptr, t.p_ln1};
+        LnBwdArgs g{a.x, s.stats1, P[PTX_TB_LN1_W], t.dxln, t.dx1, none, none, a.n, R, C, a.dx, nullptr, t.p_ln1, a.dx_add};
         hipLaunchKernelGGL(k_t_ln_bwd<false>, dim3(chunks), dim3(256), (size_t)4 * 2 * C * 4, st, g);
         PTX_LAUNCHED("k_t_ln_bwd");
         fin.add(t.p_ln1, G[PTX_TB_LN1_W], chunks, C, 2l * C);
@@ -1333,6 +1355,24 @@ int ptx_train_block_bwd(const PtxTrainBlock *ap, void *stream)
     PTX_TRY(fin.launch(st));
     PTX_TRY(ptx_op_slotbias_bwd(t.dtab, a.n, a.s, C, G[PTX_TB_PB], G[PTX_TB_PC], G[PTX_TB_PR], st));
     return PTX_OK;
+}
+
+size_t ptx_op_head_bwd_tmp_floats(int R, int C, int nout) { return (size_t)cdiv(R, kRowsPerChunk) * nout * C + 64; }
+
+int ptx_op_head_bwd(const float *dt, const float *coef, const float *x, const float *w, int R, int C, int nout, float *dx, float *dw,
+                    float *tmp, size_t tmp_floats, void *stream)
+{
+    PTX_REQUIRE(dt && x && w && dx && dw && tmp && R >= 1 && C % 64 == 0 && C <= 64 * kMaxQ && nout >= 1 && nout <= kHeadMax &&
+                tmp_floats >= ptx_op_head_bwd_tmp_floats(R, C, nout), "ptx_op_head_bwd: bad arguments (R=%d C=%d nout=%d)", R, C, nout);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int chunks = cdiv(R, kRowsPerChunk);
+    const size_t lds = ((size_t)4 * nout * C + (size_t)nout * C) * 4;
+    PTX_TRY(set_lds<0>(reinterpret_cast<const void *>(&k_t_head_bwd), lds));
+    hipLaunchKernelGGL(k_t_head_bwd, dim3(chunks), dim3(256), lds, st, dt, coef, x, w, R, C, nout, dx, tmp);
+    PTX_LAUNCHED("k_t_head_bwd");
+    FinList fin;
+    fin.add(tmp, dw, chunks, (long)nout * C, (long)nout * C);
+    return fin.launch(st);
 }
 
 size_t ptx_train_attn_tmp_floats(int B, int n, int L, int heads, int C)

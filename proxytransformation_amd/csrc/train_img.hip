@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void k_ti_dx(const float *__restrict__ dS, con
 
 // out[c] = sum_p part[p * stride + c] in double, p in order (bias gradients over the images, K slices of dwc / dpos)
 struct TiSum { const float *part; float *out; int nparts; long ncols, stride; };
-struct TiSums { TiSum j[8]; int blk0[9]; int n; };
+struct TiSums { TiSum j[12]; int blk0[13]; int n; };
 __global__ __launch_bounds__(256) void k_ti_sums(TiSums J)
 {
     int k = 0;
@@ -300,7 +300,7 @@ struct TiSumList {
     TiSumList() { J.n = 0; blocks = 0; J.blk0[0] = 0; }
     void add(const float *part, float *out, int nparts, long ncols, long stride)
     {
-        if (!out || J.n >= 8) return;
+        if (!out || J.n >= 12) return;
         J.j[J.n] = TiSum{part, out, nparts, ncols, stride};
         blocks += (int)((ncols + 255) / 256); J.n += 1; J.blk0[J.n] = blocks;
     }
@@ -315,7 +315,7 @@ struct TiSumList {
 
 // ---------------------------------------------------------------------------------------------- host side
 struct TiBufs {
-    float *t0, *q, *g, *posb, *Acat, *Ycat, *Wcat, *Bcat, *sig;      // save
+    float *t0, *q, *g, *posb, *Acat, *Ycat, *Wcat, *Bcat, *sig, *o, *y, *stats;      // save
     size_t save_total;
 };
 struct TiCarve { float *base; size_t off; float *take(size_t n) { float *p = base ? base + off : nullptr; off += (n + 63) / 64 * 64; return p; } };
@@ -329,6 +329,7 @@ static void ti_layout(const PtxTrainImgPool &a, float *base, TiBufs &s)
     s.Wcat = c.take(2 * NH * T);                      // [dS ; P]
     s.Bcat = c.take((2 * NH + nimg) * Cin);           // [e' ; wc^T dg ; wc^T dt0]
     s.sig = c.take(NH);
+    s.o = c.take(nimg * C); s.y = c.take(nimg * C); s.stats = c.take(2 * nimg);       // the c_proj + norm_img tail
     s.save_total = c.off;
 }
 static int ti_ksplit(int M, int N, int K)
@@ -341,7 +342,7 @@ static int ti_ksplit(int M, int N, int K)
     return ks < 1 ? 1 : (ks > 64 ? 64 : ks);
 }
 static size_t ti_tmp_fwd(const PtxTrainImgPool &a) { return (size_t)a.nimg * kTiHeads * (a.hw + 1) + 64; }
-struct TiBwd { float *dps, *u, *dq, *p_wc, *p_pos; int ks_wc, ks_pos; size_t total; };
+struct TiBwd { float *dps, *u, *dq, *p_wc, *p_pos, *dy, *dotail, *p_ln; int ks_wc, ks_pos; size_t total; };
 static void ti_bwd_layout(const PtxTrainImgPool &a, float *base, TiBwd &t)
 {
     const size_t nimg = a.nimg, NH = nimg * kTiHeads, C = a.C, Cin = a.Cin, T = a.hw + 1;
@@ -349,6 +350,7 @@ static void ti_bwd_layout(const PtxTrainImgPool &a, float *base, TiBwd &t)
     t.dps = c.take(NH * T); t.u = c.take(NH * C); t.dq = c.take(nimg * C);
     t.ks_wc = ti_ksplit(a.C, a.Cin, (int)(2 * NH + nimg)); t.ks_pos = ti_ksplit(a.hw, a.C, (int)(2 * NH));
     t.p_wc = c.take((size_t)t.ks_wc * C * Cin); t.p_pos = c.take((size_t)t.ks_pos * a.hw * C);
+    t.dy = c.take(nimg * C); t.dotail = c.take(nimg * C); t.p_ln = c.take((size_t)t_ln_chunks((int)nimg) * 2 * C);
     t.total = c.off;
 }
 static int ti_check(const PtxTrainImgPool *a)
@@ -410,7 +412,8 @@ int ptx_train_imgpool_fwd(const PtxTrainImgPool *ap, void *stream)
 {
     PTX_TRY(ti_check(ap));
     const PtxTrainImgPool &a = *ap;
-    PTX_REQUIRE(a.o, "ptx_train_imgpool_fwd: null output");
+    const bool tail = a.cw != nullptr;
+    PTX_REQUIRE(tail ? (a.cb && a.lnw && a.lnb && a.proxy) : a.o != nullptr, "ptx_train_imgpool_fwd: null output / tail parameter");
     hipStream_t st = static_cast<hipStream_t>(stream);
     TiBufs s;
     ti_layout(a, a.save, s);
@@ -419,6 +422,7 @@ int ptx_train_imgpool_fwd(const PtxTrainImgPool *ap, void *stream)
     const float scale = 1.0f / sqrtf((float)hd);
     float *w = s.Acat, *Ypool = s.Ycat + (size_t)NH * Cin, *xbar = s.Ycat + (size_t)2 * NH * Cin, *P = s.Wcat + (size_t)NH * T, *e = s.Bcat;
     float *sp = a.tmp;
+    float *o = tail ? s.o : a.o;
     {
         const long rows = (long)nimg * Cin;
         const dim3 grid((unsigned)((rows + 3) / 4));
@@ -441,10 +445,14 @@ int ptx_train_imgpool_fwd(const PtxTrainImgPool *ap, void *stream)
     }
     PTX_TRY(ti_nt(Ypool, a.wc, nullptr, s.g, NH, C, Cin, st));                                            // wc (sum_p P x_p)
     PTX_TRY(bg(Bg{P + 1, T, 1, 0, s.posb + C, C, 1, 0, s.g, C, 1, 0}, NH, C, hw, 1, 1.0f, 1, st));       // + sum_p P (bc + pos)
-    hipLaunchKernelGGL(k_ti_fix, dim3(cdiv(NH * C, 256)), dim3(256), 0, st, s.g, P, T, s.t0, nimg, C, a.o, a.bv);
+    hipLaunchKernelGGL(k_ti_fix, dim3(cdiv(NH * C, 256)), dim3(256), 0, st, s.g, P, T, s.t0, nimg, C, o, a.bv);
     PTX_LAUNCHED("k_ti_fix");
     // o[img][h hd + d] = bv + wv[h hd + d] . g[img][h]
-    PTX_TRY(bg(Bg{s.g, (long)kTiHeads * C, 1, C, a.wv, 1, C, (long)hd * C, a.o, C, 1, hd}, nimg, hd, C, kTiHeads, 1.0f, 1, st));
+    PTX_TRY(bg(Bg{s.g, (long)kTiHeads * C, 1, C, a.wv, 1, C, (long)hd * C, o, C, 1, hd}, nimg, hd, C, kTiHeads, 1.0f, 1, st));
+    if (tail) {                                                                  // c_proj, norm_img
+        PTX_TRY(ti_nt(o, a.cw, a.cb, s.y, nimg, C, C, st));
+        PTX_TRY(launch_t_ln_fwd(s.y, a.lnw, a.lnb, nimg, C, a.ln_eps, a.proxy, s.stats, st));
+    }
     return PTX_OK;
 }
 
@@ -452,8 +460,9 @@ int ptx_train_imgpool_bwd(const PtxTrainImgPool *ap, void *stream)
 {
     PTX_TRY(ti_check(ap));
     const PtxTrainImgPool &a = *ap;
-    PTX_REQUIRE(a.dout && a.dwc && a.dbc && a.dpos && a.dwq && a.dbq && a.dwk && a.dbk && a.dwv && a.dbv,
-                "ptx_train_imgpool_bwd: null gradient buffer");
+    const bool tail = a.cw != nullptr;
+    PTX_REQUIRE((tail ? (a.dproxy && a.dcw && a.dcb && a.dlnw && a.dlnb && a.lnw) : a.dout != nullptr) && a.dwc && a.dbc && a.dpos && a.dwq &&
+                a.dbq && a.dwk && a.dbk && a.dwv && a.dbv, "ptx_train_imgpool_bwd: null gradient buffer");
     hipStream_t st = static_cast<hipStream_t>(stream);
     TiBufs s; TiBwd t;
     ti_layout(a, a.save, s);
@@ -464,9 +473,21 @@ int ptx_train_imgpool_bwd(const PtxTrainImgPool *ap, void *stream)
     float *w = s.Acat, *dg = s.Acat + (size_t)NH * C, *dt0 = s.Acat + (size_t)2 * NH * C, *dbcv = dt0 + (size_t)nimg * C;
     float *Yd = s.Ycat, *dS = s.Wcat, *P = s.Wcat + (size_t)NH * T, *e = s.Bcat, *Bv = s.Bcat + (size_t)NH * Cin;
     float *b0 = s.Bcat + (size_t)2 * NH * Cin;
+    TiSumList sums;
+    const float *dout = a.dout;
+    if (tail) {                                                                  // norm_img, c_proj
+        PTX_TRY(launch_t_ln_bwd(s.y, s.stats, a.lnw, a.dproxy, nimg, C, t.dy, t.p_ln, st));
+        const int ch = t_ln_chunks(nimg);
+        sums.add(t.p_ln, a.dlnw, ch, C, 2l * C);
+        sums.add(t.p_ln + C, a.dlnb, ch, C, 2l * C);
+        sums.add(t.dy, a.dcb, nimg, C, C);
+        PTX_TRY(bg(Bg{t.dy, C, 1, 0, a.cw, C, 1, 0, t.dotail, C, 1, 0}, nimg, C, C, 1, 1.0f, 0, st));             // do = dy cw
+        PTX_TRY(bg(Bg{t.dy, 1, C, 0, s.o, C, 1, 0, a.dcw, C, 1, 0}, C, C, nimg, 1, 1.0f, 0, st));                  // dcw = dy (x) o
+        dout = t.dotail;
+    }
     // dg[img][h][:] = sum_d do[img][h hd + d] wv[h hd + d][:];  dwv_h = do_h (x) g_h over the images
-    PTX_TRY(bg(Bg{a.dout, C, 1, hd, a.wv, C, 1, (long)hd * C, dg, (long)kTiHeads * C, 1, C}, nimg, C, hd, kTiHeads, 1.0f, 0, st));
-    PTX_TRY(bg(Bg{a.dout, 1, C, hd, s.g, (long)kTiHeads * C, 1, C, a.dwv, C, 1, (long)hd * C}, hd, C, nimg, kTiHeads, 1.0f, 0, st));
+    PTX_TRY(bg(Bg{dout, C, 1, hd, a.wv, C, 1, (long)hd * C, dg, (long)kTiHeads * C, 1, C}, nimg, C, hd, kTiHeads, 1.0f, 0, st));
+    PTX_TRY(bg(Bg{dout, 1, C, hd, s.g, (long)kTiHeads * C, 1, C, a.dwv, C, 1, (long)hd * C}, hd, C, nimg, kTiHeads, 1.0f, 0, st));
     PTX_TRY(bg(Bg{dg, C, 1, 0, a.wc, Cin, 1, 0, Bv, Cin, 1, 0}, NH, Cin, C, 1, 1.0f, 0, st));             // wc^T dg
     PTX_TRY(bg(Bg{dg, C, 1, 0, s.posb, 1, C, 0, t.dps, T, 1, 0}, NH, T, C, 1, 1.0f, 0, st));              // dg . (bc + pos_t)
     {
@@ -489,8 +510,6 @@ int ptx_train_imgpool_bwd(const PtxTrainImgPool *ap, void *stream)
     PTX_TRY(bg(Bg{t.dq, C, 1, 0, a.wq, C, 1, 0, dt0, C, 1, 0}, nimg, C, C, 1, 1.0f, 1, st));              // + wq^T dq
     PTX_TRY(bg(Bg{t.dq, 1, C, 0, s.t0, C, 1, 0, a.dwq, C, 1, 0}, C, C, nimg, 1, 1.0f, 0, st));            // dwq = dq (x) t0
     // gradients of the conv / positional parameters and of the features from the rank-(2 heads + 1) form
-    float *xbar = s.Ycat + (size_t)2 * NH * Cin; (void)xbar;
-    TiSumList sums;
     {
         const int K = 2 * NH + nimg;
         if (t.ks_wc > 1) {
@@ -508,7 +527,7 @@ int ptx_train_imgpool_bwd(const PtxTrainImgPool *ap, void *stream)
     sums.add(dt0, a.dpos, nimg, C, C);
     sums.add(dt0, a.dbc, 2 * nimg, C, C);             // dt0 rows followed by the dbcv rows
     sums.add(t.dq, a.dbq, nimg, C, C);
-    sums.add(a.dout, a.dbv, nimg, C, C);
+    sums.add(dout, a.dbv, nimg, C, C);
     PTX_TRY(sums.launch(st));
     if (a.dimg) {
         PTX_TRY(bg(Bg{dt0, C, 1, 0, a.wc, Cin, 1, 0, b0, Cin, 1, 0}, nimg, Cin, C, 1, 1.0f, 0, st));      // wc^T dt0

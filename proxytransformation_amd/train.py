@@ -409,8 +409,18 @@ class _OffsetHead(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dc):
         pooled, map_w, dcoef = ctx.saved_tensors
-        draw = eltwise(8, _c(dc), dcoef)
         w2 = map_w.reshape(3, -1)
+        n, W = pooled.shape
+        if W % 64 == 0 and W <= 512:        # one pass: dpooled rows and the chunk partials of dmap_w, then their fixed-order sum
+            lib = _abi.lib()
+            dpooled = torch.empty_like(pooled)
+            dw = torch.empty((3, W), dtype=_F32, device=pooled.device)
+            nt = lib.ptx_op_head_bwd_tmp_floats(n, W, 3)
+            tmp = torch.empty((nt,), dtype=_F32, device=pooled.device)
+            _ck(lib.ptx_op_head_bwd(_p(_c(dc)), _p(dcoef), _p(pooled), _p(_c(w2)), n, W, 3, _p(dpooled), _p(dw), _p(tmp), nt, _st()),
+                "ptx_op_head_bwd")
+            return dpooled, dw.view_as(map_w), None, None, None, None
+        draw = eltwise(8, _c(dc), dcoef)
         return mm(draw, w2), mm(draw, pooled, ta=True).view_as(map_w), None, None, None, None
 
 
@@ -649,31 +659,41 @@ class _AttnPoolCore(torch.autograd.Function):
 
 
 class _ImgPool(torch.autograd.Function):
-    """channel_mapper + AttentionPool2d up to (not including) c_proj as ONE node on the folded form of csrc/train_img.hip: the
-    pixel tokens, their keys and values are never materialised (only token 0 queries)."""
+    """channel_mapper + AttentionPool2d as ONE node on the folded form of csrc/train_img.hip: the pixel tokens, their keys and
+    values are never materialised (only token 0 queries).  Without the tail arguments the node ends at the attention output (before
+    c_proj); with ``cw, cb, lnw, lnb`` the same two calls also run c_proj and norm_img (PRE:177, 450) and the node returns the
+    image proxies."""
 
     @staticmethod
-    def forward(ctx, img, wc, bc, pos, wq, bq, wk, bk, wv, bv, heads):
+    def forward(ctx, img, wc, bc, pos, wq, bq, wk, bk, wv, bv, heads, cw=None, cb=None, lnw=None, lnb=None, eps=1e-5):
         lib = _abi.lib()
         img = _c(img)
         nimg, Cin, hw = img.shape
         C = wc.shape[0]
+        tail = cw is not None
         a = _abi.PtxTrainImgPool()
         a.nimg, a.Cin, a.hw, a.C, a.heads = nimg, Cin, hw, C, heads
         a.img_dtype = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[img.dtype]
-        params = tuple(_c(t) for t in (wc.reshape(C, Cin), bc, pos, wq, bq, wk, bk, wv, bv))
+        params = tuple(_c(t) for t in (wc.reshape(C, Cin), bc, pos, wq, bq, wk, bk, wv, bv) + ((cw, cb, lnw, lnb) if tail else ()))
         a.img = _p(img)
-        a.wc, a.bc, a.pos, a.wq, a.bq, a.wk, a.bk, a.wv, a.bv = (_p(t) for t in params)
+        a.wc, a.bc, a.pos, a.wq, a.bq, a.wk, a.bk, a.wv, a.bv = (_p(t) for t in params[:9])
+        if tail:
+            a.cw, a.cb, a.lnw, a.lnb = (_p(t) for t in params[9:])
+            a.ln_eps = eps
         s0, s1, s2 = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
         _ck(lib.ptx_train_imgpool_sizes(ctypes.byref(a), ctypes.byref(s0), ctypes.byref(s1), ctypes.byref(s2)), "ptx_train_imgpool_sizes")
         dev = img.device
         save = torch.empty((s0.value,), dtype=_F32, device=dev)
         tmp = torch.empty((s1.value,), dtype=_F32, device=dev)
         o = torch.empty((nimg, C), dtype=_F32, device=dev)
-        a.o, a.save, a.save_floats, a.tmp, a.tmp_floats = _p(o), _p(save), s0.value, _p(tmp), s1.value
+        if tail:
+            a.proxy = _p(o)
+        else:
+            a.o = _p(o)
+        a.save, a.save_floats, a.tmp, a.tmp_floats = _p(save), s0.value, _p(tmp), s1.value
         _ck(lib.ptx_train_imgpool_fwd(ctypes.byref(a), _st()), "ptx_train_imgpool_fwd")
         ctx.save_for_backward(img, save, *params)
-        ctx.args, ctx.bwd_floats, ctx.wc_shape = a, s2.value, wc.shape
+        ctx.args, ctx.bwd_floats, ctx.wc_shape, ctx.tail = a, s2.value, wc.shape, tail
         return o
 
     @staticmethod
@@ -686,11 +706,18 @@ class _ImgPool(torch.autograd.Function):
         grads = _flat_grads(params, dev)
         dimg = torch.empty_like(img) if ctx.needs_input_grad[0] else None
         tmp = torch.empty((ctx.bwd_floats,), dtype=_F32, device=dev)
-        a.dout, a.dimg, a.tmp, a.tmp_floats = _p(do), _p(dimg), _p(tmp), ctx.bwd_floats
-        a.dwc, a.dbc, a.dpos, a.dwq, a.dbq, a.dwk, a.dbk, a.dwv, a.dbv = (_p(g) for g in grads)
+        a.dimg, a.tmp, a.tmp_floats = _p(dimg), _p(tmp), ctx.bwd_floats
+        a.dwc, a.dbc, a.dpos, a.dwq, a.dbq, a.dwk, a.dbk, a.dwv, a.dbv = (_p(g) for g in grads[:9])
+        if ctx.tail:
+            a.dproxy = _p(do)
+            a.dcw, a.dcb, a.dlnw, a.dlnb = (_p(g) for g in grads[9:])
+        else:
+            a.dout = _p(do)
         _ck(lib.ptx_train_imgpool_bwd(ctypes.byref(a), _st()), "ptx_train_imgpool_bwd")
         grads[0] = grads[0].view(ctx.wc_shape)
-        return (dimg, *grads, None)
+        if not ctx.tail:
+            grads = grads + [None] * 4
+        return (dimg, *grads[:9], None, *grads[9:], None)
 
 
 def _imgpool_ok(img3, C, heads):
@@ -708,7 +735,7 @@ class _AffineApply(torch.autograd.Function):
     def forward(ctx, kcenter, translate, transform, pts, tag, opos, kidx, kcluster, shape, ws, n_keep):
         lib = _abi.lib()
         B, N = pts.shape[0], pts.shape[1]
-        out = torch.zeros((B, N, 3), dtype=_F32, device=pts.device)
+        out = torch.empty((B, N, 3), dtype=_F32, device=pts.device)       # only the rows below the counts are returned
         counts = torch.empty((B,), dtype=torch.int32, device=pts.device)
         kcenter, translate, transform = _c(kcenter), _c(translate), _c(transform)
         _ck(lib.ptx_affine_compact(ctypes.byref(shape), _p(pts), _p(tag), _p(kcenter), _p(translate), _p(transform),
@@ -807,7 +834,8 @@ class _BlockFused(torch.autograd.Function):
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, dx_add=None):
+        # dx_add (one-node step only): a gradient of the same rows that is added into dx by the last kernel of this backward
         lib = _abi.lib()
         saved = ctx.saved_tensors
         x, proxy, save = saved[0], saved[1], saved[2]
@@ -822,6 +850,7 @@ class _BlockFused(torch.autograd.Function):
         dx, dproxy = torch.empty_like(x), torch.empty_like(proxy)
         tmp = torch.empty((ctx.bwd_floats,), dtype=_F32, device=dev)
         a.dout, a.dx, a.dproxy, a.tmp, a.tmp_floats = _p(dout), _p(dx), _p(dproxy), _p(tmp), ctx.bwd_floats
+        a.dx_add = _p(dx_add)
         _ck(lib.ptx_train_block_bwd(ctypes.byref(a), _st()), "ptx_train_block_bwd")
         return (dx, dproxy, None, None, None, None, *grads)
 
@@ -1121,13 +1150,10 @@ class _TrainStep(torch.autograd.Function):
             side.wait_stream(main)
         with torch.cuda.stream(side if side is not None else main):
             T["ip"] = _Ctx((ctx.needs_input_grad[2],))
-            o = _ImgPool.forward(T["ip"], img3, mod.channel_mapper.weight, mod.channel_mapper.bias, ap.positional_embedding,
-                                 ap.q_proj.weight, ap.q_proj.bias, ap.k_proj.weight, ap.k_proj.bias, ap.v_proj.weight, ap.v_proj.bias,
-                                 mod.num_heads)
-            T["cp"] = _Ctx((True, True, True))
-            y = _Linear.forward(T["cp"], o, ap.c_proj.weight, ap.c_proj.bias)
-            T["ni"] = _Ctx()
-            img_proxy = _LayerNorm.forward(T["ni"], y, mod.norm_img.weight, mod.norm_img.bias, mod.norm_img.eps)
+            img_proxy = _ImgPool.forward(T["ip"], img3, mod.channel_mapper.weight, mod.channel_mapper.bias, ap.positional_embedding,
+                                         ap.q_proj.weight, ap.q_proj.bias, ap.k_proj.weight, ap.k_proj.bias, ap.v_proj.weight,
+                                         ap.v_proj.bias, mod.num_heads, ap.c_proj.weight, ap.c_proj.bias, mod.norm_img.weight,
+                                         mod.norm_img.bias, mod.norm_img.eps)
         # ---- output positions; the list lengths of PRE:467 are copied out now and awaited at the very end
         ntiles = (N + 2047) // 2048
         tile_counts = torch.empty((B * ntiles,), **i32)
@@ -1179,8 +1205,8 @@ class _TrainStep(torch.autograd.Function):
                     dict(off=(off.mlp[0].weight, off.mlp[0].bias, bn.weight, bn.bias), oh=off.channel_mapper.weight,
                          enc=(enc.mlp[0].weight, enc.mlp[0].bias, ebn.weight, ebn.bias), tb=par_t, ib=par_i,
                          ip=(mod.channel_mapper.weight, mod.channel_mapper.bias, ap.positional_embedding, ap.q_proj.weight,
-                             ap.q_proj.bias, ap.k_proj.weight, ap.k_proj.bias, ap.v_proj.weight, ap.v_proj.bias),
-                         cp=(ap.c_proj.weight, ap.c_proj.bias), ni=(mod.norm_img.weight, mod.norm_img.bias)))
+                             ap.q_proj.bias, ap.k_proj.weight, ap.k_proj.bias, ap.v_proj.weight, ap.v_proj.bias, ap.c_proj.weight,
+                             ap.c_proj.bias, mod.norm_img.weight, mod.norm_img.bias)))
         return outs
 
     @staticmethod
@@ -1204,18 +1230,13 @@ class _TrainStep(torch.autograd.Function):
             dproxy_i.record_stream(side)
             side.wait_stream(main)
         with torch.cuda.stream(side if side is not None else main):
-            r = _LayerNorm.backward(T["ni"], dproxy_i)
-            put(P["ni"], r[1:3])
-            r2 = _Linear.backward(T["cp"], r[0])
-            put(P["cp"], r2[1:3])
-            r3 = _ImgPool.backward(T["ip"], r2[0])
-            put(P["ip"], r3[1:10])
+            r3 = _ImgPool.backward(T["ip"], dproxy_i)          # (dimg, 9 grads, None, 4 tail grads, None)
+            put(P["ip"], list(r3[1:10]) + list(r3[11:15]))
             dimg = r3[0]
-            side_grads = [g for g in (list(r[1:3]) + list(r2[1:3]) + list(r3[:10])) if g is not None]
-        r = _BlockFused.backward(T["tb"], dtranslate)
-        dpp_t, dtf2 = r[0], r[1]
+            side_grads = [g for g in r3 if g is not None]
+        r = _BlockFused.backward(T["tb"], dtranslate, dpp_i)           # dx = both blocks' gradients of the point proxies
+        dpp, dtf2 = r[0], r[1]
         put(P["tb"], r[6:])
-        dpp = add_(dpp_t, dpp_i)
         r = _SlotNet.backward(T["enc"], dpp)
         put(P["enc"], r[2:6])
         dkcenter = add_(r[0], _c(dkc_aff))
