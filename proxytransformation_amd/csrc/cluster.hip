@@ -518,7 +518,9 @@ __global__ __launch_bounds__(256) void k_select(SelectArgs a)
     // coordinates through the candidate exchange instead of re-reading sx[last]: slower, 233 vs 215 us at Mt = 1210 --
     // the per-lane select of the candidate's registers and three more LDS words cost more than the saved read.
     // Eight waves with P = 3: slower as well, 273 vs 211 us -- two waves per SIMD at the barrier; the pick is bound by
-    // its synchronisation chain, not by the distance updates.)
+    // its synchronisation chain, not by the distance updates.
+    //  r04: ONE wave with twenty points per lane (packed updates, no barrier, no exchange) at Mt = 1 210: slower too, cfg4 at 6
+    //  scenes 0.533 vs 0.486 ms per step -- 160 dependent-issue VALU instructions per pick cost more than the barrier they save.)
     const int kn = Kd < Mt ? Kd : Mt;                                            // PRE:595
     {
         // the whole scene waits on this latency-bound loop while bandwidth-bound kernels of the image branch
