@@ -146,7 +146,7 @@ def test_fused_block_matches_the_node_by_node_block(monkeypatch, embed, rates):
     for fused in (True, False):
         monkeypatch.setattr(T, "_FUSED_BLOCK", fused)
         m = MODELS.build(dict(type="ProxyTransformationNormReverse", drop_rate=rates[0], attn_drop_rate=rates[1],
-                              drop_path_rate=rates[2], **cfg.module_kwargs()))
+                              drop_path_rate=rates[2], qkv_bias=embed == 512, **cfg.module_kwargs()))     # with and without the qkv bias
         m.load_state_dict({k: torch.from_numpy(v) for k, v in fill_state_dict(m.state_dict()).items()})
         m = m.cuda().train()
         B, n, L = 3, m.real_cluster_num, 6
