@@ -85,7 +85,7 @@ def _ck(rc: int, what: str) -> None:
 def _p(t: Optional[torch.Tensor], off: int = 0) -> Optional[int]:
     if t is None:
         return None
-    return t.data_ptr() + off * t.element_size()
+    return t.data_ptr() if off == 0 else t.data_ptr() + off * t.element_size()      # ~300 calls per training step
 
 
 def _c(t: torch.Tensor) -> torch.Tensor:
