@@ -460,3 +460,32 @@ def test_bf16_compute_mode_of_the_training_step():
         worst = max(worst, float((g16 - g32).abs().max()) / scale)
     assert worst < 0.5, worst
     print("bf16 compute mode: worst gradient deviation / rms =", round(worst, 4))
+
+
+def test_training_step_is_bit_reproducible():
+    """Fixed summation orders everywhere (chunk partials in chunk order, K slices in slice order, tile partials in tile order,
+    no floating-point atomics): two runs of the same step -- dropout on, same seeds -- give the same bits for every output and
+    every gradient, also with the image branch on its side stream."""
+    import copy
+    from proxytransformation_amd import MODELS
+    from tests.gpu_util import t
+    cfg = PreshapeConfig("trr", B=3, N=6000, grid_size=5, dynamic_drop_radio=0.6, L=9, V=4, text_blocks=2, img_blocks=2, seed_base=8800)
+    pts, text, mask, img = make_scene_batch(cfg)
+    m0 = MODELS.build(dict(type="ProxyTransformationNormReverse", **cfg.module_kwargs()))
+    m0.load_state_dict({k: torch.from_numpy(v) for k, v in fill_state_dict(m0.state_dict()).items()})
+    runs = []
+    for _ in range(2):
+        m = copy.deepcopy(m0).cuda().train()
+        m._instance_salt, m._train_calls = 7, 0               # the dropout seeds are a function of (torch seed, call, instance)
+        tx, ix = t(text).requires_grad_(True), t(img).requires_grad_(True)
+        outs = m([t(p) for p in pts], {"text_feats": tx, "text_token_mask": t(mask)}, ix)
+        _loss(outs).backward()
+        torch.cuda.synchronize()
+        runs.append(([o.detach().clone() for o in outs], {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None},
+                     tx.grad.clone(), ix.grad.clone()))
+    for a, b in zip(runs[0][0], runs[1][0]):
+        assert torch.equal(a, b)
+    assert sorted(runs[0][1]) == sorted(runs[1][1])
+    for k in runs[0][1]:
+        assert torch.equal(runs[0][1][k], runs[1][1][k]), k
+    assert torch.equal(runs[0][2], runs[1][2]) and torch.equal(runs[0][3], runs[1][3])
