@@ -143,6 +143,7 @@ PrepLayout prep_layout(const PtxShape &s)
         const size_t planes = mlp_fused_supported(s.C, s.hidden, 1, 0) ? (size_t)s.hidden * s.C * 3 / 2 : 0;   // bf16 x 3, in floats
         P.mlp_w1p[i] = take(planes); P.mlp_w2p[i] = take(planes);
     }
+    for (int i = 0; i < 2; ++i) P.qkvb[i] = take((size_t)s.Mk * 3 * s.C);
     P.total = o;
     return P;
 }
@@ -176,6 +177,8 @@ WsLayout ws_layout(const PtxShape &s)
     L.tile_counts = take(B * (size_t)cdiv(s.N, kTilePts) * 4);
     L.point_proxy = take(R * C * 4);
     for (int i = 0; i < 2; ++i) L.x_in[i] = take(R * C * 4);
+    L.pp_all = take(B * M * C * 4);
+    for (int i = 0; i < 2; ++i) { L.xln_all[i] = take(B * M * C * 4); L.g_all[i] = take(B * M * 3 * C * 4); }
     L.fm = take(nimg * s.in_dim * 4); L.qkv0 = take(nimg * 3 * C * 4);
     L.we = take(nimg * s.heads * (size_t)P.KT1 * 4);
     L.pool = take(img_pool_bytes((int)nimg, s.in_dim, P.KT2p - s.in_dim));
@@ -205,7 +208,7 @@ WsLayout ws_layout(const PtxShape &s)
 struct PtxContext {
     int dev = -1;
     hipStream_t st = nullptr, lo = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr, aux = nullptr, tags = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr, aux = nullptr, tags = nullptr, early_a = nullptr, early_b = nullptr;
     // device words of the in-kernel fork / join ("gates", below); null or !gates_on: events.  Word 0: fork, 32: join,
     // 40 / 44: the two probe words, 48: poison (read by k_affine), the rest spare
     uint32_t *gate = nullptr; uint32_t gate_seq = 0;
@@ -252,6 +255,8 @@ static int context_init(PtxContext *c)
     PTX_HIP(hipEventCreateWithFlags(&c->join, hipEventDisableTiming));
     PTX_HIP(hipEventCreateWithFlags(&c->aux, hipEventDisableTiming));
     PTX_HIP(hipEventCreateWithFlags(&c->tags, hipEventDisableTiming));
+    PTX_HIP(hipEventCreateWithFlags(&c->early_a, hipEventDisableTiming));
+    PTX_HIP(hipEventCreateWithFlags(&c->early_b, hipEventDisableTiming));
     if (gates_allowed()) {
         PTX_HIP(hipMalloc(reinterpret_cast<void **>(&c->gate), 256));
         PTX_HIP(hipMemset(c->gate, 0, 256));
@@ -280,6 +285,8 @@ static void context_release(PtxContext *c)
     if (c->join) (void)hipEventDestroy(c->join);
     if (c->aux) (void)hipEventDestroy(c->aux);
     if (c->tags) (void)hipEventDestroy(c->tags);
+    if (c->early_a) (void)hipEventDestroy(c->early_a);
+    if (c->early_b) (void)hipEventDestroy(c->early_b);
     if (c->st) (void)hipStreamDestroy(c->st);
     if (c->lo) (void)hipStreamDestroy(c->lo);
     c->fork = c->join = c->aux = c->tags = nullptr; c->st = c->lo = nullptr;
@@ -538,7 +545,8 @@ static bool fused_attn_pays(const PtxShape &s, const Branch *br, int nb)
 // it starts when both the GEMM and the other stream are done (no k_gate launch on the critical path: -4.8 us in the r03 trace).
 // *join is cleared when it has been attached.
 static int run_blocks(const PtxShape &s, const Branch *br, int nb, const float *point_proxy, void *ws,
-                      hipStream_t st, int phase = 0, int cd = 0, GateRef *join = nullptr, GateRef *tags_join = nullptr)
+                      hipStream_t st, int phase = 0, int cd = 0, GateRef *join = nullptr, GateRef *tags_join = nullptr,
+                      bool skip_qkv = false)
 {
     const WsLayout L = ws_layout(s);
     const int C = s.C, R = s.B * s.Mk;
@@ -546,11 +554,12 @@ static int run_blocks(const PtxShape &s, const Branch *br, int nb, const float *
         GemmBatch g{}; g.n = 0;
         for (int i = 0; i < nb; ++i) {
             const int sl = br[i].slot;
-            if (phase != 2)
+            if (phase != 2 && phase != 3 && phase != 4 && !skip_qkv)
                 g.p[g.n++] = GemmProb{br[i].x_in, br[i].blk->qkv_w, at<float>(ws, L.qkv[sl]), br[i].blk->qkv_b,
                                       nullptr, nullptr, nullptr, R, 3 * C, C, C, C, 3 * C, 0, 0, 0, EPI_NONE};
-            const bool now = phase == 0 || (phase == 1 && !br[i].late_proxy) || (phase == 2 && br[i].late_proxy);
-            if (now) {
+            // phase 3: only the late proxies' projection, then return; phase 4: every input projection has been enqueued already
+            const bool now = phase == 0 || (phase == 1 && !br[i].late_proxy) || ((phase == 2 || phase == 3) && br[i].late_proxy);
+            if (now && phase != 4) {
                 GemmProb &q = g.p[g.n++];
                 q = GemmProb{br[i].proxy, br[i].blk->pp_w, at<float>(ws, L.pt[sl]), br[i].blk->pp_b,
                              nullptr, nullptr, nullptr, s.B * br[i].Lp, C, C, C, C, C, 0, 0, 0, EPI_NONE};
@@ -562,8 +571,8 @@ static int run_blocks(const PtxShape &s, const Branch *br, int nb, const float *
             }
         }
         if (g.n > 0 && phase == 2 && join != nullptr && join->flag != nullptr) { g.tail_gate = *join; join->flag = nullptr; }
-        if (g.n > 0) PTX_TIMED(phase == 2 ? KID_BLK_PP : KID_BLK_QKV, st, launch_gemm(g, st, cd));
-        if (phase == 1) return PTX_OK;
+        if (g.n > 0) PTX_TIMED(phase == 2 || phase == 3 ? KID_BLK_PP : KID_BLK_QKV, st, launch_gemm(g, st, cd));
+        if (phase == 1 || phase == 3) return PTX_OK;
     }
     FAttnBatch fa{}; fa.nb = nb; fa.B = s.B; fa.heads = s.heads; fa.hd = C / s.heads; fa.n = s.Mk; fa.C = C;
     fa.scale = attn_scale(C / s.heads); fa.compute_dtype = cd;
@@ -1133,6 +1142,39 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
                                               centers_override, nullptr, centers0, cluster1, offsets, centers, idx2,
                                               cluster2, pad_count, cs));
 
+    // ---- early proxies (r04).  Where the clustering chain is the long one, most of it is the farthest point sampling: one
+    // work-group per scene for hundreds of dependent picks (cfg4: 519 picks, 0.2 ms), after which the point proxies, LayerNorm1 and
+    // the qkv projection of the KEPT clusters were still to come (15 + 40 us at 6 scenes).  None of the three needs the selection
+    // except for WHICH rows: so they are computed for ALL clusters on the third stream, beside the sampling (2.5x the rows at the
+    // shipped configuration, on a chip that is otherwise waiting), with (LN1(x) + posb_j) W^T + b = LN1(x) W^T + [posb_j W^T + b]
+    // and the bracket a parameter-only table (prep.hip); behind the sampling the kept rows are a gather + that table (~8 us).
+    float *point_proxy = at<float>(ws, L.point_proxy);
+    float *xin_t = at<float>(ws, L.x_in[0]), *xin_i = at<float>(ws, L.x_in[1]);
+    float *translate = at<float>(ws, L.head[0]), *transform = at<float>(ws, L.head[1]);
+    float *guide_t = (debug && debug->text_guide) ? at<float>(ws, L.guide[0]) : nullptr;
+    float *guide_i = (debug && debug->img_guide) ? at<float>(ws, L.guide[1]) : nullptr;
+    Branch br[2] = {make_branch(S, *w, pf, 0, xin_t, text_feats, S.L, text_mask, translate, guide_t),
+                    make_branch(S, *w, pf, 1, xin_i, at<float>(ws, L.cbuf), S.V, nullptr, transform, guide_i)};
+    br[1].proxy_lnp = at<float>(ws, L.lnp_img);       // norm_img is applied inside the image block's proxy_proj
+    static const int early_env = getenv("PTX_EARLY_PROXIES") ? atoi(getenv("PTX_EARLY_PROXIES")) : -1;
+    // (worth it from ~1000 kept rows per call: cfg4 at 6 scenes +5 %, one scene neutral, cfg1 -- 64 kept rows -- -6 %)
+    const bool early = cluster_on_caller && (early_env >= 0 ? early_env != 0 : (Kd >= 128 && (long)B * S.Mk >= 1024));
+    if (early) {
+        PTX_HIP(hipEventRecord(side->early_a, cs));                         // the clusters exist
+        PTX_HIP(hipStreamWaitEvent(side->lo, side->early_a, 0));
+        float *pp_all = at<float>(ws, L.pp_all), *xa_t = at<float>(ws, L.xln_all[0]), *xa_i = at<float>(ws, L.xln_all[1]);
+        PTX_TRY(launch_pointnet(pf + P.enc_ab, w->encoder, centers, cluster2, B * M, M, K, S.C, pp_all, &w->text, &w->img, nullptr,
+                                nullptr, xa_t, xa_i, S.ln_eps, nullptr, M, side->lo, nullptr, 0));
+        GemmBatch g{}; g.n = 2;
+        g.p[0] = GemmProb{xa_t, w->text.qkv_w, at<float>(ws, L.g_all[0]), nullptr, nullptr, nullptr, nullptr, B * M, 3 * S.C, S.C, S.C, S.C,
+                          3 * S.C, 0, 0, 0, EPI_NONE};
+        g.p[1] = GemmProb{xa_i, w->img.qkv_w, at<float>(ws, L.g_all[1]), nullptr, nullptr, nullptr, nullptr, B * M, 3 * S.C, S.C, S.C, S.C,
+                          3 * S.C, 0, 0, 0, EPI_NONE};
+        PTX_TRY(launch_gemm(g, side->lo, compute_dtype));
+        PTX_TRY(run_blocks(S, br, 2, point_proxy, ws, side->lo, 1, compute_dtype, nullptr, nullptr, true));    // proxy_proj of the text block
+        PTX_HIP(hipEventRecord(side->early_b, side->lo));
+    }
+
     // ---- dynamic cluster dropout (PRE:433): ordering + FPS + keep list on the chain; the slot tags and the survivor
     // counts (only k_affine and the host need them) on the low-priority stream next to it
     int32_t *order = at<int32_t>(ws, L.order), *picks = at<int32_t>(ws, L.picks), *keep = at<int32_t>(ws, L.keep);
@@ -1205,8 +1247,13 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     PTX_TRY(run_img_proxy(S, *w, pf, img_feat, img_proxy, ws, is, 2, want_img_proxy));
 
     // ---- point proxies (PRE:437) + norm1 / slot bias of both blocks; the kept clusters are read through the selection
-    float *point_proxy = at<float>(ws, L.point_proxy);
-    float *xin_t = at<float>(ws, L.x_in[0]), *xin_i = at<float>(ws, L.x_in[1]);
+    if (early) {
+        const float *const gsrc[2] = {at<float>(ws, L.g_all[0]), at<float>(ws, L.g_all[1])};
+        const float *const tb[2] = {pf + P.qkvb[0], pf + P.qkvb[1]};
+        float *const qk[2] = {at<float>(ws, L.qkv[0]), at<float>(ws, L.qkv[1])};
+        PTX_HIP(hipStreamWaitEvent(cs, side->early_b, 0));
+        PTX_TIMED(KID_POINTNET, cs, launch_qkv_gather(at<float>(ws, L.pp_all), gsrc, tb, ksrc, B, M, S.Mk, S.C, point_proxy, qk, cs));
+    } else
     PTX_TIMED(KID_POINTNET, cs, launch_pointnet(pf + P.enc_ab, w->encoder, kcenter, cluster2, B * S.Mk, S.Mk, K,
                                                 S.C, point_proxy, &w->text, &w->img, pf + P.posb_t, pf + P.posb_i, xin_t,
                                                 xin_i, S.ln_eps, ksrc, M, cs, tags_gated ? side->gate + 36 : nullptr, side->gate_seq));
@@ -1214,17 +1261,13 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
 
     // ---- both proxy blocks + heads in shared launches (PRE:440-455); the input projections that
     // do not need the image proxies still run on the clustering stream
-    float *translate = at<float>(ws, L.head[0]), *transform = at<float>(ws, L.head[1]);
-    float *guide_t = (debug && debug->text_guide) ? at<float>(ws, L.guide[0]) : nullptr;
-    float *guide_i = (debug && debug->img_guide) ? at<float>(ws, L.guide[1]) : nullptr;
-    Branch br[2] = {make_branch(S, *w, pf, 0, xin_t, text_feats, S.L, text_mask, translate, guide_t),
-                    make_branch(S, *w, pf, 1, xin_i, at<float>(ws, L.cbuf), S.V, nullptr, transform, guide_i)};
-    br[1].proxy_lnp = at<float>(ws, L.lnp_img);       // norm_img is applied inside the image block's proxy_proj
     // (The whole text branch on a third stream while the image chain finishes, leaving only the image
     // branch after the join, was measured slower: 12.6k vs 13.7k scenes/s -- eight more launches, and its
     // small kernels take CUs from the image passes that are on the critical path.)
-    PTX_TRY(run_blocks(S, br, 2, point_proxy, ws, cs, 1, compute_dtype));
+    if (!early) PTX_TRY(run_blocks(S, br, 2, point_proxy, ws, cs, 1, compute_dtype));
     if (tags_tail) PTX_TRY(enqueue_tags());
+    static const int pp_env = getenv("PTX_PP_EARLY") ? atoi(getenv("PTX_PP_EARLY")) : 1;
+    const bool pp_early = cluster_on_caller && (early || pp_env != 0);       // (see below, at the join)
     GateRef join{};                     // the join, folded into the first launch behind it (run_blocks) unless PTX_GATE_FOLD=0
     if (gated) {                        // the join through the second gate word: signalled behind the clustering stream's last kernel
         auto launch_signal = [&]() -> int {
@@ -1241,12 +1284,15 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
         }
     } else {
     if (!cluster_on_caller) PTX_HIP(hipEventRecord(side->join, cs));
+    // where the clustering chain owns the caller's stream the image block's proxy_proj runs behind the image chain on ITS stream, in
+    // front of the join, instead of behind it on the caller's (7 us + a launch gap off the long chain: cfg4 one scene +3 %)
+    if (pp_early) PTX_TRY(run_blocks(S, br, 2, point_proxy, ws, is, 3, compute_dtype));
     if (cluster_on_caller) PTX_HIP(hipEventRecord(side->join, is));
     PTX_HIP(hipStreamWaitEvent(st, side->join, 0));
     }
     GateRef tags_join{};
     if (tags_gated) tags_join = gate_ref(side, 38, side->gate_seq, 7);
-    PTX_TRY(run_blocks(S, br, 2, point_proxy, ws, st, 2, compute_dtype, &join, &tags_join));
+    PTX_TRY(run_blocks(S, br, 2, point_proxy, ws, st, pp_early ? 4 : 2, compute_dtype, &join, &tags_join));
     if (join.flag != nullptr) {         // (not attached: no launch in front of the attention took it)
         set_error("ptx_forward: the join gate was not attached to a launch");
         return PTX_ELAUNCH;

@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void k_slot_net(SlotNetArgs a)
 #pragma unroll
             for (int q = 0; q < Q; ++q) {
                 const int c = lane + 64 * q;
-                e_w[br][q] = a.n1w[br][c]; e_b[br][q] = a.n1b[br][c]; e_p[br][q] = a.posb[br][(size_t)j * W + c];
+                e_w[br][q] = a.n1w[br][c]; e_b[br][q] = a.n1b[br][c]; e_p[br][q] = a.posb[br] ? a.posb[br][(size_t)j * W + c] : 0.0f;
             }
         }
     }
@@ -421,6 +421,37 @@ int launch_pointnet(const float *ab, const PtxSlotMlp &mlp, const float *kcenter
     if (width == 256) hipLaunchKernelGGL((k_slot_net<1, 4>), dim3(cdiv(BM, 4)), dim3(256), 0, st, a);
     else              hipLaunchKernelGGL((k_slot_net<1, 8>), dim3(cdiv(BM, 4)), dim3(256), 0, st, a);
     PTX_LAUNCHED("k_slot_net<pointnet>");
+    return PTX_OK;
+}
+
+// ------------------------------------------------------------------------------ kept rows out of the all-cluster tables
+// (the early-proxy path of ptx_forward, api.hip: point proxies, LayerNorm rows and their qkv projections are computed for ALL
+//  clusters beside the farthest point sampling; afterwards the kept rows are a gather + the per-slot bias term)
+struct QkvGatherArgs { const float *pp_all, *g[2], *tb[2]; const int32_t *ksrc; int M, Mk, C; float *pp, *qkv[2]; };
+__global__ __launch_bounds__(512) void k_qkv_gather(QkvGatherArgs a)
+{
+    const int row = blockIdx.x, b = row / a.Mk, j = row - b * a.Mk;
+    const size_t src = (size_t)b * a.M + a.ksrc[row];
+    const int c4 = a.C / 4, n4 = 3 * c4;
+    for (int i = threadIdx.x; i < c4 + 2 * n4; i += blockDim.x) {          // C = 256: 448 threads, one 16-byte piece each
+        if (i < c4) {
+            reinterpret_cast<float4 *>(a.pp + (size_t)row * a.C)[i] = reinterpret_cast<const float4 *>(a.pp_all + src * a.C)[i];
+        } else {
+            const int br = (i - c4) / n4, k = (i - c4) - br * n4;
+            const float4 gv = reinterpret_cast<const float4 *>(a.g[br] + src * 3 * a.C)[k];
+            const float4 tv = reinterpret_cast<const float4 *>(a.tb[br] + (size_t)j * 3 * a.C)[k];
+            reinterpret_cast<float4 *>(a.qkv[br] + (size_t)row * 3 * a.C)[k] = make_float4(gv.x + tv.x, gv.y + tv.y, gv.z + tv.z, gv.w + tv.w);
+        }
+    }
+}
+int launch_qkv_gather(const float *pp_all, const float *const g[2], const float *const tb[2], const int32_t *ksrc, int B, int M, int Mk,
+                      int C, float *point_proxy, float *const qkv[2], hipStream_t st)
+{
+    PTX_REQUIRE(pp_all && g[0] && g[1] && tb[0] && tb[1] && ksrc && point_proxy && qkv[0] && qkv[1] && C % 4 == 0, "qkv gather: bad arguments");
+    QkvGatherArgs a{pp_all, {g[0], g[1]}, {tb[0], tb[1]}, ksrc, M, Mk, C, point_proxy, {qkv[0], qkv[1]}};
+    const int pieces = C / 4 * 7;
+    hipLaunchKernelGGL(k_qkv_gather, dim3(B * Mk), dim3(pieces <= 512 ? (pieces + 63) / 64 * 64 : 512), 0, st, a);
+    PTX_LAUNCHED("k_qkv_gather");
     return PTX_OK;
 }
 

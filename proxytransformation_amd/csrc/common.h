@@ -258,6 +258,7 @@ struct PrepLayout {
     size_t ppg_w, ppg_s, ppg_c;     // (C,C), (C), (C)
     size_t fc1g_w[2], fc1g_s[2], fc1g_c[2];   // (hidden,C), (hidden), (hidden) for the text / image block
     size_t mlp_w1p[2], mlp_w2p[2];  // fused Mlp (mlp.hip): fc1g_w / fc2_w as three bf16 planes in MFMA fragment order
+    size_t qkvb[2];                 // (Mk,3C): slot-bias rows through the qkv projection + its bias (the early-proxy path, api.hip)
     size_t total;                   // floats
     int KT1, KT2p, hd;
 };
@@ -277,6 +278,7 @@ struct WsLayout {
     size_t minmax, centers0, cluster1, offsets, centers, idx2, cluster2, pad_count;
     size_t order, picks, keep, ksrc, kcenter, kcluster, kidx, drop_idx, tile_counts;
     size_t point_proxy, x_in[2];    // x_in: LN1(x)+slot bias per branch (B*Mk,C)
+    size_t pp_all, xln_all[2], g_all[2];   // early-proxy path: point proxies / LN1 rows (B*M,C) and their qkv rows (B*M,3C) of ALL clusters
     size_t fm, qkv0, we, pool, gbuf, obuf, cbuf, img_proxy;
     size_t qkv[2], pt[2], pv[2], ao[2], x1[2], xn2[2], hbuf[2], x2[2], guide[2], head[2];
     size_t lnp_img, lnp_x1[2];      // LayerNorm partials (rows, C/32, 2) of c_proj's / proj's output
@@ -398,6 +400,9 @@ int launch_pointnet(const float *ab, const PtxSlotMlp &mlp, const float *kcenter
                     const PtxBlock *blk_t, const PtxBlock *blk_i, const float *posb_t,
                     const float *posb_i, float *xin_t, float *xin_i, float ln_eps,
                     const int32_t *ksrc, int Msrc, hipStream_t st, uint32_t *head_flag = nullptr, uint32_t head_seq = 0);
+// kept rows out of the all-cluster tables: point_proxy[row] = pp_all[src], qkv[i][row] = g[i][src] + tb[i][j]  (src = b * M + ksrc[row])
+int launch_qkv_gather(const float *pp_all, const float *const g[2], const float *const tb[2], const int32_t *ksrc, int B, int M, int Mk,
+                      int C, float *point_proxy, float *const qkv[2], hipStream_t st);
 int launch_cluster(const PtxShape &s, const uint32_t *mm_enc, const float *lin, const ScenePts &points,
                    const float *off_ab, const PtxSlotMlp &mlp, const float *map_w, const float *centers_override,
                    float *minmax_out, float *centers0, float *cluster1, float *offsets, float *centers,

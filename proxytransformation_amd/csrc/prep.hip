@@ -158,6 +158,15 @@ int run_prepare(const PtxShape &s, const PtxWeights &w, float *prep, hipStream_t
                            blk[i]->norm2_b, blk[i]->fc1_b, s.hidden, C, prep + P.fc1g_w[i], prep + P.fc1g_s[i],
                            prep + P.fc1g_c[i]);
     PTX_LAUNCHED("k_prep_lnfold");
+    // the slot-bias rows through the qkv projection (+ its bias): (LN1(x) + posb) W^T + b = LN1(x) W^T + [posb W^T + b] -- the bracket is
+    // parameter-only, which lets the early-proxy path project LN1(x) of ALL clusters before the selection is known (api.hip)
+    {
+        GemmBatch g{}; g.n = 2;
+        for (int i = 0; i < 2; ++i)
+            g.p[i] = GemmProb{prep + (i == 0 ? P.posb_t : P.posb_i), blk[i]->qkv_w, prep + P.qkvb[i], blk[i]->qkv_b, nullptr, nullptr, nullptr,
+                              s.Mk, 3 * C, C, C, C, 3 * C, 0, 0, 0, EPI_NONE};
+        PTX_TRY(launch_gemm(g, st));
+    }
     // the fused Mlp's weights, split once into bf16 planes in MFMA fragment order (mlp.hip)
     if (mlp_fused_supported(C, s.hidden, 1, 0))
         for (int i = 0; i < 2; ++i) {
