@@ -1085,7 +1085,13 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     const bool cluster_on_caller = swap_env >= 0 ? swap_env != 0 : est_cluster > est_image;
     hipStream_t cs = cluster_on_caller ? st : side->st, is = cluster_on_caller ? side->st : st;
     const bool gated = side->gates_on && !cluster_on_caller && !capturing;        // gates instead of events (see k_gate)
-    if (!gated) {
+    // r04: where the clustering chain is the long one AND the image chain has the slack for it, the image chain forks BEHIND k_cluster
+    // instead of at the top, so that the clustering kernel does not share the chip with the mean pass (k_cluster 64 -> ~45 us at
+    // cfg4 / 6 scenes: 13.04k -> 13.26k scenes/s, one scene +1 %, 3 scenes +0.8 %; 8 scenes, where the image chain is nearly as
+    // long as the sampling, -0.9 %: hence the slack rule; profiles/r04_early_proxies_ab.txt).  PTX_IMG_AFTER_CLUSTER=0 / 1 forces it.
+    static const int img_late_env = getenv("PTX_IMG_AFTER_CLUSTER") ? atoi(getenv("PTX_IMG_AFTER_CLUSTER")) : -1;
+    const bool img_late = cluster_on_caller && (img_late_env >= 0 ? img_late_env != 0 : est_image + 60.0 < 0.8 * est_cluster);
+    if (!gated && !img_late) {
         PTX_HIP(hipEventRecord(side->fork, st));
         PTX_HIP(hipStreamWaitEvent(side->st, side->fork, 0));
     }
@@ -1122,7 +1128,7 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
                               mm_fused ? &mmf : nullptr));
         PTX_TIMED(KID_GATE_FORK, cs, launch_gate(KID_GATE_FORK, cs, gate_ref(side, 0, seq, 1)));
     } else
-    PTX_TRY(run_img_proxy(S, *w, pf, img_feat, img_proxy, ws, is, 1));      // first pass starts at once
+    if (!img_late) PTX_TRY(run_img_proxy(S, *w, pf, img_feat, img_proxy, ws, is, 1));      // first pass starts at once
 
     // ---- clustering (PRE:430): bounding boxes, then everything per centre in one launch
     // The words of the workspace's zero region (encoded boxes, tags, count accumulators) are clean on entry and are
@@ -1142,6 +1148,11 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
                                               centers_override, nullptr, centers0, cluster1, offsets, centers, idx2,
                                               cluster2, pad_count, cs));
 
+    if (img_late) {
+        PTX_HIP(hipEventRecord(side->fork, st));
+        PTX_HIP(hipStreamWaitEvent(side->st, side->fork, 0));
+        PTX_TRY(run_img_proxy(S, *w, pf, img_feat, img_proxy, ws, is, 1));
+    }
     // ---- early proxies (r04).  Where the clustering chain is the long one, most of it is the farthest point sampling: one
     // work-group per scene for hundreds of dependent picks (cfg4: 519 picks, 0.2 ms), after which the point proxies, LayerNorm1 and
     // the qkv projection of the KEPT clusters were still to come (15 + 40 us at 6 scenes).  None of the three needs the selection
@@ -1247,10 +1258,20 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     PTX_TRY(run_img_proxy(S, *w, pf, img_feat, img_proxy, ws, is, 2, want_img_proxy));
 
     // ---- point proxies (PRE:437) + norm1 / slot bias of both blocks; the kept clusters are read through the selection
+    bool joined_early = false;
     if (early) {
         const float *const gsrc[2] = {at<float>(ws, L.g_all[0]), at<float>(ws, L.g_all[1])};
         const float *const tb[2] = {pf + P.qkvb[0], pf + P.qkvb[1]};
         float *const qk[2] = {at<float>(ws, L.qkv[0]), at<float>(ws, L.qkv[1])};
+        static const int jfirst_env = getenv("PTX_EARLY_JOIN_FIRST") ? atoi(getenv("PTX_EARLY_JOIN_FIRST")) : 1;
+        if (jfirst_env) {
+            // both cross-stream waits of the caller's chain in ONE place, in front of the gather (each costs ~6 us of idle between
+            // the two kernels around it): the image chain finished long before the sampling does
+            PTX_TRY(run_blocks(S, br, 2, point_proxy, ws, is, 3, compute_dtype));
+            PTX_HIP(hipEventRecord(side->join, is));
+            PTX_HIP(hipStreamWaitEvent(cs, side->join, 0));
+            joined_early = true;
+        }
         PTX_HIP(hipStreamWaitEvent(cs, side->early_b, 0));
         PTX_TIMED(KID_POINTNET, cs, launch_qkv_gather(at<float>(ws, L.pp_all), gsrc, tb, ksrc, B, M, S.Mk, S.C, point_proxy, qk, cs));
     } else
@@ -1286,9 +1307,9 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     if (!cluster_on_caller) PTX_HIP(hipEventRecord(side->join, cs));
     // where the clustering chain owns the caller's stream the image block's proxy_proj runs behind the image chain on ITS stream, in
     // front of the join, instead of behind it on the caller's (7 us + a launch gap off the long chain: cfg4 one scene +3 %)
-    if (pp_early) PTX_TRY(run_blocks(S, br, 2, point_proxy, ws, is, 3, compute_dtype));
-    if (cluster_on_caller) PTX_HIP(hipEventRecord(side->join, is));
-    PTX_HIP(hipStreamWaitEvent(st, side->join, 0));
+    if (pp_early && !joined_early) PTX_TRY(run_blocks(S, br, 2, point_proxy, ws, is, 3, compute_dtype));
+    if (cluster_on_caller && !joined_early) PTX_HIP(hipEventRecord(side->join, is));
+    if (!joined_early) PTX_HIP(hipStreamWaitEvent(st, side->join, 0));
     }
     GateRef tags_join{};
     if (tags_gated) tags_join = gate_ref(side, 38, side->gate_seq, 7);
