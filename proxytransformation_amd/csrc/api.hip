@@ -1169,7 +1169,12 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     br[1].proxy_lnp = at<float>(ws, L.lnp_img);       // norm_img is applied inside the image block's proxy_proj
     static const int early_env = getenv("PTX_EARLY_PROXIES") ? atoi(getenv("PTX_EARLY_PROXIES")) : -1;
     // (worth it from ~1000 kept rows per call: cfg4 at 6 scenes +5 %, one scene neutral, cfg1 -- 64 kept rows -- -6 %)
-    const bool early = cluster_on_caller && (early_env >= 0 ? early_env != 0 : (Kd >= 128 && (long)B * S.Mk >= 1024));
+    // ... and only where the all-cluster work fits beside the sampling: ~12 B M C^2 flop at ~70 TFLOP/s for the two qkv products, the
+    // point proxies ~0.4x that, against ~0.42 us per pick (cfg5 at 16 scenes: 4 ms of it beside 0.8 ms of picks -- 4.37k -> 3.36k
+    // scenes/s before this rule)
+    const double est_all = 1.4 * 12.0 * (double)B * M * S.C * S.C / 70e6;                        // us
+    const bool early = cluster_on_caller && (early_env >= 0 ? early_env != 0
+                                                            : (Kd >= 128 && (long)B * S.Mk >= 1024 && est_all < 0.8 * 0.42 * Kd));
     if (early) {
         PTX_HIP(hipEventRecord(side->early_a, cs));                         // the clusters exist
         PTX_HIP(hipStreamWaitEvent(side->lo, side->early_a, 0));
