@@ -41,6 +41,7 @@ _FUSED_BLOCK = os.environ.get("PTX_TRAIN_FUSED_BLOCK", "1") != "0"
 _FUSED_IMG = os.environ.get("PTX_TRAIN_FUSED_IMG", "1") != "0"
 _SIDE_STREAM = os.environ.get("PTX_TRAIN_SIDE_STREAM", "1") != "0"
 _ONE_NODE = os.environ.get("PTX_TRAIN_ONE_NODE", "1") != "0"
+_IMG_FIRST = os.environ.get("PTX_TRAIN_IMG_FIRST", "1") != "0"   # one-node step: the image branch in front of the clustering half
 _IMG_POS = int(os.environ.get("PTX_TRAIN_IMG_POS", "1"))     # where the image branch is enqueued: 0 first, 1 after the selection,
                                                               # 2 before the text block, 3 after it
 
@@ -1103,6 +1104,25 @@ class _TrainStep(torch.autograd.Function):
         pts = torch.stack([p.detach().to(_F32) for p in points]).contiguous()          # PRE:426-427
         seeds = st8["seeds"]
         T = {}                                                        # the tape: one context per node body
+        # ---- image branch on the side stream (PRE:449-450): it needs nothing from the clustering half, so it is enqueued FIRST and runs
+        # beside the ball queries and the farthest point sampling (one work-group per scene for 0.2 ms: the chip is idle next to it)
+        V = img_feat.shape[1]
+        hw = mod.img_spacial_dim ** 2
+        ap = mod.attn_pool2d
+        img3 = _c(img_feat).view(B * V, mod.input_dim, hw)
+        main = torch.cuda.current_stream(dev)
+        side = _side_stream(mod, dev) if _SIDE_STREAM else None
+
+        def run_img():
+            if side is not None:
+                side.wait_stream(main)
+            with torch.cuda.stream(side if side is not None else main):
+                T["ip"] = _Ctx((ctx.needs_input_grad[2],))
+                return _ImgPool.forward(T["ip"], img3, mod.channel_mapper.weight, mod.channel_mapper.bias, ap.positional_embedding,
+                                        ap.q_proj.weight, ap.q_proj.bias, ap.k_proj.weight, ap.k_proj.bias, ap.v_proj.weight,
+                                        ap.v_proj.bias, mod.num_heads, ap.c_proj.weight, ap.c_proj.bias, mod.norm_img.weight,
+                                        mod.norm_img.bias, mod.norm_img.eps)
+        img_proxy = run_img() if _IMG_FIRST else None
         # ---- index half, part 1 + offset network (PRE:55-62)
         minmax = torch.empty((B, 2, 3), dtype=_F32, device=dev)
         c0 = torch.empty((B, M, 3), dtype=_F32, device=dev)
@@ -1139,21 +1159,8 @@ class _TrainStep(torch.autograd.Function):
         oo = None if order_override is None else order_override.to(device=dev, dtype=torch.int32).contiguous()
         _ck(lib.ptx_select_clusters(ctypes.byref(shape), _p(idx2), _p(cdet), _p(cl2), _p(pad), _p(oo), _p(order), _p(picks),
                                     _p(keep), _p(kcenter_i), _p(kcluster), _p(kidx), _p(drop_idx), _p(tag), st), "ptx_select_clusters")
-        # ---- image branch on the side stream, beside the selection (PRE:449-450)
-        V = img_feat.shape[1]
-        hw = mod.img_spacial_dim ** 2
-        ap = mod.attn_pool2d
-        img3 = _c(img_feat).view(B * V, mod.input_dim, hw)
-        main = torch.cuda.current_stream(dev)
-        side = _side_stream(mod, dev) if _SIDE_STREAM else None
-        if side is not None:
-            side.wait_stream(main)
-        with torch.cuda.stream(side if side is not None else main):
-            T["ip"] = _Ctx((ctx.needs_input_grad[2],))
-            img_proxy = _ImgPool.forward(T["ip"], img3, mod.channel_mapper.weight, mod.channel_mapper.bias, ap.positional_embedding,
-                                         ap.q_proj.weight, ap.q_proj.bias, ap.k_proj.weight, ap.k_proj.bias, ap.v_proj.weight,
-                                         ap.v_proj.bias, mod.num_heads, ap.c_proj.weight, ap.c_proj.bias, mod.norm_img.weight,
-                                         mod.norm_img.bias, mod.norm_img.eps)
+        if img_proxy is None:
+            img_proxy = run_img()
         # ---- output positions; the list lengths of PRE:467 are copied out now and awaited at the very end
         ntiles = (N + 2047) // 2048
         tile_counts = torch.empty((B * ntiles,), **i32)
