@@ -551,7 +551,10 @@ __global__ __launch_bounds__(256) void k_select(SelectArgs a)
     // Eight waves with P = 3: slower as well, 273 vs 211 us -- two waves per SIMD at the barrier; the pick is bound by
     // its synchronisation chain, not by the distance updates.
     //  r04: ONE wave with twenty points per lane (packed updates, no barrier, no exchange) at Mt = 1 210: slower too, cfg4 at 6
-    //  scenes 0.533 vs 0.486 ms per step -- 160 dependent-issue VALU instructions per pick cost more than the barrier they save.)
+    //  scenes 0.533 vs 0.486 ms per step -- 160 dependent-issue VALU instructions per pick cost more than the barrier they save.
+    //  r04: the exchange WITHOUT the barrier -- every wave stores its candidate with the pick number's low byte as a tag and polls
+    //  the four words until all carry it: picks identical, 0.50 instead of 0.38 us per pick (cfg4, one scene: 0.401 vs 0.338 ms per
+    //  step; cfg5 1.355 vs 1.152 ms): a poll is an LDS round trip and most picks need two of them; s_barrier is the cheap part.)
     const int kn = Kd < Mt ? Kd : Mt;                                            // PRE:595
     {
         // the whole scene waits on this latency-bound loop while bandwidth-bound kernels of the image branch
