@@ -50,7 +50,7 @@ typedef struct PtxShape {
     int32_t L;          /* text proxies                                          */
     int32_t V;          /* image proxies (views)                                 */
     int32_t C;          /* embed_dim (256)                                       */
-    int32_t heads;      /* num_heads (8)                                         */
+    int32_t heads;      /* num_heads: 4, 8 (reference) or 16; head_dim 32 or 64   */
     int32_t hidden;     /* int(C*mlp_radio) (1024)                               */
     int32_t in_dim;     /* image feature channels (512)                          */
     int32_t hw;         /* img_spacial_dim^2 (225)                               */

@@ -109,8 +109,9 @@ int validate_shape(const PtxShape &s)
     PTX_REQUIRE(s.K >= 1 && s.K <= 63, "shape: num_sub K=%d must be in [1,63]", s.K);
     PTX_REQUIRE(s.Mk >= 1 && s.Mk <= s.Mt && s.Mt <= M, "shape: need 1 <= Mk=%d <= Mt=%d <= M=%ld", s.Mk, s.Mt, M);
     PTX_REQUIRE(s.C == 256 || s.C == 512, "shape: embed_dim=%d; supported: 256 (the reference, PRE:302) and 512", s.C);
-    PTX_REQUIRE(s.heads == 8, "shape: num_heads=%d; the image-pool and attention kernels are built for 8 heads "
-                "(head_dim 32 or 64)", s.heads);
+    PTX_REQUIRE((s.heads == 4 || s.heads == 8 || s.heads == 16) && (s.C / s.heads == 32 || s.C / s.heads == 64),
+                "shape: num_heads=%d with embed_dim=%d; the image-pool and attention kernels are built for 4, 8 or 16 heads of "
+                "head_dim 32 or 64", s.heads, s.C);
     PTX_REQUIRE(s.Mt <= 4096, "shape: Mt=%d clusters after the empty-drop; the farthest point sampling holds at most 4096", s.Mt);
     PTX_REQUIRE(s.hidden >= 4 && s.hidden % 4 == 0, "shape: hidden=%d", s.hidden);
     PTX_REQUIRE(s.in_dim >= 64 && s.in_dim % 64 == 0 && s.in_dim <= 512,
@@ -463,13 +464,16 @@ static int run_img_proxy(const PtxShape &s, const PtxWeights &w, const float *pr
         }
         PTX_TIMED(KID_IMG_QKV0, st, launch_gemm(g, st));
     }
+    // (a GEMM batch holds up to kMaxGroups = 8 problems: 16 heads go as two launches)
     if (!chained) {   // per head: [w_h | e_h] = q_h T1_h^T
-        GemmBatch g{}; g.n = s.heads;
-        for (int h = 0; h < s.heads; ++h)
-            g.p[h] = GemmProb{qkv0 + h * hd, prep + P.t1 + (size_t)h * P.KT1 * hd, we + (size_t)h * P.KT1,
-                              nullptr, nullptr, nullptr, nullptr, nimg, P.KT1, hd, 3 * C, hd,
-                              s.heads * P.KT1, 0, 0, 0, EPI_NONE};
-        PTX_TIMED(KID_IMG_WE, st, launch_gemm(g, st));
+        for (int h0 = 0; h0 < s.heads; h0 += kMaxGroups) {
+            GemmBatch g{}; g.n = std::min(kMaxGroups, s.heads - h0);
+            for (int h = h0; h < h0 + g.n; ++h)
+                g.p[h - h0] = GemmProb{qkv0 + h * hd, prep + P.t1 + (size_t)h * P.KT1 * hd, we + (size_t)h * P.KT1,
+                                       nullptr, nullptr, nullptr, nullptr, nimg, P.KT1, hd, 3 * C, hd,
+                                       s.heads * P.KT1, 0, 0, 0, EPI_NONE};
+            PTX_TIMED(KID_IMG_WE, st, launch_gemm(g, st));
+        }
     }
     if (dt == 0) {
         PTX_TIMED(KID_IMG_SCORES, st, launch_img_scores(img, we, qkv0, nimg, s.in_dim, s.hw, s.heads, C, P.KT1,
@@ -483,19 +487,20 @@ static int run_img_proxy(const PtxShape &s, const PtxWeights &w, const float *pr
                                                           P.KT1, P.KT2p, attn_scale(hd), gbuf, st));
         PTX_TIMED(KID_IMG_GATHER, st, launch_img_gather16(img_any, dt, nimg, s.in_dim, s.hw, s.heads, P.KT2p, gbuf, st));
     }
-    {   // per head: o_h = [g_h | a_h] T2_h^T + a_h(0) v0_h + bv_h
-        GemmBatch g{}; g.n = s.heads;
-        for (int h = 0; h < s.heads; ++h) {
-            g.p[h] = GemmProb{gbuf + (size_t)h * P.KT2p, prep + P.t2 + (size_t)h * hd * P.KT2p, obuf + h * hd,
-                              w.v_b + h * hd, nullptr, gbuf + (size_t)h * P.KT2p + s.in_dim,
-                              qkv0 + 2 * C + h * hd, nimg, hd, P.KT2p, s.heads * P.KT2p, P.KT2p, C,
-                              0, s.heads * P.KT2p, 3 * C, EPI_NONE};
+    for (int h0 = 0; h0 < s.heads; h0 += kMaxGroups) {   // per head: o_h = [g_h | a_h] T2_h^T + a_h(0) v0_h + bv_h
+        GemmBatch g{}; g.n = std::min(kMaxGroups, s.heads - h0);
+        for (int h = h0; h < h0 + g.n; ++h) {
+            GemmProb &gp = g.p[h - h0];
+            gp = GemmProb{gbuf + (size_t)h * P.KT2p, prep + P.t2 + (size_t)h * hd * P.KT2p, obuf + h * hd,
+                          w.v_b + h * hd, nullptr, gbuf + (size_t)h * P.KT2p + s.in_dim,
+                          qkv0 + 2 * C + h * hd, nimg, hd, P.KT2p, s.heads * P.KT2p, P.KT2p, C,
+                          0, s.heads * P.KT2p, 3 * C, EPI_NONE};
             if (pooled) {       // [g_h | a_h] is merged from the pooling tiles while it is loaded
-                g.p[h].A = nullptr; g.p[h].rs = nullptr;
-                g.p[h].pg = Gs + (size_t)h * s.in_dim; g.p[h].ldg = 2 * s.heads * s.in_dim; g.p[h].gslab = s.heads * s.in_dim;
-                g.p[h].pe = E + (size_t)h * EW; g.p[h].lde = s.heads * EW;
-                g.p[h].pml = ML + (size_t)h * 5; g.p[h].ldml = s.heads * 5;
-                g.p[h].kg = s.in_dim;
+                gp.A = nullptr; gp.rs = nullptr;
+                gp.pg = Gs + (size_t)h * s.in_dim; gp.ldg = 2 * s.heads * s.in_dim; gp.gslab = s.heads * s.in_dim;
+                gp.pe = E + (size_t)h * EW; gp.lde = s.heads * EW;
+                gp.pml = ML + (size_t)h * 5; gp.ldml = s.heads * 5;
+                gp.kg = s.in_dim;
             }
         }
         PTX_TIMED(KID_IMG_O, st, launch_gemm(g, st));

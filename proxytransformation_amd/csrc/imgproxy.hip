@@ -66,7 +66,7 @@ int launch_img_mean(const float *img, int nimg, int in_dim, int hw, float *fm, h
     return PTX_OK;
 }
 
-constexpr int kMaxHeads = 8;
+constexpr int kMaxHeads = 16;     // heads per image: 4, 8 (the reference's) or 16 (r04: num_heads generality, head_dim 32 / 64)
 
 // ---- pass 2: scores + softmax ---------------------------------------------------------------
 // One work-group (8 waves) per image; wave w streams channels [w*in_dim/8, (w+1)*in_dim/8).
@@ -118,12 +118,12 @@ __global__ __launch_bounds__(kScoreWaves * 64) void k_img_scores(
     // token 0: s_h(0) = scale * q_h . k0_h -- wave h computes head h up front (one load round trip that
     // overlaps the first image loads; as a 32-step scalar loop after the stream it was a chain of
     // dependent round trips that cost ~15 us per launch)
-    if (wid < heads) {
+    for (int h0 = wid; h0 < heads; h0 += NW) {
         const int hd = C / heads;
-        const float *q = qkv0 + (size_t)im * 3 * C + wid * hd;
+        const float *q = qkv0 + (size_t)im * 3 * C + h0 * hd;
         const float qk = lane < hd ? q[lane] * q[C + lane] : 0.0f;
         const float s0 = wave_sum(qk);
-        if (lane == 0) S[wid * (hw + 1)] = s0 * scale;
+        if (lane == 0) S[h0 * (hw + 1)] = s0 * scale;
     }
     // Branch-free inner loop: lanes beyond the row re-read lane 0's pixels (their accumulators are
     // never stored), so the body is one basic block and UNR row loads are in flight per wave.  (With
@@ -203,13 +203,19 @@ int launch_img_scores(const float *img, const float *we, const float *qkv0, int 
                       int hw, int heads, int C, int KT1, int KT2p, float scale, float *gbuf,
                       hipStream_t st)
 {
-    PTX_REQUIRE(heads == kMaxHeads && in_dim % (8 * kScoreWaves) == 0 && in_dim / kScoreWaves <= 64,
+    PTX_REQUIRE((heads == 4 || heads == 8 || heads == 16) && in_dim % (8 * kScoreWaves) == 0 && in_dim / kScoreWaves <= 64,
                 "img scores: heads=%d in_dim=%d unsupported", heads, in_dim);
     PTX_REQUIRE(hw >= 4 && (hw >> 2) + ((hw & 3) ? 1 : 0) <= 64, "img scores: hw=%d (supported: 4..256 pixels)", hw);
     const size_t lds = sizeof(float) * ((size_t)(kScoreWaves / 2) * heads * 256 + (size_t)heads * (hw + 1));
-    PTX_REQUIRE(lds <= 64 * 1024, "img scores: %zu B of LDS", lds);
-    hipLaunchKernelGGL(k_img_scores<kMaxHeads>, dim3(nimg), dim3(kScoreWaves * 64), lds, st, img, we, qkv0,
-                       in_dim, hw, C, KT1, KT2p, scale, gbuf);
+    PTX_REQUIRE(lds <= 160 * 1024, "img scores: %zu B of LDS", lds);
+#define PTX_SCORES(H_)                                                                                                              \
+    do {                                                                                                                          \
+        if (lds > 64 * 1024)                                                                                                      \
+            PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_img_scores<H_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(k_img_scores<H_>, dim3(nimg), dim3(kScoreWaves * 64), lds, st, img, we, qkv0, in_dim, hw, C, KT1, KT2p, scale, gbuf); \
+    } while (0)
+    if (heads == 4) PTX_SCORES(4); else if (heads == 8) PTX_SCORES(8); else PTX_SCORES(16);
+#undef PTX_SCORES
     PTX_LAUNCHED("k_img_scores");
     return PTX_OK;
 }
@@ -255,7 +261,7 @@ __global__ __launch_bounds__(256) void k_img_gather(const float *__restrict__ im
     }
     {   // all loads of the probabilities first, then the LDS stores (as one loop the compiler waited for each
         // load -- and for the feature loads above -- in turn)
-        constexpr int NR = 8;                                   // heads * hwp <= 8 * 256 (validated by the host)
+        constexpr int NR = 16;                                  // heads * hwp <= 16 * 256 (validated by the host)
         float av[NR];
 #pragma unroll
         for (int r = 0; r < NR; ++r) {

@@ -27,7 +27,7 @@ __device__ __forceinline__ float half_bits_to_float(unsigned short u)
 typedef unsigned int u4u2 __attribute__((ext_vector_type(4), aligned(2)));    // 16-B load at 2-B alignment
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int kMaxHeads = 8;
+constexpr int kMaxHeads = 16;     // heads per image: 4, 8 (the reference's) or 16 (r04: num_heads generality, head_dim 32 / 64)
 
 // widen the 8 half-precision values packed in 4 dwords (element 2i = low half of dword i)
 template <int DT>   // 1 = bf16, 2 = fp16
@@ -148,12 +148,12 @@ __global__ __launch_bounds__(kScoreWaves * 64) void k_img_scores16(
     // token 0: s_h(0) = scale * q_h . k0_h -- wave h computes head h up front (one load round trip that
     // overlaps the first image loads; as a 32-step scalar loop after the stream it was a chain of
     // dependent round trips that cost ~15 us per launch)
-    if (wid < heads) {
+    for (int h0 = wid; h0 < heads; h0 += NW) {
         const int hd = C / heads;
-        const float *q = qkv0 + (size_t)im * 3 * C + wid * hd;
+        const float *q = qkv0 + (size_t)im * 3 * C + h0 * hd;
         const float qk = lane < hd ? q[lane] * q[C + lane] : 0.0f;
         const float s0 = wave_sum(qk);
-        if (lane == 0) S[wid * (hw + 1)] = s0 * scale;
+        if (lane == 0) S[h0 * (hw + 1)] = s0 * scale;
     }
     // branch-free inner loop (see k_img_scores): lanes beyond the row re-read lane 0's pixels
     constexpr int UNR = 8;
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void k_img_gather16(const unsigned short *__re
         pf[kb] = *reinterpret_cast<const u4u2 *>(row + 32 * min(kb, nkb - 1) + 8 * kq);
     {   // all loads of the probabilities first, then the LDS stores (as one loop the compiler waited for each
         // load -- and for the feature loads above -- in turn)
-        constexpr int NR = 8;                                   // heads * hwp <= 8 * 256 (validated by the host)
+        constexpr int NR = 16;                                  // heads * hwp <= 16 * 256 (validated by the host)
         float av[NR];
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
@@ -340,17 +340,20 @@ int launch_img_scores16(const void *img, int dt, const float *we, const float *q
                         int hw, int heads, int C, int KT1, int KT2p, float scale, float *gbuf, hipStream_t st)
 {
     const unsigned short *p = static_cast<const unsigned short *>(img);
-    PTX_REQUIRE(heads == kMaxHeads && in_dim % (8 * kScoreWaves) == 0 && in_dim / kScoreWaves <= 64,
+    PTX_REQUIRE((heads == 4 || heads == 8 || heads == 16) && in_dim % (8 * kScoreWaves) == 0 && in_dim / kScoreWaves <= 64,
                 "img scores: heads=%d in_dim=%d unsupported", heads, in_dim);
     PTX_REQUIRE(hw >= 4 && (hw >> 2) + ((hw & 3) ? 1 : 0) <= 64, "img scores: hw=%d (supported: 4..256 pixels)", hw);
     const size_t lds = sizeof(float) * ((size_t)(kScoreWaves / 2) * heads * 256 + (size_t)heads * (hw + 1));
-    PTX_REQUIRE(lds <= 64 * 1024, "img scores: %zu B of LDS", lds);
-    if (dt == 1)
-        hipLaunchKernelGGL((k_img_scores16<kMaxHeads, 1>), dim3(nimg), dim3(kScoreWaves * 64), lds, st, p, we, qkv0,
-                           in_dim, hw, C, KT1, KT2p, scale, gbuf);
-    else
-        hipLaunchKernelGGL((k_img_scores16<kMaxHeads, 2>), dim3(nimg), dim3(kScoreWaves * 64), lds, st, p, we, qkv0,
-                           in_dim, hw, C, KT1, KT2p, scale, gbuf);
+    PTX_REQUIRE(lds <= 160 * 1024, "img scores: %zu B of LDS", lds);
+#define PTX_SCORES16(H_, DT_)                                                                                                       \
+    do {                                                                                                                          \
+        if (lds > 64 * 1024)                                                                                                      \
+            PTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_img_scores16<H_, DT_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_img_scores16<H_, DT_>), dim3(nimg), dim3(kScoreWaves * 64), lds, st, p, we, qkv0, in_dim, hw, C, KT1, KT2p, scale, gbuf); \
+    } while (0)
+    if (dt == 1) { if (heads == 4) PTX_SCORES16(4, 1); else if (heads == 8) PTX_SCORES16(8, 1); else PTX_SCORES16(16, 1); }
+    else { if (heads == 4) PTX_SCORES16(4, 2); else if (heads == 8) PTX_SCORES16(8, 2); else PTX_SCORES16(16, 2); }
+#undef PTX_SCORES16
     PTX_LAUNCHED("k_img_scores16");
     return PTX_OK;
 }

@@ -171,8 +171,9 @@ class ProxyTransformationNormReverse(nn.Module):
         self.compute_dtype = compute_dtype
         if act_layer is not nn.GELU or norm_layer is not nn.LayerNorm:
             raise NotImplementedError("the HIP path implements act_layer=nn.GELU, norm_layer=nn.LayerNorm")
-        if embed_dim not in _EMBED_DIMS or num_heads != 8:
-            raise NotImplementedError(f"the HIP path implements embed_dim in {_EMBED_DIMS} with num_heads=8 "
+        # r04: 4, 8 (the reference's default, PRE:282) or 16 heads of head_dim 32 / 64: (256, 4 | 8), (512, 8 | 16)
+        if embed_dim not in _EMBED_DIMS or num_heads not in (4, 8, 16) or embed_dim // num_heads not in (32, 64):
+            raise NotImplementedError(f"the HIP path implements embed_dim in {_EMBED_DIMS} with 4, 8 or 16 heads of head_dim 32 or 64 "
                                       f"(got embed_dim={embed_dim}, num_heads={num_heads})")
         self.embed_dim = embed_dim
         self.num_heads = num_heads

@@ -337,7 +337,7 @@ def test_training_step_matches_the_reference_capture():
         assert_close(buf.detach().cpu().numpy(), g["buf." + name], atol=1e-5, rtol=1e-5, what=name)
 
 
-@pytest.mark.parametrize("case", ["f32", "bf16_blocks3", "embed512_f16", "f32_graph", "f32_unfused"])
+@pytest.mark.parametrize("case", ["f32", "bf16_blocks3", "embed512_f16", "f32_graph", "f32_unfused", "heads4_f32", "embed512_heads16_f32"])
 def test_training_step_matches_the_oracle_on_fresh_scenes(case, monkeypatch):
     """The default path (the whole float half as one autograd node over the fused kernels) and its two fallbacks: the same
     fused kernels chained as separate autograd nodes (f32_graph), and one launch per operator (f32_unfused: the path of shapes
@@ -350,7 +350,12 @@ def test_training_step_matches_the_oracle_on_fresh_scenes(case, monkeypatch):
     if case == "f32_unfused":
         for flag in ("_ONE_NODE", "_FUSED_BLOCK", "_FUSED_IMG", "_FUSED_ATTN"):
             monkeypatch.setattr(T, flag, False)
-    if case.startswith("f32"):
+    if case == "heads4_f32":          # r04: other head counts (4 x 64 on 256-wide tokens; the folded image pool is built for 8: generic nodes)
+        cfg, dt = PreshapeConfig("tr4h", B=2, N=4000, grid_size=5, dynamic_drop_radio=0.6, L=9, V=4, num_heads=4, seed_base=8600), torch.float32
+    elif case == "embed512_heads16_f32":
+        cfg, dt = PreshapeConfig("tr16h", B=2, N=2500, grid_size=4, dynamic_drop_radio=0.5, L=7, V=3, embed_dim=512, num_heads=16,
+                                 seed_base=8700), torch.float32
+    elif case.startswith("f32"):
         cfg, dt = PreshapeConfig("tr1", B=3, N=5000, grid_size=5, dynamic_drop_radio=0.6, L=9, V=4, seed_base=8100), torch.float32
     elif case == "embed512_f16":      # the cfg5 generalisation (512-wide tokens, head_dim 64, 23 x 23 bias grid cropped)
         cfg, dt = PreshapeConfig("tr5", B=2, N=2500, grid_size=4, dynamic_drop_radio=0.5, L=7, V=3, embed_dim=512,

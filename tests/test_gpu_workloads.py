@@ -150,6 +150,18 @@ def test_cfg5_kernels_vs_oracle_reduced(img_dtype):
     _compare(cfg, range(cfg.B), img_dtype)
 
 
+@pytest.mark.parametrize("embed, heads, img_dtype", [(256, 4, torch.bfloat16), (256, 4, torch.float32), (512, 16, torch.float16),
+                                                     (512, 16, torch.float32)],
+                         ids=["d256_h4_bf16", "d256_h4_f32", "d512_h16_f16", "d512_h16_f32"])
+def test_other_head_counts_vs_oracle(embed, heads, img_dtype):
+    """Constructor generality (PRE:282 takes any num_heads; the reference ships 8): 4 heads of 64 on 256-wide tokens and 16 heads of
+    32 on 512-wide ones, against the oracle (whose attention is written for any head count) -- the image pool through the generic
+    score / gather kernels, the attention through the head_dim 64 / fused head_dim 32 kernels."""
+    cfg = PreshapeConfig(f"h{heads}", B=2, N=20000, grid_size=8, dynamic_drop_radio=0.75, L=24, V=12, embed_dim=embed,
+                         num_heads=heads, seed_base=5300 + heads)
+    _compare(cfg, range(cfg.B), img_dtype)
+
+
 def test_cfg5_full_size_properties():
     """BASELINE configs[4]: 500k points, gs = 16 -> 4096 -> 2868 -> 1024 kept clusters (1844 FPS picks), 64 text +
     192 image proxies, d = 512, fp16 features.  No reference parity exists: size-independent
