@@ -178,8 +178,8 @@ WsLayout ws_layout(const PtxShape &s)
     L.tile_counts = take(B * (size_t)cdiv(s.N, kTilePts) * 4);
     L.point_proxy = take(R * C * 4);
     for (int i = 0; i < 2; ++i) L.x_in[i] = take(R * C * 4);
-    L.pp_all = take(B * M * C * 4);
-    for (int i = 0; i < 2; ++i) { L.xln_all[i] = take(B * M * C * 4); L.g_all[i] = take(B * M * 3 * C * 4); }
+    L.pp_all = take(B * Mt * C * 4); L.order_e = take(B * Mt * 4);
+    for (int i = 0; i < 2; ++i) { L.xln_all[i] = take(B * Mt * C * 4); L.g_all[i] = take(B * Mt * 3 * C * 4); }
     L.fm = take(nimg * s.in_dim * 4); L.qkv0 = take(nimg * 3 * C * 4);
     L.we = take(nimg * s.heads * (size_t)P.KT1 * 4);
     L.pool = take(img_pool_bytes((int)nimg, s.in_dim, P.KT2p - s.in_dim));
@@ -1149,13 +1149,24 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     float *centers = at<float>(ws, L.centers), *cluster2 = at<float>(ws, L.cluster2);
     int32_t *idx2 = at<int32_t>(ws, L.idx2), *pad_count = at<int32_t>(ws, L.pad_count);
     if (!bbox_in && !mm_fused) PTX_TIMED(KID_MINMAX, cs, launch_minmax(sp, B, S.N, mm_ws, cs));
+    // (the `early` decision, needed here for k_cluster's completion event; its description is below)
+    static const int early_env = getenv("PTX_EARLY_PROXIES") ? atoi(getenv("PTX_EARLY_PROXIES")) : -1;
+    const double est_all = 1.8 * 12.0 * (double)B * S.Mt * S.C * S.C / 70e6;                     // us (cfg4 at 6 scenes: 147; measured ~150)
+    const bool early = cluster_on_caller && (early_env >= 0 ? early_env != 0
+                                                            : (Kd >= 128 && (long)B * S.Mk >= 1024 && est_all < 0.8 * 0.42 * Kd));
+    // r04: the streams that fork off behind the clusters (the late image chain, the early proxies) wait for k_cluster's own
+    // completion signal instead of for one event record each on the caller's stream -- two packets (~5 us each) between k_cluster and
+    // k_select on the chain the step waits for (PTX_FORK_EXT=0: the records)
+    static const bool fork_ext_env = getenv("PTX_FORK_EXT") == nullptr || atoi(getenv("PTX_FORK_EXT")) != 0;
+    static const bool ext_event_env0 = getenv("PTX_NO_EXT_EVENT") == nullptr;
+    const bool fork_ext = fork_ext_env && ext_event_env0 && !capturing && (img_late || early);
     PTX_TIMED(KID_CLUSTER, cs, launch_cluster(S, mm_enc, lin, sp, pf + P.off_ab, w->offset, w->offset_map_w,
                                               centers_override, nullptr, centers0, cluster1, offsets, centers, idx2,
-                                              cluster2, pad_count, cs));
+                                              cluster2, pad_count, cs, fork_ext ? side->early_a : nullptr));
 
     if (img_late) {
-        PTX_HIP(hipEventRecord(side->fork, st));
-        PTX_HIP(hipStreamWaitEvent(side->st, side->fork, 0));
+        if (!fork_ext) PTX_HIP(hipEventRecord(side->fork, st));
+        PTX_HIP(hipStreamWaitEvent(side->st, fork_ext ? side->early_a : side->fork, 0));
         PTX_TRY(run_img_proxy(S, *w, pf, img_feat, img_proxy, ws, is, 1));
     }
     // ---- early proxies (r04).  Where the clustering chain is the long one, most of it is the farthest point sampling: one
@@ -1172,28 +1183,28 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     Branch br[2] = {make_branch(S, *w, pf, 0, xin_t, text_feats, S.L, text_mask, translate, guide_t),
                     make_branch(S, *w, pf, 1, xin_i, at<float>(ws, L.cbuf), S.V, nullptr, transform, guide_i)};
     br[1].proxy_lnp = at<float>(ws, L.lnp_img);       // norm_img is applied inside the image block's proxy_proj
-    static const int early_env = getenv("PTX_EARLY_PROXIES") ? atoi(getenv("PTX_EARLY_PROXIES")) : -1;
-    // (worth it from ~1000 kept rows per call: cfg4 at 6 scenes +5 %, one scene neutral, cfg1 -- 64 kept rows -- -6 %)
-    // ... and only where the all-cluster work fits beside the sampling: ~12 B M C^2 flop at ~70 TFLOP/s for the two qkv products, the
+    // (`early`, decided above: worth it from ~1000 kept rows per call: cfg4 at 6 scenes +5 %, one scene neutral, cfg1 -- 64 kept rows --
+    // -6 %) ... and only where the all-cluster work fits beside the sampling: ~12 B M C^2 flop at ~70 TFLOP/s for the two qkv products, the
     // point proxies ~0.4x that, against ~0.42 us per pick (cfg5 at 16 scenes: 4 ms of it beside 0.8 ms of picks -- 4.37k -> 3.36k
     // scenes/s before this rule)
-    const double est_all = 1.4 * 12.0 * (double)B * M * S.C * S.C / 70e6;                        // us
-    const bool early = cluster_on_caller && (early_env >= 0 ? early_env != 0
-                                                            : (Kd >= 128 && (long)B * S.Mk >= 1024 && est_all < 0.8 * 0.42 * Kd));
     if (early) {
-        PTX_HIP(hipEventRecord(side->early_a, cs));                         // the clusters exist
+        if (!fork_ext) PTX_HIP(hipEventRecord(side->early_a, cs));          // the clusters exist
         PTX_HIP(hipStreamWaitEvent(side->lo, side->early_a, 0));
+        // only the Mt clusters that enter the sampling (the least padded ones, PRE:372-385: 70 % of the grid), in the sampling's
+        // order: k_order repeats step 1 of k_select on this stream, the rows below are indexed by position in that order
         float *pp_all = at<float>(ws, L.pp_all), *xa_t = at<float>(ws, L.xln_all[0]), *xa_i = at<float>(ws, L.xln_all[1]);
-        PTX_TRY(launch_pointnet(pf + P.enc_ab, w->encoder, centers, cluster2, B * M, M, K, S.C, pp_all, &w->text, &w->img, nullptr,
-                                nullptr, xa_t, xa_i, S.ln_eps, nullptr, M, side->lo, nullptr, 0));
+        int32_t *order_e = at<int32_t>(ws, L.order_e);
+        PTX_TRY(launch_order(S, pad_count, order_override, order_e, side->lo));
+        PTX_TRY(launch_pointnet(pf + P.enc_ab, w->encoder, centers, cluster2, B * S.Mt, S.Mt, K, S.C, pp_all, &w->text, &w->img, nullptr,
+                                nullptr, xa_t, xa_i, S.ln_eps, order_e, M, side->lo, nullptr, 0, true));
         GemmBatch g{}; g.n = 2;
-        g.p[0] = GemmProb{xa_t, w->text.qkv_w, at<float>(ws, L.g_all[0]), nullptr, nullptr, nullptr, nullptr, B * M, 3 * S.C, S.C, S.C, S.C,
+        g.p[0] = GemmProb{xa_t, w->text.qkv_w, at<float>(ws, L.g_all[0]), nullptr, nullptr, nullptr, nullptr, B * S.Mt, 3 * S.C, S.C, S.C, S.C,
                           3 * S.C, 0, 0, 0, EPI_NONE};
-        g.p[1] = GemmProb{xa_i, w->img.qkv_w, at<float>(ws, L.g_all[1]), nullptr, nullptr, nullptr, nullptr, B * M, 3 * S.C, S.C, S.C, S.C,
+        g.p[1] = GemmProb{xa_i, w->img.qkv_w, at<float>(ws, L.g_all[1]), nullptr, nullptr, nullptr, nullptr, B * S.Mt, 3 * S.C, S.C, S.C, S.C,
                           3 * S.C, 0, 0, 0, EPI_NONE};
         PTX_TRY(launch_gemm(g, side->lo, compute_dtype));
         PTX_TRY(run_blocks(S, br, 2, point_proxy, ws, side->lo, 1, compute_dtype, nullptr, nullptr, true));    // proxy_proj of the text block
-        PTX_HIP(hipEventRecord(side->early_b, side->lo));
+        // (early_b is recorded where the caller's stream is told to wait for it, below)
     }
 
     // ---- dynamic cluster dropout (PRE:433): ordering + FPS + keep list on the chain; the slot tags and the survivor
@@ -1274,16 +1285,21 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
         const float *const tb[2] = {pf + P.qkvb[0], pf + P.qkvb[1]};
         float *const qk[2] = {at<float>(ws, L.qkv[0]), at<float>(ws, L.qkv[1])};
         static const int jfirst_env = getenv("PTX_EARLY_JOIN_FIRST") ? atoi(getenv("PTX_EARLY_JOIN_FIRST")) : 1;
+        static const bool join_chain_env = getenv("PTX_JOIN_CHAIN") == nullptr || atoi(getenv("PTX_JOIN_CHAIN")) != 0;
         if (jfirst_env) {
             // both cross-stream waits of the caller's chain in ONE place, in front of the gather (each costs ~6 us of idle between
-            // the two kernels around it): the image chain finished long before the sampling does
+            // the two kernels around it): the image chain finished long before the sampling does.  r04: and as ONE wait -- the third
+            // stream (early proxies done) waits for the image chain, the caller's stream for the third stream (PTX_JOIN_CHAIN=0: two)
             PTX_TRY(run_blocks(S, br, 2, point_proxy, ws, is, 3, compute_dtype));
             PTX_HIP(hipEventRecord(side->join, is));
-            PTX_HIP(hipStreamWaitEvent(cs, side->join, 0));
+            if (join_chain_env) PTX_HIP(hipStreamWaitEvent(side->lo, side->join, 0));
+            else PTX_HIP(hipStreamWaitEvent(cs, side->join, 0));
             joined_early = true;
         }
+        PTX_HIP(hipEventRecord(side->early_b, side->lo));
         PTX_HIP(hipStreamWaitEvent(cs, side->early_b, 0));
-        PTX_TIMED(KID_POINTNET, cs, launch_qkv_gather(at<float>(ws, L.pp_all), gsrc, tb, ksrc, B, M, S.Mk, S.C, point_proxy, qk, cs));
+        // (kept cluster j of a scene = position keep[j] of the sampling's order = row keep[j] of the early tables)
+        PTX_TIMED(KID_POINTNET, cs, launch_qkv_gather(at<float>(ws, L.pp_all), gsrc, tb, keep, B, S.Mt, S.Mk, S.C, point_proxy, qk, cs));
     } else
     PTX_TIMED(KID_POINTNET, cs, launch_pointnet(pf + P.enc_ab, w->encoder, kcenter, cluster2, B * S.Mk, S.Mk, K,
                                                 S.C, point_proxy, &w->text, &w->img, pf + P.posb_t, pf + P.posb_i, xin_t,

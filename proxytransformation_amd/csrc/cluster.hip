@@ -160,6 +160,7 @@ struct SlotNetArgs {
     float *proxy; const float *n1w[2]; const float *n1b[2]; const float *posb[2]; float *xin[2];
     float ln_eps;
     const int32_t *ksrc; int Msrc;                  // MODE 1: cluster rows gathered through the selection when ksrc != null
+    int center_src;                                 // MODE 1 with ksrc: the centre is an un-gathered row as well (early proxies)
     uint32_t *head_flag; uint32_t head_seq;         // the first thread of the launch stores head_seq (api.hip, "gates": the stream being
                                                     // in order, k_select in front of this launch has completed by then), or null
 };
@@ -269,7 +270,8 @@ __global__ __launch_bounds__(256) void k_slot_net(SlotNetArgs a)
             }
         }
     }
-    const float cx = a.center[(size_t)w * 3], cy = a.center[(size_t)w * 3 + 1], cz = a.center[(size_t)w * 3 + 2];
+    const size_t cw = (MODE == 1 && a.center_src) ? (size_t)src : (size_t)w;
+    const float cx = a.center[cw * 3], cy = a.center[cw * 3 + 1], cz = a.center[cw * 3 + 2];
     // lane k (< K) prepares slot k
     float x[6] = {0, 0, 0, 0, 0, 0};
     if (lane < a.K) {
@@ -378,13 +380,16 @@ __global__ __launch_bounds__(256) void k_cluster(ClusterArgs a)
 int launch_cluster(const PtxShape &s, const uint32_t *mm_enc, const float *lin, const ScenePts &points,
                    const float *off_ab, const PtxSlotMlp &mlp, const float *map_w, const float *centers_override,
                    float *minmax_out, float *centers0, float *cluster1, float *offsets, float *centers,
-                   int32_t *idx2, float *cluster2, int32_t *pad_count, hipStream_t st)
+                   int32_t *idx2, float *cluster2, int32_t *pad_count, hipStream_t st, hipEvent_t done)
 {
     const int M = s.grid_size * s.grid_size * s.grid_size;
     ClusterArgs a{mm_enc, lin, s.grid_size, s.margin, s.radius, points, s.B * M, M, s.N, s.K,
                   off_ab, mlp.conv_w, mlp.conv_b, map_w, centers_override,
                   minmax_out, centers0, cluster1, offsets, centers, idx2, cluster2, pad_count};
-    hipLaunchKernelGGL(k_cluster, dim3(cdiv(s.B * M, 4)), dim3(256), 0, st, a);
+    // `done` (the streams that fork off behind the clusters wait for it) rides on the kernel's own completion signal, like
+    // k_select's: an event record is a packet of its own between this kernel and the next one of the stream
+    if (done != nullptr) hipExtLaunchKernelGGL(k_cluster, dim3(cdiv(s.B * M, 4)), dim3(256), 0, st, nullptr, done, 0, a);
+    else hipLaunchKernelGGL(k_cluster, dim3(cdiv(s.B * M, 4)), dim3(256), 0, st, a);
     PTX_LAUNCHED("k_cluster");
     return PTX_OK;
 }
@@ -407,11 +412,12 @@ int launch_pointnet(const float *ab, const PtxSlotMlp &mlp, const float *kcenter
                     const float *kcluster, int BM, int Mk, int K, int width, float *point_proxy,
                     const PtxBlock *blk_t, const PtxBlock *blk_i, const float *posb_t,
                     const float *posb_i, float *xin_t, float *xin_i, float ln_eps,
-                    const int32_t *ksrc, int Msrc, hipStream_t st, uint32_t *head_flag, uint32_t head_seq)
+                    const int32_t *ksrc, int Msrc, hipStream_t st, uint32_t *head_flag, uint32_t head_seq, bool center_src)
 {
     // ksrc given: kcluster is the UN-gathered (B,Msrc,K,3) array and kept cluster j of scene b reads row ksrc[b][j]
-    // (kcenter is always the gathered (B,Mk,3) array)
+    // (kcenter is the gathered (B,Mk,3) array unless center_src says it is un-gathered too)
     SlotNetArgs a{};
+    a.center_src = center_src && ksrc != nullptr ? 1 : 0;
     a.ab = ab; a.conv_w = mlp.conv_w; a.conv_b = mlp.conv_b; a.center = kcenter; a.cluster = kcluster;
     a.BM = BM; a.Mper = Mk; a.K = K; a.proxy = point_proxy; a.ln_eps = ln_eps;
     a.ksrc = ksrc; a.Msrc = Msrc; a.head_flag = head_flag; a.head_seq = head_seq;
@@ -472,6 +478,69 @@ struct SelectArgs {
                              // zeroed here so that the next call finds them clean (no memset launch per call)
 };
 
+// Step 1 of the selection for one scene (one work-group of 256 threads): the stable counting sort of the clusters by padding count
+// (keys 0..K), first Mt (PRE:372-385), into s_order (LDS); s_hist: 64 ints of LDS.  Shared by k_select and k_order.
+__device__ __forceinline__ void select_order(const int32_t *__restrict__ pc, const int32_t *__restrict__ order_override, int M, int Mt,
+                                             int *s_order, int *s_hist)
+{
+    const int T = blockDim.x, tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
+    if (order_override != nullptr) {
+        for (int t = tid; t < Mt; t += T) s_order[t] = order_override[t];
+        __syncthreads();
+        return;
+    }
+    if (tid < 64) s_hist[tid] = 0;
+    __syncthreads();
+    for (int m = tid; m < M; m += T) atomicAdd(&s_hist[pc[m]], 1);
+    __syncthreads();
+    if (wid == 0) {
+        // lane v holds the next free position of bucket v (K + 1 <= 64 buckets)
+        int cnt = s_hist[lane];
+        int incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { int n = __shfl_up(incl, o, 64); if (lane >= o) incl += n; }
+        int base = incl - cnt;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        for (int m0 = 0; m0 < M; m0 += 64) {
+            const int m = m0 + lane;
+            const bool valid = m < M;
+            const int c = valid ? pc[m] : -1;
+            unsigned long long remaining = __ballot(valid);
+            while (remaining) {
+                const int leader = __ffsll((long long)remaining) - 1;
+                const int v = __shfl(c, leader, 64);
+                const bool mine = valid && c == v;
+                const unsigned long long match = __ballot(mine);
+                const int start = __shfl(base, v, 64);
+                const int pos = start + __popcll(match & lt);
+                if (mine && pos < Mt) s_order[pos] = m;
+                if (lane == v) base += __popcll(match);
+                remaining &= ~match;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// The ordering alone (early proxies, api.hip: the third stream needs WHICH Mt clusters enter the sampling -- not their selection --
+// while k_select is still picking; the same code on the same counts gives the same order)
+__global__ __launch_bounds__(256) void k_order(const int32_t *__restrict__ pad_count, const int32_t *__restrict__ order_override, int M,
+                                               int Mt, int32_t *__restrict__ order)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int *s_order = reinterpret_cast<int *>(smem), *s_hist = s_order + Mt;
+    const int b = blockIdx.x;
+    select_order(pad_count + (size_t)b * M, order_override ? order_override + (size_t)b * Mt : nullptr, M, Mt, s_order, s_hist);
+    for (int t = threadIdx.x; t < Mt; t += blockDim.x) order[(size_t)b * Mt + t] = s_order[t];
+}
+int launch_order(const PtxShape &s, const int32_t *pad_count, const int32_t *order_override, int32_t *order, hipStream_t st)
+{
+    const int M = s.grid_size * s.grid_size * s.grid_size;
+    hipLaunchKernelGGL(k_order, dim3(s.B), dim3(256), sizeof(int) * ((size_t)s.Mt + 64), st, pad_count, order_override, M, s.Mt, order);
+    PTX_LAUNCHED("k_order");
+    return PTX_OK;
+}
+
 // P points per lane of the FPS; ONE: a single wave holds all points (64 P >= Mt) and picks without any exchange or barrier
 // (small Mt: the benchmark shape's 359 centres), otherwise the four waves share them (256 P >= Mt)
 template <int P, bool ONE>
@@ -494,42 +563,7 @@ __global__ __launch_bounds__(256) void k_select(SelectArgs a)
 
     const int32_t *pc = a.pad_count + (size_t)b * M;
     // ---- 1. ordering
-    if (a.order_override != nullptr) {
-        for (int t = tid; t < Mt; t += T) s_order[t] = a.order_override[(size_t)b * Mt + t];
-        __syncthreads();
-    } else {
-        if (tid < 64) s_hist[tid] = 0;
-        __syncthreads();
-        for (int m = tid; m < M; m += T) atomicAdd(&s_hist[pc[m]], 1);
-        __syncthreads();
-        if (wid == 0) {
-            // lane v holds the next free position of bucket v (K + 1 <= 64 buckets)
-            int cnt = s_hist[lane];
-            int incl = cnt;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { int n = __shfl_up(incl, o, 64); if (lane >= o) incl += n; }
-            int base = incl - cnt;
-            const unsigned long long lt = (1ull << lane) - 1ull;
-            for (int m0 = 0; m0 < M; m0 += 64) {
-                const int m = m0 + lane;
-                const bool valid = m < M;
-                const int c = valid ? pc[m] : -1;
-                unsigned long long remaining = __ballot(valid);
-                while (remaining) {
-                    const int leader = __ffsll((long long)remaining) - 1;
-                    const int v = __shfl(c, leader, 64);
-                    const bool mine = valid && c == v;
-                    const unsigned long long match = __ballot(mine);
-                    const int start = __shfl(base, v, 64);
-                    const int pos = start + __popcll(match & lt);
-                    if (mine && pos < Mt) s_order[pos] = m;
-                    if (lane == v) base += __popcll(match);
-                    remaining &= ~match;
-                }
-            }
-        }
-        __syncthreads();
-    }
+    select_order(pc, a.order_override ? a.order_override + (size_t)b * Mt : nullptr, M, Mt, s_order, s_hist);
     for (int t = tid; t < Mt; t += T) {
         const int src = s_order[t];
         a.order[(size_t)b * Mt + t] = src;

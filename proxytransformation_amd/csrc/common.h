@@ -278,7 +278,8 @@ struct WsLayout {
     size_t minmax, centers0, cluster1, offsets, centers, idx2, cluster2, pad_count;
     size_t order, picks, keep, ksrc, kcenter, kcluster, kidx, drop_idx, tile_counts;
     size_t point_proxy, x_in[2];    // x_in: LN1(x)+slot bias per branch (B*Mk,C)
-    size_t pp_all, xln_all[2], g_all[2];   // early-proxy path: point proxies / LN1 rows (B*M,C) and their qkv rows (B*M,3C) of ALL clusters
+    size_t pp_all, xln_all[2], g_all[2];   // early-proxy path: point proxies / LN1 rows (B*Mt,C) and their qkv rows (B*Mt,3C) of the Mt
+    size_t order_e;                        // clusters that enter the sampling, in its order (order_e: the ordering, computed beside k_select)
     size_t fm, qkv0, we, pool, gbuf, obuf, cbuf, img_proxy;
     size_t qkv[2], pt[2], pv[2], ao[2], x1[2], xn2[2], hbuf[2], x2[2], guide[2], head[2];
     size_t lnp_img, lnp_x1[2];      // LayerNorm partials (rows, C/32, 2) of c_proj's / proj's output
@@ -399,14 +400,16 @@ int launch_pointnet(const float *ab, const PtxSlotMlp &mlp, const float *kcenter
                     const float *kcluster, int BM, int Mk, int K, int width, float *point_proxy,
                     const PtxBlock *blk_t, const PtxBlock *blk_i, const float *posb_t,
                     const float *posb_i, float *xin_t, float *xin_i, float ln_eps,
-                    const int32_t *ksrc, int Msrc, hipStream_t st, uint32_t *head_flag = nullptr, uint32_t head_seq = 0);
+                    const int32_t *ksrc, int Msrc, hipStream_t st, uint32_t *head_flag = nullptr, uint32_t head_seq = 0,
+                    bool center_src = false);
+int launch_order(const PtxShape &s, const int32_t *pad_count, const int32_t *order_override, int32_t *order, hipStream_t st);
 // kept rows out of the all-cluster tables: point_proxy[row] = pp_all[src], qkv[i][row] = g[i][src] + tb[i][j]  (src = b * M + ksrc[row])
 int launch_qkv_gather(const float *pp_all, const float *const g[2], const float *const tb[2], const int32_t *ksrc, int B, int M, int Mk,
                       int C, float *point_proxy, float *const qkv[2], hipStream_t st);
 int launch_cluster(const PtxShape &s, const uint32_t *mm_enc, const float *lin, const ScenePts &points,
                    const float *off_ab, const PtxSlotMlp &mlp, const float *map_w, const float *centers_override,
                    float *minmax_out, float *centers0, float *cluster1, float *offsets, float *centers,
-                   int32_t *idx2, float *cluster2, int32_t *pad_count, hipStream_t st);
+                   int32_t *idx2, float *cluster2, int32_t *pad_count, hipStream_t st, hipEvent_t done = nullptr);
 int launch_select(const PtxShape &s, const int32_t *idx, const float *centers, const float *cluster,
                   const int32_t *pad_count, const int32_t *order_override, int32_t *order,
                   int32_t *picks, int32_t *keep, float *kcenter, float *kcluster, int32_t *kidx,
