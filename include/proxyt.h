@@ -124,7 +124,8 @@ int ptx_context_destroy(PtxContext *ctx);
  * ptx_context_check returns PTX_EGATE once for such a failure -- ptx_forward makes the same check on entry -- and the
  * context orders its streams with events from then on.  The gates are used only after a probe per (context, caller
  * stream) has shown that the two streams run concurrently (they may share a hardware queue); PTX_GATE=0 / 1 forces
- * events / gates.  ptx_context_gates: 1 while the context uses gates.  There is no reference counterpart (PRE runs on
+ * events / gates.  ptx_context_gates: nonzero while the context uses gates (bit 0; bit 1: its low-priority stream may carry
+ * gate words as well).  There is no reference counterpart (PRE runs on
  * one stream). */
 int ptx_context_check(PtxContext *ctx);
 int ptx_context_gates(const PtxContext *ctx);

@@ -369,7 +369,7 @@ static int gate_check(PtxContext *c)
     const uint32_t e = *reinterpret_cast<volatile uint32_t *>(c->gate_err);
     if (e == 0u) return PTX_OK;
     static const char *const site_name[] = {"?", "fork (clustering stream waiting for the caller's stream)",
-                                            "join (caller's stream waiting for the clustering stream)", "probe, fork direction",
+                                            "join (caller's stream waiting for the other chain)", "probe, fork direction",
                                             "probe, join direction", "?", "slot tags' fork (tag stream waiting for the selection)",
                                             "slot tags' join (caller's stream waiting for the tags)"};
     const unsigned site = (e >> 24) & 0x7fu;
@@ -575,7 +575,7 @@ static int run_blocks(const PtxShape &s, const Branch *br, int nb, const float *
                 }
             }
         }
-        if (g.n > 0 && phase == 2 && join != nullptr && join->flag != nullptr) { g.tail_gate = *join; join->flag = nullptr; }
+        if (g.n > 0 && (phase == 2 || phase == 1) && join != nullptr && join->flag != nullptr) { g.tail_gate = *join; join->flag = nullptr; }
         if (g.n > 0) PTX_TIMED(phase == 2 || phase == 3 ? KID_BLK_PP : KID_BLK_QKV, st, launch_gemm(g, st, cd));
         if (phase == 1 || phase == 3) return PTX_OK;
     }
@@ -799,7 +799,7 @@ int ptx_context_check(PtxContext *ctx)
     return gate_check(ctx);
 }
 
-int ptx_context_gates(const PtxContext *ctx) { return ctx != nullptr && ctx->gates_on ? 1 : 0; }
+int ptx_context_gates(const PtxContext *ctx) { return ctx != nullptr && ctx->gates_on ? (ctx->lo_ok ? 3 : 1) : 0; }
 
 int ptx_wait_counts(const int32_t *counts_host, int B, int64_t timeout_us)
 {
@@ -1160,6 +1160,22 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     static const bool fork_ext_env = getenv("PTX_FORK_EXT") == nullptr || atoi(getenv("PTX_FORK_EXT")) != 0;
     static const bool ext_event_env0 = getenv("PTX_NO_EXT_EVENT") == nullptr;
     const bool fork_ext = fork_ext_env && ext_event_env0 && !capturing && (img_late || early);
+    // r04, "cgate": where the clustering chain owns the caller's stream its two cross-stream waits -- for the image chain / the early
+    // proxies in front of the attention, for the slot tags in front of k_affine -- are device words as well, each folded into the launch
+    // in FRONT of the wait (its first work-group ends with the poll, as at the benchmark shape's join): no barrier packet (~6 us of
+    // idle each) on the chain the step waits for.  Needs the probed side-by-side progress of the streams (gates_on, lo_ok); the
+    // failure path is the gates' (error word, NaN outputs, PTX_EGATE, events from then on).  PTX_CGATE=0: the events.
+    static const bool cgate_env = getenv("PTX_CGATE") == nullptr || atoi(getenv("PTX_CGATE")) != 0;
+    const bool cgate = cluster_on_caller && cgate_env && side->gates_on && side->lo_ok && !capturing && ext_event_env0;
+    if (cgate) ++side->gate_seq;
+    const bool fault_cjoin = cgate && fault && fault[0] == 'j', fault_ctags = cgate && fault && fault[0] == 't';
+    static const int jfirst_env = getenv("PTX_EARLY_JOIN_FIRST") ? atoi(getenv("PTX_EARLY_JOIN_FIRST")) : 1;
+    static const bool join_chain_env = getenv("PTX_JOIN_CHAIN") == nullptr || atoi(getenv("PTX_JOIN_CHAIN")) != 0;
+    // the join's word (52): stored by the third stream behind the early proxies AND the image chain (early), or by the image stream
+    // behind its last launch (otherwise); waited for at the END of k_select (early: the gather is next) / of the qkv GEMM (otherwise)
+    const bool cg_join_select = cgate && early && jfirst_env && join_chain_env;
+    const bool cg_join_qkv = cgate && !early;
+    GateRef cjoin = (cg_join_select || cg_join_qkv) ? gate_ref(side, 52, side->gate_seq, 2) : GateRef{};
     PTX_TIMED(KID_CLUSTER, cs, launch_cluster(S, mm_enc, lin, sp, pf + P.off_ab, w->offset, w->offset_map_w,
                                               centers_override, nullptr, centers0, cluster1, offsets, centers, idx2,
                                               cluster2, pad_count, cs, fork_ext ? side->early_a : nullptr));
@@ -1228,7 +1244,8 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     const bool tags_gated = gated && side->lo_ok && tags_gated_env;
     const bool tags_tail = !cluster_on_caller && tail_env != 0 && !tags_gated;
     PTX_TIMED(KID_SELECT, cs, launch_select_order(S, centers, pad_count, order_override, order, picks, keep, kcenter,
-                                                  ksrc, bbox_in ? nullptr : mm_ws, cs, cluster_on_caller, ext_event && !tags_tail ? side->aux : nullptr));
+                                                  ksrc, bbox_in ? nullptr : mm_ws, cs, cluster_on_caller, ext_event && !tags_tail ? side->aux : nullptr,
+                                                  cg_join_select ? &cjoin : nullptr));
     int32_t *tile_counts = at<int32_t>(ws, L.tile_counts);
     // The slot tags / survivor counts: only k_affine and the host need them.  When the clustering chain is the long one
     // (it owns the caller's stream) they run on the low-priority stream next to it, after the point proxies.  When the
@@ -1266,6 +1283,11 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
                 return PTX_OK;
             };
             PTX_TIMED(KID_SIGNAL_TAGS, ts, sig());
+        } else if (cgate) {
+            if (!fault_ctags) {
+                hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, ts, side->gate + 56, side->gate_seq);
+                PTX_LAUNCHED("k_signal[ctags]");
+            }
         } else if (!tags_tail) PTX_HIP(hipEventRecord(side->tags, ts));
         return PTX_OK;
     };
@@ -1284,8 +1306,6 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
         const float *const gsrc[2] = {at<float>(ws, L.g_all[0]), at<float>(ws, L.g_all[1])};
         const float *const tb[2] = {pf + P.qkvb[0], pf + P.qkvb[1]};
         float *const qk[2] = {at<float>(ws, L.qkv[0]), at<float>(ws, L.qkv[1])};
-        static const int jfirst_env = getenv("PTX_EARLY_JOIN_FIRST") ? atoi(getenv("PTX_EARLY_JOIN_FIRST")) : 1;
-        static const bool join_chain_env = getenv("PTX_JOIN_CHAIN") == nullptr || atoi(getenv("PTX_JOIN_CHAIN")) != 0;
         if (jfirst_env) {
             // both cross-stream waits of the caller's chain in ONE place, in front of the gather (each costs ~6 us of idle between
             // the two kernels around it): the image chain finished long before the sampling does.  r04: and as ONE wait -- the third
@@ -1296,8 +1316,15 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
             else PTX_HIP(hipStreamWaitEvent(cs, side->join, 0));
             joined_early = true;
         }
-        PTX_HIP(hipEventRecord(side->early_b, side->lo));
-        PTX_HIP(hipStreamWaitEvent(cs, side->early_b, 0));
+        if (cg_join_select) {               // k_select ends with the wait for this word: no packet between it and the gather
+            if (!fault_cjoin) {
+                hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, side->lo, side->gate + 52, side->gate_seq);
+                PTX_LAUNCHED("k_signal[cjoin]");
+            }
+        } else {
+            PTX_HIP(hipEventRecord(side->early_b, side->lo));
+            PTX_HIP(hipStreamWaitEvent(cs, side->early_b, 0));
+        }
         // (kept cluster j of a scene = position keep[j] of the sampling's order = row keep[j] of the early tables)
         PTX_TIMED(KID_POINTNET, cs, launch_qkv_gather(at<float>(ws, L.pp_all), gsrc, tb, keep, B, S.Mt, S.Mk, S.C, point_proxy, qk, cs));
     } else
@@ -1311,7 +1338,11 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     // (The whole text branch on a third stream while the image chain finishes, leaving only the image
     // branch after the join, was measured slower: 12.6k vs 13.7k scenes/s -- eight more launches, and its
     // small kernels take CUs from the image passes that are on the critical path.)
-    if (!early) PTX_TRY(run_blocks(S, br, 2, point_proxy, ws, cs, 1, compute_dtype));
+    if (!early) PTX_TRY(run_blocks(S, br, 2, point_proxy, ws, cs, 1, compute_dtype, cg_join_qkv ? &cjoin : nullptr));
+    if (cg_join_qkv && cjoin.flag != nullptr) {
+        set_error("ptx_forward: the join gate was not attached to the qkv launch");
+        return PTX_ELAUNCH;
+    }
     if (tags_tail) PTX_TRY(enqueue_tags());
     static const int pp_env = getenv("PTX_PP_EARLY") ? atoi(getenv("PTX_PP_EARLY")) : 1;
     const bool pp_early = cluster_on_caller && (early || pp_env != 0);       // (see below, at the join)
@@ -1334,11 +1365,19 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     // where the clustering chain owns the caller's stream the image block's proxy_proj runs behind the image chain on ITS stream, in
     // front of the join, instead of behind it on the caller's (7 us + a launch gap off the long chain: cfg4 one scene +3 %)
     if (pp_early && !joined_early) PTX_TRY(run_blocks(S, br, 2, point_proxy, ws, is, 3, compute_dtype));
+    if (cg_join_qkv) {                      // the qkv GEMM on the caller's stream ends with the wait for this word
+        if (!fault_cjoin) {
+            hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, is, side->gate + 52, side->gate_seq);
+            PTX_LAUNCHED("k_signal[cjoin]");
+        }
+    } else {
     if (cluster_on_caller && !joined_early) PTX_HIP(hipEventRecord(side->join, is));
     if (!joined_early) PTX_HIP(hipStreamWaitEvent(st, side->join, 0));
     }
+    }
     GateRef tags_join{};
     if (tags_gated) tags_join = gate_ref(side, 38, side->gate_seq, 7);
+    if (cgate) tags_join = gate_ref(side, 56, side->gate_seq, 7);      // the proj GEMM ends with the wait for the tags' word
     PTX_TRY(run_blocks(S, br, 2, point_proxy, ws, st, pp_early ? 4 : 2, compute_dtype, &join, &tags_join));
     if (join.flag != nullptr) {         // (not attached: no launch in front of the attention took it)
         set_error("ptx_forward: the join gate was not attached to a launch");
@@ -1348,10 +1387,14 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     // ---- submanifold reshape + scatter + drop (PRE:459-467); k_affine is the last reader of the tags and clears them
     // (r03: waiting for the tags next to the join instead -- they are final long before it at the benchmark shape -- does not
     //  shorten the heads -> affine boundary: 0.276 / 0.283 vs 0.271 / 0.275 ms per step)
-    if (!tags_tail && !tags_gated) PTX_HIP(hipStreamWaitEvent(st, side->tags, 0));
+    if (cgate && tags_join.flag != nullptr) {
+        set_error("ptx_forward: the tags gate was not attached to the proj launch");
+        return PTX_ELAUNCH;
+    }
+    if (!tags_tail && !tags_gated && !cgate) PTX_HIP(hipStreamWaitEvent(st, side->tags, 0));
     PTX_DBG(tag, tag, (size_t)B * S.N * 4);
     PTX_TIMED(KID_AFFINE, st, launch_affine(S, sp, tag, kcenter, translate, transform, out, counts, tile_counts,
-                                            true, true, st, gated ? side->gate + 48 : nullptr));
+                                            true, true, st, (gated || cgate) ? side->gate + 48 : nullptr));
 
     PTX_DBG(centers0, centers0, (size_t)B * M * 3 * 4);
     PTX_DBG(cluster1, cluster1, (size_t)B * M * K * 3 * 4);

@@ -476,6 +476,8 @@ struct SelectArgs {
     int32_t *ksrc;           // (B,Mk) row of kept cluster j in the un-gathered arrays (= order[keep[j]]), or null
     uint32_t *mm_clear;      // forward only: the encoded bounding boxes (B,6), last read before this launch, are
                              // zeroed here so that the next call finds them clean (no memset launch per call)
+    GateRef tail;            // flag != null: the launch ends with the wait for another stream's word (api.hip, "cgate"): the kernel
+                             // behind it on this stream starts when both the selection and that stream are done -- no barrier packet
 };
 
 // Step 1 of the selection for one scene (one work-group of 256 threads): the stable counting sort of the clusters by padding count
@@ -706,6 +708,7 @@ __global__ __launch_bounds__(256) void k_select(SelectArgs a)
         a.kcenter[((size_t)b * Mk + j) * 3 + 1] = sy[t];
         a.kcenter[((size_t)b * Mk + j) * 3 + 2] = sz[t];
     }
+    if (a.tail.flag != nullptr && b == 0 && tid == 0) gate_wait(a.tail);
 }
 
 // One thread per slot of the kept clusters (gather xyz + idx, ownership tag) and of the dropped
@@ -760,18 +763,19 @@ static SelectArgs select_args(const PtxShape &s, const int32_t *idx, const float
 {
     return SelectArgs{idx, centers, cluster, pad_count, order_override, order, picks, keep, kcenter,
                       kcluster, kidx, drop_idx, tag, s.grid_size * s.grid_size * s.grid_size, s.K, s.Mt,
-                      s.Mk, s.Mt - s.Mk, s.N, nullptr, mm_clear};
+                      s.Mk, s.Mt - s.Mk, s.N, nullptr, mm_clear, GateRef{}};
 }
 
 // ordering + FPS + keep list + kept centres (one work-group per scene)
 int launch_select_order(const PtxShape &s, const float *centers, const int32_t *pad_count,
                         const int32_t *order_override, int32_t *order, int32_t *picks, int32_t *keep,
                         float *kcenter, int32_t *ksrc, uint32_t *mm_clear, hipStream_t st, bool critical,
-                        hipEvent_t done)
+                        hipEvent_t done, const GateRef *tail)
 {
     SelectArgs a = select_args(s, nullptr, centers, nullptr, pad_count, order_override, order, picks, keep, kcenter,
                                nullptr, nullptr, nullptr, nullptr, mm_clear);
     a.ksrc = ksrc;
+    if (tail != nullptr) a.tail = *tail;
     size_t lds = select_lds_bytes(s);
     PTX_REQUIRE(lds <= 160 * 1024, "select: Mt=%d needs %zu B of LDS (> 160 KiB)", s.Mt, lds);
     // r04: where the step waits for this kernel (`critical`: the clustering chain owns the caller's stream -- the shipped gs = 12

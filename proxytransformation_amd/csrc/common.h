@@ -417,7 +417,7 @@ int launch_select(const PtxShape &s, const int32_t *idx, const float *centers, c
 int launch_select_order(const PtxShape &s, const float *centers, const int32_t *pad_count,
                         const int32_t *order_override, int32_t *order, int32_t *picks, int32_t *keep,
                         float *kcenter, int32_t *ksrc, uint32_t *mm_clear, hipStream_t st, bool critical,
-                        hipEvent_t done);
+                        hipEvent_t done, const GateRef *tail = nullptr);
 int launch_tags(const PtxShape &s, const int32_t *idx, const int32_t *order, const int32_t *picks, const int32_t *ksrc,
                 uint32_t *tag, int32_t *tile_counts, int32_t *counts, int32_t *scene_acc, hipStream_t st);
 int launch_select_slots(const PtxShape &s, const int32_t *idx, const float *cluster, const int32_t *order,

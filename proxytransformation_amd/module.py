@@ -718,6 +718,14 @@ class ProxyTransformationNormReverse(nn.Module):
         lane = self._lanes.get((str(dev), tstream.cuda_stream))
         return bool(lane is not None and _abi.lib().ptx_context_gates(lane.ctx))
 
+    def stream_gate_bits(self, stream=None) -> int:
+        """``ptx_context_gates`` of the lane: bit 0 gates in use, bit 1 the low-priority stream may carry gate words too (the
+        clustering-chain layout's join / tags words need both)."""
+        dev = next(self.parameters()).device
+        tstream = stream if stream is not None else torch.cuda.current_stream(dev)
+        lane = self._lanes.get((str(dev), tstream.cuda_stream))
+        return int(_abi.lib().ptx_context_gates(lane.ctx)) if lane is not None else 0
+
     def _batch_norms(self):
         return (("get_deformable_cluster.get_offsets.mlp.1", self.get_deformable_cluster.get_offsets.mlp[1]),
                 ("simple_encoder.mlp.1", self.simple_encoder.mlp[1]),

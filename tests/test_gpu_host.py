@@ -359,7 +359,10 @@ import os, sys, hashlib, torch
 sys.path.insert(0, %r)
 from proxytransformation_amd.synth import PreshapeConfig, make_scene_batch
 from tests.util import build_module
-cfg = PreshapeConfig("gatefault", B=2, N=30000, grid_size=8, dynamic_drop_radio=0.4, L=16, V=180, seed_base=4242)
+if os.environ.get("GATE_TEST_SHAPE", "image") == "cluster":      # the clustering chain owns the caller's stream ("cgate" words)
+    cfg = PreshapeConfig("gatefault", B=2, N=30000, grid_size=8, dynamic_drop_radio=0.75, L=16, V=6, seed_base=4242)
+else:
+    cfg = PreshapeConfig("gatefault", B=2, N=30000, grid_size=8, dynamic_drop_radio=0.4, L=16, V=180, seed_base=4242)
 m, _ = build_module(cfg)
 m = m.cuda()
 pts, text, mask, img = make_scene_batch(cfg)
@@ -389,6 +392,7 @@ with torch.no_grad():
             calls.append("raised: " + str(e)[:160].replace("\n", " "))
         if i == 0 and mode != "stall":
             print("GATES_BEFORE", m.uses_stream_gates() or "raised" in calls[0])
+            print("GATE_BITS", m.stream_gate_bits())
     for c in calls:
         print("CALL", c)
     print("GATES_AFTER", m.uses_stream_gates())
@@ -439,6 +443,26 @@ def test_stream_gate_timeout_fails_loudly(tmp_path, fault):
     assert calls[2] == "ok nan=0", calls
     assert got["GATES_AFTER"] == ["False"]                              # events from the failure on
     assert got["DIGEST"] == ref["DIGEST"]                               # and the result is right again
+
+
+@pytest.mark.parametrize("fault", ["join", "tags"])
+def test_stream_gate_timeout_fails_loudly_on_the_clustering_layout(tmp_path, fault):
+    """The same for the words of the layout in which the clustering chain owns the caller's stream (r04 "cgate": the wait for the
+    image chain rides at the end of the qkv GEMM / of k_select, the wait for the slot tags at the end of the proj GEMM): a dropped
+    releasing store gives NaN outputs, a RuntimeError naming the gate on the next call, events from then on, and the right result."""
+    ref = _run_gate_worker(tmp_path, PTX_GATE="0", GATE_TEST_SHAPE="cluster")
+    assert ref["GATES_AFTER"] == ["False"] and all(c == "ok nan=0" for c in ref["CALL"])
+    got = _run_gate_worker(tmp_path, PTX_GATE_TIMEOUT_MS="30", PTX_GATE_FAULT=fault, GATE_TEST_SHAPE="cluster")
+    clean = _run_gate_worker(tmp_path, GATE_TEST_SHAPE="cluster")        # nothing injected: the gated layout gives the events' result
+    assert all(c == "ok nan=0" for c in clean["CALL"]) and clean["DIGEST"] == ref["DIGEST"]
+    if clean["GATE_BITS"] != ["3"]:
+        pytest.skip("this environment orders the streams with events (profiler / serialised queues / failed probe)")
+    calls = got["CALL"]
+    assert calls[0] == "ok nan=1", calls
+    assert calls[1].startswith("raised:") and "stream gate timed out" in calls[1] and ("tags" if fault == "tags" else "join") in calls[1], calls
+    assert calls[2] == "ok nan=0", calls
+    assert got["GATES_AFTER"] == ["False"]
+    assert got["DIGEST"] == ref["DIGEST"]
 
 
 
