@@ -445,21 +445,30 @@ def test_stream_gate_timeout_fails_loudly(tmp_path, fault):
     assert got["DIGEST"] == ref["DIGEST"]                               # and the result is right again
 
 
-@pytest.mark.parametrize("fault", ["join", "tags"])
+@pytest.mark.parametrize("fault", ["join", "tags", "join-early"])
 def test_stream_gate_timeout_fails_loudly_on_the_clustering_layout(tmp_path, fault):
     """The same for the words of the layout in which the clustering chain owns the caller's stream (r04 "cgate": the wait for the
     image chain rides at the end of the qkv GEMM / of k_select, the wait for the slot tags at the end of the proj GEMM): a dropped
     releasing store gives NaN outputs, a RuntimeError naming the gate on the next call, events from then on, and the right result."""
-    ref = _run_gate_worker(tmp_path, PTX_GATE="0", GATE_TEST_SHAPE="cluster")
+    # join-early: the early-proxy form of the layout (forced at this small shape), where the join's wait is the end of k_select
+    extra = dict(GATE_TEST_SHAPE="cluster", **({"PTX_EARLY_PROXIES": "1"} if fault == "join-early" else {}))
+    fault = fault.split("-")[0]
+    ref = _run_gate_worker(tmp_path, PTX_GATE="0", **extra)
     assert ref["GATES_AFTER"] == ["False"] and all(c == "ok nan=0" for c in ref["CALL"])
-    got = _run_gate_worker(tmp_path, PTX_GATE_TIMEOUT_MS="30", PTX_GATE_FAULT=fault, GATE_TEST_SHAPE="cluster")
-    clean = _run_gate_worker(tmp_path, GATE_TEST_SHAPE="cluster")        # nothing injected: the gated layout gives the events' result
+    got = _run_gate_worker(tmp_path, PTX_GATE_TIMEOUT_MS="30", PTX_GATE_FAULT=fault, **extra)
+    clean = _run_gate_worker(tmp_path, **extra)                         # nothing injected: the gated layout gives the events' result
     assert all(c == "ok nan=0" for c in clean["CALL"]) and clean["DIGEST"] == ref["DIGEST"]
     if clean["GATE_BITS"] != ["3"]:
         pytest.skip("this environment orders the streams with events (profiler / serialised queues / failed probe)")
     calls = got["CALL"]
-    assert calls[0] == "ok nan=1", calls
-    assert calls[1].startswith("raised:") and "stream gate timed out" in calls[1] and ("tags" if fault == "tags" else "join") in calls[1], calls
+    if "PTX_EARLY_PROXIES" in extra:
+        # the wait sits at the end of k_select, in front of the slot tags that publish the survivor counts: the error word is there
+        # before the counts, so the SAME call raises (like a failed fork)
+        assert calls[0].startswith("raised:") and "stream gate timed out" in calls[0] and "join" in calls[0], calls
+        assert calls[1] == "ok nan=0", calls
+    else:
+        assert calls[0] == "ok nan=1", calls
+        assert calls[1].startswith("raised:") and "stream gate timed out" in calls[1] and ("tags" if fault == "tags" else "join") in calls[1], calls
     assert calls[2] == "ok nan=0", calls
     assert got["GATES_AFTER"] == ["False"]
     assert got["DIGEST"] == ref["DIGEST"]
