@@ -1234,14 +1234,17 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     static const bool ext_event_env = getenv("PTX_NO_EXT_EVENT") == nullptr;
     const bool ext_event = ext_event_env && !capturing;
     static const int tail_env = getenv("PTX_TAGS_TAIL") ? atoi(getenv("PTX_TAGS_TAIL")) : 1;
-    // r04, opt-in (PTX_TAGS_GATED=1): with the gates the tags can leave the chain altogether -- a third (low-priority) stream waits
+    // r04 (PTX_TAGS_GATED=0 / 1 forces it): with the gates the tags can leave the chain altogether -- a third (low-priority) stream waits
     // for the first thread of the point-proxy kernel (k_select in front of it has completed), runs k_tags beside the point proxies /
     // qkv GEMM and signals a word that the proj GEMM's work-group 0 waits for in front of k_affine: no event record or wait on
     // either chain.  Measured (profiles/r04_tags_off_chain_ab.txt): 18.44-18.75k against 18.68-19.09k scenes/s at 4 scenes per GPU,
     // neutral at 8 and 32 -- k_tags (16 work-groups of 1024 threads, 128 KB of LDS each) now runs beside the qkv GEMM of the same
     // stream's tail, which takes 22 instead of 13 us: the clustering stream ends where it did.
-    static const bool tags_gated_env = getenv("PTX_TAGS_GATED") != nullptr && atoi(getenv("PTX_TAGS_GATED")) != 0;
-    const bool tags_gated = gated && side->lo_ok && tags_gated_env;
+    // End of r04: on by default where the two chains are about as long as each other (the benchmark shape: est_image < 1.6 est_cluster),
+    // i.e. where the 12 us of k_tags at the tail of the clustering stream decide the join: 18.41k -> 18.58k scenes/s at 4 scenes per GPU
+    // over six interleaved pairs, +0.3 ... +1.2 % in three sessions; 6 scenes -0.6 %, 2 and 8 neutral (profiles/r04_tags_gated_rule_ab.txt).
+    static const int tags_gated_env = getenv("PTX_TAGS_GATED") ? atoi(getenv("PTX_TAGS_GATED")) : -1;
+    const bool tags_gated = gated && side->lo_ok && (tags_gated_env >= 0 ? tags_gated_env != 0 : est_image < 1.6 * est_cluster);
     const bool tags_tail = !cluster_on_caller && tail_env != 0 && !tags_gated;
     PTX_TIMED(KID_SELECT, cs, launch_select_order(S, centers, pad_count, order_override, order, picks, keep, kcenter,
                                                   ksrc, bbox_in ? nullptr : mm_ws, cs, cluster_on_caller, ext_event && !tags_tail ? side->aux : nullptr,
