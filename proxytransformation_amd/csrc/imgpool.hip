@@ -1,6 +1,6 @@
 // Attention pooling of bf16- / fp16-stored image features in ONE pass over the features after the mean
 // (AttentionPool2d query 0, PRE:158-176; algebra in imgproxy.hip).  It replaced three launches -- scores on the
-// matrix pipe, a softmax launch, weighted sums on the matrix pipe -- whose measurements are kept below.
+// matrix pipe, a softmax launch, weighted sums on the matrix pipe -- whose measurements are kept in profiles/LAB_NOTES_imgpool.md.
 //
 // A work unit is (image, tile of 128 pixels): 512 channel rows x 256 B = 128 KB, which is held in the
 // REGISTERS of one 8-wave work-group (16 loads of 16 B per lane) from the moment it is loaded until it has
@@ -21,91 +21,9 @@
 // Every product is of two bf16 values (exact in fp32) accumulated in fp32: the result is the fp32 value in a
 // different summation order.
 //
-// Measurements behind the design (cfg2, B = 4: 784 images, 180.6 MB of bf16 features; us per launch):
-//   * three-pass predecessors: VALU scores 57-62 + f32-MFMA weighted sums 72-76.  Moving the weighted sums to the
-//     bf16 pipe alone changed nothing (75): the matrix time was never the limit, the load map was --
-//   * a wave instruction streams at full rate only if ADJACENT LANES READ ADJACENT 16-B CHUNKS in groups of four
-//     (scratch/pattern_bench.hip, loads only: whole rows 24.6; 4 rows x 256 B with quads contiguous 24.5; the
-//     natural MFMA map, lane & 15 = row, 45.5; 4 rows x 256 B with lane & 3 = row 52).  Hence one MFMA of stage 3
-//     covers FOUR channel rows x 128 pixels (A row = (channel m >> 2, pixel set m & 3), B column = (head, pixel
-//     set)); only the blocks with equal sets mean anything -- 1/4 of a cheap MFMA
-//   * separate matrix-pipe kernels: scores over (image, half the channels) units 54 + softmax launch 9 + weighted
-//     sums 46 = 109; removing any ONE of {weight prologue, MFMA work, reduction + output} from the scores kernel
-//     left it at 50-54: what remained was the serial chain inside each round of work-groups
-//   * this kernel with the two tiles of an image on different XCDs: 71; on one XCD: 58-60 (the tiles share a
-//     cache line per row and the run-on lanes of tile 1 read the head of the next row; loads only: 50 vs 33)
-//   * phases of a unit (s_memtime, 2.35 GHz): waiting for the 16 loads 53 %, scores 8 %, softmax 7 %, weighted sums
-//     27 %, barriers 3 %; a unit lives 12.3 us, two are resident per CU (120 VGPRs x 8 waves), 1568 units on 512
-//     slots = 3.06 rounds, i.e. four: ~20 % of the launch is the last, nearly empty round
-//   * whole images as units (both tiles in sequence in one work-group, running sums rescaled, no partials and no
-//     merge launch; 128 VGPRs once the tile code was straight-line -- as a loop the allocator kept two copies of
-//     the 64 tile registers): 90 us vs 59 + 13 -- 784 units on 512 slots are two rounds of 32-us lifetimes
-//   * 32 "double" units (both tiles of an image in one work-group, started first) so that 1536 units fill three
-//     rounds exactly: as a second copy of the tile code or a loop around the body the kernel needs 150-190 VGPRs
-//     (one work-group per CU: 76-110 us for everybody); as a separate kernel on a second stream the 32 work-groups
-//     start late (event hand-over) and become the tail themselves: 77 us
-//   * persistent, double-buffered variants (64-pixel tiles, or 16 waves x 32 channels) in isolation: the loads
-//     alone take 57 / 43 us instead of 33 (128-B runs per row; one work-group per CU), and time spent between
-//     issuing a prefetch and using it is simply added on top (scratch/pattern_bench.hip Q*/R*) -- not pursued
-//   * r02, cold inputs (three input sets rotated, > Infinity Cache): cache policy of the mean pass and of this pass
-//     (nt / default, all four combinations) and the image order (same / reverse of the mean pass): 61.4-64.0 us in
-//     every case -- the second read gets nothing from the 256 MiB cache; the kernel waits on its own load / compute
-//     phases, not on DRAM.  Two independent batches in flight on two streams: no gain either (12.7-13.9k scenes/s):
-//     the resident pooling work-groups fill the register files and the other batch's small kernels stretch 3-5x
-//   * r02, two more attempts at hiding a unit's load wait: (a) every other image of the first residents started half a
-//     period late (s_sleep) so that half of the chip streams while the other half computes: purely additive, +5 us per
-//     3.4 us of delay -- the launch is not bandwidth-bound in rounds, each slot simply runs ~3 units of fixed latency;
-//     (b) a persistent work-group per CU with two register sets (242 VGPRs, no spills), the next unit's 28 loads issued
-//     before the current unit is processed, LDS-only barriers (s_waitcnt lgkmcnt(0); s_barrier): 107 us on 256
-//     work-groups, 146 us on 128 -- 11.9-17.5 us per unit, i.e. no overlap at all: across the loop's back edge hipcc's
-//     wait-count pass falls back to s_waitcnt vmcnt(0) in stage 1, so the prefetch is drained before it can help;
-//     making it work needs the loads and their waits in inline assembly
-//   * r03, where the 59 us go (profiles/r03_pool_phase_stamps.txt: s_memrealtime stamps of every unit; r03_pool_l2_requests.txt:
-//     TCP counters; r03_rowspan_loadmaps.txt: the load maps alone; r03_pool_variants.txt: lab builds with phases removed, timed
-//     inside the bench step).  The tile map alone, cold, takes 33 us (5.5 TB/s; 34.7 with ONE work-group per CU: 8 requesting
-//     waves per CU are enough) with 1.70 L2 requests per 128-B line -- a 256-B run at 2-byte alignment touches three lines and
-//     the line in the middle of a row is requested by both tiles; whole rows as "row pairs" need 1.28 and take 29 us, the
-//     same as contiguous reads.  This kernel with stages 1-3 and every store removed (held at two work-groups per CU): 41-45 us
-//     (head weights 18.5 MB, ramp, tail); with only the stores removed 53-54.  So: ~42 us of requests as these work-groups
-//     issue them, ~8 us for the 31.5 MB of write-through partials on the same memory path (fetch 220 MB + write 31.5 MB at the
-//     5.4 TB/s the mean pass reaches = 46.5 us is the floor of THIS decomposition), ~10 us of a unit's compute that the
-//     co-resident unit's requests do not cover.  (Variants that drop single stages do not price them: without stage 3 the
-//     kernel compiles to 142 VGPRs -- one work-group per CU, 59.7 us -- and spills when capped at 128.)  In the stamps a unit's requests take 8 us to the first barrier +
-//     2.6 us to the end of stage 1 (5.7 us per unit in the loads-only kernel); the two resident work-groups of a CU
-//     alternate on their own (one of them requesting 57-72 % of the time, both 17-30 %), the dispatch gap is 0.5 us; ~65 L2
-//     requests are in flight per CU (118 in the loads-only kernel).
-//   * r03, load policy again, whole step, interleaved pairs (scratch/ld_policy_variants.py): plain instead of streaming loads in
-//     this kernel -1.0 % at 4 scenes and -1.5 % at 32; in the mean pass this kernel drops to 54 us at 4 scenes (it finds lines of
-//     the mean pass in the caches) but the mean pass loses more (41 vs 38 us between events): step -2 %; both -6 % / -3 %
-//   * r03, stage 3 as ONE basic block: hipcc turns `if (ps == 0) G[..] = x` and the ?: chain that picks the accumulator row into
-//     exec-masked control flow, so every (kb, i, hg) step is its own block and runs strictly after the previous one (bpermute
-//     latency, three dependent MFMAs, accumulator read, DPP adds).  With every lane storing (three of a quad into dump words
-//     behind G, one per-lane base + immediates) and the row picked by per-lane bit masks the scheduler interleaves the
-//     bpermutes of later steps with the MFMAs and pairs the stores -- parity-green, the launch 59.4-61.5 instead of 61.5-62.2 us
-//     in the step, the step itself unchanged (17.26k / 17.33k / 16.83k vs 17.52k / 17.42k / 17.38k at 4 scenes, 25.13k vs 25.23k
-//     at 32): the launch does not wait for stage 3 either.  Not kept
-//   * r03, NOT the cause (each built, parity-green, timed in the step on one box against the shipped build): the number of
-//     memory instructions per wave (head weights as two 16-B loads per lane with wave = head, positional terms as one 8-B
-//     load: 21 instead of 28 instructions, 60.2 vs 60.5 us, 17.60k vs 17.60k scenes/s)
-//   * r03, persistent work-groups (2 per CU, static stride over the units; loop-invariant lane values re-derived per stage
-//     from an opaque thread id and amdgpu_waves_per_eu(4, 4) to stay at 128 VGPRs -- as loop invariants they cost 160):
-//     plain loop 75 us in the step (59 fresh); with the next unit's tile requested into the registers stage 3 has just
-//     finished with (one load behind every bpermute group) the unit lives 15.5 instead of 18.2 us and the launch alone is
-//     7 % shorter at 16 scenes -- but inside the step, next to the clustering stream, 66 us at 4 scenes and 0.38 instead of
-//     0.45 of the HBM peak at 32: a work-group that gets its slot late still owes its whole share, and the slots never free
-//     up for the other stream's kernels
-//   * r03, whole rows: unit = (image, half of the channels, ALL pixels), a wave owns 32 rows and requests both 256-B runs of
-//     a row group back to back (the middle line and the run-on merge at the CU), the two halves of an image exchange their
-//     partial scores (8 heads x 256 pixels) through memory around a ticket and take one soft-max over the image; same
-//     register / lane maps, same result format.  No dead-lock (the halves are adjacent in dispatch order), but 98 us: the
-//     request phase of a unit doubles (13 + 7 us -- the spinning partners' agent-scope polls share the memory path) and a
-//     unit then waits 8 us for its partner with its registers idle; with two work-groups per CU nothing fills that hole.
-//     Fewer requests per line need a unit that sees whole rows WITHOUT a partner: a 16-wave work-group per image (both
-//     tiles side by side on one CU, the next image's rows requested as stage 3 frees registers) -- not built
-//   * r03, tile-1 windows wholly beyond the row (pixels >= 232) re-reading the row's last window instead of running on into the
-//     next row (a 208-B run touches 2.6 instead of 3 lines on average: -6 % of the tile requests; branch-free, the columns are
-//     ignored anyway): 17.58k / 17.39k vs 17.66k / 17.51k scenes/s at 4 scenes, 25.25k / 25.19k vs 25.11k / 25.15k at 32 -- inside
-//     the box-to-box noise, not kept
+// The measurements behind this design -- every decomposition, load map, cache policy and scheduling variant that was built and timed
+// in rounds 1-3 (three-pass predecessors, whole-image and persistent units, whole rows with a partner, ...) -- are in
+// profiles/LAB_NOTES_imgpool.md; round 4's in DESIGN.md 5.2.
 #include <cstdlib>
 #include <hip/hip_ext.h>
 
