@@ -1,7 +1,7 @@
 """Fork / join soak for the device-word gates: the inputs of every forward are (re)written IN PLACE on the caller's stream right
 before the call (copies from three resident variants into the same tensors), so a clustering stream that started too early, or
 read stale lines, gives different indices / coordinates than the first pass over that variant; outputs compared bitwise.
-python scratch/soak_fork.py [config] [forwards] [f32]"""
+python scratch/soak_fork.py [config] [forwards] [f32]   (SOAK_B=<scenes per call>)"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import build_module, InputSets
@@ -10,6 +10,9 @@ name = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1500
 f32 = len(sys.argv) > 3 and sys.argv[3] == "f32"
 cfg = CONFIGS[name]; dev = torch.device("cuda:0")
+if os.environ.get("SOAK_B"):                                  # scenes per call (default: the configuration's own)
+    import dataclasses
+    cfg = dataclasses.replace(cfg, B=int(os.environ["SOAK_B"]))
 mod, _ = build_module(cfg, dev)
 inp = InputSets(cfg, cfg.B, 3, 0, 1, dev, torch.float32 if f32 else torch.bfloat16)
 variants = [inp.args(k) for k in range(3)]
