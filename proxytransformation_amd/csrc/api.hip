@@ -1153,7 +1153,7 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     static const int early_env = getenv("PTX_EARLY_PROXIES") ? atoi(getenv("PTX_EARLY_PROXIES")) : -1;
     const double est_all = 1.8 * 12.0 * (double)B * S.Mt * S.C * S.C / 70e6;                     // us (cfg4 at 6 scenes: 147; measured ~150)
     const bool early = cluster_on_caller && (early_env >= 0 ? early_env != 0
-                                                            : (Kd >= 128 && (long)B * S.Mk >= 1024 && est_all < 0.8 * 0.42 * Kd));
+                                                            : (Kd >= 128 && (long)B * S.Mk >= 1024 && est_all < 3.0 * 0.42 * Kd));
     // r04: the streams that fork off behind the clusters (the late image chain, the early proxies) wait for k_cluster's own
     // completion signal instead of for one event record each on the caller's stream -- two packets (~5 us each) between k_cluster and
     // k_select on the chain the step waits for (PTX_FORK_EXT=0: the records)
@@ -1200,9 +1200,12 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
                     make_branch(S, *w, pf, 1, xin_i, at<float>(ws, L.cbuf), S.V, nullptr, transform, guide_i)};
     br[1].proxy_lnp = at<float>(ws, L.lnp_img);       // norm_img is applied inside the image block's proxy_proj
     // (`early`, decided above: worth it from ~1000 kept rows per call: cfg4 at 6 scenes +5 %, one scene neutral, cfg1 -- 64 kept rows --
-    // -6 %) ... and only where the all-cluster work fits beside the sampling: ~12 B M C^2 flop at ~70 TFLOP/s for the two qkv products, the
-    // point proxies ~0.4x that, against ~0.42 us per pick (cfg5 at 16 scenes: 4 ms of it beside 0.8 ms of picks -- 4.37k -> 3.36k
-    // scenes/s before this rule)
+    // -6 %) ... and only while the early work (est_all: ~12 B Mt C^2 flop at ~70 TFLOP/s for the two qkv products, the point proxies
+    // ~0.4x that) is less than ~3x the sampling (0.42 us per pick): the early rows are 1 / 0.57 of the kept ones, so what does not fit
+    // beside the sampling still costs less than the kept-row kernels behind it until then.  Measured at the end of r04
+    // (profiles/r04_early_rule_ab.txt): cfg4 at 7 / 8 / 10 / 11 scenes +8.4 / +8.6 / +6.3 / +6.7 % (ratio 0.8 ... 1.25), cfg5 at
+    // 3 / 4 / 6 / 8 / 10 / 12 scenes +3.5 / +4.6 / +7 / +6.5 / +3.2 / -2.5 % (ratio 0.9 ... 3.6); cfg5 at 16 scenes with ALL grid clusters
+    // as early rows (before k_order): 4 ms beside 0.8 ms of picks, 4.37k -> 3.36k scenes/s.
     if (early) {
         if (!fork_ext) PTX_HIP(hipEventRecord(side->early_a, cs));          // the clusters exist
         PTX_HIP(hipStreamWaitEvent(side->lo, side->early_a, 0));
