@@ -1188,9 +1188,9 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     // ---- early proxies (r04).  Where the clustering chain is the long one, most of it is the farthest point sampling: one
     // work-group per scene for hundreds of dependent picks (cfg4: 519 picks, 0.2 ms), after which the point proxies, LayerNorm1 and
     // the qkv projection of the KEPT clusters were still to come (15 + 40 us at 6 scenes).  None of the three needs the selection
-    // except for WHICH rows: so they are computed for ALL clusters on the third stream, beside the sampling (2.5x the rows at the
-    // shipped configuration, on a chip that is otherwise waiting), with (LN1(x) + posb_j) W^T + b = LN1(x) W^T + [posb_j W^T + b]
-    // and the bracket a parameter-only table (prep.hip); behind the sampling the kept rows are a gather + that table (~8 us).
+    // except for WHICH rows: so they are computed for all Mt clusters that enter the sampling, on the third stream beside it (1.75x the
+    // kept rows at the shipped configuration, on a chip that is otherwise waiting), with (LN1(x) + posb_j) W^T + b = LN1(x) W^T +
+    // [posb_j W^T + b] and the bracket a parameter-only table (prep.hip); behind the sampling the kept rows are a gather + that table.
     float *point_proxy = at<float>(ws, L.point_proxy);
     float *xin_t = at<float>(ws, L.x_in[0]), *xin_i = at<float>(ws, L.x_in[1]);
     float *translate = at<float>(ws, L.head[0]), *transform = at<float>(ws, L.head[1]);

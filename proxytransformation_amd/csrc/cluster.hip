@@ -430,9 +430,9 @@ int launch_pointnet(const float *ab, const PtxSlotMlp &mlp, const float *kcenter
     return PTX_OK;
 }
 
-// ------------------------------------------------------------------------------ kept rows out of the all-cluster tables
-// (the early-proxy path of ptx_forward, api.hip: point proxies, LayerNorm rows and their qkv projections are computed for ALL
-//  clusters beside the farthest point sampling; afterwards the kept rows are a gather + the per-slot bias term)
+// ------------------------------------------------------------------------------ kept rows out of the early tables
+// (the early-proxy path of ptx_forward, api.hip: point proxies, LayerNorm rows and their qkv projections are computed for the Mt
+//  clusters that enter the farthest point sampling, beside it; afterwards the kept rows are a gather + the per-slot bias term)
 struct QkvGatherArgs { const float *pp_all, *g[2], *tb[2]; const int32_t *ksrc; int M, Mk, C; float *pp, *qkv[2]; };
 __global__ __launch_bounds__(512) void k_qkv_gather(QkvGatherArgs a)
 {

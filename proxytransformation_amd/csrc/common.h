@@ -403,7 +403,7 @@ int launch_pointnet(const float *ab, const PtxSlotMlp &mlp, const float *kcenter
                     const int32_t *ksrc, int Msrc, hipStream_t st, uint32_t *head_flag = nullptr, uint32_t head_seq = 0,
                     bool center_src = false);
 int launch_order(const PtxShape &s, const int32_t *pad_count, const int32_t *order_override, int32_t *order, hipStream_t st);
-// kept rows out of the all-cluster tables: point_proxy[row] = pp_all[src], qkv[i][row] = g[i][src] + tb[i][j]  (src = b * M + ksrc[row])
+// kept rows out of the early tables: point_proxy[row] = pp_all[src], qkv[i][row] = g[i][src] + tb[i][j]  (src = b * M + ksrc[row]; M rows per scene)
 int launch_qkv_gather(const float *pp_all, const float *const g[2], const float *const tb[2], const int32_t *ksrc, int B, int M, int Mk,
                       int C, float *point_proxy, float *const qkv[2], hipStream_t st);
 int launch_cluster(const PtxShape &s, const uint32_t *mm_enc, const float *lin, const ScenePts &points,
