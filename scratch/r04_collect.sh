@@ -7,6 +7,16 @@ cp $O/r04_pmc_traffic.json $P/r04_pmc_traffic.json
 cp $O/r04_timeline_bf16.txt $P/r04_final_timeline_bf16.txt; cp $O/r04_timeline_f32.txt $P/r04_final_timeline_f32.txt
 for n in b1 b32 cfg1 cfg4 cfg4_b6 cfg5 cfg5_b16 driver_args; do cp $F/bench_$n.json $P/r04_final_bench_$n.json; done
 cp $F/r04_timeline_cfg4_b6.txt $P/r04_final_timeline_cfg4_b6.txt
+python - "$(find $F/stats_cfg4_b6 -name '*kernel_stats.csv' | head -1)" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+with open("profiles/r04_final_kernel_stats_cfg4_b6.csv", "w") as out:
+    out.write("kernel,calls,total_us,avg_us,min_us,max_us,percent\n")
+    for r in rows[:24]:
+        n = r["Name"].replace("ptx::", "").split("(")[0]
+        out.write('"%s",%s,%.1f,%.2f,%.2f,%.2f,%s\n' % (n, r["Calls"], float(r["TotalDurationNs"]) / 1e3, float(r["AverageNs"]) / 1e3,
+                                                        float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
+PY
 grep -v amdgpu.ids $F/vox_time.txt > $P/r04_final_vox_time.txt; grep -v amdgpu.ids $F/ingest_time.txt > $P/r04_final_ingest_time.txt
 T=gpurun_out/r04train
 cp $T/r04_train_kernel_stats.csv $T/r04_train_step_trace.txt $P/; grep -v amdgpu.ids $T/r04_train_time.txt > $P/r04_train_time.txt
