@@ -84,6 +84,11 @@ CONFIGS: Dict[str, PreshapeConfig] = {
     # cfg4: the reference's only shipped config (CFG:41): gs=12, ddr=0.6, 3+3 blocks
     "cfg4": PreshapeConfig("cfg4", B=1, N=100000, grid_size=12, dynamic_drop_radio=0.6,
                            L=20, V=50, text_blocks=3, img_blocks=3, seed_base=4000),
+    # cfg4 in the regime a real ScanNet room puts it in (SURVEY 8d's second distribution): every side of a (7, 5, 3) m room is
+    # shorter than 2 * margin = 8 m, so PRE:48 yields an inverted grid, PRE:62 clamps it and both ball queries fill their 30 slots
+    # from the first few hundred points of the scene (no padded slot anywhere, ~100 distinct clustered points per scene)
+    "cfg4_room": PreshapeConfig("cfg4_room", B=1, N=100000, grid_size=12, dynamic_drop_radio=0.6,
+                                L=20, V=50, text_blocks=3, img_blocks=3, extent=(7.0, 5.0, 3.0), seed_base=4000),
     # cfg5: stress / roofline run; the reference itself cannot run d=512
     "cfg5": PreshapeConfig("cfg5", B=1, N=500000, grid_size=16, dynamic_drop_radio=0.75,
                            L=64, V=192, embed_dim=512, seed_base=5000),

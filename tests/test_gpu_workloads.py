@@ -84,6 +84,34 @@ def test_shipped_config_at_its_training_batch_vs_oracle():
     _compare(cfg, range(6), torch.float32)
 
 
+@pytest.mark.parametrize("inject", [True, False], ids=["injected", "uninjected"])
+def test_shipped_config_in_the_room_regime_vs_oracle(inject):
+    """BASELINE configs[3] in the distribution SURVEY 8d prescribes for it: CFG:41 (gs = 12, ddr = 0.6, 3 + 3 blocks) on
+    (7, 5, 3) m rooms at N = 100 000, the training batch of six scenes, fp32 features (DET:372-377).  Every side is shorter than
+    2 * margin, so PRE:48's grid is inverted and PRE:62 clamps the centres: both ball queries stop within the first few hundred
+    points, no slot is padded (the ordering is all ties), ~100 distinct points per scene are clustered by 1 728 centres, and
+    the scatter's last-writer rule (PRE:495) decides nearly every written point."""
+    from oracle import oracle
+    cfg = CONFIGS["cfg4_room"]
+    assert (cfg.N, cfg.M, cfg.Mt, cfg.M_keep, cfg.Kd, cfg.extent) == (100000, 1728, 1210, 691, 519, (7.0, 5.0, 3.0))
+    _compare(cfg, range(6), torch.float32, inject=inject)
+    # the regime itself (not only the agreement): prefix of a few hundred points, nothing padded
+    pts, text, mask, img = make_scene_batch(cfg, scene_ids=range(2))
+    _, sd = build_module(cfg)
+    ref = oracle.forward(sd, **oracle_kwargs(cfg), points=pts, text_feats=text, text_mask=mask, img_feat=img,
+                         stop_after="cluster", num_threads=8)
+    assert ref["idx2"].max() < 1000 and ref["idx2"].min() >= 0
+
+
+def test_cfg2_at_32_scenes_in_one_call_vs_oracle():
+    """What bench.py's `at_32_scenes_per_gpu` / `roofline_passes[1]` lines run: ONE call over 32 cfg2 scenes with bf16 features --
+    6 272 images (the pooling pass stores its partials as streaming lines from 4 096 images on), 8 192 cluster tokens per branch
+    (`k_mlp<LITE>`, two work-groups per CU) and the un-split attention together; every index tensor bit-identical, coordinates
+    within 1e-4 of the oracle for all 32 scenes."""
+    cfg = CONFIGS["cfg2"]
+    _compare(cfg, range(32), torch.bfloat16)
+
+
 @pytest.mark.parametrize("name, img_dtype, nscenes", [("cfg2", torch.bfloat16, 4), ("cfg4", torch.float32, 2)],
                          ids=["cfg2-bf16", "cfg4-f32"])
 def test_full_size_forward_without_injected_centres(name, img_dtype, nscenes):
