@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PTX_ABI_VERSION 10
+#define PTX_ABI_VERSION 11
 
 #define PTX_OK          0
 #define PTX_EINVAL     -1   /* bad shape / null pointer / unsupported size */
@@ -118,7 +118,7 @@ int ptx_context_create(PtxContext **ctx);
 int ptx_context_destroy(PtxContext *ctx);
 /* Stream gates (ABI 6).  Where the image chain owns the caller's stream the fork and the join of the two chains are device
  * words instead of event record + wait (one waiting wave / one waiting work-group instead of two queue packets).  A waiter
- * is bounded in wall-clock time (PTX_GATE_TIMEOUT_MS, default 10 s -- the fork legitimately waits for everything queued
+ * is bounded in wall-clock time (PTX_GATE_TIMEOUT_MS, default 30 s for a fork, twice that for a join -- the fork legitimately waits for everything queued
  * ahead of the forward on the caller's stream); when the bound runs out it does NOT let go silently: it stores a sticky
  * error word in pinned host memory, the outputs of that forward become NaN, and (PTX_GATE_TRAP=1) it traps.
  * ptx_context_check returns PTX_EGATE once for such a failure -- ptx_forward makes the same check on entry -- and the
@@ -128,6 +128,15 @@ int ptx_context_destroy(PtxContext *ctx);
  * gate words as well).  There is no reference counterpart (PRE runs on
  * one stream). */
 int ptx_context_check(PtxContext *ctx);
+/* ABI 11.  The same check BEHIND a drain of the context's streams and of the caller stream of its latest forward.  A join (or
+ * slot-tag) gate fails after the survivor counts have been published, i.e. after a host that only waits for the counts has gone
+ * on: ptx_context_check right behind ptx_wait_counts reports fork failures only, the join's surfaces with the NEXT
+ * ptx_forward on the context -- or here.  Call it before trusting the outputs of forwards that were not synchronised on (end
+ * of a loop, before results leave the process, at teardown); the Python module does so in check(), close() / __del__ and at
+ * interpreter exit.  A C caller that sees PTX_EGATE must ptx_workspace_init its workspace again (the clean-on-entry words of
+ * the failed forward cannot be trusted).  A fork's bound is PTX_GATE_TIMEOUT_MS (default 30 s: it covers everything the caller
+ * queued ahead of the forward), a join's twice that (it may sit through a fork that runs into its bound). */
+int ptx_context_sync_check(PtxContext *ctx);
 int ptx_context_gates(const PtxContext *ctx);
 
 /* Per-kernel timing of ptx_forward for roofline measurement (bench.py): select ONE launch

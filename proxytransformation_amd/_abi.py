@@ -13,7 +13,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libproxyt_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 c_float_p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 
@@ -118,6 +118,7 @@ SIGNATURES = {
     "ptx_context_create": (_I, [C.POINTER(C.c_void_p)]),
     "ptx_context_destroy": (_I, [_P]),
     "ptx_context_check": (_I, [_P]),
+    "ptx_context_sync_check": (_I, [_P]),
     "ptx_context_gates": (_I, [_P]),
     "ptx_forward": (_I, [_P, _SH, _W, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z,
                          C.POINTER(PtxDebug), _P]),

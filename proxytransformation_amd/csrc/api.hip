@@ -268,7 +268,7 @@ static int context_init(PtxContext *c)
         // The bound of a waiting wave.  The fork legitimately waits for everything the caller queued ahead of the forward on its
         // stream (seconds, in a training step), so the default is generous; PTX_GATE_TIMEOUT_MS overrides (tests: a few ms)
         const char *ms_env = getenv("PTX_GATE_TIMEOUT_MS");
-        const long ms = ms_env ? atol(ms_env) : 10000;
+        const long ms = ms_env ? atol(ms_env) : 30000;
         c->gate_ticks = (uint64_t)(ms > 0 ? ms : 1) * (uint64_t)khz;
         c->probe_ticks = (uint64_t)20 * (uint64_t)khz;          // probe: 20 ms on an idle pair of streams
         c->gate_trap = env_on("PTX_GATE_TRAP") ? 1 : 0;
@@ -357,8 +357,11 @@ __global__ void k_gate(GateRef g)
 
 static GateRef gate_ref(const PtxContext *c, int word, uint32_t seq, uint32_t site, bool probe = false)
 {
-    return GateRef{c->gate + word, seq, c->gate_err, probe ? nullptr : c->gate + 48, probe ? c->probe_ticks : c->gate_ticks,
-                   site, probe ? 0 : c->gate_trap};
+    // A JOIN (sites 2, 7) gets twice the bound of a fork (1, 6): it may have to sit through a fork that runs into its own bound and
+    // then through the chain behind it -- with equal bounds the join of a forward whose fork word never arrives lets go FIRST and the
+    // post-join kernels consume a workspace the other chain has not written yet
+    const uint64_t ticks = probe ? c->probe_ticks : ((site == 2 || site == 7) ? 2 * c->gate_ticks : c->gate_ticks);
+    return GateRef{c->gate + word, seq, c->gate_err, probe ? nullptr : c->gate + 48, ticks, site, probe ? 0 : c->gate_trap};
 }
 
 // A gate of a previous forward timed out (or the probe failed): report it ONCE as PTX_EGATE, switch the context to events for good.
@@ -796,6 +799,20 @@ int ptx_context_check(PtxContext *ctx)
 {
     PTX_REQUIRE(ctx != nullptr, "ptx_context_check: null context");
     std::lock_guard<std::mutex> lk(ctx->mu);
+    return gate_check(ctx);
+}
+
+// ptx_context_check behind a drain of the context's streams and of the caller stream of its latest forward: a JOIN (or slot-tag) gate
+// that runs out of time does so after the survivor counts have been published, i.e. after the host has the outputs' lengths, so
+// ptx_context_check right behind ptx_wait_counts cannot see it yet.  This is the call a host makes when it is about to TRUST the
+// outputs of forwards it did not synchronise on (end of a loop, before handing results on, at teardown).
+int ptx_context_sync_check(PtxContext *ctx)
+{
+    PTX_REQUIRE(ctx != nullptr, "ptx_context_sync_check: null context");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    PTX_HIP(hipStreamSynchronize(ctx->last_st));             // (a null handle is the default stream: torch's current stream by default)
+    PTX_HIP(hipStreamSynchronize(ctx->st));
+    PTX_HIP(hipStreamSynchronize(ctx->lo));
     return gate_check(ctx);
 }
 

@@ -1055,11 +1055,14 @@ __global__ __launch_bounds__(256) void k_affine(AffineArgs a)
     constexpr int R = kTilePts / 256;
     __shared__ int s_cnt[R][4];
     __shared__ int s_base;
+    __shared__ uint32_t s_poison;
     const float *kc = a.kcenter + (size_t)b * a.Mk * 3, *kT = a.transform + (size_t)b * a.Mk * 9, *kt = a.translate + (size_t)b * a.Mk * 3;
     // ---- requests: the counts of the tiles in front (one per thread), the table, then tags and points
     int acc = 0;
     if (COMPACT) acc = a.tile_counts[b * ntiles + min(tid, ntiles - 1)];
-    const uint32_t poisoned = a.poison != nullptr ? __hip_atomic_load(a.poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    // (ONE thread reads the word and the work-group takes its value behind the barrier below: the poisoned path leaves the kernel
+    //  early and must be taken by every thread or by none, also when the word is stored while this work-group runs)
+    if (tid == 0) s_poison = a.poison != nullptr ? __hip_atomic_load(a.poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     constexpr int kBatch = 8;
     const int c3 = 3 * a.Mk, c12 = 12 * a.Mk, c15 = 15 * a.Mk;
     auto tab_src = [&](int i) {                             // (the address is selected, not the load: no branch per request)
@@ -1110,6 +1113,18 @@ __global__ __launch_bounds__(256) void k_affine(AffineArgs a)
         if (lane == 0) s_cnt[0][wid] = acc;
     }
     __syncthreads();                                        // table (and count partials) visible
+    if (s_poison != 0u) {
+        // A stream gate of this forward timed out: the chains were not ordered, so the tags, the tile counts and the transform rows
+        // may be ANYTHING (r05: a garbage tile count sent the compacted stores out of bounds -- a GPU memory fault instead of the
+        // reported error).  Nothing index-like is used: every point's row becomes NaN in place, the tags are left for the
+        // re-initialisation that follows the error (module: ws_dirty; C callers: ptx_workspace_init, proxyt.h).
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int n = tile * kTilePts + r * 256 + tid;
+            if (n < a.N) { out[(size_t)n * 3] = out[(size_t)n * 3 + 1] = out[(size_t)n * 3 + 2] = __uint_as_float(0x7fc00000u); }
+        }
+        return;
+    }
     if (COMPACT) {
         base = s_cnt[0][0] + s_cnt[0][1] + s_cnt[0][2] + s_cnt[0][3];
         __syncthreads();                                    // s_cnt[0] is re-used below
@@ -1147,7 +1162,6 @@ __global__ __launch_bounds__(256) void k_affine(AffineArgs a)
                 const float rz = fmaf(T[8], dz, fmaf(T[7], dy, T[6] * dx));
                 x = (rx + c[0]) + tr[0]; y = (ry + c[1]) + tr[1]; z = (rz + c[2]) + tr[2];
             }
-            if (poisoned) x = y = z = __uint_as_float(0x7fc00000u);
             v[r][0] = x; v[r][1] = y; v[r][2] = z;
         }
         bal[r] = __ballot(keep[r]);

@@ -16,8 +16,11 @@ extension is missing, or the inputs are not on a GPU, ``forward`` raises.
 """
 from __future__ import annotations
 
+import atexit
 import ctypes
 import os
+import sys
+import weakref
 from typing import Dict, List, Optional
 
 import torch
@@ -124,7 +127,7 @@ class _Lane:
     count buffer.  Calls on different torch streams use different lanes, so independent batches can be in flight
     on the GPU at the same time (a serving loop alternating between two streams overlaps the bandwidth-bound
     image passes of one batch with the latency-bound proxy blocks of the other)."""
-    __slots__ = ("ctx", "ws", "ws_key", "ws_dirty", "counts", "counts_np", "stream", "quant")
+    __slots__ = ("ctx", "ws", "ws_key", "ws_dirty", "counts", "counts_np", "stream", "quant", "unchecked")
 
     def __init__(self, stream):
         self.stream = stream
@@ -133,6 +136,18 @@ class _Lane:
         self.ws, self.ws_key, self.ws_dirty = None, None, True
         self.counts = self.counts_np = None
         self.quant = None                   # scratch of module.quantize (voxel hash, pinned count buffers)
+        self.unchecked = False              # a forward was handed out whose join gate has not been checked behind a drain yet
+
+    def sync_check(self) -> Optional[str]:
+        """Drain this lane's streams and ask the library whether a stream gate of a forward issued on it failed (a join gate fails
+        AFTER the survivor counts are out, i.e. after forward() has returned): the error text, or None."""
+        if self.ctx is None or not self.unchecked:
+            return None
+        self.unchecked = False
+        if _abi.lib().ptx_context_sync_check(self.ctx) != 0:
+            self.ws_dirty = True            # the clean-on-entry words of that forward cannot be trusted
+            return _abi.lib().ptx_last_error().decode()
+        return None
 
     def release(self):
         ctx, self.ctx = self.ctx, None
@@ -142,6 +157,32 @@ class _Lane:
 
 
 _MAX_LANES = 4                       # streams served concurrently by one module (least recently used is retired)
+
+
+# Every live module is known to the interpreter-exit hook below: a forward whose join gate failed after forward() returned (outputs
+# NaN, csrc/api.hip "gates") must not let the process end quietly with exit code 0 when it was the LAST forward of a loop.
+_LIVE_MODULES = weakref.WeakSet()
+
+
+def _exit_check():
+    failed = []
+    for mod in list(_LIVE_MODULES):
+        try:
+            mod.check()
+        except RuntimeError as e:
+            failed.append(str(e))
+        except Exception:               # interpreter shutdown: the runtime may already be gone
+            pass
+    if failed:
+        sys.stderr.write("proxytransformation_amd: UNREPORTED FAILURE at interpreter exit -- " + " | ".join(failed) + "\n")
+        sys.stderr.flush()
+        try:
+            sys.stdout.flush()
+        finally:
+            os._exit(70)                # EX_SOFTWARE: results of this process are not to be trusted
+
+
+atexit.register(_exit_check)
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -220,6 +261,7 @@ class ProxyTransformationNormReverse(nn.Module):
         self._train_pin = None               # train mode: pinned words + event of the early count read-back, per batch size
         ProxyTransformationNormReverse._instances += 1
         self._instance_salt = ProxyTransformationNormReverse._instances      # dropout masks differ between instances
+        _LIVE_MODULES.add(self)
         self._warned_eval_grad = False
         self._lin_t = None
         # stochastic-depth rate of the blocks that are live (the last of each list; PRE:298-299)
@@ -241,7 +283,8 @@ class ProxyTransformationNormReverse(nn.Module):
     # host caches that hold ctypes pointers / device scratch: never copied or pickled (copy.deepcopy(model),
     # torch.save(model), EMA / SWA copies made after the first forward); a copy rebuilds them on its first call
     _HOST_CACHES = dict(_tensors=None, _slots=None, _lanes=None, _lin_t=None, _wkey=None, _wstruct=None, _prep=None,
-                        _lin=None, _shapes=None, _graph_keepalive=None, _train_pin=None, _train_side=None, _train_live=None)
+                        _lin=None, _shapes=None, _graph_keepalive=None, _train_pin=None, _train_side=None, _train_live=None,
+                        _train_mods=None)
 
     def __getstate__(self):
         state = self.__dict__.copy()
@@ -253,6 +296,7 @@ class ProxyTransformationNormReverse(nn.Module):
         self.__dict__.update(state)
         ProxyTransformationNormReverse._instances += 1
         self._instance_salt = ProxyTransformationNormReverse._instances
+        _LIVE_MODULES.add(self)
 
     def __deepcopy__(self, memo):
         import copy
@@ -412,8 +456,32 @@ class ProxyTransformationNormReverse(nn.Module):
         for lane in lanes.values():
             lane.release()
 
+    def check(self) -> None:
+        """Raise if a stream gate of any forward this module has handed out failed (not in the reference: PRE runs on one stream).
+
+        ``forward`` returns as soon as the per-scene lengths are known -- before the forward has drained -- so a JOIN gate that
+        runs out of time afterwards (the outputs of that forward are NaN) cannot be reported by the call itself; it is reported
+        by the next ``forward`` on the same stream, by ``check()`` (which drains the streams the module used), by ``close()``, when
+        the module is garbage-collected (a warning) and at interpreter exit (exit code 70).  A loop that does not set
+        ``sync_outputs`` should call ``check()`` once behind its last forward."""
+        errs = [e for e in (lane.sync_check() for lane in list(self._lanes.values())) if e]
+        if errs:
+            raise RuntimeError("ptx_forward: " + " | ".join(errs))
+
+    def close(self) -> None:
+        """``check()``, then release the library contexts / workspaces of every stream this module was called on."""
+        try:
+            self.check()
+        finally:
+            self._release_lanes()
+
     def __del__(self):
         try:
+            try:
+                self.check()
+            except RuntimeError as e:
+                import warnings
+                warnings.warn(f"{type(self).__name__} collected with an unreported failure: {e}", RuntimeWarning)
             self._release_lanes()
         except Exception:          # interpreter shutdown: modules may already be torn down
             pass
@@ -540,10 +608,14 @@ class ProxyTransformationNormReverse(nn.Module):
             ctypes.byref(opts) if opts is not None else None, stream),
             "ptx_forward")
         lane.ws_dirty = False
+        drained = False
         if debug or self.sync_outputs or lib.ptx_wait_counts(counts.data_ptr(), B, _COUNTS_TIMEOUT_US) != 0:
             tstream.synchronize()                          # full drain; also surfaces device faults
-        # a stream gate that ran out of time (csrc/api.hip, "gates") has stored its error word by now if it was the fork;
-        # a join that fails later turns this call's outputs into NaN and is reported by the next call
+            drained = True
+        # a stream gate that ran out of time (csrc/api.hip, "gates") has stored its error word by now if it was the fork; a join
+        # that fails later (after the counts) turns this call's outputs into NaN and is reported by the next forward on this
+        # stream, by check() / close(), at garbage collection and at interpreter exit -- or here, when the call drained the stream
+        lane.unchecked = not drained and lib.ptx_context_gates(lane.ctx) != 0
         if lib.ptx_context_check(lane.ctx) != 0:
             lane.ws_dirty = True                           # the workspace's clean-on-entry words cannot be trusted
             raise RuntimeError("ptx_forward: " + lib.ptx_last_error().decode())
@@ -600,6 +672,7 @@ class ProxyTransformationNormReverse(nn.Module):
             img.data_ptr(), None, None, out.data_ptr(), counts.data_ptr(), ws.data_ptr(), ws.numel(), None,
             ctypes.byref(opts) if opts is not None else None, stream), "ptx_forward")
         lane.ws_dirty = False
+        lane.unchecked = not capturing and lib.ptx_context_gates(lane.ctx) != 0     # nothing was waited for: check() is the caller's
         if capturing:
             # the captured kernels read these through raw pointers: they have to outlive the graph
             keep = self.__dict__.get("_graph_keepalive") or []
@@ -676,7 +749,17 @@ class ProxyTransformationNormReverse(nn.Module):
         (B, N, dev), pts, plist, text_feats, mask_u8, img = self._check_inputs(points, text_dict, img_feat)
         if B > _MAX_SCENES_PER_CALL:
             raise RuntimeError(f"train mode takes at most {_MAX_SCENES_PER_CALL} scenes per call (got {B})")
-        if self._train_checked != str(dev):
+        # identity of every live parameter / buffer OBJECT, read from the owning dicts on every step (~10 us): a Parameter swapped in
+        # without load_state_dict / .to() / train() -- a reparametrisation, convert_sync_batchnorm after the first step -- must not
+        # keep receiving `grad None` through a stale gradient list, nor skip the layout / BatchNorm checks below
+        mod_ids = tuple([id(m) for m in self.modules()])          # a swapped sub-MODULE (convert_sync_batchnorm) owns new dicts
+        if getattr(self, "_train_mods", None) != mod_ids:
+            self._train_mods = mod_ids
+            self.invalidate_weights()
+        if self._slots is None:
+            self._weights_key()
+        live_ids = tuple([id(d[k]) for d, k in self._slots])
+        if self._train_checked != (str(dev), live_ids):
             self._train_live = None
             # layout of every parameter / buffer: once per (device, storage generation) -- invalidate_weights() (load_state_dict,
             # .to(), train() / eval()) asks for it again; walking the state_dict on every step cost 0.1 ms
@@ -689,7 +772,7 @@ class ProxyTransformationNormReverse(nn.Module):
                                               "statistics (the reference trains with plain DDP, no SyncBatchNorm)")
                 if bn.momentum is None:
                     raise NotImplementedError(f"{name}.momentum=None (cumulative moving average) is not implemented")
-            self._train_checked = str(dev)
+            self._train_checked = (str(dev), live_ids)
         if dev.index is not None and dev.index != torch.cuda.current_device():
             raise RuntimeError(f"inputs are on {dev} but the current device is cuda:{torch.cuda.current_device()}")
         shape = self._shape(B, N, text_feats.shape[1], img.shape[1], _IMG_DTYPES[img.dtype])

@@ -928,8 +928,13 @@ def forward_train(mod, points: List[torch.Tensor], text_feats, text_mask, img_fe
         st8 = dict(args=(mod, points, text_mask, shape, ws, order_override), seeds=seeds)
         if getattr(mod, "_train_live", None) is None:
             mod._train_live = live_params(mod)              # dropped with the layout check (module.invalidate_weights)
-        outs = _TrainStep.apply(st8, text_feats, img_feat, *mod._train_live)
-        return list(outs), st8["aux"]
+        res = _TrainStep.apply(st8, text_feats, img_feat, *mod._train_live)
+        aux = st8["aux"]
+        # the per-cluster transforms are OUTPUTS of the node: a regulariser on module.forward(..., return_transforms=True)'s
+        # kcenter / translate / transform reaches the parameters, as it did through the per-operator graph
+        n = len(res) - 3
+        aux["kcenter"], aux["translate"], aux["transform"] = res[n:]
+        return list(res[:n]), aux
     pts = torch.stack([p.detach().to(_F32) for p in points]).contiguous()          # PRE:426-427
 
     V = img_feat.shape[1]
@@ -1207,6 +1212,8 @@ class _TrainStep(torch.autograd.Function):
                           centers=centers, translate=translate, transform=transform, point_proxy=pp, img_proxy=img_proxy,
                           kcenter=kcenter, opos=opos)
         ctx.tape = T
+        ctx.set_materialize_grads(False)                # unused outputs (normally the three transforms) arrive as None, not as zero fills
+        ctx.out_like = [(o.shape, o.dtype) for o in outs]
         ctx.streams = (main, side)
         ctx.meta = (text_feats.shape, text_feats.dtype, img_feat.shape, [id(p) for p in params],
                     dict(off=(off.mlp[0].weight, off.mlp[0].bias, bn.weight, bn.bias), oh=off.channel_mapper.weight,
@@ -1214,7 +1221,7 @@ class _TrainStep(torch.autograd.Function):
                          ip=(mod.channel_mapper.weight, mod.channel_mapper.bias, ap.positional_embedding, ap.q_proj.weight,
                              ap.q_proj.bias, ap.k_proj.weight, ap.k_proj.bias, ap.v_proj.weight, ap.v_proj.bias, ap.c_proj.weight,
                              ap.c_proj.bias, mod.norm_img.weight, mod.norm_img.bias)))
-        return outs
+        return (*outs, kcenter, translate, transform)
 
     @staticmethod
     def backward(ctx, *douts):
@@ -1228,7 +1235,17 @@ class _TrainStep(torch.autograd.Function):
                 if p_ is not None and g_ is not None:
                     G[id(p_)] = g_
 
+        n = len(ctx.out_like)
+        g_kc, g_tr, g_tf = douts[n:n + 3]               # gradients that arrive through return_transforms' tensors (None: unused)
+        dev = T["aff"].saved_tensors[3].device
+        douts = [g if g is not None else torch.zeros(shp, dtype=dt_, device=dev) for g, (shp, dt_) in zip(douts[:n], ctx.out_like)]
         dkc_aff, dtranslate, dtransform = _AffineApply.backward(T["aff"], *douts)[:3]
+        if g_kc is not None:
+            dkc_aff = add_(_c(dkc_aff), _c(g_kc.to(_F32)).view(dkc_aff.shape))
+        if g_tr is not None:
+            dtranslate = add_(_c(dtranslate), _c(g_tr.to(_F32)).view(dtranslate.shape))
+        if g_tf is not None:
+            dtransform = add_(_c(dtransform), _c(g_tf.to(_F32)).view(dtransform.shape))
         r = _BlockFused.backward(T["ib"], dtransform)
         dpp_i, dproxy_i = r[0], r[1]
         put(P["ib"], r[6:])

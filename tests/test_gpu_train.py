@@ -494,3 +494,73 @@ def test_training_step_is_bit_reproducible():
     for k in runs[0][1]:
         assert torch.equal(runs[0][1][k], runs[1][1][k]), k
     assert torch.equal(runs[0][2], runs[1][2]) and torch.equal(runs[0][3], runs[1][3])
+
+
+def test_returned_transforms_are_differentiable_in_the_one_node_step(monkeypatch):
+    """``forward(..., return_transforms=True)`` in train mode hands out kcenter / translate / transform; a regulariser on
+    them must reach the parameters.  The one-node step returns them as outputs of the node: a loss built from the transforms ALONE,
+    and one built from outputs + transforms, give the gradients of the per-operator graph (which was always differentiable)."""
+    import copy
+    import proxytransformation_amd.train as T
+    from proxytransformation_amd import MODELS
+    from tests.gpu_util import t
+    cfg = PreshapeConfig("trx", B=3, N=5000, grid_size=5, dynamic_drop_radio=0.6, L=9, V=4, seed_base=8900)
+    pts, text, mask, img = make_scene_batch(cfg)
+    m0 = MODELS.build(dict(type="ProxyTransformationNormReverse", drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.0,
+                           **cfg.module_kwargs()))
+    m0.load_state_dict({k: torch.from_numpy(v) for k, v in fill_state_dict(m0.state_dict()).items()})
+    g = torch.Generator().manual_seed(5)
+    wk, wt, wf = (torch.randn(cfg.B, cfg.M_keep, n, generator=g).to(_dev()) for n in (3, 3, 9))
+
+    def run(one_node, with_outputs):
+        monkeypatch.setattr(T, "_ONE_NODE", one_node)
+        m = copy.deepcopy(m0).cuda().train()
+        tx = t(text).requires_grad_(True)
+        outs, tf = m([t(p) for p in pts], {"text_feats": tx, "text_token_mask": t(mask)}, t(img), return_transforms=True)
+        assert all(tf[k].requires_grad for k in ("kcenter", "translate", "transform"))
+        loss = (tf["kcenter"] * wk).sum() + (tf["translate"] * wt).sum() + (tf["transform"] * wf).sum()
+        if with_outputs:
+            loss = loss + _loss(outs)
+        loss.backward()
+        return {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}, tx.grad.clone()
+    for with_outputs in (False, True):
+        got, gtx = run(True, with_outputs)
+        ref, rtx = run(False, with_outputs)
+        assert sorted(got) == sorted(ref)
+        assert any(float(v.abs().max()) > 0 for k, v in got.items() if "text_trans" in k)
+        assert any(float(v.abs().max()) > 0 for k, v in got.items() if "get_offsets" in k)      # through kcenter
+        for k in ref:
+            if float(ref[k].abs().max()) < 1e-6:            # e.g. the key bias of the attention pool: a rounding-level zero in the reference too
+                assert float(got[k].abs().max()) < 1e-5, k
+                continue
+            if k.endswith("mlp.0.bias"):                    # a bias in front of a batch-statistics BatchNorm: its true gradient is 0, both
+                wk_ = k[:-4] + "weight"                     # evaluations are cancellation noise -- small against the layer's weight gradient
+                assert float(got[k].abs().max()) < 1e-2 * float(ref[wk_].double().pow(2).mean().sqrt()) + 1e-6, k
+                continue
+            # (the offset network's gradients are sums with heavy cancellation over all B M K slots: two correct fp32 evaluations differ
+            #  by ~1e-2 of the tensor's RMS, DESIGN.md 3)
+            _rel(got[k], ref[k], 5e-2 if "get_offsets" in k else 2e-3, k)
+        _rel(gtx, rtx, 2e-3, "text_feats.grad")
+
+
+def test_swapped_parameter_objects_are_seen_by_the_training_step():
+    """a Parameter replaced WITHOUT load_state_dict / .to() / train() after the first step (a reparametrisation, a manual
+    ``mod.x.weight = nn.Parameter(...)``) must receive its gradient on the next step -- the live-parameter list of the one-node step is
+    validated against the owning dicts on every call -- and a BatchNorm swapped for a SyncBatchNorm must be refused."""
+    from proxytransformation_amd import MODELS
+    from tests.gpu_util import t
+    cfg = PreshapeConfig("trs", B=2, N=3000, grid_size=4, dynamic_drop_radio=0.5, L=6, V=3, seed_base=8950)
+    m = MODELS.build(dict(type="ProxyTransformationNormReverse", **cfg.module_kwargs()))
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in fill_state_dict(m.state_dict()).items()})
+    m = m.cuda().train()
+    pts, text, mask, img = make_scene_batch(cfg)
+    args = ([t(p) for p in pts], {"text_feats": t(text), "text_token_mask": t(mask)}, t(img))
+    _loss(m(*args)).backward()
+    old = m.text_trans.weight
+    assert old.grad is not None
+    m.text_trans.weight = torch.nn.Parameter(old.detach().clone() * 0.5)
+    _loss(m(*args)).backward()
+    assert m.text_trans.weight.grad is not None and float(m.text_trans.weight.grad.abs().max()) > 0
+    m.text_trans_norm = torch.nn.SyncBatchNorm(3).cuda()
+    with pytest.raises(NotImplementedError):
+        m(*args)
