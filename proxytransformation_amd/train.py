@@ -155,6 +155,26 @@ def dropout_k(x, p, seed, group=1):
 
 
 # --------------------------------------------------------------------------- autograd nodes
+class _StreamHop(torch.autograd.Function):
+    """Identity on the forward stream; its backward (same stream) tells the allocator that the gradient it passes on is about to be
+    READ ON ANOTHER STREAM.  The image branch of the per-operator graph runs on a side stream: the gradient of its output is allocated
+    by the image block's backward on the main stream, consumed by the side stream's nodes and dropped as soon as the first of them
+    returns -- without the record the block goes back to the main stream's pool while the side stream still reads it (r05: the
+    gradients of the image pool's parameters came out different from run to run once a second loss term changed the order in which
+    the engine ran its nodes).  The one-node step records its hand-over itself."""
+
+    @staticmethod
+    def forward(ctx, x, stream):
+        ctx.stream = stream
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        g.record_stream(ctx.stream)
+        return g, None
+
+
 class _Fork(torch.autograd.Function):
     """n handles of one tensor; the backward sums the n gradients with HIP launches (no torch add)."""
 
@@ -1057,6 +1077,7 @@ def forward_train(mod, points: List[torch.Tensor], text_feats, text_mask, img_fe
     _tick("img_branch")
     if side is not None:
         main.wait_stream(side)
+        img_proxy = _StreamHop.apply(img_proxy, side)
     transform = _block(mod, mod.imgformer[-1], mod.img_norm[-1], mod.img_trans, mod.img_trans_norm, pp_i1, pp_i2,
                        img_proxy, None, B, Mk, V, seeds[1])
 
