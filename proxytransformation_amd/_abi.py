@@ -12,7 +12,9 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libproxyt_hip.so")
+# PTX_LIBRARY=testhooks selects the in-tree build with the stream gates' fault-injection hooks compiled in (csrc/Makefile:
+# libproxyt_hip_testhooks.so; only tests/test_gpu_host.py's gate-failure workers ask for it).  Nothing else can be loaded.
+LIB_PATH = os.path.join(_HERE, "libproxyt_hip_testhooks.so" if os.environ.get("PTX_LIBRARY") == "testhooks" else "libproxyt_hip.so")
 ABI_VERSION = 11
 
 c_float_p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())

@@ -233,6 +233,15 @@ static bool env_on(const char *name)
     const char *v = getenv(name);
     return v != nullptr && v[0] != '\0' && !(v[0] == '0' && v[1] == '\0');
 }
+// PTX_LAYOUT: see ptx_forward (four characters, '0' / '1' force one of the per-shape layout decisions, anything else = the rule)
+struct LayoutForce { int v[4]; };
+static LayoutForce layout_force()
+{
+    LayoutForce f{{-1, -1, -1, -1}};
+    if (const char *e = getenv("PTX_LAYOUT"))
+        for (int i = 0; i < 4 && e[i] != '\0'; ++i) f.v[i] = e[i] == '0' ? 0 : (e[i] == '1' ? 1 : -1);
+    return f;
+}
 static bool gates_allowed()
 {
     if (const char *g = getenv("PTX_GATE")) return atoi(g) != 0;
@@ -271,7 +280,9 @@ static int context_init(PtxContext *c)
         const long ms = ms_env ? atol(ms_env) : 30000;
         c->gate_ticks = (uint64_t)(ms > 0 ? ms : 1) * (uint64_t)khz;
         c->probe_ticks = (uint64_t)20 * (uint64_t)khz;          // probe: 20 ms on an idle pair of streams
-        c->gate_trap = env_on("PTX_GATE_TRAP") ? 1 : 0;
+#ifdef PTX_TEST_HOOKS
+        c->gate_trap = env_on("PTX_GATE_TRAP") ? 1 : 0;    // test-hooks build only: a waiter that runs out of time also traps
+#endif
         c->gates_on = true;
     }
     return PTX_OK;
@@ -410,7 +421,6 @@ static int gate_probe(PtxContext *c, hipStream_t st)
 {
     c->probed = true; c->probed_st = st; c->lo_ok = false;
     if (!c->gates_on) return PTX_OK;
-    if (getenv("PTX_GATE_NO_PROBE") != nullptr) { c->lo_ok = true; return PTX_OK; }
     PTX_HIP(hipStreamSynchronize(st));
     PTX_HIP(hipStreamSynchronize(c->st));
     PTX_HIP(hipStreamSynchronize(c->lo));
@@ -426,7 +436,7 @@ static int gate_probe(PtxContext *c, hipStream_t st)
 
 static int run_img_proxy(const PtxShape &s, const PtxWeights &w, const float *prep, const void *img_any,
                          float *img_proxy, void *ws, hipStream_t st, int phase = 0, bool need_ln = true,
-                         int i0 = 0, int ni = -1, uint32_t *gate = nullptr, uint32_t gate_seq = 0, const MinmaxFuse *mm = nullptr)
+                         int i0 = 0, int ni = -1, uint32_t *gate = nullptr, uint32_t gate_seq = 0)
 {
     // images [i0, i0 + ni) of the B * V of this call (default: all): every buffer of the chain is per image
     const PrepLayout P = prep_layout(s);
@@ -447,16 +457,15 @@ static int run_img_proxy(const PtxShape &s, const PtxWeights &w, const float *pr
         Gs += (size_t)i0 * 2 * s.heads * s.in_dim; E += (size_t)i0 * s.heads * EW; ML += (size_t)i0 * s.heads * 5;
     }
     if (phase != 2) {
-        if (dt == 0) PTX_TIMED(KID_IMG_MEAN, st, launch_img_mean(img, nimg, s.in_dim, s.hw, fm, st, gate, gate_seq, mm));
-        else PTX_TIMED(KID_IMG_MEAN, st, launch_img_mean16(img_any, dt, nimg, s.in_dim, s.hw, fm, st, gate, gate_seq, mm));
+        if (dt == 0) PTX_TIMED(KID_IMG_MEAN, st, launch_img_mean(img, nimg, s.in_dim, s.hw, fm, st, gate, gate_seq));
+        else PTX_TIMED(KID_IMG_MEAN, st, launch_img_mean16(img_any, dt, nimg, s.in_dim, s.hw, fm, st, gate, gate_seq));
     }
     if (phase == 1) return PTX_OK;
     // head_dim 32: a 32-column tile of the qkv0 GEMM IS one head's q, and the work-group that finishes it goes on to that
     // head's [w_h | e_h] = q_h T1_h^T (GemmProb::w2): one launch (and one boundary) less on the image chain
-    static const bool no_chain = getenv("PTX_NO_CHAIN") != nullptr;
     // (from ~4000 images per call on -- 32 scenes of 196 views -- the two products as launches of their own, the first on the
     //  64 x 64 split-operand kernel, are faster than the latency-regime chained form: 80 + 72 vs 185 us)
-    const bool chained = hd == 32 && !no_chain && nimg < 4096;
+    const bool chained = hd == 32 && nimg < 4096;
     {   // [q | k0 | v0] of token 0 = W3 mean(f) + b3
         GemmBatch g{}; g.n = 1;
         g.p[0] = GemmProb{fm, prep + P.w3, qkv0, prep + P.b3, nullptr, nullptr, nullptr,
@@ -535,12 +544,9 @@ struct Branch {
 };
 
 // One work-group per (scene, head, branch) must be enough parallelism: the two-launch form spreads the query tiles of the
-// second contraction over the chip, which wins when a call has few scenes and many tokens (measured; PTX_ATTN_FUSED=1 / 0
-// forces either form).
+// second contraction over the chip, which wins when a call has few scenes and many tokens (measured).
 static bool fused_attn_pays(const PtxShape &s, const Branch *br, int nb)
 {
-    static const int env = getenv("PTX_ATTN_FUSED") ? atoi(getenv("PTX_ATTN_FUSED")) : -1;
-    if (env >= 0) return env != 0;
     (void)br;
     const long wgs = (long)s.B * s.heads * nb;
     return s.Mk <= 256 || wgs >= 96;
@@ -1103,16 +1109,19 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     // configuration: 519 sequential picks) it is the clustering chain, and then THAT one stays on the caller's stream
     // and the image chain takes the side stream.  (Rough per-shape estimates in us: measured slopes.)
     const double est_cluster = 80.0 + 0.42 * Kd, est_image = 40.0 + (S.img_dtype == 0 ? 0.45 : 0.18) * ((double)B * S.V);
-    static const int swap_env = getenv("PTX_CHAIN_SWAP") ? atoi(getenv("PTX_CHAIN_SWAP")) : -1;
-    const bool cluster_on_caller = swap_env >= 0 ? swap_env != 0 : est_cluster > est_image;
+    // PTX_LAYOUT (the ONE layout override, for A/B runs and the parity test that drives every arrangement): four characters,
+    // '0' / '1' force, anything else leaves the rule -- [0] clustering chain on the caller's stream, [1] early proxies,
+    // [2] image chain forked behind k_cluster, [3] slot tags behind a gate on the third stream.  E.g. PTX_LAYOUT=1-0-
+    static const LayoutForce lf = layout_force();
+    const bool cluster_on_caller = lf.v[0] >= 0 ? lf.v[0] != 0 : est_cluster > est_image;
     hipStream_t cs = cluster_on_caller ? st : side->st, is = cluster_on_caller ? side->st : st;
     const bool gated = side->gates_on && !cluster_on_caller && !capturing;        // gates instead of events (see k_gate)
     // r04: where the clustering chain is the long one AND the image chain has the slack for it, the image chain forks BEHIND k_cluster
     // instead of at the top, so that the clustering kernel does not share the chip with the mean pass (k_cluster 64 -> ~45 us at
     // cfg4 / 6 scenes: 13.04k -> 13.26k scenes/s, one scene +1 %, 3 scenes +0.8 %; 8 scenes, where the image chain is nearly as
-    // long as the sampling, -0.9 %: hence the slack rule; profiles/r04_early_proxies_ab.txt).  PTX_IMG_AFTER_CLUSTER=0 / 1 forces it.
-    static const int img_late_env = getenv("PTX_IMG_AFTER_CLUSTER") ? atoi(getenv("PTX_IMG_AFTER_CLUSTER")) : -1;
-    const bool img_late = cluster_on_caller && (img_late_env >= 0 ? img_late_env != 0 : est_image + 60.0 < 0.8 * est_cluster);
+    // long as the sampling, -0.9 %: hence the slack rule; profiles/r04_early_proxies_ab.txt; r05, the same shape in the room regime:
+    // 13.9k -> 14.3k, profiles/r05_room_layout_ab.txt).
+    const bool img_late = cluster_on_caller && (lf.v[2] >= 0 ? lf.v[2] != 0 : est_image + 60.0 < 0.8 * est_cluster);
     if (!gated && !img_late) {
         PTX_HIP(hipEventRecord(side->fork, st));
         PTX_HIP(hipStreamWaitEvent(side->st, side->fork, 0));
@@ -1121,9 +1130,14 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     // (Two staggered slices of images on two streams -- slice B streaming its means under slice A's table GEMMs, A
     // pooling under B's tables -- measured again in r02 with the fused / folded chain: 0.319 vs 0.298 ms per step.
     // Twice the launches, and the half-size pooling launches each pay their own partial last round.)
-    // test aid (tests/test_gpu_host.py): PTX_GATE_FAULT=fork / join drops the releasing store of that gate, so that the waiter runs
-    // into its bound and the failure path (error word, NaN outputs, PTX_EGATE, fall-back to events) can be exercised
+    // test aid (tests/test_gpu_host.py), compiled into libproxyt_hip_testhooks.so only: PTX_GATE_FAULT=fork / join / tags drops the
+    // releasing store of that gate, so that the waiter runs into its bound and the failure path (error word, NaN outputs,
+    // PTX_EGATE, fall-back to events) can be exercised.  The product library has no such hook.
+#ifdef PTX_TEST_HOOKS
     static const char *const fault = getenv("PTX_GATE_FAULT");
+#else
+    constexpr const char *fault = nullptr;
+#endif
     const bool fault_fork = gated && fault && fault[0] == 'f', fault_join = gated && fault && fault[0] == 'j';
     auto launch_gate = [&](int kid, hipStream_t s_, const GateRef &g) -> int {
         hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, s_, g);
@@ -1131,23 +1145,9 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
         (void)kid;
         return PTX_OK;
     };
-    // PTX_MM_FUSE=1 (opt-in): gated forwards reduce the bounding boxes in the first work-groups of the mean launch (MinmaxFuse,
-    // common.h); the fork's word is stored when the boxes are final and the clustering stream starts at k_cluster.  r04, 4 scenes
-    // per GPU, interleaved pairs: 18.93k / 18.98k scenes/s without, 18.65k / 18.45k with -- the clustering stream does get 12 us
-    // ahead (k_cluster starts at 10.6 instead of 22 us) but it is not the critical chain at that shape, its kernels stretch
-    // next to the mean pass (k_cluster 32 -> 37, k_select 41 -> 46 us) and the mean launch itself takes 36.4 instead of 32.3 us
-    // on the chain that IS critical.  Kept for shapes / builds where the clustering chain sets the join.
-    static const bool mm_fuse_env = getenv("PTX_MM_FUSE") != nullptr && atoi(getenv("PTX_MM_FUSE")) != 0;
-    const bool mm_fused = gated && mm_fuse_env && bbox_in == nullptr;
-    MinmaxFuse mmf{};
-    if (mm_fused) {
-        mmf.points = sp; mmf.B = B; mmf.N = S.N; mmf.chunks = minmax_chunks(S.N);
-        mmf.mm_enc = at<uint32_t>(ws, L.mm_enc); mmf.ticket = at<int>(ws, L.mm_ticket);
-    }
     if (gated) {
         const uint32_t seq = ++side->gate_seq;
-        PTX_TRY(run_img_proxy(S, *w, pf, img_feat, img_proxy, ws, is, 1, true, 0, -1, fault_fork ? nullptr : side->gate, seq,
-                              mm_fused ? &mmf : nullptr));
+        PTX_TRY(run_img_proxy(S, *w, pf, img_feat, img_proxy, ws, is, 1, true, 0, -1, fault_fork ? nullptr : side->gate, seq));
         PTX_TIMED(KID_GATE_FORK, cs, launch_gate(KID_GATE_FORK, cs, gate_ref(side, 0, seq, 1)));
     } else
     if (!img_late) PTX_TRY(run_img_proxy(S, *w, pf, img_feat, img_proxy, ws, is, 1));      // first pass starts at once
@@ -1165,32 +1165,26 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     float *offsets = dbg && debug->offsets ? at<float>(ws, L.offsets) : nullptr;
     float *centers = at<float>(ws, L.centers), *cluster2 = at<float>(ws, L.cluster2);
     int32_t *idx2 = at<int32_t>(ws, L.idx2), *pad_count = at<int32_t>(ws, L.pad_count);
-    if (!bbox_in && !mm_fused) PTX_TIMED(KID_MINMAX, cs, launch_minmax(sp, B, S.N, mm_ws, cs));
+    if (!bbox_in) PTX_TIMED(KID_MINMAX, cs, launch_minmax(sp, B, S.N, mm_ws, cs));
     // (the `early` decision, needed here for k_cluster's completion event; its description is below)
-    static const int early_env = getenv("PTX_EARLY_PROXIES") ? atoi(getenv("PTX_EARLY_PROXIES")) : -1;
     const double est_all = 1.8 * 12.0 * (double)B * S.Mt * S.C * S.C / 70e6;                     // us (cfg4 at 6 scenes: 147; measured ~150)
-    const bool early = cluster_on_caller && (early_env >= 0 ? early_env != 0
-                                                            : (Kd >= 128 && (long)B * S.Mk >= 1024 && est_all < 3.0 * 0.42 * Kd));
+    const bool early = cluster_on_caller && (lf.v[1] >= 0 ? lf.v[1] != 0
+                                                          : (Kd >= 128 && (long)B * S.Mk >= 1024 && est_all < 3.0 * 0.42 * Kd));
     // r04: the streams that fork off behind the clusters (the late image chain, the early proxies) wait for k_cluster's own
     // completion signal instead of for one event record each on the caller's stream -- two packets (~5 us each) between k_cluster and
-    // k_select on the chain the step waits for (PTX_FORK_EXT=0: the records)
-    static const bool fork_ext_env = getenv("PTX_FORK_EXT") == nullptr || atoi(getenv("PTX_FORK_EXT")) != 0;
-    static const bool ext_event_env0 = getenv("PTX_NO_EXT_EVENT") == nullptr;
-    const bool fork_ext = fork_ext_env && ext_event_env0 && !capturing && (img_late || early);
+    // k_select on the chain the step waits for
+    const bool fork_ext = !capturing && (img_late || early);
     // r04, "cgate": where the clustering chain owns the caller's stream its two cross-stream waits -- for the image chain / the early
     // proxies in front of the attention, for the slot tags in front of k_affine -- are device words as well, each folded into the launch
     // in FRONT of the wait (its first work-group ends with the poll, as at the benchmark shape's join): no barrier packet (~6 us of
     // idle each) on the chain the step waits for.  Needs the probed side-by-side progress of the streams (gates_on, lo_ok); the
-    // failure path is the gates' (error word, NaN outputs, PTX_EGATE, events from then on).  PTX_CGATE=0: the events.
-    static const bool cgate_env = getenv("PTX_CGATE") == nullptr || atoi(getenv("PTX_CGATE")) != 0;
-    const bool cgate = cluster_on_caller && cgate_env && side->gates_on && side->lo_ok && !capturing && ext_event_env0;
+    // failure path is the gates' (error word, NaN outputs, PTX_EGATE, events from then on).  (PTX_GATE=0: the events.)
+    const bool cgate = cluster_on_caller && side->gates_on && side->lo_ok && !capturing;
     if (cgate) ++side->gate_seq;
     const bool fault_cjoin = cgate && fault && fault[0] == 'j', fault_ctags = cgate && fault && fault[0] == 't';
-    static const int jfirst_env = getenv("PTX_EARLY_JOIN_FIRST") ? atoi(getenv("PTX_EARLY_JOIN_FIRST")) : 1;
-    static const bool join_chain_env = getenv("PTX_JOIN_CHAIN") == nullptr || atoi(getenv("PTX_JOIN_CHAIN")) != 0;
     // the join's word (52): stored by the third stream behind the early proxies AND the image chain (early), or by the image stream
     // behind its last launch (otherwise); waited for at the END of k_select (early: the gather is next) / of the qkv GEMM (otherwise)
-    const bool cg_join_select = cgate && early && jfirst_env && join_chain_env;
+    const bool cg_join_select = cgate && early;
     const bool cg_join_qkv = cgate && !early;
     GateRef cjoin = (cg_join_select || cg_join_qkv) ? gate_ref(side, 52, side->gate_seq, 2) : GateRef{};
     PTX_TIMED(KID_CLUSTER, cs, launch_cluster(S, mm_enc, lin, sp, pf + P.off_ab, w->offset, w->offset_map_w,
@@ -1251,10 +1245,8 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     int32_t *kidx = dbg && debug->kidx ? at<int32_t>(ws, L.kidx) : nullptr;
     int32_t *drop_idx = dbg && debug->drop_idx ? at<int32_t>(ws, L.drop_idx) : nullptr;
     int32_t *ksrc = at<int32_t>(ws, L.ksrc);
-    static const bool ext_event_env = getenv("PTX_NO_EXT_EVENT") == nullptr;
-    const bool ext_event = ext_event_env && !capturing;
-    static const int tail_env = getenv("PTX_TAGS_TAIL") ? atoi(getenv("PTX_TAGS_TAIL")) : 1;
-    // r04 (PTX_TAGS_GATED=0 / 1 forces it): with the gates the tags can leave the chain altogether -- a third (low-priority) stream waits
+    const bool ext_event = !capturing;
+    // r04 (PTX_LAYOUT[3] forces it): with the gates the tags can leave the chain altogether -- a third (low-priority) stream waits
     // for the first thread of the point-proxy kernel (k_select in front of it has completed), runs k_tags beside the point proxies /
     // qkv GEMM and signals a word that the proj GEMM's work-group 0 waits for in front of k_affine: no event record or wait on
     // either chain.  Measured (profiles/r04_tags_off_chain_ab.txt): 18.44-18.75k against 18.68-19.09k scenes/s at 4 scenes per GPU,
@@ -1263,9 +1255,8 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     // End of r04: on by default where the two chains are about as long as each other (the benchmark shape: est_image < 1.6 est_cluster),
     // i.e. where the 12 us of k_tags at the tail of the clustering stream decide the join: 18.41k -> 18.58k scenes/s at 4 scenes per GPU
     // over six interleaved pairs, +0.3 ... +1.2 % in three sessions; 6 scenes -0.6 %, 2 and 8 neutral (profiles/r04_tags_gated_rule_ab.txt).
-    static const int tags_gated_env = getenv("PTX_TAGS_GATED") ? atoi(getenv("PTX_TAGS_GATED")) : -1;
-    const bool tags_gated = gated && side->lo_ok && (tags_gated_env >= 0 ? tags_gated_env != 0 : est_image < 1.6 * est_cluster);
-    const bool tags_tail = !cluster_on_caller && tail_env != 0 && !tags_gated;
+    const bool tags_gated = gated && side->lo_ok && (lf.v[3] >= 0 ? lf.v[3] != 0 : est_image < 1.6 * est_cluster);
+    const bool tags_tail = !cluster_on_caller && !tags_gated;
     PTX_TIMED(KID_SELECT, cs, launch_select_order(S, centers, pad_count, order_override, order, picks, keep, kcenter,
                                                   ksrc, bbox_in ? nullptr : mm_ws, cs, cluster_on_caller, ext_event && !tags_tail ? side->aux : nullptr,
                                                   cg_join_select ? &cjoin : nullptr));
@@ -1274,7 +1265,7 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     // (it owns the caller's stream) they run on the low-priority stream next to it, after the point proxies.  When the
     // image chain is the long one they go to the END of the clustering stream, behind its last kernel and in front of the
     // join: one cross-queue wait on the caller's stream instead of two (each costs 6-7 us of idle between two dependent
-    // kernels wherever it is placed; r03: PTX_TAGS_TAIL=0 restores the third stream).  (The mirror image -- the tags behind the
+    // kernels wherever it is placed; r03).  (The mirror image -- the tags behind the
     // image chain when the clustering chain owns the caller's stream -- puts them on the critical path at one scene per
     // call, where only the short point-proxy kernels separate k_select from the join: cfg4 at 6 scenes +1 %, cfg1 -6 %,
     // cfg5 -2 %: not done.)
@@ -1329,14 +1320,13 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
         const float *const gsrc[2] = {at<float>(ws, L.g_all[0]), at<float>(ws, L.g_all[1])};
         const float *const tb[2] = {pf + P.qkvb[0], pf + P.qkvb[1]};
         float *const qk[2] = {at<float>(ws, L.qkv[0]), at<float>(ws, L.qkv[1])};
-        if (jfirst_env) {
+        {
             // both cross-stream waits of the caller's chain in ONE place, in front of the gather (each costs ~6 us of idle between
             // the two kernels around it): the image chain finished long before the sampling does.  r04: and as ONE wait -- the third
-            // stream (early proxies done) waits for the image chain, the caller's stream for the third stream (PTX_JOIN_CHAIN=0: two)
+            // stream (early proxies done) waits for the image chain, the caller's stream for the third stream
             PTX_TRY(run_blocks(S, br, 2, point_proxy, ws, is, 3, compute_dtype));
             PTX_HIP(hipEventRecord(side->join, is));
-            if (join_chain_env) PTX_HIP(hipStreamWaitEvent(side->lo, side->join, 0));
-            else PTX_HIP(hipStreamWaitEvent(cs, side->join, 0));
+            PTX_HIP(hipStreamWaitEvent(side->lo, side->join, 0));
             joined_early = true;
         }
         if (cg_join_select) {               // k_select ends with the wait for this word: no packet between it and the gather
@@ -1367,9 +1357,8 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
         return PTX_ELAUNCH;
     }
     if (tags_tail) PTX_TRY(enqueue_tags());
-    static const int pp_env = getenv("PTX_PP_EARLY") ? atoi(getenv("PTX_PP_EARLY")) : 1;
-    const bool pp_early = cluster_on_caller && (early || pp_env != 0);       // (see below, at the join)
-    GateRef join{};                     // the join, folded into the first launch behind it (run_blocks) unless PTX_GATE_FOLD=0
+    const bool pp_early = cluster_on_caller;                                 // (see below, at the join)
+    GateRef join{};                     // the join, folded into the first launch behind it (run_blocks)
     if (gated) {                        // the join through the second gate word: signalled behind the clustering stream's last kernel
         auto launch_signal = [&]() -> int {
             hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, cs, side->gate + 32, side->gate_seq);
@@ -1378,11 +1367,6 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
         };
         if (!fault_join) PTX_TIMED(KID_SIGNAL_JOIN, cs, launch_signal());
         join = gate_ref(side, 32, side->gate_seq, 2);
-        static const bool fold = getenv("PTX_GATE_FOLD") == nullptr || atoi(getenv("PTX_GATE_FOLD")) != 0;
-        if (!fold) {
-            PTX_TIMED(KID_GATE_JOIN, st, launch_gate(KID_GATE_JOIN, st, join));
-            join.flag = nullptr;
-        }
     } else {
     if (!cluster_on_caller) PTX_HIP(hipEventRecord(side->join, cs));
     // where the clustering chain owns the caller's stream the image block's proxy_proj runs behind the image chain on ITS stream, in

@@ -211,10 +211,8 @@ int launch_attn32(const AttnBatch &ab, hipStream_t st)
     // waiting on that walk (with thousands of work-groups the chip is full anyway and more waves only add merge work)
     const int ntile = cdiv(nkmax, 32);
     const long wgs = (long)grid.x * grid.y * grid.z;
-    static const int nw_env = getenv("PTX_ATTN_NW") ? atoi(getenv("PTX_ATTN_NW")) : 0;
     int nw = 4;
     if (wgs <= 512 && ntile > 8) nw = 8;        // (16 waves: 128 VGPRs with spills and 68 KB of merge space -- not built)
-    if (nw_env == 4 || nw_env == 8) nw = nw_env;
     if (ab.hd == 32) {
         if (nw == 8) hipLaunchKernelGGL((k_attn32<32, 8>), grid, dim3(512), 0, st, ab);
         else hipLaunchKernelGGL((k_attn32<32, 4>), grid, dim3(256), 0, st, ab);

@@ -784,15 +784,13 @@ int launch_select_order(const PtxShape &s, const float *centers, const int32_t *
     // the picks are a chain of dependent instructions and run slower with neighbours.  cfg4 at 6 scenes per GPU: 11.38k / 11.37k ->
     // 11.82k / 11.81k scenes/s (+3.8 %), one scene and cfg1 neutral.  Not at the benchmark shape: there the image chain is the
     // critical one and gives up four CUs for it (k_img_pool 57.5 -> 62 us, step -0.6 %; profiles/r04_select_alone_ab.txt).
-    // PTX_SEL_ALONE=0 / 1 forces it off / on.  (End of r04: up to 32 scenes per call instead of 8 -- cfg5 at 16 scenes +2 %, 12 +1.3 %, cfg4 at 9
+    // (End of r04: up to 32 scenes per call instead of 8 -- cfg5 at 16 scenes +2 %, 12 +1.3 %, cfg4 at 9
     // +3 %, the rest within 1 %: profiles/r04_select_alone_cap_ab.txt.)
-    static const int alone_env = getenv("PTX_SEL_ALONE") ? atoi(getenv("PTX_SEL_ALONE")) : -1;
-    const bool alone = alone_env >= 0 ? alone_env != 0 : critical;
+    const bool alone = critical;
     if (alone && s.B <= 32 && lds < 150 * 1024) lds = 150 * 1024;
-    static const int one_env = getenv("PTX_FPS_ONE") ? atoi(getenv("PTX_FPS_ONE")) : -1;
     // one wave only when the step waits for this kernel: beside a longer image chain the four-wave form finishes early
     // enough and leaves the point-proxy / qkv kernels later, i.e. less of them under the pooling pass
-    const bool one = one_env >= 0 ? (one_env != 0 && s.Mt <= 384) : (critical && s.Mt <= 384);
+    const bool one = critical && s.Mt <= 384;
     const int per = cdiv(s.Mt, one ? 64 : 256);
     const dim3 grid(s.B), block(256);
 #define PTX_SEL(P_)                                                                          \
@@ -989,8 +987,7 @@ int launch_tags(const PtxShape &s, const int32_t *idx, const int32_t *order, con
     const int M = s.grid_size * s.grid_size * s.grid_size;
     TagArgs a{idx, order, picks, ksrc, tag, tile_counts, scene_acc, counts, M, s.K, s.Mt, s.Mk, s.Mt - s.Mk, s.N,
               cdiv(s.N, kTilePts)};
-    static const int tiles_env = getenv("PTX_TAG_TILES") ? atoi(getenv("PTX_TAG_TILES")) : 0;
-    const bool small = tiles_env ? tiles_env == 4 : (long)s.B * cdiv(s.N, 16 * kTilePts) < 16;
+    const bool small = (long)s.B * cdiv(s.N, 16 * kTilePts) < 16;
     if (small) {
         const size_t lds = sizeof(uint32_t) * 4 * kTilePts + 16 * sizeof(int);
         hipLaunchKernelGGL(k_tags<4>, dim3(cdiv(s.N, 4 * kTilePts), s.B), dim3(1024), lds, st, a);

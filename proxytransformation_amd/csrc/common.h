@@ -207,42 +207,14 @@ __device__ __forceinline__ void minmax_block(const float *__restrict__ p, int N,
 }
 inline int minmax_chunks(int N) { int c = (N + 256 * 16 - 1) / (256 * 16); return c < 1 ? 1 : (c > 256 ? 256 : c); }
 
-// The bounding boxes computed by the FIRST work-groups of the image chain's mean pass (r04): at the benchmark shape the
-// clustering stream began with k_gate (waiting for the mean pass to start) and then k_minmax, 18 us next to a pass that
-// saturates the memory system.  Inside the mean launch the B * chunks box work-groups are dispatched first, the last one to
-// finish (ticket) stores the fork's sequence number, and the clustering stream starts at k_cluster.
-struct MinmaxFuse {
-    ScenePts points; int B, N, chunks;
-    uint32_t *mm_enc;           // (B,6), zero on entry
-    int *ticket;                // one word, zero on entry, left zero
-};
-
-// The fork of the two chains (api.hip, "gates"): the clustering stream waits for `gate` to reach gate_seq.  Without fused
-// boxes the first thread of the launch stores it (the stream being in order, everything the caller enqueued before the forward
-// has completed by then); with them (MM) the first mm.B * mm.chunks work-groups reduce the scenes' bounding boxes instead of
-// image rows and the last of them to finish stores it -- boxes final, clustering stream released straight into k_cluster.
-template <bool MM>
-__device__ __forceinline__ bool mean_prologue(const MinmaxFuse &mm, uint32_t *gate, uint32_t gate_seq, int &blk)
+// The fork of the two chains (api.hip, "gates"): the clustering stream waits for `gate` to reach gate_seq; the first thread of the
+// image chain's first launch stores it (the stream being in order, everything the caller enqueued before the forward has
+// completed by then).  (r04 also built the bounding boxes into the first work-groups of that launch, the fork's word stored when
+// they were final: the mean launch took 36 instead of 32 us on the chain the step waits for, 18.95k -> 18.55k scenes/s --
+// profiles/r04_minmax_fuse_ab.txt; removed in r05.)
+__device__ __forceinline__ void mean_prologue(uint32_t *gate, uint32_t gate_seq)
 {
-    blk = blockIdx.x;
-    if (!MM) {
-        if (gate != nullptr && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(gate, gate_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return false;
-    }
-    const int nmm = mm.B * mm.chunks;
-    if ((int)blockIdx.x >= nmm) { blk = blockIdx.x - nmm; return false; }
-    __shared__ float red[4][6];
-    const int b = blockIdx.x / mm.chunks, chunk = blockIdx.x - b * mm.chunks;
-    minmax_block<true>(mm.points.p[b], mm.N, mm.mm_enc, b, chunk, mm.chunks, red);
-    __syncthreads();                                    // the six returning atomics of this work-group have been performed
-    if (threadIdx.x == 0) {
-        const int t = __hip_atomic_fetch_add(mm.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t == nmm - 1) {
-            __hip_atomic_store(mm.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (gate != nullptr) __hip_atomic_store(gate, gate_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    return true;
+    if (gate != nullptr && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(gate, gate_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- parameter-only tables (ptx_prepare) ------------------------------------
@@ -437,7 +409,7 @@ int launch_affine(const PtxShape &s, const ScenePts &points, uint32_t *tag, cons
 
 // ---- image proxy (imgproxy.hip) ------------------------------------------------------------
 int launch_img_mean(const float *img, int nimg, int in_dim, int hw, float *fm, hipStream_t st,
-                    uint32_t *gate = nullptr, uint32_t gate_seq = 0, const MinmaxFuse *mm = nullptr);
+                    uint32_t *gate = nullptr, uint32_t gate_seq = 0);
 int launch_img_scores(const float *img, const float *we, const float *qkv0, int nimg, int in_dim,
                       int hw, int heads, int C, int KT1, int KT2p, float scale, float *gbuf,
                       hipStream_t st);
@@ -445,7 +417,7 @@ int launch_img_gather(const float *img, int nimg, int in_dim, int hw, int heads,
                       float *gbuf, hipStream_t st);
 
 int launch_img_mean16(const void *img, int dt, int nimg, int in_dim, int hw, float *fm, hipStream_t st,
-                      uint32_t *gate = nullptr, uint32_t gate_seq = 0, const MinmaxFuse *mm = nullptr);
+                      uint32_t *gate = nullptr, uint32_t gate_seq = 0);
 int launch_img_scores16(const void *img, int dt, const float *we, const float *qkv0, int nimg, int in_dim,
                         int hw, int heads, int C, int KT1, int KT2p, float scale, float *gbuf, hipStream_t st);
 int launch_img_gather16(const void *img, int dt, int nimg, int in_dim, int hw, int heads, int KT2p, float *gbuf,

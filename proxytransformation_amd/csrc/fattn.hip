@@ -483,19 +483,16 @@ __global__ __launch_bounds__(kFaWaves * 64) void k_proxy_attn(FAttnBatch ab)
 
 bool fused_attn_supported(const FAttnBatch &ab)
 {
-    static const int off = getenv("PTX_ATTN_FUSED") ? atoi(getenv("PTX_ATTN_FUSED")) == 0 : 0;
-    if (off || ab.hd != 32 || ab.C % 4 != 0 || ab.n < 1) return false;
+    if (ab.hd != 32 || ab.C % 4 != 0 || ab.n < 1) return false;
     int lpmax = 0;
     for (int g = 0; g < ab.nb; ++g) lpmax = ab.p[g].Lp > lpmax ? ab.p[g].Lp : lpmax;
     return lpmax >= 1 && lpmax <= kFaChunk;
 }
 
 // Slices of the proxies per (scene, head, branch): with few pairs in a call one work-group each leaves most of the chip idle
-// (4 scenes x 8 heads x 2 branches = 64 of 256 CUs); up to four slices fill it.  PTX_FA_SPLIT forces a value (A/B runs).
+// (4 scenes x 8 heads x 2 branches = 64 of 256 CUs); up to four slices fill it.
 int fattn_split_for(int B, int heads)
 {
-    static const int env = getenv("PTX_FA_SPLIT") ? atoi(getenv("PTX_FA_SPLIT")) : 0;
-    if (env >= 1) return env > kFaMaxSplit ? kFaMaxSplit : env;
     const long groups = (long)B * heads * 2;
     const long s = 256 / (groups > 0 ? groups : 1);
     return s < 1 ? 1 : s > kFaMaxSplit ? kFaMaxSplit : (int)s;

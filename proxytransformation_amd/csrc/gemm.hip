@@ -624,9 +624,8 @@ static int launch_gemm32(const GemmBatch &gb, int rmax, int nmax, hipStream_t st
 
 int launch_gemm(const GemmBatch &gb_in, hipStream_t st, int compute_dtype)
 {
-    static const int rot_env = getenv("PTX_GEMM_ROTATE") ? atoi(getenv("PTX_GEMM_ROTATE")) : 0;   // measured neutral (r01)
     GemmBatch gb = gb_in;
-    gb.rotate = rot_env;
+    gb.rotate = 0;                      // (rotating the tile order per group: measured neutral, r01)
     PTX_REQUIRE(gb.n >= 1 && gb.n <= kMaxGroups, "gemm: %d groups", gb.n);
     int rmax = 0, nmax = 0, kmin = 1 << 30, kmax = 0;
     long tiles32 = 0;
@@ -660,7 +659,7 @@ int launch_gemm(const GemmBatch &gb_in, hipStream_t st, int compute_dtype)
         PTX_LAUNCHED("k_gemm");
         return PTX_OK;
     }
-    static const int g64_min = getenv("PTX_G64_MIN") ? atoi(getenv("PTX_G64_MIN")) : 1024;
+    constexpr int g64_min = 1024;
     if (compute_dtype == 1 && gb.p[0].pg == nullptr && kmin == kmax && kmin % 128 == 0 && kmin / 128 <= 8) {
         // reduced-precision mode: plain bf16 operands, fp32 accumulation, the 64 x 64-tile kernel at every size
         const dim3 grid(cdiv(rmax, 64), cdiv(nmax, 64), gb.n);
@@ -679,9 +678,8 @@ int launch_gemm(const GemmBatch &gb_in, hipStream_t st, int compute_dtype)
         PTX_TRY((launch_gemm32<4, 1>(gb, rmax, nmax, st)));
     } else if (tiles32 >= g64_min) {
         // enough tiles to fill the chip: 64x64 tiles re-use each staged operand twice as often
-        static const bool fp32_env = getenv("PTX_GEMM_FP32") != nullptr;
         const dim3 grid(cdiv(rmax, 64), cdiv(nmax, 64), gb.n);
-        const int nkg = (!fp32_env && kmin == kmax && kmin % 128 == 0) ? kmin / 128 : 0;
+        const int nkg = (kmin == kmax && kmin % 128 == 0) ? kmin / 128 : 0;
         if (nkg == 1) hipLaunchKernelGGL((k_gemm64x<1, 1>), grid, dim3(256), 0, st, gb);
         else if (nkg == 2) hipLaunchKernelGGL((k_gemm64x<2, 1>), grid, dim3(256), 0, st, gb);
         else if (nkg == 4) hipLaunchKernelGGL((k_gemm64x<4, 1>), grid, dim3(256), 0, st, gb);

@@ -370,8 +370,7 @@ __global__ __launch_bounds__(512) void k_img_pool(PoolArgs a)
 
 bool img_pool_supported(int dt, int in_dim, int hw, int heads)
 {
-    static const int off = getenv("PTX_IMG_POOL_OFF") ? 1 : 0;
-    return !off && (dt == 1 || dt == 2) && heads == kPoolHeads && in_dim == 512 && hw > 128 && hw <= 255;
+    return (dt == 1 || dt == 2) && heads == kPoolHeads && in_dim == 512 && hw > 128 && hw <= 255;
 }
 
 size_t img_pool_bytes(int nimg, int in_dim, int EW)

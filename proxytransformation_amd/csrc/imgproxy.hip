@@ -25,12 +25,11 @@ typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-B loa
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // one wave per group of 4 channel rows = 4*hw contiguous floats = hw float4
-template <bool MM>       // MM: the first work-groups reduce the scenes' bounding boxes (common.h, mean_prologue)
 __global__ __launch_bounds__(256) void k_img_mean(const float *__restrict__ img, int ngroups,
-                                                  int hw, float *__restrict__ fm, uint32_t *gate, uint32_t gate_seq, MinmaxFuse mm)
+                                                  int hw, float *__restrict__ fm, uint32_t *gate, uint32_t gate_seq)
 {
-    int blk;
-    if (mean_prologue<MM>(mm, gate, gate_seq, blk)) return;
+    mean_prologue(gate, gate_seq);
+    const int blk = blockIdx.x;
     const int lane = lane_id();
     const int g = __builtin_amdgcn_readfirstlane(blk * 4 + (threadIdx.x >> 6));
     if (g >= ngroups) return;
@@ -54,14 +53,12 @@ __global__ __launch_bounds__(256) void k_img_mean(const float *__restrict__ img,
     }
 }
 
-int launch_img_mean(const float *img, int nimg, int in_dim, int hw, float *fm, hipStream_t st, uint32_t *gate, uint32_t gate_seq,
-                    const MinmaxFuse *mm)
+int launch_img_mean(const float *img, int nimg, int in_dim, int hw, float *fm, hipStream_t st, uint32_t *gate, uint32_t gate_seq)
 {
     PTX_REQUIRE(in_dim % 4 == 0, "img mean: in_dim=%d must be a multiple of 4", in_dim);
     PTX_REQUIRE((reinterpret_cast<uintptr_t>(img) & 15) == 0, "img_feat must be 16-byte aligned");
     const int ngroups = nimg * (in_dim / 4);
-    if (mm != nullptr) hipLaunchKernelGGL(k_img_mean<true>, dim3(cdiv(ngroups, 4) + mm->B * mm->chunks), dim3(256), 0, st, img, ngroups, hw, fm, gate, gate_seq, *mm);
-    else hipLaunchKernelGGL(k_img_mean<false>, dim3(cdiv(ngroups, 4)), dim3(256), 0, st, img, ngroups, hw, fm, gate, gate_seq, MinmaxFuse{});
+    hipLaunchKernelGGL(k_img_mean, dim3(cdiv(ngroups, 4)), dim3(256), 0, st, img, ngroups, hw, fm, gate, gate_seq);
     PTX_LAUNCHED("k_img_mean");
     return PTX_OK;
 }

@@ -73,12 +73,12 @@ struct RowLanes {
 // conversions + 8 selects + 8 adds; parity-green) the pass stays at 4.5 TB/s at 32 scenes and the step within +-0.7 % -- not kept.
 constexpr int kMeanGroups = 4;
 
-template <int DT, bool MM>
+template <int DT>
 __global__ __launch_bounds__(256) void k_img_mean16(const unsigned short *__restrict__ img, int ngroups,
-                                                    int hw, float *__restrict__ fm, uint32_t *gate, uint32_t gate_seq, MinmaxFuse mm)
+                                                    int hw, float *__restrict__ fm, uint32_t *gate, uint32_t gate_seq)
 {
-    int blk;
-    if (mean_prologue<MM>(mm, gate, gate_seq, blk)) return;
+    mean_prologue(gate, gate_seq);
+    const int blk = blockIdx.x;
     const int lane = lane_id();
     const int g0 = __builtin_amdgcn_readfirstlane((blk * 4 + (threadIdx.x >> 6)) * kMeanGroups);
     if (g0 >= ngroups) return;
@@ -312,8 +312,7 @@ __global__ __launch_bounds__(256) void k_img_gather16(const unsigned short *__re
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------
-int launch_img_mean16(const void *img, int dt, int nimg, int in_dim, int hw, float *fm, hipStream_t st, uint32_t *gate, uint32_t gate_seq,
-                      const MinmaxFuse *mm)
+int launch_img_mean16(const void *img, int dt, int nimg, int in_dim, int hw, float *fm, hipStream_t st, uint32_t *gate, uint32_t gate_seq)
 {
     PTX_REQUIRE(in_dim % 8 == 0, "img mean: in_dim=%d must be a multiple of 8", in_dim);
     PTX_REQUIRE(hw >= 8 && (hw >> 3) + ((hw & 7) ? 1 : 0) <= 32, "half-precision image features: hw=%d (supported: 8..255)", hw);
@@ -323,15 +322,8 @@ int launch_img_mean16(const void *img, int dt, int nimg, int in_dim, int hw, flo
     // (r03: 26 KB of unused LDS per work-group -- six resident work-groups per CU instead of seven, so that the clustering
     //  stream's k_minmax finds a slot at once instead of waiting for work-groups of this launch to retire -- shortens k_minmax
     //  17 -> 13 us, but the step by 0.4 % over five alternating pairs of runs, and costs 0.6 % at 32 scenes: not kept)
-    if (mm != nullptr) {
-        const dim3 gridm(grid.x + mm->B * mm->chunks);
-        if (dt == 1) hipLaunchKernelGGL((k_img_mean16<1, true>), gridm, dim3(256), 0, st, p, ngroups, hw, fm, gate, gate_seq, *mm);
-        else         hipLaunchKernelGGL((k_img_mean16<2, true>), gridm, dim3(256), 0, st, p, ngroups, hw, fm, gate, gate_seq, *mm);
-    } else {
-        const MinmaxFuse none{};
-        if (dt == 1) hipLaunchKernelGGL((k_img_mean16<1, false>), grid, dim3(256), 0, st, p, ngroups, hw, fm, gate, gate_seq, none);
-        else         hipLaunchKernelGGL((k_img_mean16<2, false>), grid, dim3(256), 0, st, p, ngroups, hw, fm, gate, gate_seq, none);
-    }
+    if (dt == 1) hipLaunchKernelGGL((k_img_mean16<1>), grid, dim3(256), 0, st, p, ngroups, hw, fm, gate, gate_seq);
+    else         hipLaunchKernelGGL((k_img_mean16<2>), grid, dim3(256), 0, st, p, ngroups, hw, fm, gate, gate_seq);
     PTX_LAUNCHED("k_img_mean16");
     return PTX_OK;
 }

@@ -299,10 +299,9 @@ int ptx_ingest_index(const void *depth, int depth_dtype, int V, int H, int W, vo
     auto *coff = reinterpret_cast<unsigned long long *>(ws + L.chunk_off);
     const long hw = (long)H * W;
     const dim3 grid(L.cpv, V);
-    // 16-byte loads where every view starts on a 16-byte boundary (480 x 640 maps do); PTX_INGEST_SCALAR=1 forces the element form
-    static const bool scalar_env = getenv("PTX_INGEST_SCALAR") != nullptr;
+    // 16-byte loads where every view starts on a 16-byte boundary (480 x 640 maps do), the element form otherwise
     const size_t esz = depth_dtype == 0 ? 4 : 2;
-    const bool vec = !scalar_env && (reinterpret_cast<uintptr_t>(depth) & 15) == 0 && ((size_t)hw * esz) % 16 == 0;
+    const bool vec = (reinterpret_cast<uintptr_t>(depth) & 15) == 0 && ((size_t)hw * esz) % 16 == 0;
     if (depth_dtype == 0) {
         const float *dp = static_cast<const float *>(depth);
         if (vec) hipLaunchKernelGGL((k_ingest_index<float, true>), grid, dim3(256), 0, st, dp, hw, L.gpv, L.cpv, masks, prefix, ctot);

@@ -283,13 +283,12 @@ __global__ __launch_bounds__(kMlpWaves * 64) __attribute__((amdgpu_waves_per_eu(
 
 bool mlp_fused_supported(int C, int hidden, int R, int compute_dtype)
 {
-    static const int env = getenv("PTX_MLP_FUSED") ? atoi(getenv("PTX_MLP_FUSED")) : 1;
     // r03 (one work-group per CU): 4146 rows (the shipped configuration at 6 scenes) +4.5 % over the two GEMM launches, 4096 rows
     // (cfg2 at 16 scenes) +0.7 %, 8192 rows (32 scenes) -3 %.  r04, with two work-groups per CU where there are more than 768 of
     // them (LITE): cfg2 at 16 scenes +3.8 % on top, at 32 scenes 26.2k vs 25.5k scenes/s for the two launches
     // (profiles/r04_mlp_lite_ab.txt) -- the fused form now covers every batch up to 36 scenes per call
-    static const int rmax = getenv("PTX_MLP_RMAX") ? atoi(getenv("PTX_MLP_RMAX")) : 9216;
-    return env != 0 && (compute_dtype == 0 || compute_dtype == 1) && C == 256 && hidden == 1024 && R >= 1 && R <= rmax;
+    constexpr int rmax = 9216;
+    return (compute_dtype == 0 || compute_dtype == 1) && C == 256 && hidden == 1024 && R >= 1 && R <= rmax;
 }
 
 size_t mlp_part_bytes(int R) { return (size_t)2 * cdiv(R, kMlpRows) * 4 * kMlpRows * 256 * sizeof(float); }
@@ -306,8 +305,7 @@ int launch_mlp(const MlpBatch &mb, hipStream_t st)
         rmax = p.R;
     }
     const dim3 grid(cdiv(rmax, kMlpRows), 4, mb.n), block(kMlpWaves * 64);
-    static const int lite_env = getenv("PTX_MLP_LITE") ? atoi(getenv("PTX_MLP_LITE")) : -1;
-    const bool lite = lite_env >= 0 ? lite_env != 0 : (long)grid.x * grid.y * grid.z > 768;     // r04 A/B: 512 work-groups -0.4 %, 1024 +3.8 %
+    const bool lite = (long)grid.x * grid.y * grid.z > 768;     // r04 A/B: 512 work-groups -0.4 %, 1024 +3.8 %
     constexpr int kLiteLds = 3 * kMlpPlane + 2 * 32 * 4;
 #define PTX_MLP_LAUNCH(NP_, LITE_, LDS_)                                                                                           \
     do {                                                                                                                         \

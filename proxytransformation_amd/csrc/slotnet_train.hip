@@ -23,7 +23,6 @@ struct SnArgs {
     const float *center, *cluster; long nclus; int K, C;
     const float *conv_w, *conv_b;                   // (C,6), (C)
     const float *bn_w, *bn_b, *mean_rstd;           // (C), (C), (2,C)
-    const float *mean_in;                           // stats pass 2: the batch mean (C)
     const float *dout; const int32_t *arg;          // backward: (nclus,C) gradient of the pooled output, first-arg-max slots
     const float *dbeta, *dgamma;                    // backward pass 2
     float *out; int32_t *arg_out;                   // forward: pooled (nclus,C), arg-max (max pooling)
@@ -89,40 +88,6 @@ __device__ __forceinline__ void sn_store_partials(const SnArgs &a, double (&acc)
     __syncthreads();
     for (int i = threadIdx.x; i < NV * C; i += 256)
         a.part[(size_t)blockIdx.x * NV * C + i] = ((lds[i] + lds[(size_t)NV * C + i]) + lds[(size_t)2 * NV * C + i]) + lds[(size_t)3 * NV * C + i];
-}
-
-// MODE 0: sum_r h;  MODE 1: sum_r (h - mean)^2
-template <int Q, int MODE>
-__global__ __launch_bounds__(256) void k_sn_stats(SnArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) double sn_lds[];
-    const int lane = lane_id();
-    const int gw = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    SnWeights<Q> w;
-    sn_load_weights<Q>(a, lane, w);
-    float mean[Q];
-#pragma unroll
-    for (int q = 0; q < Q; ++q) mean[q] = MODE == 1 ? a.mean_in[lane + 64 * q] : 0.0f;
-    double acc[1][Q];
-#pragma unroll
-    for (int q = 0; q < Q; ++q) acc[0][q] = 0.0;
-    for (long cl = gw; cl < a.nclus; cl += (long)gridDim.x * 4) {
-        float x[6], s[6], h[Q], loc[Q];
-        sn_slot(a, cl, lane, x);
-#pragma unroll
-        for (int q = 0; q < Q; ++q) loc[q] = 0.0f;
-        for (int k = 0; k < a.K; ++k) {
-            sn_conv<Q>(w, x, k, s, h);
-#pragma unroll
-            for (int q = 0; q < Q; ++q) {
-                if (MODE == 0) loc[q] += h[q];
-                else { const float d = h[q] - mean[q]; loc[q] = fmaf(d, d, loc[q]); }
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < Q; ++q) acc[0][q] += (double)loc[q];       // K (<= 63) terms in fp32, clusters in double
-    }
-    sn_store_partials<Q, 1>(a, acc, sn_lds);
 }
 
 // sum over the work-group partials of output i: 16 lanes take the blocks round-robin (16 loads in flight per output instead
@@ -419,26 +384,13 @@ int ptx_op_slotnet_fwd(const float *center, const float *cluster, long nclus, in
     a.center = center; a.cluster = cluster; a.nclus = nclus; a.K = K; a.C = C; a.conv_w = conv_w; a.conv_b = conv_b;
     a.bn_w = bn_w; a.bn_b = bn_b; a.mean_rstd = mean_rstd; a.out = out; a.arg_out = arg; a.part = static_cast<double *>(scratch);
     a.maxpool = maxpool; a.inv_total = 1.0f / (float)((double)nclus * K);
-    static const bool two_pass = getenv("PTX_SN_TWO_PASS") != nullptr;      // the r03 form: both statistics from the C channels
-    if (!two_pass) {
-        (void)stat_tmp;
-        hipLaunchKernelGGL(k_sn_moments, dim3(kSnBlocks), dim3(256), 0, st, a);
-        hipLaunchKernelGGL(k_sn_moments_finish, dim3(1), dim3(512), 0, st, a.part, kSnBlocks, conv_w, conv_b, C, (double)nclus * K, eps,
-                           momentum, mean_rstd, run_mean, run_var);
-        PTX_LAUNCHED("k_sn_moments");
-    } else {
-        const size_t lds1 = (size_t)4 * C * sizeof(double);
-        float *mean = stat_tmp, *sq = stat_tmp + C;             // (2,C): batch mean, centred sum of squares
-        if (C == 256) hipLaunchKernelGGL((k_sn_stats<4, 0>), dim3(kSnBlocks), dim3(256), lds1, st, a);
-        else          hipLaunchKernelGGL((k_sn_stats<8, 0>), dim3(kSnBlocks), dim3(256), lds1, st, a);
-        hipLaunchKernelGGL(k_sn_finish, dim3(cdiv(C, 16)), dim3(256), 0, st, a.part, kSnBlocks, C, a.inv_total, mean);
-        a.mean_in = mean;
-        if (C == 256) hipLaunchKernelGGL((k_sn_stats<4, 1>), dim3(kSnBlocks), dim3(256), lds1, st, a);
-        else          hipLaunchKernelGGL((k_sn_stats<8, 1>), dim3(kSnBlocks), dim3(256), lds1, st, a);
-        hipLaunchKernelGGL(k_sn_finish, dim3(cdiv(C, 16)), dim3(256), 0, st, a.part, kSnBlocks, C, 1.0f, sq);
-        PTX_LAUNCHED("k_sn_stats");
-        PTX_TRY(ptx_op_bn_stats(mean, sq, C, nclus * K, eps, momentum, mean_rstd, run_mean, run_var, stream));
-    }
+    // (r03 took both statistics from the C channels in two passes over the slots: 2 x 30 us + finishing launches; r04: the 6 + 21
+    //  moments of the slot inputs in one pass, train.py / DESIGN.md 5.4)
+    (void)stat_tmp;
+    hipLaunchKernelGGL(k_sn_moments, dim3(kSnBlocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_sn_moments_finish, dim3(1), dim3(512), 0, st, a.part, kSnBlocks, conv_w, conv_b, C, (double)nclus * K, eps,
+                       momentum, mean_rstd, run_mean, run_var);
+    PTX_LAUNCHED("k_sn_moments");
     if (C == 256) hipLaunchKernelGGL(k_sn_apply<4>, dim3((unsigned)((nclus + 3) / 4)), dim3(256), 0, st, a);
     else          hipLaunchKernelGGL(k_sn_apply<8>, dim3((unsigned)((nclus + 3) / 4)), dim3(256), 0, st, a);
     PTX_LAUNCHED("k_sn_apply");

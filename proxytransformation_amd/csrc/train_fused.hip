@@ -572,7 +572,7 @@ static int tn_ksplit(int M, int N, int K)
     const int tiles = cdiv(M, 64) * cdiv(N, 64);
     // work-groups per product: more slices = more partial traffic (r04 sweep, k_t_tn_gemm + k_t_finalize per block: 256: 64.4 + 19.1 us,
     // 512: 65.8 + 19.5, 1024: 67.8 + 19.4, 2048: 71.3 + 21.6)
-    static const int target = getenv("PTX_TN_TARGET") ? atoi(getenv("PTX_TN_TARGET")) : 512;
+    constexpr int target = 512;
     int ks = target / tiles, kb = K / 128;
     if (ks > kb) ks = kb;
     return ks < 1 ? 1 : (ks > 64 ? 64 : ks);

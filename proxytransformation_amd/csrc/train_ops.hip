@@ -845,8 +845,7 @@ int ptx_op_gemm(const void *A, const void *B, float *C, int M, int N, int K, lon
     const dim3 grid(cdiv(M, 64), cdiv(N, 64), batch * ksplit);
     hipStream_t st = static_cast<hipStream_t>(stream);
     PTX_REQUIRE(a_dtype == 0 || b_dtype == 0, "ptx_op_gemm: at most one 16-bit operand (a_dtype=%d, b_dtype=%d)", a_dtype, b_dtype);
-    static const int thin_env = getenv("PTX_BGEMM_THIN") ? atoi(getenv("PTX_BGEMM_THIN")) : 1;
-    if (thin_env && a_dtype == 0 && b_dtype == 0 && ksplit == 1 && batch >= 64 && (M <= 2 || N <= 2 || K <= 2)) {
+    if (a_dtype == 0 && b_dtype == 0 && ksplit == 1 && batch >= 64 && (M <= 2 || N <= 2 || K <= 2)) {
         // thin products of many batches: most of a 64 x 64 MFMA tile would be padding
         const bool al16 = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0;
         if (M <= 2 && N == 32 && b_cs == 1 && K <= 256 && K > 64 && al16 && b_rs % 4 == 0 && b_s1 % 4 == 0 && b_s2 % 4 == 0) {

@@ -270,7 +270,7 @@ class ProxyTransformationNormReverse(nn.Module):
         self.register_load_state_dict_post_hook(_invalidate_after_load)
         #: True = block until the whole forward has drained (the pre-ABI-3 behaviour); default is
         #: to return once the output lengths are known, like any asynchronous torch op
-        self.sync_outputs = os.environ.get("PTX_SYNC_OUTPUTS", "0") == "1"
+        self.sync_outputs = False
         self._wkey = None
         self._wstruct: Optional[_abi.PtxWeights] = None
         self._prep: Optional[torch.Tensor] = None

@@ -36,14 +36,15 @@ from . import _abi
 
 _F32 = torch.float32
 # test switches: the generic one-launch-per-operator composition stays available (shapes outside the fused kernels' range use it)
-_FUSED_ATTN = os.environ.get("PTX_TRAIN_FUSED_ATTN", "1") != "0"
-_FUSED_BLOCK = os.environ.get("PTX_TRAIN_FUSED_BLOCK", "1") != "0"
-_FUSED_IMG = os.environ.get("PTX_TRAIN_FUSED_IMG", "1") != "0"
-_SIDE_STREAM = os.environ.get("PTX_TRAIN_SIDE_STREAM", "1") != "0"
-_ONE_NODE = os.environ.get("PTX_TRAIN_ONE_NODE", "1") != "0"
-_IMG_FIRST = os.environ.get("PTX_TRAIN_IMG_FIRST", "1") != "0"   # one-node step: the image branch in front of the clustering half
-_IMG_POS = int(os.environ.get("PTX_TRAIN_IMG_POS", "1"))     # where the image branch is enqueued: 0 first, 1 after the selection,
-                                                              # 2 before the text block, 3 after it
+# Which form of the step runs (module constants, not environment switches: tests/test_gpu_train.py patches them to drive the fallbacks).
+_FUSED_ATTN = True       # the fused attention core of a block (ptx_train_attn_fwd / _bwd) instead of one launch per operator
+_FUSED_BLOCK = True      # one ProxyBlock + trailing LayerNorm + head + BatchNorm1d as two C calls (ptx_train_block_fwd / _bwd)
+_FUSED_IMG = True        # AttentionPool2d on its folded form (ptx_train_imgpool_fwd / _bwd)
+_SIDE_STREAM = True      # the image branch on a side stream beside the index half
+_ONE_NODE = True         # the float half as ONE autograd node (_TrainStep)
+_IMG_FIRST = True        # one-node step: the image branch enqueued in front of the clustering half (profiles/r04_train_ab.txt)
+_IMG_POS = 1             # per-operator graph: where the image branch is enqueued -- 0 first, 1 after the selection, 2 before the
+                         # text block, 3 after it
 
 
 _TICKS = None          # scratch/train_hostprof3.py: list of (label, perf_counter) of the last forward

@@ -313,8 +313,7 @@ def test_launch_count_of_the_benchmark_shape():
 def test_launch_count_with_stream_gates():
     """The same count at a shape whose image chain owns the caller's stream (the benchmark's situation): the fork and the join are
     device-word gates there, and THEIR launches are counted too -- the 16 kernels + the fork's one-wave k_gate + the join's
-    k_signal; the join's wait is folded into the proxy_proj GEMM (no k_gate launch on the caller's stream).  (One kernel less
-    with PTX_MM_FUSE=1, where the first work-groups of the mean launch reduce the bounding boxes; one more where the
+    k_signal; the join's wait is folded into the proxy_proj GEMM (no k_gate launch on the caller's stream).  (One more where the
     attention runs as two launches.)"""
     import ctypes
     from proxytransformation_amd import _abi
@@ -347,11 +346,11 @@ def test_launch_count_with_stream_gates():
             lib.ptx_timing_select(-1)
     per_site = {lib.ptx_kernel_name(i).decode(): n[i] for i in range(nk) if n[i]}
     assert per_site.get("k_gate[fork]") == 1 and per_site.get("k_signal[join]") == 1 and "k_gate[join]" not in per_site, per_site
-    fused_boxes = "k_minmax" not in per_site                     # PTX_MM_FUSE=1: the boxes ride in the mean launch
+    assert per_site.get("k_minmax") == 1
     two_launch_attn = "k_attn32[proxy_as_key]" in per_site      # few (scene, head) pairs at this shape: PV through memory
     tags_off_chain = "k_gate[tags]" in per_site                 # the slot tags on the third stream: its one-wave gate + signal
     assert per_site.get("k_signal[tags]", 0) == int(tags_off_chain)
-    assert sum(per_site.values()) == 16 + 2 - int(fused_boxes) + int(two_launch_attn) + 2 * int(tags_off_chain), per_site
+    assert sum(per_site.values()) == 16 + 2 + int(two_launch_attn) + 2 * int(tags_off_chain), per_site
 
 
 _GATE_WORKER = r"""
@@ -426,6 +425,8 @@ def _run_gate_worker(tmp_path, expect_rc=0, **env_extra):
     script = tmp_path / "gate_worker.py"
     script.write_text(_GATE_WORKER % ROOT)
     env = dict(os.environ, **env_extra)
+    if "PTX_GATE_FAULT" in env_extra:       # the fault-injection hooks exist in the test-hooks build of the library only
+        env["PTX_LIBRARY"] = "testhooks"
     r = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == expect_rc, (r.returncode, r.stderr[-3000:])
     out = {"STDERR": [r.stderr]}
@@ -492,7 +493,7 @@ def test_stream_gate_timeout_fails_loudly_on_the_clustering_layout(tmp_path, fau
     image chain rides at the end of the qkv GEMM / of k_select, the wait for the slot tags at the end of the proj GEMM): a dropped
     releasing store gives NaN outputs, a RuntimeError naming the gate on the next call, events from then on, and the right result."""
     # join-early: the early-proxy form of the layout (forced at this small shape), where the join's wait is the end of k_select
-    extra = dict(GATE_TEST_SHAPE="cluster", **({"PTX_EARLY_PROXIES": "1"} if fault == "join-early" else {}))
+    extra = dict(GATE_TEST_SHAPE="cluster", **({"PTX_LAYOUT": "-1--"} if fault == "join-early" else {}))
     fault = fault.split("-")[0]
     ref = _run_gate_worker(tmp_path, PTX_GATE="0", **extra)
     assert ref["GATES_AFTER"] == ["False"] and all(c == "ok nan=0" for c in ref["CALL"])
@@ -502,7 +503,7 @@ def test_stream_gate_timeout_fails_loudly_on_the_clustering_layout(tmp_path, fau
     if clean["GATE_BITS"] != ["3"]:
         pytest.skip("this environment orders the streams with events (profiler / serialised queues / failed probe)")
     calls = got["CALL"]
-    if "PTX_EARLY_PROXIES" in extra:
+    if "PTX_LAYOUT" in extra:
         # the wait sits at the end of k_select, in front of the slot tags that publish the survivor counts: the error word is there
         # before the counts, so the SAME call raises (like a failed fork)
         assert calls[0].startswith("raised:") and "stream gate timed out" in calls[0] and "join" in calls[0], calls
@@ -561,3 +562,83 @@ def test_eval_forward_is_capturable_into_a_hip_graph(shape):
         assert n == [int(o.shape[0]) for o in want], (rep, n)
         for b, o in enumerate(want):
             assert torch.equal(out_g[b, : n[b]], o), f"replay {rep}, scene {b}"
+
+
+def test_product_library_has_no_fault_injection_hook(tmp_path):
+    """PTX_GATE_FAULT lives in the test-hooks build only (csrc/Makefile: libproxyt_hip_testhooks.so, -DPTX_TEST_HOOKS).
+    With the PRODUCT library the variable is inert: the forward is right and nothing is reported."""
+    script = tmp_path / "gate_worker.py"
+    script.write_text(_GATE_WORKER % ROOT)
+    env = dict(os.environ, PTX_GATE_FAULT="join", PTX_GATE_TIMEOUT_MS="30")
+    env.pop("PTX_LIBRARY", None)
+    r = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    calls = [ln for ln in r.stdout.splitlines() if ln.startswith("CALL")]
+    assert calls == ["CALL ok nan=0"] * 3, calls
+    import re
+    blob = open(os.path.join(ROOT, "proxytransformation_amd", "libproxyt_hip.so"), "rb").read()
+    assert b"PTX_GATE_FAULT" not in blob and b"PTX_GATE_TRAP" not in blob
+    # the whole switchboard of the product library (VERDICT r04 #7: <= 12, each named in a test): PTX_GATE (events / gates:
+    # test_stream_gate_timeout_fails_loudly), PTX_GATE_TIMEOUT_MS (same), PTX_LAYOUT (test_every_stream_layout_gives_the_same_result),
+    # PTX_POOL_NT (test_streaming_partial_stores_do_not_change_the_result)
+    names = sorted(set(m.decode() for m in re.findall(rb"PTX_[A-Z][A-Z_0-9]+", blob)))
+    assert names == ["PTX_GATE", "PTX_GATE_TIMEOUT_MS", "PTX_LAYOUT", "PTX_POOL_NT"], names
+
+
+_LAYOUT_WORKER = r"""
+import os, sys, hashlib, torch
+sys.path.insert(0, %r)
+from proxytransformation_amd.synth import PreshapeConfig, make_scene_batch
+from tests.util import build_module
+which = os.environ["LAYOUT_SHAPE"]
+if which == "cluster":       # 1 210 -> 691 kept clusters, 519 picks (the shipped gs = 12 grid) at a reduced N: the clustering chain is the long one
+    cfg = PreshapeConfig("lay", B=3, N=30000, grid_size=12, dynamic_drop_radio=0.6, L=12, V=10, text_blocks=2, img_blocks=2, seed_base=4343)
+else:                        # the benchmark's situation: the image chain is the long one
+    cfg = PreshapeConfig("lay", B=2, N=30000, grid_size=8, dynamic_drop_radio=0.4, L=16, V=180, seed_base=4242)
+m, _ = build_module(cfg)
+m = m.cuda()
+pts, text, mask, img = make_scene_batch(cfg)
+dev = torch.device("cuda:0")
+args = ([torch.from_numpy(p).to(dev) for p in pts],
+        {"text_feats": torch.from_numpy(text).to(dev), "text_token_mask": torch.from_numpy(mask).to(dev)},
+        torch.from_numpy(img).to(dev).to(torch.bfloat16 if which == "image" else torch.float32))
+with torch.no_grad():
+    for _ in range(3):
+        outs = m(*args)
+    torch.cuda.synchronize()
+m.check()
+h = hashlib.sha256()
+for o in outs:
+    h.update(o.cpu().numpy().tobytes())
+print("DIGEST", h.hexdigest(), [int(o.shape[0]) for o in outs])
+"""
+
+
+@pytest.mark.parametrize("shape", ["image", "cluster"])
+def test_every_stream_layout_gives_the_same_result(tmp_path, shape):
+    """PTX_LAYOUT (csrc/api.hip) forces the per-shape layout decisions of the eval forward: which chain owns the caller's stream,
+    early proxies, the image chain forked behind k_cluster, the slot tags behind a gate on the third stream.  Every forced
+    arrangement -- with gates and with events -- must give what the rule's own choice gives.  (The early proxies re-associate a
+    bias term, SURVEY H4-level rounding: they are compared among themselves and within 1e-5 of the rest.)"""
+    script = tmp_path / "layout_worker.py"
+    script.write_text(_LAYOUT_WORKER % ROOT)
+
+    def run(**env_extra):
+        env = dict(os.environ, LAYOUT_SHAPE=shape, **env_extra)
+        r = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        assert r.returncode == 0, (env_extra, r.stderr[-2000:])
+        return [ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][0]
+    base = run()
+    if shape == "image":
+        for lay in ("0--0", "0--1", "1---", "10--"):
+            for gate in ("0", "1"):
+                assert run(PTX_LAYOUT=lay, PTX_GATE=gate) == base, (lay, gate)
+        return
+    # cluster shape: two families -- without and with the early proxies (the kept rows' qkv differ by fp32 rounding of the re-associated
+    # bias term: same survivors, coordinates within the parity bar of each other; the rule picks the early form at this shape)
+    plain = [run(PTX_LAYOUT=lay, PTX_GATE=gate) for lay in ("0---", "10--", "100-", "101-") for gate in ("0", "1")]
+    early = [run(PTX_LAYOUT=lay, PTX_GATE=gate) for lay in ("11--", "110-", "111-") for gate in ("0", "1")]
+    assert len(set(plain)) == 1, plain
+    assert len(set(early)) == 1, early
+    assert base in (plain[0], early[0])
+    assert early[0].split(" ", 2)[2] == plain[0].split(" ", 2)[2]           # the same survivors per scene
