@@ -202,7 +202,28 @@ def train_step_ms(device, steps=20):
     mod.compute_dtype = "bf16"          # opt-in: the blocks' Linear layers and their gradients on plain bf16 operands (what --amp gives them)
     ms_bf16 = timed(False)
     mod.compute_dtype = "fp32"
-    return dict(ms=ms, ms_with_scalar_loss=ms_loss, ms_bf16_compute=ms_bf16, steps=steps,
+    # the same step (forward + backward, drop rates 0) through the CPU oracle on this box's host cores: a bounded sample, the
+    # checker used only as the reported baseline
+    cpu = None
+    try:
+        from oracle import oracle
+        threads = min(os.cpu_count() or 1, 32)
+        sd0 = fill_state_dict(mod.state_dict())
+        kw = dict(grid_size=cfg.grid_size, dynamic_drop_radio=cfg.dynamic_drop_radio, num_sub=cfg.num_sub, num_heads=cfg.num_heads,
+                  text_blocks=cfg.text_blocks, img_blocks=cfg.img_blocks, points=pts, text_feats=text, text_mask=mask, img_feat=img,
+                  num_threads=threads)
+        oracle.forward_train(sd0, **kw)                    # warm-up (library load, thread pool)
+        reps, t0 = 0, time.perf_counter()
+        while reps < 3 and (reps == 0 or time.perf_counter() - t0 < 10.0):
+            oracle.forward_train(sd0, **kw)
+            reps += 1
+        el = (time.perf_counter() - t0) / reps
+        cpu = dict(value=round(1e3 * el, 1), unit="ms per step", cores=threads, kind="port",
+                   sample=f"{reps} steps of oracle.forward_train (torch-CPU autograd + C ball query / FPS, drop rates 0) on {threads} of "
+                          f"{os.cpu_count()} host threads")
+    except Exception as e:                                 # never sinks the GPU numbers
+        cpu = dict(value=None, error=repr(e))
+    return dict(ms=ms, ms_with_scalar_loss=ms_loss, ms_bf16_compute=ms_bf16, steps=steps, cpu_baseline=cpu,
                 shape="6 scenes x 100k points, gs=12 -> 691 kept clusters, L=20, V=20 fp32 features, 3+3 blocks (CFG:41,108,145); "
                       "drop rates 0.2; forward + backward, output gradients handed in (ms) / a scalar loss built from the "
                       "outputs (ms_with_scalar_loss)")
@@ -348,7 +369,15 @@ def site_times(lib, names, mod, inputs, steps):
     return {nm: 1e3 * ms[i] / n[i] for i, nm in enumerate(names) if n[i] > 0}
 
 
-def passes_report(cfg, B, us, dt_bytes):
+def prefix_max(mod, inputs):
+    """P_max of SURVEY 8d's prefix-aware bound: the largest point index the (second) ball query scans in any scene of input set 0 --
+    the early-exit query reads a PREFIX of the cloud per centre (first K hits in index order), not the scene."""
+    d = mod.forward_debug(*inputs.args(0))
+    torch.cuda.synchronize()
+    return int(d["idx2"].max()) + 1
+
+
+def passes_report(cfg, B, us, dt_bytes, p_max=None, step_s=None):
     byts, flops = work_model(cfg, B, dt_bytes)
     rep = {"scenes_per_gpu": B}
 
@@ -364,6 +393,21 @@ def passes_report(cfg, B, us, dt_bytes):
         return dict(us=round(t, 2), GFLOP=round(f / 1e9, 3), achieved_TFLOPs=round(f / t / 1e6, 2),
                     frac_of_f32_mfma_peak=round(f / t / 1e6 / MFMA_F32_PEAK_TFLOPS, 4)) if t > 0 else None
     rep["clustering_pass_hbm"] = hbm(["k_minmax", "k_cluster"])
+    rep["clustering_pass_hbm"]["bound"] = "upper: each ball-query pass reads every point once (SURVEY 8d: 12 N + 2 x 12 N + writes)"
+    if p_max is not None and "k_minmax" in us and "k_cluster" in us:
+        # SURVEY 8d's prefix-aware LOWER bound, reported alongside: the min / max pass reads the scene (12 N), each query pass only
+        # the prefix it scans (12 P_max), plus the cluster writes.  This is the bound that matches the algorithm -- the early exit
+        # is why the pass is latency-bound (one wave per centre walking ~P_max points), not a bandwidth kernel
+        N, M, K = cfg.N, cfg.M, cfg.num_sub
+        lo = B * (12 * N + 2 * 12 * p_max + M * K * (4 + 12) + M * 16)
+        t = us["k_minmax"] + us["k_cluster"]
+        rep["clustering_pass_hbm_prefix_bound"] = dict(
+            us=round(t, 2), P_max=p_max, algorithmic_MB=round(lo / 1e6, 2), achieved_GBs=round(lo / t / 1e3, 1),
+            frac_of_hbm_peak=round(lo / t / 1e3 / HBM_PEAK_GBS, 4),
+            k_minmax_alone=dict(us=round(us["k_minmax"], 2), algorithmic_MB=round(B * 12 * N / 1e6, 2),
+                                frac_of_hbm_peak=round(B * 12 * N / us["k_minmax"] / 1e3 / HBM_PEAK_GBS, 4)),
+            what="12 N (min/max) + 2 x 12 P_max (the two early-exit query passes, P_max = largest scanned index of input set 0) + "
+                 "cluster writes; k_minmax is the only kernel of the pass that streams the scene")
     rep["apply_pass_hbm"] = hbm(["k_tags", "k_affine<compact>"])
     rep["k_minmax"] = hbm(["k_minmax"])
     rep["k_affine"] = hbm(["k_affine<compact>"])
@@ -373,6 +417,16 @@ def passes_report(cfg, B, us, dt_bytes):
     rep["proxy_attention_mfma"] = mfma(["k_attn32[proxy_as_query]", "k_attn32[proxy_as_key]", "k_proxy_attn[fused]"])
     rep["block_gemms_mfma"] = mfma(["k_gemm_nt[qkv+proxy_proj]", "k_gemm_nt[pp_img]", "k_gemm_nt[proj]",
                                     "k_gemm_nt[fc1]", "k_gemm_nt[fc2]", "k_mlp[fc1+gelu+fc2]"])
+    if step_s is not None:
+        # the whole step against the HBM roofline: SURVEY 8d's algorithmic bytes of one forward -- point side 60 N + 40 M K per scene
+        # (min/max read, two query passes at their upper bound, cluster writes, apply read + write) + ONE read of img_feat -- over
+        # the measured step time.  (The step is a dependency chain of ~10 launches at this batch: DESIGN.md 5.2.)
+        N, M, K = cfg.N, cfg.M, cfg.num_sub
+        img = B * cfg.V * cfg.input_dim * cfg.img_spacial_dim ** 2 * dt_bytes
+        alg = B * (60 * N + 40 * M * K) + img
+        rep["whole_step"] = dict(ms=round(1e3 * step_s, 4), algorithmic_MB=round(alg / 1e6, 2), achieved_GBs=round(alg / step_s / 1e9, 1),
+                                 frac_of_hbm_peak=round(alg / step_s / 1e9 / HBM_PEAK_GBS, 4),
+                                 what="(60 N + 40 M K) per scene + one read of img_feat, / ms_per_step / 8 TB/s")
     rep["site_us"] = {k: round(v, 2) for k, v in us.items()}
     return rep
 
@@ -500,13 +554,14 @@ def main():
             # per-pass reports: single-rank runs only -- this block is rank 0's alone, so nothing in it may touch the process group
             # (its timed_steps get the local barrier); with N > 1 the other ranks would sit in the census all-gather meanwhile
             if rank == 0 and world == 1:
-                extras["passes"] = [passes_report(cfg, B, site_times(lib, names, mod, inputs, 20), inputs.sets[0]["img"].element_size())]
+                pm = prefix_max(mod, inputs)
+                extras["passes"] = [passes_report(cfg, B, site_times(lib, names, mod, inputs, 20), inputs.sets[0]["img"].element_size(),
+                                                  pm, sorted(block_s)[len(block_s) // 2] / args.steps)]
                 if cfg.name == "cfg2" and B * 8 <= 32:
                     wide = inputs.widened(8)
                     for i in range(3):
                         mod(*wide.args(i))
-                    extras["passes"].append(passes_report(cfg, wide.B, site_times(lib, names, mod, wide, 9),
-                                                          wide.sets[0]["img"].element_size()))
+                    wide_us = site_times(lib, names, mod, wide, 9)
                     # the same two compute modes at 32 scenes per GPU (whole step, cold inputs)
                     t32 = {}
                     for cdt in ("fp32", "bf16"):
@@ -517,6 +572,7 @@ def main():
                     mod.compute_dtype = "fp32"
                     extras["wide"] = dict(scenes_per_gpu=wide.B, value_fp32_compute=round(wide.B / t32["fp32"], 2),
                                           value_bf16_compute=round(wide.B / t32["bf16"], 2))
+                    extras["passes"].append(passes_report(cfg, wide.B, wide_us, wide.sets[0]["img"].element_size(), pm, t32["fp32"]))
                     del wide
         if not args.no_passes and rank == 0 and world == 1:
             with torch.enable_grad():

@@ -343,7 +343,10 @@ int ptx_ingest_gather(const void *depth, int depth_dtype, float depth_shift, int
  * coords (B*Ncap,4) int32 and feats (B*Ncap,3) capacity; inverse (B,Ncap) int32 voxel row of every point (-1 past the
  * valid rows) or NULL; nvox_overflow: 2 int32 = {voxel rows written, points whose voxel index left +-2^18}, device memory or
  * device-mapped pinned host memory: published with system scope as soon as the count is KNOWN (preset to -1 and poll with
- * ptx_wait_counts instead of draining the stream); the rows themselves are ordered on `stream` like any other result. */
+ * ptx_wait_counts instead of draining the stream); the rows themselves are ordered on `stream` like any other result.
+ * Rows written == PTX_VOX_BROKEN (0x7fffffff): a tile of the single-pass emit gave up waiting for the tiles in front of it
+ * (2^24 polls); rows, inverse and the count of that call are invalid. */
+#define PTX_VOX_BROKEN 0x7fffffff
 size_t ptx_voxel_workspace_bytes(int B, int Ncap);
 int ptx_voxelize(const float *points, const int32_t *counts, int B, int Ncap, float voxel_size, int32_t *coords,
                  float *feats, int32_t *inverse, int32_t *nvox_overflow, void *workspace, size_t ws_bytes, void *stream);

@@ -1105,15 +1105,25 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
         side->last_st = st;
         if (side->gates_on && (!side->probed || side->probed_st != st)) PTX_TRY(gate_probe(side, st));
     }
-    // Which chain is the longer one depends on the shape: with many farthest-point picks (the reference's own gs = 12
-    // configuration: 519 sequential picks) it is the clustering chain, and then THAT one stays on the caller's stream
-    // and the image chain takes the side stream.  (Rough per-shape estimates in us: measured slopes.)
-    const double est_cluster = 80.0 + 0.42 * Kd, est_image = 40.0 + (S.img_dtype == 0 ? 0.45 : 0.18) * ((double)B * S.V);
+    // Which chain stays on the caller's stream (no cross-queue hop on the path the step waits for) depends on the shape.  Estimates in
+    // us -- functions of what the chains move and do, not of a named configuration:
+    //   image chain      40 + (bytes of img_feat: B V in_dim hw esz) x 0.78 us / MB (16-bit) | 0.98 us / MB (fp32): two / three streaming
+    //                    passes at ~5 / ~4 TB/s plus the table GEMMs (cfg2 bf16: 35 us per scene of 196 views; cfg4: 22.5 us per 50 views)
+    //   clustering chain 80 + 0.42 us per farthest-point pick (Kd): the picks are sequential and one work-group per scene, so the chain
+    //                    does not grow with the batch; k_minmax / k_cluster (~50 us at 100k points) run beside the mean pass
+    // The image chain on the caller's stream is the cheaper arrangement by itself (fork and join ride in kernels that exist anyway),
+    // so the clustering chain takes the caller's stream only when it is longer BY A MARGIN.  r05 validation, interleaved A/B of the
+    // forced layouts (PTX_LAYOUT, profiles/r05_layout_rule_ab.txt): cfg2 bf16 at 1 / 2 / 3 / 4 scenes image chain +2.5 / +1.5 / +9 /
+    // +8 % (the r04 rule, est_cluster > est_image, put 1 and 2 scenes on the other side), cfg2 fp32 features at 1 / 2 / 3 scenes +6 / +8 /
+    // +6 %; cfg4 (519 picks) at 6 / 8 / 10 / 12 / 16 scenes clustering chain +13 / +10 / +1 / -2 / -11 %; cfg1 at 1 / 4 scenes +10 / +9 %;
+    // cfg5 (1 844 picks) at 1 / 8 scenes +2 / +10 %.  The margin of 60 us decides every one of these correctly except cfg4 at 10 scenes (1 %).
+    const double img_mb = (double)B * S.V * S.in_dim * S.hw * (S.img_dtype == 0 ? 4.0 : 2.0) * 1e-6;
+    const double est_cluster = 80.0 + 0.42 * Kd, est_image = 40.0 + (S.img_dtype == 0 ? 0.98 : 0.78) * img_mb;
     // PTX_LAYOUT (the ONE layout override, for A/B runs and the parity test that drives every arrangement): four characters,
     // '0' / '1' force, anything else leaves the rule -- [0] clustering chain on the caller's stream, [1] early proxies,
     // [2] image chain forked behind k_cluster, [3] slot tags behind a gate on the third stream.  E.g. PTX_LAYOUT=1-0-
     static const LayoutForce lf = layout_force();
-    const bool cluster_on_caller = lf.v[0] >= 0 ? lf.v[0] != 0 : est_cluster > est_image;
+    const bool cluster_on_caller = lf.v[0] >= 0 ? lf.v[0] != 0 : est_cluster > est_image + 60.0;
     hipStream_t cs = cluster_on_caller ? st : side->st, is = cluster_on_caller ? side->st : st;
     const bool gated = side->gates_on && !cluster_on_caller && !capturing;        // gates instead of events (see k_gate)
     // r04: where the clustering chain is the long one AND the image chain has the slack for it, the image chain forks BEHIND k_cluster

@@ -121,7 +121,12 @@ __global__ __launch_bounds__(256) void k_vox_emit(VoxArgs a)
         unsigned spins = 0;
         while (((w = __hip_atomic_load(a.tile_word + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 63) == 0ull) {
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1u << 24)) break;                // (a lower tile that never publishes: give up rather than hang the device)
+            if (++spins > (1u << 24)) {
+                // a lower tile that never publishes: give up rather than hang the device -- but not silently: the sticky
+                // word next to the overflow counter turns the published row count into PTX_VOX_BROKEN
+                __hip_atomic_store(a.overflow + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
         }
         before += (long long)(w & 0x7fffffffull);
     }
@@ -160,7 +165,11 @@ __global__ __launch_bounds__(256) void k_vox_emit(VoxArgs a)
         // every row of the call is written when the LAST tile's rows are?  No: other tiles may still be emitting.  The count is
         // only a size; the rows themselves are ordered on the stream like any other result (ptx_voxelize's contract).
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(a.nvox_overflow, base + total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // (this tile has waited for EVERY tile in front: whoever gave up on a tile did so no later than this one)
+        if (tid == 0) {
+            const int broken = __hip_atomic_load(a.overflow + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.nvox_overflow, broken ? 0x7fffffff : base + total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 

@@ -22,6 +22,8 @@ import ctypes
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence
 
+import threading
+
 import numpy as np
 import torch
 
@@ -118,8 +120,11 @@ class MultiViewIngest:
     class _Slot:
         __slots__ = ("key", "ws", "counts", "counts_np", "stage", "stage_np", "stage_dev", "copied")
 
-    def _slot(self, b: int, V: int, H: int, W: int, N: int, dev) -> "MultiViewIngest._Slot":
-        slots = self.__dict__.setdefault("_slots", [])
+    def _slot(self, b: int, V: int, H: int, W: int, N: int, dev, stream: int) -> "MultiViewIngest._Slot":
+        # one set of slots per (thread, stream): two calls on different streams or from different threads (prefetch threads, serving
+        # lanes) must not share a workspace, a staging buffer or the -1 preset of the pinned counts
+        per = self.__dict__.setdefault("_slots", {})
+        slots = per.setdefault((threading.get_ident(), stream), [])
         while len(slots) <= b:
             slots.append(None)
         key = (V, H, W, N, str(dev))
@@ -150,7 +155,9 @@ class MultiViewIngest:
         st = torch.cuda.current_stream(dev)
         out = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
         bbox = torch.empty((B, 6), dtype=torch.int32, device=dev)
-        status = torch.empty((B,), dtype=torch.int32, device=dev)      # cleared by ptx_ingest_gather; a device-side safety net
+        # (cleared and set by ptx_ingest_gather: bit 0 = a rank beyond the scene's pixels.  The host has already checked the ranks
+        #  against the published counts below, so the word is not read back -- the C ABI wants the buffer)
+        status = torch.empty((B,), dtype=torch.int32, device=dev)
         work = []
         for b, sc in enumerate(scenes):                          # 1. index every scene's depth maps (one pass each)
             depth = sc["depth_img"]
@@ -158,7 +165,7 @@ class MultiViewIngest:
                 raise RuntimeError(f"depth_img must be a contiguous (V,H,W) float32 / uint16 tensor on {dev}, got "
                                    f"{tuple(depth.shape)} {depth.dtype} on {depth.device}")
             V, H, W = depth.shape
-            sl = self._slot(b, V, H, W, N, dev)
+            sl = self._slot(b, V, H, W, N, dev, st.cuda_stream)
             sl.counts_np[:V] = -1                                # published by the scan kernel with system scope
             _abi.check(lib.ptx_ingest_index(depth.data_ptr(), _DEPTH_DTYPES[depth.dtype], V, H, W, sl.ws.data_ptr(), sl.ws.numel(),
                                             sl.counts.data_ptr(), st.cuda_stream), "ptx_ingest_index")

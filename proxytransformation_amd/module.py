@@ -866,6 +866,11 @@ class ProxyTransformationNormReverse(nn.Module):
         nvox, overflow = (int(x) for x in q["info_np"])
         if nvox < 0:
             raise RuntimeError("ptx_voxelize finished without publishing its row count")
+        if nvox == 0x7fffffff:           # PTX_VOX_BROKEN: a tile of the emit pass gave up waiting for the tiles in front of it
+            raise RuntimeError("ptx_voxelize: the single-pass scan of the emit kernel timed out (a tile never published its count); "
+                               "rows, inverse and the row count of this call are invalid")
+        # (the rows themselves -- coords / feats / inverse -- are ordered on the stream like any other result; only the COUNT is known
+        #  here: a consumer on another stream has to wait for this stream, as for any torch tensor)
         if overflow:
             raise RuntimeError(f"quantize: {overflow} points fall outside +-2^18 voxels of size {voxel_size}")
         res = (coords[:nvox], feats[:nvox])
