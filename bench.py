@@ -107,8 +107,8 @@ def build_module(cfg, device):
 
 # the kernel behind a launch site depends on the storage type of the image features
 SITE_KERNEL = {
-    "img_pass2": {"bf16": "k_img_pool", "f32": "k_img_scores", "f16": "k_img_pool"},
-    "img_pass3": {"bf16": None, "f32": "k_img_gather", "f16": None},      # 16-bit features: no third launch
+    "img_pass2": {"bf16": "k_img_pool", "f32": "k_img_pool32", "f16": "k_img_pool"},
+    "img_pass3": {"bf16": None, "f32": None, "f16": None},      # r05: no third launch for fp32 features either (k_img_pool32)
     "k_img_mean": {"bf16": "k_img_mean16", "f32": "k_img_mean", "f16": "k_img_mean16"},
 }
 
@@ -139,7 +139,7 @@ def work_model(cfg, B, dt_bytes):
     R = B * Mk
     img = B * V * cfg.input_dim * cfg.img_spacial_dim ** 2 * dt_bytes
     byts = {
-        "k_img_mean": img, "img_pass2": img, "img_pass3": img if dt_bytes == 4 else None,
+        "k_img_mean": img, "img_pass2": img, "img_pass3": None,
         "k_minmax": B * N * 12,
         # two ball-query passes (upper bound: every point read once per pass) + cluster writes of the second
         "k_cluster": B * (2 * 12 * N + M * K * (4 + 12) + M * 16),

@@ -451,7 +451,8 @@ static int run_img_proxy(const PtxShape &s, const PtxWeights &w, const float *pr
     const float *img = static_cast<const float *>(img_any);
     float *Gs = nullptr, *E = nullptr, *ML = nullptr;
     const int EW = P.KT2p - s.in_dim;
-    const bool pooled = img_pool_supported(dt, s.in_dim, s.hw, s.heads);
+    const bool pooled32 = img_pool32_supported(dt, s.in_dim, s.hw, s.heads);        // r05: fp32 features in two passes, not three
+    const bool pooled = pooled32 || img_pool_supported(dt, s.in_dim, s.hw, s.heads);
     if (pooled) {
         img_pool_layout(at<float>(ws, L.pool), nall, s.in_dim, EW, &Gs, &E, &ML);
         Gs += (size_t)i0 * 2 * s.heads * s.in_dim; E += (size_t)i0 * s.heads * EW; ML += (size_t)i0 * s.heads * 5;
@@ -487,7 +488,9 @@ static int run_img_proxy(const PtxShape &s, const PtxWeights &w, const float *pr
             PTX_TIMED(KID_IMG_WE, st, launch_gemm(g, st));
         }
     }
-    if (dt == 0) {
+    if (pooled32) {
+        PTX_TIMED_EXT(KID_IMG_SCORES, st, launch_img_pool32(img, we, qkv0, nimg, s.in_dim, s.hw, C, P.KT1, EW, attn_scale(hd), Gs, E, ML, st));
+    } else if (dt == 0) {
         PTX_TIMED(KID_IMG_SCORES, st, launch_img_scores(img, we, qkv0, nimg, s.in_dim, s.hw, s.heads, C, P.KT1,
                                                         P.KT2p, attn_scale(hd), gbuf, st));
         PTX_TIMED(KID_IMG_GATHER, st, launch_img_gather(img, nimg, s.in_dim, s.hw, s.heads, P.KT2p, gbuf, st));

@@ -429,6 +429,12 @@ void img_pool_layout(float *scratch, int nimg, int in_dim, int EW, float **Gs, f
 int launch_img_pool(const void *img, int dt, const float *we, const float *qkv0, int nimg, int in_dim, int hw, int C,
                     int KT1, int EW, float scale, float *Gs, float *E, float *ML, hipStream_t st);
 
+// imgpool32.hip (r05): the same single pass for fp32 features -- a unit = (image, 128 pixels) = a PAIR of the 16-bit kernel's units,
+// results in the same (Gs, E, ML) layout
+bool img_pool32_supported(int dt, int in_dim, int hw, int heads);
+int launch_img_pool32(const float *img, const float *we, const float *qkv0, int nimg, int in_dim, int hw, int C, int KT1, int EW,
+                      float scale, float *Gs, float *E, float *ML, hipStream_t st);
+
 // ---- prep (prep.hip) ----------------------------------------------------------------------------
 int run_prepare(const PtxShape &s, const PtxWeights &w, float *prep, hipStream_t st);
 

@@ -514,6 +514,9 @@ def test_returned_transforms_are_differentiable_in_the_one_node_step(monkeypatch
 
     def run(one_node, with_outputs):
         monkeypatch.setattr(T, "_ONE_NODE", one_node)
+        # the reference evaluation is the per-operator graph on ONE stream (the engine's own ordering, nothing to race with); the
+        # graph's side-stream form is held to run-to-run determinism by scratch/train_race_stress.py
+        monkeypatch.setattr(T, "_SIDE_STREAM", one_node)
         m = copy.deepcopy(m0).cuda().train()
         tx = t(text).requires_grad_(True)
         outs, tf = m([t(p) for p in pts], {"text_feats": tx, "text_token_mask": t(mask)}, t(img), return_transforms=True)
