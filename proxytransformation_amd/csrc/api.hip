@@ -149,6 +149,33 @@ PrepLayout prep_layout(const PtxShape &s)
     return P;
 }
 
+// ---- the per-shape layout decisions of ptx_forward (described there): pure functions of the shape and of PTX_LAYOUT, so that the
+// workspace can leave out what a layout never touches
+struct LayoutForce { int v[4]; };
+static LayoutForce layout_force()
+{
+    LayoutForce f{{-1, -1, -1, -1}};
+    if (const char *e = getenv("PTX_LAYOUT"))
+        for (int i = 0; i < 4 && e[i] != '\0'; ++i) f.v[i] = e[i] == '0' ? 0 : (e[i] == '1' ? 1 : -1);
+    return f;
+}
+struct LayoutChoice { double est_cluster, est_image; bool cluster_on_caller, img_late, early; LayoutForce lf; };
+static LayoutChoice choose_layout(const PtxShape &S)
+{
+    static const LayoutForce lf = layout_force();
+    LayoutChoice c{};
+    c.lf = lf;
+    const int B = S.B, Kd = S.Mt - S.Mk;
+    const double img_mb = (double)B * S.V * S.in_dim * S.hw * (S.img_dtype == 0 ? 4.0 : 2.0) * 1e-6;
+    c.est_cluster = 80.0 + 0.42 * Kd;
+    c.est_image = 40.0 + (S.img_dtype == 0 ? 0.98 : 0.78) * img_mb;
+    c.cluster_on_caller = lf.v[0] >= 0 ? lf.v[0] != 0 : c.est_cluster > c.est_image + 60.0;
+    c.img_late = c.cluster_on_caller && (lf.v[2] >= 0 ? lf.v[2] != 0 : c.est_image + 60.0 < 0.8 * c.est_cluster);
+    const double est_all = 1.8 * 12.0 * (double)B * S.Mt * S.C * S.C / 70e6;        // us (cfg4 at 6 scenes: 147; measured ~150)
+    c.early = c.cluster_on_caller && (lf.v[1] >= 0 ? lf.v[1] != 0 : (Kd >= 128 && (long)B * S.Mk >= 1024 && est_all < 3.0 * 0.42 * Kd));
+    return c;
+}
+
 WsLayout ws_layout(const PtxShape &s)
 {
     WsLayout L{};
@@ -178,17 +205,29 @@ WsLayout ws_layout(const PtxShape &s)
     L.tile_counts = take(B * (size_t)cdiv(s.N, kTilePts) * 4);
     L.point_proxy = take(R * C * 4);
     for (int i = 0; i < 2; ++i) L.x_in[i] = take(R * C * 4);
-    L.pp_all = take(B * Mt * C * 4); L.order_e = take(B * Mt * 4);
-    for (int i = 0; i < 2; ++i) { L.xln_all[i] = take(B * Mt * C * 4); L.g_all[i] = take(B * Mt * 3 * C * 4); }
+    // the early-proxy tables (all Mt clusters through the slot network, LayerNorm1 and qkv): only where that layout can be chosen --
+    // for ANY storage type of the features (the choice depends on it, the module's workspace key does not): 3.3 of 28 MB per scene
+    // at the benchmark shape, where the image chain owns the caller's stream
+    bool may_early = false;
+    for (int dt = 0; dt < 3; ++dt) { PtxShape t = s; t.img_dtype = dt; may_early = may_early || choose_layout(t).early; }
+    const size_t em = may_early ? 1 : 0;
+    L.pp_all = take(em * B * Mt * C * 4); L.order_e = take(em * B * Mt * 4);
+    for (int i = 0; i < 2; ++i) { L.xln_all[i] = take(em * B * Mt * C * 4); L.g_all[i] = take(em * B * Mt * 3 * C * 4); }
     L.fm = take(nimg * s.in_dim * 4); L.qkv0 = take(nimg * 3 * C * 4);
     L.we = take(nimg * s.heads * (size_t)P.KT1 * 4);
-    L.pool = take(img_pool_bytes((int)nimg, s.in_dim, P.KT2p - s.in_dim));
-    L.gbuf = take(nimg * s.heads * (size_t)P.KT2p * 4);
+    // the pooling kernels' partials (k_img_pool / k_img_pool32) and the generic score / gather kernels' [g_h | a_h] rows are never
+    // both in use for a shape: ONE region (r05: 4.6 of 35 MB per scene at the benchmark shape)
+    {
+        const size_t pool_b = img_pool_bytes((int)nimg, s.in_dim, P.KT2p - s.in_dim), gbuf_b = nimg * s.heads * (size_t)P.KT2p * 4;
+        L.pool = L.gbuf = take(pool_b > gbuf_b ? pool_b : gbuf_b);
+    }
     L.obuf = take(nimg * C * 4); L.cbuf = take(nimg * C * 4); L.img_proxy = take(nimg * C * 4);
     for (int i = 0; i < 2; ++i) {
         L.qkv[i] = take(R * 3 * C * 4); L.pt[i] = take(B * Lp * C * 4); L.pv[i] = take(B * Lp * C * 4);
-        L.ao[i] = take(R * C * 4); L.x1[i] = take(R * C * 4); L.xn2[i] = take(R * C * 4);
-        L.hbuf[i] = take(R * (size_t)s.hidden * 4); L.x2[i] = take(R * C * 4); L.guide[i] = take(R * C * 4);
+        L.ao[i] = take(R * C * 4); L.x1[i] = take(R * C * 4); L.xn2[i] = take(0);          // (xn2: unused since the LayerNorm folds of r02)
+        // (the hidden activations leave the CU only where the fused Mlp launch does not apply: 1 MB per scene and branch otherwise unused)
+        L.hbuf[i] = take(mlp_fused_supported(s.C, s.hidden, (int)R, 0) ? 0 : R * (size_t)s.hidden * 4);
+        L.x2[i] = take(R * C * 4); L.guide[i] = take(R * C * 4);
         L.head[i] = take(R * 9 * 4);
         L.lnp_x1[i] = take(R * (C / 32) * 2 * 4);
     }
@@ -232,15 +271,6 @@ static bool env_on(const char *name)
 {
     const char *v = getenv(name);
     return v != nullptr && v[0] != '\0' && !(v[0] == '0' && v[1] == '\0');
-}
-// PTX_LAYOUT: see ptx_forward (four characters, '0' / '1' force one of the per-shape layout decisions, anything else = the rule)
-struct LayoutForce { int v[4]; };
-static LayoutForce layout_force()
-{
-    LayoutForce f{{-1, -1, -1, -1}};
-    if (const char *e = getenv("PTX_LAYOUT"))
-        for (int i = 0; i < 4 && e[i] != '\0'; ++i) f.v[i] = e[i] == '0' ? 0 : (e[i] == '1' ? 1 : -1);
-    return f;
 }
 static bool gates_allowed()
 {
@@ -1120,13 +1150,13 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     // +8 % (the r04 rule, est_cluster > est_image, put 1 and 2 scenes on the other side), cfg2 fp32 features at 1 / 2 / 3 scenes +6 / +8 /
     // +6 %; cfg4 (519 picks) at 6 / 8 / 10 / 12 / 16 scenes clustering chain +13 / +10 / +1 / -2 / -11 %; cfg1 at 1 / 4 scenes +10 / +9 %;
     // cfg5 (1 844 picks) at 1 / 8 scenes +2 / +10 %.  The margin of 60 us decides every one of these correctly except cfg4 at 10 scenes (1 %).
-    const double img_mb = (double)B * S.V * S.in_dim * S.hw * (S.img_dtype == 0 ? 4.0 : 2.0) * 1e-6;
-    const double est_cluster = 80.0 + 0.42 * Kd, est_image = 40.0 + (S.img_dtype == 0 ? 0.98 : 0.78) * img_mb;
+    const LayoutChoice lc = choose_layout(S);
+    const double est_cluster = lc.est_cluster, est_image = lc.est_image;
     // PTX_LAYOUT (the ONE layout override, for A/B runs and the parity test that drives every arrangement): four characters,
     // '0' / '1' force, anything else leaves the rule -- [0] clustering chain on the caller's stream, [1] early proxies,
     // [2] image chain forked behind k_cluster, [3] slot tags behind a gate on the third stream.  E.g. PTX_LAYOUT=1-0-
-    static const LayoutForce lf = layout_force();
-    const bool cluster_on_caller = lf.v[0] >= 0 ? lf.v[0] != 0 : est_cluster > est_image + 60.0;
+    const LayoutForce &lf = lc.lf;
+    const bool cluster_on_caller = lc.cluster_on_caller;
     hipStream_t cs = cluster_on_caller ? st : side->st, is = cluster_on_caller ? side->st : st;
     const bool gated = side->gates_on && !cluster_on_caller && !capturing;        // gates instead of events (see k_gate)
     // r04: where the clustering chain is the long one AND the image chain has the slack for it, the image chain forks BEHIND k_cluster
@@ -1134,7 +1164,7 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     // cfg4 / 6 scenes: 13.04k -> 13.26k scenes/s, one scene +1 %, 3 scenes +0.8 %; 8 scenes, where the image chain is nearly as
     // long as the sampling, -0.9 %: hence the slack rule; profiles/r04_early_proxies_ab.txt; r05, the same shape in the room regime:
     // 13.9k -> 14.3k, profiles/r05_room_layout_ab.txt).
-    const bool img_late = cluster_on_caller && (lf.v[2] >= 0 ? lf.v[2] != 0 : est_image + 60.0 < 0.8 * est_cluster);
+    const bool img_late = lc.img_late;
     if (!gated && !img_late) {
         PTX_HIP(hipEventRecord(side->fork, st));
         PTX_HIP(hipStreamWaitEvent(side->st, side->fork, 0));
@@ -1180,9 +1210,7 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     int32_t *idx2 = at<int32_t>(ws, L.idx2), *pad_count = at<int32_t>(ws, L.pad_count);
     if (!bbox_in) PTX_TIMED(KID_MINMAX, cs, launch_minmax(sp, B, S.N, mm_ws, cs));
     // (the `early` decision, needed here for k_cluster's completion event; its description is below)
-    const double est_all = 1.8 * 12.0 * (double)B * S.Mt * S.C * S.C / 70e6;                     // us (cfg4 at 6 scenes: 147; measured ~150)
-    const bool early = cluster_on_caller && (lf.v[1] >= 0 ? lf.v[1] != 0
-                                                          : (Kd >= 128 && (long)B * S.Mk >= 1024 && est_all < 3.0 * 0.42 * Kd));
+    const bool early = lc.early;
     // r04: the streams that fork off behind the clusters (the late image chain, the early proxies) wait for k_cluster's own
     // completion signal instead of for one event record each on the caller's stream -- two packets (~5 us each) between k_cluster and
     // k_select on the chain the step waits for
