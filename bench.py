@@ -48,7 +48,7 @@ from proxytransformation_amd.synth import CONFIGS, fill_state_dict, make_scene_b
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix (v_mfma_f32_32x32x2_f32), 256 CUs
-PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
 
 
 def so_sha16():
