@@ -114,8 +114,8 @@ int validate_shape(const PtxShape &s)
                 "head_dim 32 or 64", s.heads, s.C);
     PTX_REQUIRE(s.Mt <= 4096, "shape: Mt=%d clusters after the empty-drop; the farthest point sampling holds at most 4096", s.Mt);
     PTX_REQUIRE(s.hidden >= 4 && s.hidden % 4 == 0, "shape: hidden=%d", s.hidden);
-    PTX_REQUIRE(s.in_dim >= 64 && s.in_dim % 64 == 0 && s.in_dim <= 512,
-                "shape: in_dim=%d must be a multiple of 64, at most 512", s.in_dim);
+    PTX_REQUIRE(s.in_dim >= 64 && s.in_dim % 64 == 0 && s.in_dim <= 2048,
+                "shape: in_dim=%d must be a multiple of 64, at most 2048", s.in_dim);
     PTX_REQUIRE(s.L >= 1 && s.V >= 1, "shape: L=%d V=%d", s.L, s.V);
     PTX_REQUIRE(s.img_dtype >= 0 && s.img_dtype <= 2, "shape: img_dtype=%d (0 fp32, 1 bf16, 2 fp16)", s.img_dtype);
     if (s.img_dtype == 0) PTX_REQUIRE(s.hw >= 4 && s.hw <= 256, "shape: H*W=%d (fp32 image features: 4..256 pixels)", s.hw);

