@@ -31,6 +31,31 @@ def test_library_exports_every_declared_symbol():
     assert lib.ptx_abi_version() == _abi.ABI_VERSION
 
 
+def test_the_switchboard_of_the_product_library_is_four_variables():
+    """VERDICT r04 #7 (no GPU needed): the product library reads exactly four environment variables -- each driven by a GPU test
+    (tests/test_gpu_host.py) -- and carries no fault-injection hook; the hooks exist in the test-hooks build only, which in turn
+    exports the same C ABI."""
+    from proxytransformation_amd import _abi
+    here = os.path.join(ROOT, "proxytransformation_amd")
+    blob = open(os.path.join(here, "libproxyt_hip.so"), "rb").read()
+    names = sorted(set(m.decode() for m in re.findall(rb"PTX_[A-Z][A-Z_0-9]+", blob)))
+    assert names == ["PTX_GATE", "PTX_GATE_TIMEOUT_MS", "PTX_LAYOUT", "PTX_POOL_NT"], names
+    hooks = os.path.join(here, "libproxyt_hip_testhooks.so")
+    assert os.path.exists(hooks), "make -C proxytransformation_amd/csrc builds both libraries"
+    hblob = open(hooks, "rb").read()
+    assert b"PTX_GATE_FAULT" in hblob and b"PTX_GATE_TRAP" in hblob
+    h = ctypes.CDLL(hooks)
+    for sname in _abi.SIGNATURES:
+        getattr(h, sname)
+    # the source agrees: getenv appears in the library only for these (and the two hooks under PTX_TEST_HOOKS)
+    src = ""
+    for fn in sorted(os.listdir(os.path.join(here, "csrc"))):
+        if fn.endswith((".hip", ".h")):
+            src += open(os.path.join(here, "csrc", fn)).read()
+    read = sorted(set(re.findall(r'(?:getenv|env_on)\("(PTX_[A-Z_0-9]+)"\)', src)))
+    assert read == ["PTX_GATE", "PTX_GATE_FAULT", "PTX_GATE_TIMEOUT_MS", "PTX_GATE_TRAP", "PTX_LAYOUT", "PTX_POOL_NT"], read
+
+
 def test_struct_layout_matches_header():
     """ctypes mirrors must have the size the C compiler gives the header's structs."""
     from proxytransformation_amd import _abi
