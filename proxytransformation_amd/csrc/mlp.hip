@@ -305,7 +305,11 @@ int launch_mlp(const MlpBatch &mb, hipStream_t st)
         rmax = p.R;
     }
     const dim3 grid(cdiv(rmax, kMlpRows), 4, mb.n), block(kMlpWaves * 64);
-    const bool lite = (long)grid.x * grid.y * grid.z > 768;     // r04 A/B: 512 work-groups -0.4 %, 1024 +3.8 %
+    // r04 A/B: 512 work-groups -0.4 %, 1024 +3.8 %.  r05: also where the one-per-CU form would run a second round that is less than
+    // ~60 % full (257 .. 400 work-groups: cfg2 at 5 / 6 scenes +1.6 / +1.1 %, cfg4 at 2 scenes +2.5 %; 448 and 512 work-groups: 0 / -0.5 %,
+    // profiles/r05_mlp_lite_mid_ab.txt)
+    const long wgs = (long)grid.x * grid.y * grid.z;
+    const bool lite = wgs > 768 || (wgs > 256 && wgs <= 400);
     constexpr int kLiteLds = 3 * kMlpPlane + 2 * 32 * 4;
 #define PTX_MLP_LAUNCH(NP_, LITE_, LDS_)                                                                                           \
     do {                                                                                                                         \
