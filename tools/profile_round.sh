@@ -32,6 +32,7 @@ python $R/tools/profile_digest.py "$O" "$TAG"
 # the headline line once more, now that the traffic digest of THIS build exists (bench.py reads profiles/<tag>_pmc_traffic.json)
 cp "$O/${TAG}_pmc_traffic.json" "$R/profiles/${TAG}_pmc_traffic.json"
 python $R/bench.py > "$O/bench.json" 2>> "$O/bench.err"
+python $R/bench.py --img-dtype f32 --no-cpu-baseline --no-passes > "$O/bench_f32.json" 2>> "$O/bench.err"
 for dt in bf16 f32; do
   python $R/tools/timeline.py "$(find "$O/stats_$dt" -name '*kernel_trace.csv' | head -1)" > "$O/${TAG}_timeline_$dt.txt" 2>/dev/null
 done
