@@ -192,12 +192,14 @@ def test_back_to_back_calls_do_not_wait_for_the_gpu():
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("side,V", [(13, 9), (12, 3), (11, 4), (16, 2)])
-def test_half_precision_features_at_other_feature_map_sizes(side, V, dtype):
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("side,V", [(13, 9), (12, 3), (14, 5), (11, 4), (16, 2)])
+def test_features_at_other_feature_map_sizes(side, V, dtype):
     """16-bit features take the single-pass pooling kernel when 128 < H*W <= 255 (two pixel tiles per image,
     the second one ragged: 169 = 128 + 41, 144 = 128 + 16; odd and even row lengths, image counts that are
-    not a multiple of the XCD count) and the three-pass kernels otherwise (121 and 256 pixels)."""
+    not a multiple of the XCD count) and the three-pass kernels otherwise (121 and 256 pixels).  fp32 features
+    take k_img_pool32 in the same window (two half-image units of 7 + 6, 6 + 6, 7 + 7 rows; 32-pixel tiles with
+    a ragged last one and the shifted load at the end of the tensor) and the three-pass kernels outside it."""
     from oracle import oracle
     from tests.gpu_util import t
     cfg = PreshapeConfig(f"s{side}", B=2, N=3000, grid_size=4, dynamic_drop_radio=0.5, L=5, V=V, seed_base=40 + side,
