@@ -41,6 +41,7 @@ _FUSED_ATTN = True       # the fused attention core of a block (ptx_train_attn_f
 _FUSED_BLOCK = True      # one ProxyBlock + trailing LayerNorm + head + BatchNorm1d as two C calls (ptx_train_block_fwd / _bwd)
 _FUSED_IMG = True        # AttentionPool2d on its folded form (ptx_train_imgpool_fwd / _bwd)
 _SIDE_STREAM = True      # the image branch on a side stream beside the index half
+_BLOCKS_APART = False    # one-node step: the image block on the side stream too, beside the text block (forward and backward)
 _ONE_NODE = True         # the float half as ONE autograd node (_TrainStep)
 _IMG_FIRST = True        # one-node step: the image branch enqueued in front of the clustering half (profiles/r04_train_ab.txt)
 _IMG_POS = 1             # per-operator graph: where the image branch is enqueued -- 0 first, 1 after the selection, 2 before the
@@ -1215,16 +1216,26 @@ class _TrainStep(torch.autograd.Function):
         L = text_feats.shape[1]
         tf2 = _c(text_feats.to(_F32)).view(B * L, C)
         cfg_t, par_t = _block_cfg(mod, mod.textformer[-1], mod.text_norm[-1], mod.text_trans, mod.text_trans_norm, B, Mk, L, seeds[0])
-        T["tb"] = _Ctx()
+        cfg_i, par_i = _block_cfg(mod, mod.imgformer[-1], mod.img_norm[-1], mod.img_trans, mod.img_trans_norm, B, Mk, V, seeds[1])
+        T["tb"], T["ib"] = _Ctx(), _Ctx()
+        apart = side is not None and _BLOCKS_APART
+        if apart:
+            # the image block follows its pooling pass on the side stream, beside the text block on the caller's stream: the two
+            # blocks share nothing but their input rows, and half of their kernels are too small to fill the chip alone
+            pp.record_stream(side)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                transform = _BlockFused.forward(T["ib"], pp, img_proxy, None, cfg_i, mod.img_trans_norm.running_mean,
+                                                mod.img_trans_norm.running_var, *par_i)
+            transform.record_stream(main)
         translate = _BlockFused.forward(T["tb"], pp, tf2, text_mask, cfg_t, mod.text_trans_norm.running_mean,
                                         mod.text_trans_norm.running_var, *par_t)
         if side is not None:
             img_proxy.record_stream(main)
             main.wait_stream(side)
-        cfg_i, par_i = _block_cfg(mod, mod.imgformer[-1], mod.img_norm[-1], mod.img_trans, mod.img_trans_norm, B, Mk, V, seeds[1])
-        T["ib"] = _Ctx()
-        transform = _BlockFused.forward(T["ib"], pp, img_proxy, None, cfg_i, mod.img_trans_norm.running_mean,
-                                        mod.img_trans_norm.running_var, *par_i)
+        if not apart:
+            transform = _BlockFused.forward(T["ib"], pp, img_proxy, None, cfg_i, mod.img_trans_norm.running_mean,
+                                            mod.img_trans_norm.running_var, *par_i)
         # ---- submanifold reshape + scatter + drop (PRE:459-467)
         pin[1].synchronize()
         n_keep = pin[0].tolist()
@@ -1243,7 +1254,10 @@ class _TrainStep(torch.autograd.Function):
                          ip=(mod.channel_mapper.weight, mod.channel_mapper.bias, ap.positional_embedding, ap.q_proj.weight,
                              ap.q_proj.bias, ap.k_proj.weight, ap.k_proj.bias, ap.v_proj.weight, ap.v_proj.bias, ap.c_proj.weight,
                              ap.c_proj.bias, mod.norm_img.weight, mod.norm_img.bias)))
-        return (*outs, kcenter, translate, transform)
+        # fresh aliases, NOT the objects the tape holds: a returned tensor gets this node as its grad_fn, and the node owns ctx ->
+        # tape -> that tensor -- a cycle through C++ that Python's collector cannot see (r05: every step's activations, 190 MiB at
+        # the training shape, stayed allocated for good)
+        return (*outs, kcenter.detach(), translate.detach(), transform.detach())
 
     @staticmethod
     def backward(ctx, *douts):
@@ -1268,20 +1282,41 @@ class _TrainStep(torch.autograd.Function):
             dtranslate = add_(_c(dtranslate), _c(g_tr.to(_F32)).view(dtranslate.shape))
         if g_tf is not None:
             dtransform = add_(_c(dtransform), _c(g_tf.to(_F32)).view(dtransform.shape))
-        r = _BlockFused.backward(T["ib"], dtransform)
-        dpp_i, dproxy_i = r[0], r[1]
-        put(P["ib"], r[6:])
-        # image branch on its side stream, overlapping the text block's backward below
-        if side is not None:
-            dproxy_i.record_stream(side)
+        apart = side is not None and _BLOCKS_APART
+        side_grads = []
+        if apart:
+            # image block AND image branch on the side stream, beside the text block's backward on the caller's stream
+            dtransform = _c(dtransform)
+            dtransform.record_stream(side)
             side.wait_stream(main)
+            with torch.cuda.stream(side):
+                r = _BlockFused.backward(T["ib"], dtransform)
+                dpp_i, dproxy_i = r[0], r[1]
+                put(P["ib"], r[6:])
+                side_grads += [g for g in r[6:] if g is not None]
+                dpp_ready = torch.cuda.Event()
+                dpp_ready.record(side)
+        else:
+            r = _BlockFused.backward(T["ib"], dtransform)
+            dpp_i, dproxy_i = r[0], r[1]
+            put(P["ib"], r[6:])
+            # image branch on its side stream, overlapping the text block's backward below
+            if side is not None:
+                dproxy_i.record_stream(side)
+                side.wait_stream(main)
         with torch.cuda.stream(side if side is not None else main):
             r3 = _ImgPool.backward(T["ip"], dproxy_i)          # (dimg, 9 grads, None, 4 tail grads, None)
             put(P["ip"], list(r3[1:10]) + list(r3[11:15]))
             dimg = r3[0]
-            side_grads = [g for g in r3 if g is not None]
-        r = _BlockFused.backward(T["tb"], dtranslate, dpp_i)           # dx = both blocks' gradients of the point proxies
-        dpp, dtf2 = r[0], r[1]
+            side_grads += [g for g in r3 if g is not None]
+        if apart:
+            r = _BlockFused.backward(T["tb"], dtranslate)
+            dpp_i.record_stream(main)
+            main.wait_event(dpp_ready)
+            dpp, dtf2 = add_(r[0], dpp_i), r[1]
+        else:
+            r = _BlockFused.backward(T["tb"], dtranslate, dpp_i)       # dx = both blocks' gradients of the point proxies
+            dpp, dtf2 = r[0], r[1]
         put(P["tb"], r[6:])
         r = _SlotNet.backward(T["enc"], dpp)
         put(P["enc"], r[2:6])
