@@ -257,6 +257,7 @@ class ProxyTransformationNormReverse(nn.Module):
         self._train_calls = 0
         self._train_checked = None
         self._train_live = None              # train mode: the parameters that receive a gradient (one-node step)
+        self._train_static = None            # train mode: sub-modules / parameter tuples of the one-node step (train._static)
         self._train_side = None              # train mode: side stream of the image branch, per device
         self._train_pin = None               # train mode: pinned words + event of the early count read-back, per batch size
         ProxyTransformationNormReverse._instances += 1
@@ -284,7 +285,7 @@ class ProxyTransformationNormReverse(nn.Module):
     # torch.save(model), EMA / SWA copies made after the first forward); a copy rebuilds them on its first call
     _HOST_CACHES = dict(_tensors=None, _slots=None, _lanes=None, _lin_t=None, _wkey=None, _wstruct=None, _prep=None,
                         _lin=None, _shapes=None, _graph_keepalive=None, _train_pin=None, _train_side=None, _train_live=None,
-                        _train_mods=None)
+                        _train_mods=None, _train_static=None)
 
     def __getstate__(self):
         state = self.__dict__.copy()
@@ -752,15 +753,17 @@ class ProxyTransformationNormReverse(nn.Module):
         # identity of every live parameter / buffer OBJECT, read from the owning dicts on every step (~10 us): a Parameter swapped in
         # without load_state_dict / .to() / train() -- a reparametrisation, convert_sync_batchnorm after the first step -- must not
         # keep receiving `grad None` through a stale gradient list, nor skip the layout / BatchNorm checks below
-        mod_ids = tuple([id(m) for m in self.modules()])          # a swapped sub-MODULE (convert_sync_batchnorm) owns new dicts
-        if getattr(self, "_train_mods", None) != mod_ids:
-            self._train_mods = mod_ids
+        # a swapped sub-MODULE (convert_sync_batchnorm) owns new dicts: every (owner's _modules dict, name, child) edge of the tree
+        # is compared by identity -- walking self.modules() itself cost 0.1 ms of a host-bound 2 ms step (r05)
+        edges = getattr(self, "_train_mods", None)
+        if edges is None or not all([d.get(k) is c for d, k, c in edges]):
+            self._train_mods = [(m._modules, k, c) for m in self.modules() for k, c in m._modules.items()]
             self.invalidate_weights()
         if self._slots is None:
             self._weights_key()
         live_ids = tuple([id(d[k]) for d, k in self._slots])
         if self._train_checked != (str(dev), live_ids):
-            self._train_live = None
+            self._train_live = self._train_static = None
             # layout of every parameter / buffer: once per (device, storage generation) -- invalidate_weights() (load_state_dict,
             # .to(), train() / eval()) asks for it again; walking the state_dict on every step cost 0.1 ms
             for name, t in self.state_dict(keep_vars=True).items():

@@ -41,7 +41,7 @@ _FUSED_ATTN = True       # the fused attention core of a block (ptx_train_attn_f
 _FUSED_BLOCK = True      # one ProxyBlock + trailing LayerNorm + head + BatchNorm1d as two C calls (ptx_train_block_fwd / _bwd)
 _FUSED_IMG = True        # AttentionPool2d on its folded form (ptx_train_imgpool_fwd / _bwd)
 _SIDE_STREAM = True      # the image branch on a side stream beside the index half
-_BLOCKS_APART = False    # one-node step: the image block on the side stream too, beside the text block (forward and backward)
+_BLOCKS_APART = True     # one-node step: the image block on the side stream too, beside the text block (forward and backward)
 _ONE_NODE = True         # the float half as ONE autograd node (_TrainStep)
 _IMG_FIRST = True        # one-node step: the image branch enqueued in front of the clustering half (profiles/r04_train_ab.txt)
 _IMG_POS = 1             # per-operator graph: where the image branch is enqueued -- 0 first, 1 after the selection, 2 before the
@@ -884,17 +884,49 @@ def _block_fused_ok(mod, blk, head, n, L):
             and mod.embed_dim <= 512 and blk.mlp.fc1.weight.shape[0] <= 2048)
 
 
-def _block_cfg(mod, blk, out_norm, head, head_bn, B, n, L, seeds):
-    """(cfg tuple, parameters in PTX_TB_* order) of one fused block call."""
+def _block_params(blk, out_norm, head, head_bn):
+    """The parameters of one fused block call in PTX_TB_* order."""
     a = blk.attn
-    cfg = (B, n, L, mod.embed_dim, blk.mlp.fc1.weight.shape[0], mod.num_heads, a.pc_bias.shape[2], head.weight.shape[0],
-           blk.norm1.eps, blk.norm2.eps, out_norm.eps, head_bn.eps, head_bn.momentum, float(mod.attn_drop_rate),
+    return (blk.norm1.weight, blk.norm1.bias, a.pb_bias, a.pc_bias, a.pr_bias, a.qkv.weight, a.qkv.bias, a.proxy_proj.weight,
+            a.proxy_proj.bias, a.proj.weight, a.proj.bias, blk.norm2.weight, blk.norm2.bias, blk.mlp.fc1.weight, blk.mlp.fc1.bias,
+            blk.mlp.fc2.weight, blk.mlp.fc2.bias, out_norm.weight, out_norm.bias, head.weight, head.bias, head_bn.weight,
+            head_bn.bias)
+
+
+def _block_cfg(mod, blk, out_norm, head, head_bn, B, n, L, seeds, mods=None, params=None):
+    """(cfg tuple, parameters in PTX_TB_* order) of one fused block call.  ``mods`` = (norm1, norm2) and ``params`` come from the
+    module's per-weights cache in the one-node step (_static); the scalars are read from their owners on every call."""
+    if params is None:
+        params = _block_params(blk, out_norm, head, head_bn)
+    n1, n2 = mods if mods is not None else (blk.norm1, blk.norm2)
+    cfg = (B, n, L, mod.embed_dim, params[13].shape[0], mod.num_heads, params[3].shape[2], params[19].shape[0],
+           n1.eps, n2.eps, out_norm.eps, head_bn.eps, head_bn.momentum, float(mod.attn_drop_rate),
            float(mod.drop_rate), float(mod._dpr_last(blk)), tuple(seeds), 1 if getattr(mod, "compute_dtype", "fp32") == "bf16" else 0)
-    params = (blk.norm1.weight, blk.norm1.bias, a.pb_bias, a.pc_bias, a.pr_bias, a.qkv.weight, a.qkv.bias, a.proxy_proj.weight,
-              a.proxy_proj.bias, a.proj.weight, a.proj.bias, blk.norm2.weight, blk.norm2.bias, blk.mlp.fc1.weight, blk.mlp.fc1.bias,
-              blk.mlp.fc2.weight, blk.mlp.fc2.bias, out_norm.weight, out_norm.bias, head.weight, head.bias, head_bn.weight,
-              head_bn.bias)
     return cfg, params
+
+
+def _static(mod):
+    """Sub-modules and parameter tuples of the one-node step, looked up once per weights generation (nn.Module.__getattr__ is
+    slow: ~250 look-ups per step were 3 % of a host-bound step).  Dropped together with the live-parameter list whenever a
+    Parameter / buffer / sub-module OBJECT changes (module._run_train), so swapped objects are seen; scalars (eps, momentum,
+    drop rates) are NOT cached."""
+    s = getattr(mod, "_train_static", None)
+    if s is None:
+        off, enc, ap = mod.get_deformable_cluster.get_offsets, mod.simple_encoder, mod.attn_pool2d
+        bn, ebn = off.mlp[1], enc.mlp[1]
+        tb, ib = mod.textformer[-1], mod.imgformer[-1]
+        tn, inn, tt, it, ttn, itn = mod.text_norm[-1], mod.img_norm[-1], mod.text_trans, mod.img_trans, mod.text_trans_norm, mod.img_trans_norm
+        s = mod._train_static = dict(
+            off=off, bn=bn, enc=enc, ebn=ebn, ap=ap, norm_img=mod.norm_img,
+            off_par=(off.mlp[0].weight, off.mlp[0].bias, bn.weight, bn.bias), off_run=(bn.running_mean, bn.running_var),
+            oh=off.channel_mapper.weight,
+            enc_par=(enc.mlp[0].weight, enc.mlp[0].bias, ebn.weight, ebn.bias), enc_run=(ebn.running_mean, ebn.running_var),
+            ip_par=(mod.channel_mapper.weight, mod.channel_mapper.bias, ap.positional_embedding, ap.q_proj.weight, ap.q_proj.bias,
+                    ap.k_proj.weight, ap.k_proj.bias, ap.v_proj.weight, ap.v_proj.bias, ap.c_proj.weight, ap.c_proj.bias,
+                    mod.norm_img.weight, mod.norm_img.bias),
+            tb=(tb, tn, tt, ttn, (tb.norm1, tb.norm2), _block_params(tb, tn, tt, ttn), (ttn.running_mean, ttn.running_var)),
+            ib=(ib, inn, it, itn, (ib.norm1, ib.norm2), _block_params(ib, inn, it, itn), (itn.running_mean, itn.running_var)))
+    return s
 
 
 def _block(mod, blk, out_norm, head, head_bn, xa, xb, proxy2d, mask_u8, B, n, L, seeds):
@@ -1136,7 +1168,8 @@ class _TrainStep(torch.autograd.Function):
         # beside the ball queries and the farthest point sampling (one work-group per scene for 0.2 ms: the chip is idle next to it)
         V = img_feat.shape[1]
         hw = mod.img_spacial_dim ** 2
-        ap = mod.attn_pool2d
+        S = _static(mod)
+        ip_par = S["ip_par"]
         img3 = _c(img_feat).view(B * V, mod.input_dim, hw)
         main = torch.cuda.current_stream(dev)
         side = _side_stream(mod, dev) if _SIDE_STREAM else None
@@ -1146,10 +1179,7 @@ class _TrainStep(torch.autograd.Function):
                 side.wait_stream(main)
             with torch.cuda.stream(side if side is not None else main):
                 T["ip"] = _Ctx((ctx.needs_input_grad[2],))
-                return _ImgPool.forward(T["ip"], img3, mod.channel_mapper.weight, mod.channel_mapper.bias, ap.positional_embedding,
-                                        ap.q_proj.weight, ap.q_proj.bias, ap.k_proj.weight, ap.k_proj.bias, ap.v_proj.weight,
-                                        ap.v_proj.bias, mod.num_heads, ap.c_proj.weight, ap.c_proj.bias, mod.norm_img.weight,
-                                        mod.norm_img.bias, mod.norm_img.eps)
+                return _ImgPool.forward(T["ip"], img3, *ip_par[:9], mod.num_heads, *ip_par[9:], S["norm_img"].eps)
         img_proxy = run_img() if _IMG_FIRST else None
         # ---- index half, part 1 + offset network (PRE:55-62)
         minmax = torch.empty((B, 2, 3), dtype=_F32, device=dev)
@@ -1161,13 +1191,11 @@ class _TrainStep(torch.autograd.Function):
         idx1 = torch.empty((B, M, K), **i32)
         cl1 = torch.empty((B, M, K, 3), dtype=_F32, device=dev)
         _ck(lib.ptx_ball_query(_p(c0), _p(pts), B, M, N, K, 3.0, _p(idx1), _p(cl1), None, st), "ptx_ball_query")
-        off = mod.get_deformable_cluster.get_offsets
-        bn = off.mlp[1]
+        bn = S["bn"]
         T["off"] = _Ctx((False,) * 11)
-        pooled = _SlotNet.forward(T["off"], c0.view(B * M, 3), cl1, off.mlp[0].weight, off.mlp[0].bias, bn.weight, bn.bias,
-                                  bn.running_mean, bn.running_var, bn.eps, bn.momentum, False)
+        pooled = _SlotNet.forward(T["off"], c0.view(B * M, 3), cl1, *S["off_par"], *S["off_run"], bn.eps, bn.momentum, False)
         T["oh"] = _Ctx()
-        centers = _OffsetHead.forward(T["oh"], pooled, off.channel_mapper.weight, c0, minmax, M, 4.0)
+        centers = _OffsetHead.forward(T["oh"], pooled, S["oh"], c0, minmax, M, 4.0)
         # ---- index half, part 2 (PRE:65, 352-420, 478-523)
         cdet = centers
         if mod._centers_override is not None:
@@ -1208,15 +1236,14 @@ class _TrainStep(torch.autograd.Function):
         # ---- float half (PRE:437-455)
         T["g"] = _Ctx()
         kcenter = _GatherRows.forward(T["g"], centers, src)
-        enc = mod.simple_encoder
-        ebn = enc.mlp[1]
+        ebn = S["ebn"]
         T["enc"] = _Ctx((True,) + (False,) * 10)
-        pp = _SlotNet.forward(T["enc"], kcenter, kcluster, enc.mlp[0].weight, enc.mlp[0].bias, ebn.weight, ebn.bias, ebn.running_mean,
-                              ebn.running_var, ebn.eps, ebn.momentum, True)
+        pp = _SlotNet.forward(T["enc"], kcenter, kcluster, *S["enc_par"], *S["enc_run"], ebn.eps, ebn.momentum, True)
         L = text_feats.shape[1]
         tf2 = _c(text_feats.to(_F32)).view(B * L, C)
-        cfg_t, par_t = _block_cfg(mod, mod.textformer[-1], mod.text_norm[-1], mod.text_trans, mod.text_trans_norm, B, Mk, L, seeds[0])
-        cfg_i, par_i = _block_cfg(mod, mod.imgformer[-1], mod.img_norm[-1], mod.img_trans, mod.img_trans_norm, B, Mk, V, seeds[1])
+        tbm, ibm = S["tb"], S["ib"]
+        cfg_t, par_t = _block_cfg(mod, *tbm[:4], B, Mk, L, seeds[0], tbm[4], tbm[5])
+        cfg_i, par_i = _block_cfg(mod, *ibm[:4], B, Mk, V, seeds[1], ibm[4], ibm[5])
         T["tb"], T["ib"] = _Ctx(), _Ctx()
         apart = side is not None and _BLOCKS_APART
         if apart:
@@ -1225,17 +1252,14 @@ class _TrainStep(torch.autograd.Function):
             pp.record_stream(side)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                transform = _BlockFused.forward(T["ib"], pp, img_proxy, None, cfg_i, mod.img_trans_norm.running_mean,
-                                                mod.img_trans_norm.running_var, *par_i)
+                transform = _BlockFused.forward(T["ib"], pp, img_proxy, None, cfg_i, *ibm[6], *par_i)
             transform.record_stream(main)
-        translate = _BlockFused.forward(T["tb"], pp, tf2, text_mask, cfg_t, mod.text_trans_norm.running_mean,
-                                        mod.text_trans_norm.running_var, *par_t)
+        translate = _BlockFused.forward(T["tb"], pp, tf2, text_mask, cfg_t, *tbm[6], *par_t)
         if side is not None:
             img_proxy.record_stream(main)
             main.wait_stream(side)
         if not apart:
-            transform = _BlockFused.forward(T["ib"], pp, img_proxy, None, cfg_i, mod.img_trans_norm.running_mean,
-                                            mod.img_trans_norm.running_var, *par_i)
+            transform = _BlockFused.forward(T["ib"], pp, img_proxy, None, cfg_i, *ibm[6], *par_i)
         # ---- submanifold reshape + scatter + drop (PRE:459-467)
         pin[1].synchronize()
         n_keep = pin[0].tolist()
@@ -1249,11 +1273,7 @@ class _TrainStep(torch.autograd.Function):
         ctx.out_like = [(o.shape, o.dtype) for o in outs]
         ctx.streams = (main, side)
         ctx.meta = (text_feats.shape, text_feats.dtype, img_feat.shape, [id(p) for p in params],
-                    dict(off=(off.mlp[0].weight, off.mlp[0].bias, bn.weight, bn.bias), oh=off.channel_mapper.weight,
-                         enc=(enc.mlp[0].weight, enc.mlp[0].bias, ebn.weight, ebn.bias), tb=par_t, ib=par_i,
-                         ip=(mod.channel_mapper.weight, mod.channel_mapper.bias, ap.positional_embedding, ap.q_proj.weight,
-                             ap.q_proj.bias, ap.k_proj.weight, ap.k_proj.bias, ap.v_proj.weight, ap.v_proj.bias, ap.c_proj.weight,
-                             ap.c_proj.bias, mod.norm_img.weight, mod.norm_img.bias)))
+                    dict(off=S["off_par"], oh=S["oh"], enc=S["enc_par"], tb=par_t, ib=par_i, ip=ip_par))
         # fresh aliases, NOT the objects the tape holds: a returned tensor gets this node as its grad_fn, and the node owns ctx ->
         # tape -> that tensor -- a cycle through C++ that Python's collector cannot see (r05: every step's activations, 190 MiB at
         # the training shape, stayed allocated for good)
@@ -1293,7 +1313,7 @@ class _TrainStep(torch.autograd.Function):
                 r = _BlockFused.backward(T["ib"], dtransform)
                 dpp_i, dproxy_i = r[0], r[1]
                 put(P["ib"], r[6:])
-                side_grads += [g for g in r[6:] if g is not None]
+                side_grads += [g for g in r[6:] if g is not None][:1]      # views of ONE allocation (_flat_grads): one record covers it
                 dpp_ready = torch.cuda.Event()
                 dpp_ready.record(side)
         else:

@@ -1,7 +1,7 @@
 """r05 A/B: the one-node training step with the image block on the side stream beside the text block (_BLOCKS_APART) vs both
 blocks on the caller's stream.  Interleaved rounds of 30 steps each at the reference's training shape (bench.py --train)."""
 import sys, time
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 from proxytransformation_amd import MODELS, train
 from proxytransformation_amd.synth import PreshapeConfig, fill_state_dict, make_scene_batch

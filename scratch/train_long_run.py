@@ -1,7 +1,7 @@
 """r05: does the training step stay at its speed over a long run?  N steps at the training shape, a line per 100 steps:
 ms/step, allocator state, python object count.  argv: steps [side 0/1] [apart 0/1] [one_node 0/1]"""
 import gc, sys, time
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 from proxytransformation_amd import MODELS, train
 from proxytransformation_amd.synth import PreshapeConfig, fill_state_dict, make_scene_batch
@@ -38,14 +38,28 @@ print(f"side={train._SIDE_STREAM} apart={train._BLOCKS_APART} one_node={train._O
 for _ in range(5):
     step()
 torch.cuda.synchronize()
+
+
+class TimedEvent(torch.cuda.Event):
+    waited = 0.0
+
+    def synchronize(self):
+        t = time.perf_counter()
+        super().synchronize()
+        TimedEvent.waited += time.perf_counter() - t
+
+
+for k, (buf, ev) in list(mod._train_pin.items()):
+    mod._train_pin[k] = (buf, TimedEvent())
 for blk in range(steps // 100):
     t0 = time.perf_counter()
+    TimedEvent.waited = 0.0
     for _ in range(100):
         step()
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     ms = torch.cuda.memory_stats()
-    print(f"steps {blk * 100:5d}+: {10 * (t2 - t0):7.3f} ms/step (host enqueue {10 * (t1 - t0):7.3f})  allocated {ms['allocated_bytes.all.current'] >> 20} MiB "
+    print(f"steps {blk * 100:5d}+: {10 * (t2 - t0):7.3f} ms/step (host {10 * (t1 - t0):7.3f}, of which waiting for the counts {10 * TimedEvent.waited:6.3f})  allocated {ms['allocated_bytes.all.current'] >> 20} MiB "
           f"reserved {ms['reserved_bytes.all.current'] >> 20} MiB  segments {ms['segment.all.current']}  live blocks {ms['allocation.all.current']} "
           f"inactive-split {ms['inactive_split.all.current']}  gos {len(gos)}  py objects {len(gc.get_objects())}", flush=True)

@@ -48,3 +48,11 @@ for one in (True, False):
                 if not torch.equal(r[k], base[k]):
                     bad[k] = bad.get(k, 0) + 1
         print(f"one_node={one} img_grad={ig}: 40 repeats, tensors that differed from the first run: {bad if bad else 'none'}", flush=True)
+# the two stream arrangements of the one-node step give the same bits
+T._BLOCKS_APART = True
+a = run(True, True)
+T._BLOCKS_APART = False
+b = run(True, True)
+T._BLOCKS_APART = True
+diff = [k for k in a if not torch.equal(a[k], b[k])]
+print("blocks apart vs serial, tensors that differ:", diff if diff else "none")

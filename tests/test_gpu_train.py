@@ -337,16 +337,22 @@ def test_training_step_matches_the_reference_capture():
         assert_close(buf.detach().cpu().numpy(), g["buf." + name], atol=1e-5, rtol=1e-5, what=name)
 
 
-@pytest.mark.parametrize("case", ["f32", "bf16_blocks3", "embed512_f16", "f32_graph", "f32_unfused", "heads4_f32", "embed512_heads16_f32"])
+@pytest.mark.parametrize("case", ["f32", "bf16_blocks3", "embed512_f16", "f32_graph", "f32_unfused", "heads4_f32", "embed512_heads16_f32",
+                                  "f32_blocks_serial", "f32_one_stream"])
 def test_training_step_matches_the_oracle_on_fresh_scenes(case, monkeypatch):
-    """The default path (the whole float half as one autograd node over the fused kernels) and its two fallbacks: the same
-    fused kernels chained as separate autograd nodes (f32_graph), and one launch per operator (f32_unfused: the path of shapes
-    outside the fused kernels' range)."""
+    """The default path (the whole float half as one autograd node over the fused kernels, the image block on the side stream
+    beside the text block) and its fallbacks: the same fused kernels chained as separate autograd nodes (f32_graph), one launch
+    per operator (f32_unfused: the path of shapes outside the fused kernels' range), the two blocks one after the other on the
+    caller's stream (f32_blocks_serial) and everything on one stream (f32_one_stream)."""
     from oracle import oracle
     from proxytransformation_amd import MODELS, train as T
     from tests.gpu_util import t
     if case == "f32_graph":
         monkeypatch.setattr(T, "_ONE_NODE", False)
+    if case == "f32_blocks_serial":
+        monkeypatch.setattr(T, "_BLOCKS_APART", False)
+    if case == "f32_one_stream":
+        monkeypatch.setattr(T, "_SIDE_STREAM", False)
     if case == "f32_unfused":
         for flag in ("_ONE_NODE", "_FUSED_BLOCK", "_FUSED_IMG", "_FUSED_ATTN"):
             monkeypatch.setattr(T, flag, False)
