@@ -157,7 +157,7 @@ def work_model(cfg, B, dt_bytes):
     return byts, flops
 
 
-def train_step_ms(device, steps=20):
+def train_step_ms(device, steps=60):
     """One training step (train-mode forward + backward through every live parameter, text_feats and img_feat) at the
     reference's training shape -- CFG:41, 108, 145: 6 scenes per GPU, 100k points, gs = 12, 3 + 3 blocks, 20 views."""
     from proxytransformation_amd.synth import PreshapeConfig
@@ -189,7 +189,7 @@ def train_step_ms(device, steps=20):
         torch.autograd.backward(outs, gos[key])
 
     def timed(scalar_loss):
-        for _ in range(3):
+        for _ in range(10):             # the allocator's per-stream pools settle within the first few steps
             step(scalar_loss)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
