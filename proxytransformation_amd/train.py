@@ -1161,7 +1161,8 @@ class _TrainStep(torch.autograd.Function):
         M, K, Mt, Mk, C = mod.num_cluster, mod.num_sub, shape.Mt, shape.Mk, mod.embed_dim
         Kd = Mt - Mk
         i32 = dict(dtype=torch.int32, device=dev)
-        pts = torch.stack([p.detach().to(_F32) for p in points]).contiguous()          # PRE:426-427
+        # PRE:426-427 (no graph is recorded inside a Function's forward: no detach; _check_inputs has already looked at the dtypes)
+        pts = torch.stack(points) if all([p.dtype == _F32 for p in points]) else torch.stack([p.to(_F32) for p in points])
         seeds = st8["seeds"]
         T = {}                                                        # the tape: one context per node body
         # ---- image branch on the side stream (PRE:449-450): it needs nothing from the clustering half, so it is enqueued FIRST and runs
@@ -1272,7 +1273,9 @@ class _TrainStep(torch.autograd.Function):
         ctx.set_materialize_grads(False)                # unused outputs (normally the three transforms) arrive as None, not as zero fills
         ctx.out_like = [(o.shape, o.dtype) for o in outs]
         ctx.streams = (main, side)
-        ctx.meta = (text_feats.shape, text_feats.dtype, img_feat.shape, [id(p) for p in params],
+        if S.get("pids_of") is not mod._train_live or len(S["pids"]) != len(params):     # `params` IS mod._train_live (forward_train)
+            S["pids_of"], S["pids"] = mod._train_live, [id(p) for p in params]
+        ctx.meta = (text_feats.shape, text_feats.dtype, img_feat.shape, S["pids"],
                     dict(off=S["off_par"], oh=S["oh"], enc=S["enc_par"], tb=par_t, ib=par_i, ip=ip_par))
         # fresh aliases, NOT the objects the tape holds: a returned tensor gets this node as its grad_fn, and the node owns ctx ->
         # tape -> that tensor -- a cycle through C++ that Python's collector cannot see (r05: every step's activations, 190 MiB at

@@ -1,7 +1,7 @@
 """r05: does the training step stay at its speed over a long run?  N steps at the training shape, a line per 100 steps:
 ms/step, allocator state, python object count.  argv: steps [side 0/1] [apart 0/1] [one_node 0/1]"""
 import gc, sys, time
-import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import os; sys.path.insert(0, os.environ.get("PTX_PKG_ROOT") or os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 from proxytransformation_amd import MODELS, train
 from proxytransformation_amd.synth import PreshapeConfig, fill_state_dict, make_scene_batch
@@ -51,15 +51,30 @@ class TimedEvent(torch.cuda.Event):
 
 for k, (buf, ev) in list(mod._train_pin.items()):
     mod._train_pin[k] = (buf, TimedEvent())
+GC = {"t": 0.0, "n": [0, 0, 0], "t0": 0.0}
+
+
+def _gc_cb(phase, info):
+    if phase == "start":
+        GC["t0"] = time.perf_counter()
+    else:
+        GC["t"] += time.perf_counter() - GC["t0"]
+        GC["n"][info["generation"]] += 1
+
+
+gc.callbacks.append(_gc_cb)
+if os.environ.get("GC_FREEZE"):
+    gc.collect(); gc.freeze()
 for blk in range(steps // 100):
     t0 = time.perf_counter()
     TimedEvent.waited = 0.0
+    GC["t"], GC["n"] = 0.0, [0, 0, 0]
     for _ in range(100):
         step()
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     ms = torch.cuda.memory_stats()
-    print(f"steps {blk * 100:5d}+: {10 * (t2 - t0):7.3f} ms/step (host {10 * (t1 - t0):7.3f}, of which waiting for the counts {10 * TimedEvent.waited:6.3f})  allocated {ms['allocated_bytes.all.current'] >> 20} MiB "
+    print(f"steps {blk * 100:5d}+: {10 * (t2 - t0):7.3f} ms/step (host {10 * (t1 - t0):7.3f}, of which waiting for the counts {10 * TimedEvent.waited:6.3f}, in the collector {10 * GC['t']:6.3f}: {GC['n']} runs)  allocated {ms['allocated_bytes.all.current'] >> 20} MiB "
           f"reserved {ms['reserved_bytes.all.current'] >> 20} MiB  segments {ms['segment.all.current']}  live blocks {ms['allocation.all.current']} "
           f"inactive-split {ms['inactive_split.all.current']}  gos {len(gos)}  py objects {len(gc.get_objects())}", flush=True)
