@@ -115,12 +115,14 @@ __global__ __launch_bounds__(512) void k_ti_pool(TiPool a)
 #pragma unroll
         for (int h = 0; h < 8; ++h) acc[h] = 0.0f;
         if (p < hw) {
-            for (int c = c0; c < c1; c += 8) {
-                float xv[8];
+            // 16 rows in flight per thread: with one work-group per image on half of the CUs this pass waits for memory, not for issue
+            // slots (r05: 8 in flight = 16 KB per CU made the two passes of this kernel 90-100 us for 55 MB)
+            for (int c = c0; c < c1; c += 16) {
+                float xv[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) xv[u] = ti_load<DT>(a.x, xbase + (size_t)min(c + u, c1 - 1) * hw + p);
+                for (int u = 0; u < 16; ++u) xv[u] = ti_load<DT>(a.x, xbase + (size_t)min(c + u, c1 - 1) * hw + p);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < 16; ++u) {
                     if (c + u < c1) {
                         const float4 v0 = *reinterpret_cast<const float4 *>(&Vt[(c + u) * 8]);
                         const float4 v1 = *reinterpret_cast<const float4 *>(&Vt[(c + u) * 8 + 4]);
@@ -172,27 +174,52 @@ __global__ __launch_bounds__(512) void k_ti_pool(TiPool a)
         }
     }
     __syncthreads();
-    // pooling: wave w owns channels w, w + 8, ...; lanes own pixels lane + 64 s
+    // pooling: wave w owns channels 4 w .. 4 w + 3, then + 32, ...; lanes own pixels lane + 64 s.  Four channels per trip = 16 loads
+    // in flight per wave, and their 4 x 8 per-lane partial sums are reduced TOGETHER: a halving butterfly (each exchange keeps half of
+    // the values: 16 + 8 + 4 + 2 + 1 + 1 = 32 lane exchanges instead of 32 x 6) that leaves value (lane >> 1) complete in both lanes
+    // of a pair; pairing order = wave_sum's (32, 16, 8, 4, 2, 1)
     {
+        constexpr int UN = 4;
         float wt[kTiSlots][8];
 #pragma unroll
         for (int s = 0; s < kTiSlots; ++s)
 #pragma unroll
             for (int h = 0; h < 8; ++h) { const int p = lane + 64 * s; wt[s][h] = p < hw ? Wl[h * T + 1 + p] : 0.0f; }
-        for (int c = wv; c < Cin; c += 8) {
-            float xv[kTiSlots];
+        for (int c = wv * UN; c < Cin; c += 8 * UN) {
+            float xv[UN][kTiSlots];
 #pragma unroll
-            for (int s = 0; s < kTiSlots; ++s) { const int p = lane + 64 * s; xv[s] = ti_load<DT>(a.x, xbase + (size_t)c * hw + min(p, hw - 1)); }
-            float mine = 0.0f;
+            for (int u = 0; u < UN; ++u)
 #pragma unroll
-            for (int h = 0; h < 8; ++h) {
-                float s = 0.0f;
+                for (int s = 0; s < kTiSlots; ++s) {
+                    const int p = lane + 64 * s;
+                    xv[u][s] = ti_load<DT>(a.x, xbase + (size_t)min(c + u, Cin - 1) * hw + min(p, hw - 1));
+                }
+            float v[UN * 8];
 #pragma unroll
-                for (int sl = 0; sl < kTiSlots; ++sl) s = fmaf(wt[sl][h], xv[sl], s);
-                s = wave_sum(s);
-                if (lane == h) mine = s;
+            for (int u = 0; u < UN; ++u)
+#pragma unroll
+                for (int h = 0; h < 8; ++h) {
+                    float s = 0.0f;
+#pragma unroll
+                    for (int sl = 0; sl < kTiSlots; ++sl) s = fmaf(wt[sl][h], xv[u][sl], s);
+                    v[u * 8 + h] = s;
+                }
+            // (written out step by step: with the step count as a loop variable the compiler indexes v[] dynamically -- 2 000 compare /
+            // select instructions per trip)
+#define PTX_TI_BFLY(n_, bit_)                                                                        \
+            {                                                                                        \
+                const bool up = (lane & (bit_)) != 0;                                                \
+                _Pragma("unroll") for (int i = 0; i < (n_); ++i) {                                   \
+                    const float send = up ? v[i] : v[i + (n_)], keep = up ? v[i + (n_)] : v[i];      \
+                    v[i] = keep + __shfl_xor(send, (bit_));                                          \
+                }                                                                                    \
             }
-            if (lane < 8) a.pooled[((size_t)img * 8 + lane) * Cin + c] = mine;
+            static_assert(UN == 4, "the exchange steps below are written for 32 values");
+            PTX_TI_BFLY(16, 32) PTX_TI_BFLY(8, 16) PTX_TI_BFLY(4, 8) PTX_TI_BFLY(2, 4) PTX_TI_BFLY(1, 2)
+#undef PTX_TI_BFLY
+            const float tot = v[0] + __shfl_xor(v[0], 1);
+            const int idx = lane >> 1, u = idx >> 3, h = idx & 7;
+            if ((lane & 1) == 0 && c + u < Cin) a.pooled[((size_t)img * 8 + h) * Cin + c + u] = tot;
         }
     }
 }

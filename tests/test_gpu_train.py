@@ -338,7 +338,7 @@ def test_training_step_matches_the_reference_capture():
 
 
 @pytest.mark.parametrize("case", ["f32", "bf16_blocks3", "embed512_f16", "f32_graph", "f32_unfused", "heads4_f32", "embed512_heads16_f32",
-                                  "f32_blocks_serial", "f32_one_stream"])
+                                  "f32_blocks_serial", "f32_one_stream", "in128_side13_f32", "in1024_side12_bf16"])
 def test_training_step_matches_the_oracle_on_fresh_scenes(case, monkeypatch):
     """The default path (the whole float half as one autograd node over the fused kernels, the image block on the side stream
     beside the text block) and its fallbacks: the same fused kernels chained as separate autograd nodes (f32_graph), one launch
@@ -361,6 +361,12 @@ def test_training_step_matches_the_oracle_on_fresh_scenes(case, monkeypatch):
     elif case == "embed512_heads16_f32":
         cfg, dt = PreshapeConfig("tr16h", B=2, N=2500, grid_size=4, dynamic_drop_radio=0.5, L=7, V=3, embed_dim=512, num_heads=16,
                                  seed_base=8700), torch.float32
+    elif case == "in128_side13_f32":   # r05: other input widths / feature-map sizes through the training image pool (k_ti_pool's trips of
+        cfg, dt = PreshapeConfig("tri128", B=2, N=3000, grid_size=4, dynamic_drop_radio=0.5, L=6, V=3, input_dim=128,    # 16 + 4 channels)
+                                 img_spacial_dim=13, seed_base=8750), torch.float32
+    elif case == "in1024_side12_bf16":
+        cfg, dt = PreshapeConfig("tri1024", B=2, N=3000, grid_size=4, dynamic_drop_radio=0.5, L=6, V=3, input_dim=1024,
+                                 img_spacial_dim=12, seed_base=8760), torch.bfloat16
     elif case.startswith("f32"):
         cfg, dt = PreshapeConfig("tr1", B=3, N=5000, grid_size=5, dynamic_drop_radio=0.6, L=9, V=4, seed_base=8100), torch.float32
     elif case == "embed512_f16":      # the cfg5 generalisation (512-wide tokens, head_dim 64, 23 x 23 bias grid cropped)
