@@ -526,29 +526,30 @@ def main():
             extras["bf16c_err"] = max(float((a - b).abs().max()) if a.shape == b.shape else float("inf")
                                       for a, b in zip(got, ref_out))
             mod.compute_dtype = "fp32"
-            # the same step as a captured HIP graph (module.forward_padded: no host wait, padded outputs + device counts), one
-            # graph per input set, replayed back to back: what a serving loop that does not need the lengths on the host gets
+            # the same step as a captured HIP graph (module.forward_padded: no host wait, padded outputs + device counts): ONE graph
+            # holding one forward per input set, replayed back to back -- what a serving loop that does not need the lengths on the
+            # host gets.  (r05: one graph PER input set replayed in rotation, the r04 form of this measurement, pays ~0.15 ms per
+            # switch of graph executable on this stack and read 0.36-0.39 ms per forward: profiles/r05_graph_replay_forms.txt)
             try:
                 gs = torch.cuda.Stream()
-                graphs = []
+                nset = len(inputs.sets)
                 with torch.cuda.stream(gs):
-                    for j in range(len(inputs.sets)):
+                    for j in range(nset):
                         mod.forward_padded(*inputs.args(j))
                 torch.cuda.synchronize()
-                for j in range(len(inputs.sets)):
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=gs):
-                        res = mod.forward_padded(*inputs.args(j))
-                    graphs.append((g, res))
-                for i in range(6):
-                    graphs[i % len(graphs)][0].replay()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=gs):
+                    res = [mod.forward_padded(*inputs.args(j)) for j in range(nset)]
+                for i in range(4):
+                    g.replay()
                 barrier()
                 t0g = time.perf_counter()
-                for i in range(steps2):
-                    graphs[i % len(graphs)][0].replay()
+                nrep = max(10, args.steps // nset)              # as many forwards as one timed block of the eager value
+                for i in range(nrep):
+                    g.replay()
                 barrier()
-                extras["graph"] = (time.perf_counter() - t0g) / steps2
-                del graphs
+                extras["graph"] = (time.perf_counter() - t0g) / (nrep * nset)
+                del g, res
             except Exception as e:                              # never sinks the headline
                 extras["graph_error"] = repr(e)
             # per-pass reports: single-rank runs only -- this block is rank 0's alone, so nothing in it may touch the process group
@@ -655,7 +656,7 @@ def main():
         if graph_step > 0:
             line["value_graph_replay"] = round(world * B / graph_step, 2)
             line["graph_replay"] = dict(ms_per_step=round(1e3 * graph_step, 4),
-                                        what="the same forward captured into a HIP graph (module.forward_padded: padded outputs + device "
+                                        what="one HIP graph holding one forward per input set (module.forward_padded: padded outputs + device "
                                              "counts, no host wait) and replayed back to back; not the headline value")
         elif "graph_error" in extras:
             line["graph_replay"] = dict(error=extras["graph_error"])
