@@ -206,7 +206,7 @@ int ptx_offset_net(const PtxShape *s, const PtxWeights *w, const void *prep,
  * order_override (B,Mt) int32 or NULL: test-only replay of a captured argsort.
  * Outputs: order (B,Mt), picks (B,Kd) FPS positions, keep (B,Mk) positions,
  * kcenter (B,Mk,3), kcluster (B,Mk,K,3), kidx (B,Mk,K), drop_idx (B,Kd*K);
- * tag (B,N) uint32 must be zero on entry: low 31 bits <- 1 + last (m,k) slot that owns the
+ * tag (B,N) uint32 (every word is written; since r05 the buffer need not be cleared): low 31 bits <- 1 + last (m,k) slot that owns the
  * point (pt_replace's last-writer rule, PRE:478-495), bit 31 <- point is dropped
  * (remove_points_by_index, PRE:516-523). */
 int ptx_select_clusters(const PtxShape *s, const int32_t *idx, const float *centers,

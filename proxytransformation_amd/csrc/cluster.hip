@@ -840,7 +840,12 @@ int launch_select(const PtxShape &s, const int32_t *idx, const float *centers, c
                   int32_t *drop_idx, uint32_t *tag, hipStream_t st)
 {
     PTX_TRY(launch_select_order(s, centers, pad_count, order_override, order, picks, keep, kcenter, nullptr, nullptr, st, true, nullptr));
-    return launch_select_slots(s, idx, cluster, order, picks, keep, kcluster, kidx, drop_idx, tag, st);
+    // r05: the gathers chip-wide without the tag atomics (~50k device-scope atomics per scene: 72 us of the training step's
+    // forward at 6 scenes), the tags by the forward path's k_tags (LDS-owned ranges, plain stores; it writes EVERY word of the tag
+    // rows, so the caller's buffer need not be cleared): 72 -> 14 + 32 us
+    PTX_TRY(launch_select_slots(s, idx, cluster, order, picks, keep, kcluster, kidx, drop_idx, nullptr, st));
+    if (tag == nullptr) return PTX_OK;
+    return launch_tags(s, idx, order, picks, nullptr, tag, nullptr, nullptr, nullptr, st, keep);
 }
 
 // ------------------------------------------------------------------------------ apply
@@ -890,7 +895,8 @@ __global__ __launch_bounds__(256) void k_tile_count(const uint32_t *__restrict__
 // TILES 2048-point tiles per work-group: 16 (32768 points, 128 KB of LDS) when there are many scenes, 4 when a single
 // scene would otherwise sit on four work-groups (each of them scans every slot of the scene)
 struct TagArgs {
-    const int32_t *idx, *order, *picks, *ksrc;  // ksrc (B,Mk): source row of kept cluster j (= order[keep[j]])
+    const int32_t *idx, *order, *picks, *ksrc;  // ksrc (B,Mk): source row of kept cluster j (= order[keep[j]]); null: read through keep
+    const int32_t *keep;                        // (B,Mk) rank of kept cluster j in the order (stage API: k_select did not write ksrc)
     uint32_t *tag; int32_t *tile_counts, *scene_acc, *counts;
     int M, K, Mt, Mk, Kd, N, ntiles;
 };
@@ -908,6 +914,7 @@ __global__ __launch_bounds__(1024) void k_tags(TagArgs a)
     if (tid < TILES) s_cnt[tid] = 0;
     __syncthreads();
     const int32_t *idx = a.idx + (size_t)b * M * K;
+    const int32_t *order = a.order + (size_t)b * Mt;
     // (four slots per thread and trip: the two dependent loads of a slot are the cost of this scan, not its arithmetic)
     for (int e0 = tid; e0 < Mk * K; e0 += 4 * 1024) {           // owners
         int id[4];
@@ -915,7 +922,8 @@ __global__ __launch_bounds__(1024) void k_tags(TagArgs a)
         for (int u = 0; u < 4; ++u) {
             const int e = e0 + u * 1024;
             const int ec = min(e, Mk * K - 1), j = ec / K, k = ec - j * K;
-            id[u] = e < Mk * K ? idx[(size_t)a.ksrc[(size_t)b * Mk + j] * K + k] : -1;
+            const int src = a.ksrc != nullptr ? a.ksrc[(size_t)b * Mk + j] : order[a.keep[(size_t)b * Mk + j]];
+            id[u] = e < Mk * K ? idx[(size_t)src * K + k] : -1;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -924,7 +932,6 @@ __global__ __launch_bounds__(1024) void k_tags(TagArgs a)
         }
     }
     __syncthreads();
-    const int32_t *order = a.order + (size_t)b * Mt;
     for (int e0 = tid; e0 < Kd * K; e0 += 4 * 1024) {           // drops
         int id[4];
 #pragma unroll
@@ -966,7 +973,7 @@ __global__ __launch_bounds__(1024) void k_tags(TagArgs a)
     }
     __syncthreads();
     const int t0 = blockIdx.x * TILES;
-    if (tid < TILES && t0 + tid < a.ntiles) a.tile_counts[b * a.ntiles + t0 + tid] = s_cnt[tid];
+    if (a.tile_counts != nullptr && tid < TILES && t0 + tid < a.ntiles) a.tile_counts[b * a.ntiles + t0 + tid] = s_cnt[tid];
     if (tid == 0 && a.scene_acc != nullptr) {
         int total = 0;
         for (int t = 0; t < TILES; ++t) total += s_cnt[t];
@@ -982,10 +989,10 @@ __global__ __launch_bounds__(1024) void k_tags(TagArgs a)
 }
 
 int launch_tags(const PtxShape &s, const int32_t *idx, const int32_t *order, const int32_t *picks, const int32_t *ksrc,
-                uint32_t *tag, int32_t *tile_counts, int32_t *counts, int32_t *scene_acc, hipStream_t st)
+                uint32_t *tag, int32_t *tile_counts, int32_t *counts, int32_t *scene_acc, hipStream_t st, const int32_t *keep)
 {
     const int M = s.grid_size * s.grid_size * s.grid_size;
-    TagArgs a{idx, order, picks, ksrc, tag, tile_counts, scene_acc, counts, M, s.K, s.Mt, s.Mk, s.Mt - s.Mk, s.N,
+    TagArgs a{idx, order, picks, ksrc, keep, tag, tile_counts, scene_acc, counts, M, s.K, s.Mt, s.Mk, s.Mt - s.Mk, s.N,
               cdiv(s.N, kTilePts)};
     const bool small = (long)s.B * cdiv(s.N, 16 * kTilePts) < 16;
     if (small) {

@@ -391,7 +391,8 @@ int launch_select_order(const PtxShape &s, const float *centers, const int32_t *
                         float *kcenter, int32_t *ksrc, uint32_t *mm_clear, hipStream_t st, bool critical,
                         hipEvent_t done, const GateRef *tail = nullptr);
 int launch_tags(const PtxShape &s, const int32_t *idx, const int32_t *order, const int32_t *picks, const int32_t *ksrc,
-                uint32_t *tag, int32_t *tile_counts, int32_t *counts, int32_t *scene_acc, hipStream_t st);
+                uint32_t *tag, int32_t *tile_counts, int32_t *counts, int32_t *scene_acc, hipStream_t st,
+                const int32_t *keep = nullptr);
 int launch_select_slots(const PtxShape &s, const int32_t *idx, const float *cluster, const int32_t *order,
                         const int32_t *picks, const int32_t *keep, float *kcluster, int32_t *kidx,
                         int32_t *drop_idx, uint32_t *tag, hipStream_t st);

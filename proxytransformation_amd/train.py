@@ -1058,7 +1058,7 @@ def forward_train(mod, points: List[torch.Tensor], text_feats, text_mask, img_fe
     kcluster = torch.empty((B, Mk, K, 3), dtype=_F32, device=dev)
     kidx = torch.empty((B, Mk, K), **i32)
     drop_idx = torch.empty((B, max(Kd, 1) * K), **i32)
-    tag = torch.zeros((B, N), **i32)
+    tag = torch.empty((B, N), **i32)                      # every word is written by ptx_select_clusters
     oo = None if order_override is None else order_override.to(device=dev, dtype=torch.int32).contiguous()
     _ck(lib.ptx_select_clusters(ctypes.byref(shape), _p(idx2), _p(cdet), _p(cl2), _p(pad), _p(oo), _p(order), _p(picks),
                                 _p(keep), _p(kcenter_i), _p(kcluster), _p(kidx), _p(drop_idx), _p(tag), st), "ptx_select_clusters")
@@ -1212,7 +1212,7 @@ class _TrainStep(torch.autograd.Function):
         kcluster = torch.empty((B, Mk, K, 3), dtype=_F32, device=dev)
         kidx = torch.empty((B, Mk, K), **i32)
         drop_idx = torch.empty((B, max(Kd, 1) * K), **i32)
-        tag = torch.zeros((B, N), **i32)
+        tag = torch.empty((B, N), **i32)                      # every word is written by ptx_select_clusters
         oo = None if order_override is None else order_override.to(device=dev, dtype=torch.int32).contiguous()
         _ck(lib.ptx_select_clusters(ctypes.byref(shape), _p(idx2), _p(cdet), _p(cl2), _p(pad), _p(oo), _p(order), _p(picks),
                                     _p(keep), _p(kcenter_i), _p(kcluster), _p(kidx), _p(drop_idx), _p(tag), st), "ptx_select_clusters")

@@ -72,7 +72,7 @@ class Stages:
                  keep=torch.empty((B, s.Mk), **i32), kcenter=torch.empty((B, s.Mk, 3), device=dev()),
                  kcluster=torch.empty((B, s.Mk, s.K, 3), device=dev()),
                  kidx=torch.empty((B, s.Mk, s.K), **i32), drop_idx=torch.empty((B, max(Kd, 1) * s.K), **i32),
-                 tag=torch.zeros((B, s.N), **i32))
+                 tag=torch.full((B, s.N), 0x5a5a5a5a, **i32))      # garbage on entry: ptx_select_clusters writes every word (r05)
         _abi.check(self.lib.ptx_select_clusters(
             self._s(), idx.data_ptr(), centers.data_ptr(), cluster.data_ptr(), pad_count.data_ptr(),
             None if order_override is None else order_override.data_ptr(),
