@@ -320,7 +320,50 @@ __global__ __launch_bounds__(256) void k_t_gelu_bwd(const float *__restrict__ hp
                                                     int H, float *__restrict__ dhpre, float *__restrict__ part)
 {
     extern __shared__ float red[];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, nq = H / 64;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if ((H & 255) == 0) {
+        // r05: 16-byte accesses -- lane l owns columns 256 g + 4 l .. + 3 (the dword form below moved 51 MB in 35 us at the training
+        // shape); the same sums in the same order per column: rows in wave order, waves combined as in chunk_partials
+        const int ng = H >> 8;
+        float acc[kMaxQH / 4][4];
+#pragma unroll
+        for (int g = 0; g < kMaxQH / 4; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[g][j] = 0.0f;
+        for (int rr = wv; rr < kRowsPerChunk; rr += 4) {
+            const int row = blockIdx.x * kRowsPerChunk + rr;
+            if (row >= R) break;
+            const size_t base = (size_t)row * H;
+            float4 hv[kMaxQH / 4], dv[kMaxQH / 4];
+#pragma unroll
+            for (int g = 0; g < kMaxQH / 4; ++g)
+                if (g < ng) {
+                    const size_t i = base + 256 * g + 4 * lane;
+                    hv[g] = *reinterpret_cast<const float4 *>(hpre + i);
+                    dv[g] = *reinterpret_cast<const float4 *>(dhact + i);
+                }
+#pragma unroll
+            for (int g = 0; g < kMaxQH / 4; ++g)
+                if (g < ng) {
+                    const size_t i = base + 256 * g + 4 * lane;
+                    float4 o;
+                    o.x = drop_apply(d, dv[g].x, i) * tf_gelu_g(hv[g].x);
+                    o.y = drop_apply(d, dv[g].y, i + 1) * tf_gelu_g(hv[g].y);
+                    o.z = drop_apply(d, dv[g].z, i + 2) * tf_gelu_g(hv[g].z);
+                    o.w = drop_apply(d, dv[g].w, i + 3) * tf_gelu_g(hv[g].w);
+                    *reinterpret_cast<float4 *>(dhpre + i) = o;
+                    acc[g][0] += o.x; acc[g][1] += o.y; acc[g][2] += o.z; acc[g][3] += o.w;
+                }
+        }
+#pragma unroll
+        for (int g = 0; g < kMaxQH / 4; ++g)
+            if (g < ng) *reinterpret_cast<float4 *>(&red[wv * H + 256 * g + 4 * lane]) = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
+        __syncthreads();
+        for (int i = threadIdx.x; i < H; i += 256)
+            part[(size_t)blockIdx.x * H + i] = ((red[i] + red[H + i]) + red[2 * H + i]) + red[3 * H + i];
+        return;
+    }
+    const int nq = H / 64;
     float acc[1][kMaxQH];
 #pragma unroll
     for (int q = 0; q < kMaxQH; ++q) acc[0][q] = 0.0f;
