@@ -269,6 +269,86 @@ __global__ __launch_bounds__(256) void k_t_ln_bwd(LnBwdArgs g)
     extern __shared__ float red[];
     constexpr int NS = DD ? 3 : 2;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, C = g.C, nq = C / 64;
+    if ((C & 255) == 0) {
+        // r05: 16-byte accesses -- lane l owns columns 256 u + 4 l .. + 3 (C = 256: one float4 per array and row); column partials in
+        // the same order as in the dword form below (rows in wave order, then the four waves)
+        constexpr int NG = kMaxQ / 4;
+        const int ng = C >> 8;
+        float acc4[NS][NG][4];
+#pragma unroll
+        for (int k = 0; k < NS; ++k)
+#pragma unroll
+            for (int u = 0; u < NG; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc4[k][u][j] = 0.0f;
+        float w4[NG][4];
+#pragma unroll
+        for (int u = 0; u < NG; ++u) {
+            const float4 t = u < ng ? *reinterpret_cast<const float4 *>(g.w + 256 * u + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
+            w4[u][0] = t.x; w4[u][1] = t.y; w4[u][2] = t.z; w4[u][3] = t.w;
+        }
+        for (int rr = wv; rr < kRowsPerChunk; rr += 4) {
+            const int row = blockIdx.x * kRowsPerChunk + rr;
+            if (row >= g.R) break;
+            const size_t base = (size_t)row * C;
+            const float mean = g.stats[2 * row], rstd = g.stats[2 * row + 1];
+            float xh[NG][4], gg[NG][4], dyv[NG][4], r1[NG][4], r2[NG][4], s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+            for (int u = 0; u < NG; ++u) {
+                const bool on = u < ng;
+                const size_t i = base + 256 * u + 4 * lane;
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 xv = on ? *reinterpret_cast<const float4 *>(g.x + i) : z, dv = on ? *reinterpret_cast<const float4 *>(g.dy + i) : z;
+                const float4 a1 = (on && g.dres) ? *reinterpret_cast<const float4 *>(g.dres + i) : z;
+                const float4 a2 = (on && g.dres2) ? *reinterpret_cast<const float4 *>(g.dres2 + i) : z;
+                const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
+                r1[u][0] = a1.x; r1[u][1] = a1.y; r1[u][2] = a1.z; r1[u][3] = a1.w;
+                r2[u][0] = a2.x; r2[u][1] = a2.y; r2[u][2] = a2.z; r2[u][3] = a2.w;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    xh[u][j] = on ? (xs[j] - mean) * rstd : 0.0f;
+                    dyv[u][j] = ds[j];
+                    gg[u][j] = ds[j] * w4[u][j];
+                    s1 += gg[u][j]; s2 = fmaf(gg[u][j], xh[u][j], s2);
+                }
+            }
+            s1 = wave_sum(s1) / (float)C; s2 = wave_sum(s2) / (float)C;
+            const uint64_t scene = (uint64_t)(row / g.rows_per_scene);
+#pragma unroll
+            for (int u = 0; u < NG; ++u) {
+                if (u < ng) {
+                    const size_t i = base + 256 * u + 4 * lane;
+                    float v[4], o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v[j] = rstd * (gg[u][j] - s1 - xh[u][j] * s2);
+                        if (g.dres) v[j] = r1[u][j] + v[j];
+                        if (g.dres2) v[j] = v[j] + r2[u][j];
+                        acc4[0][u][j] += dyv[u][j] * xh[u][j];
+                        acc4[1][u][j] += dyv[u][j];
+                        if (DD) {
+                            o[j] = drop_apply(g.d2, v[j], scene);
+                            o[j] = drop_apply(g.d1, o[j], i + j);
+                            acc4[NS - 1][u][j] += o[j];
+                        }
+                    }
+                    *reinterpret_cast<float4 *>(g.dx + i) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (DD) *reinterpret_cast<float4 *>(g.dd + i) = make_float4(o[0], o[1], o[2], o[3]);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NS; ++k)
+#pragma unroll
+            for (int u = 0; u < NG; ++u)
+                if (u < ng)
+                    *reinterpret_cast<float4 *>(&red[(wv * NS + k) * C + 256 * u + 4 * lane]) =
+                        make_float4(acc4[k][u][0], acc4[k][u][1], acc4[k][u][2], acc4[k][u][3]);
+        __syncthreads();
+        for (int i = threadIdx.x; i < NS * C; i += 256)
+            g.part[(size_t)blockIdx.x * NS * C + i] = ((red[i] + red[NS * C + i]) + red[2 * NS * C + i]) + red[3 * NS * C + i];
+        return;
+    }
     float acc[NS][kMaxQ];
 #pragma unroll
     for (int k = 0; k < NS; ++k)
