@@ -220,7 +220,7 @@ def train_step_ms(device, steps=40):
         sd0 = fill_state_dict(mod.state_dict())
         kw = dict(grid_size=cfg.grid_size, dynamic_drop_radio=cfg.dynamic_drop_radio, num_sub=cfg.num_sub, num_heads=cfg.num_heads,
                   text_blocks=cfg.text_blocks, img_blocks=cfg.img_blocks, points=pts, text_feats=text, text_mask=mask, img_feat=img,
-                  num_threads=threads)
+                  num_threads=threads, timing_only=True)
         oracle.forward_train(sd0, **kw)                    # warm-up (library load, thread pool)
         reps, t0 = 0, time.perf_counter()
         while reps < 3 and (reps == 0 or time.perf_counter() - t0 < 10.0):

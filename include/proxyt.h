@@ -32,6 +32,10 @@ extern "C" {
 
 #define PTX_ABI_VERSION 11
 
+/* The library is built with -fvisibility=hidden: the entry points below are its ONLY dynamic symbols
+ * (tests/test_host_cpu.py::test_library_exports_every_declared_symbol asserts "these and nothing else"). */
+#define PTX_API __attribute__((visibility("default")))
+
 #define PTX_OK          0
 #define PTX_EINVAL     -1   /* bad shape / null pointer / unsupported size */
 #define PTX_ELAUNCH    -2   /* HIP launch or runtime error */
@@ -104,8 +108,8 @@ typedef struct PtxWeights {
     PtxBn1d      text_trans_norm, img_trans_norm;  /* PRE:329-330                */
 } PtxWeights;
 
-int         ptx_abi_version(void);
-const char *ptx_last_error(void);
+PTX_API int         ptx_abi_version(void);
+PTX_API const char *ptx_last_error(void);
 
 /* Library-owned streams and events of ONE caller (one nn.Module instance): the clustering chain and the
  * image chain of a forward run concurrently on private side streams that fork from / join into the
@@ -114,8 +118,8 @@ const char *ptx_last_error(void);
  * streams first.  ptx_forward(ctx = NULL) uses a process-wide per-device default context and serialises
  * its enqueue section with a mutex. */
 typedef struct PtxContext PtxContext;
-int ptx_context_create(PtxContext **ctx);
-int ptx_context_destroy(PtxContext *ctx);
+PTX_API int ptx_context_create(PtxContext **ctx);
+PTX_API int ptx_context_destroy(PtxContext *ctx);
 /* Stream gates (ABI 6).  Where the image chain owns the caller's stream the fork and the join of the two chains are device
  * words instead of event record + wait (one waiting wave / one waiting work-group instead of two queue packets).  A waiter
  * is bounded in wall-clock time (PTX_GATE_TIMEOUT_MS, default 30 s for a fork, twice that for a join -- the fork legitimately waits for everything queued
@@ -127,7 +131,7 @@ int ptx_context_destroy(PtxContext *ctx);
  * events / gates.  ptx_context_gates: nonzero while the context uses gates (bit 0; bit 1: its low-priority stream may carry
  * gate words as well).  There is no reference counterpart (PRE runs on
  * one stream). */
-int ptx_context_check(PtxContext *ctx);
+PTX_API int ptx_context_check(PtxContext *ctx);
 /* ABI 11.  The same check BEHIND a drain of the context's streams and of the caller stream of its latest forward.  A join (or
  * slot-tag) gate fails after the survivor counts have been published, i.e. after a host that only waits for the counts has gone
  * on: ptx_context_check right behind ptx_wait_counts reports fork failures only, the join's surfaces with the NEXT
@@ -136,42 +140,42 @@ int ptx_context_check(PtxContext *ctx);
  * interpreter exit.  A C caller that sees PTX_EGATE must ptx_workspace_init its workspace again (the clean-on-entry words of
  * the failed forward cannot be trusted).  A fork's bound is PTX_GATE_TIMEOUT_MS (default 30 s: it covers everything the caller
  * queued ahead of the forward), a join's twice that (it may sit through a fork that runs into its bound). */
-int ptx_context_sync_check(PtxContext *ctx);
-int ptx_context_gates(const PtxContext *ctx);
+PTX_API int ptx_context_sync_check(PtxContext *ctx);
+PTX_API int ptx_context_gates(const PtxContext *ctx);
 
 /* Per-kernel timing of ptx_forward for roofline measurement (bench.py): select ONE launch
  * site by id (0 .. ptx_kernel_count()-1, -1 = off); every later ptx_forward brackets that
  * launch with HIP events recorded on the stream the kernel runs on.  ptx_timing_read()
  * waits for the recorded events and returns launches and summed milliseconds [host pointers],
  * then clears the record.  Do not enable while a stream capture is active. */
-int         ptx_kernel_count(void);
-const char *ptx_kernel_name(int kid);
-int         ptx_timing_select(int kid);
-int         ptx_timing_read(int *launches, float *total_ms);
+PTX_API int         ptx_kernel_count(void);
+PTX_API const char *ptx_kernel_name(int kid);
+PTX_API int         ptx_timing_select(int kid);
+PTX_API int         ptx_timing_read(int *launches, float *total_ms);
 /* Time only every n-th launch of a selected site (default 1 = every launch): an event record is a packet of its own and costs
  * the stream ~6 us of idle between the two kernels around it. */
-int         ptx_timing_every(int n);
+PTX_API int         ptx_timing_every(int n);
 /* Several launch sites at once (bit k of `mask` = site k); ptx_timing_read_sites fills two [host] arrays of
  * ptx_kernel_count() entries.  The event records perturb the step a little: use the single-site form inside a
  * timed region and the mask form for per-pass breakdowns. */
-int         ptx_timing_select_mask(uint64_t mask);
-int         ptx_timing_read_sites(int *launches, float *total_ms, int n);
+PTX_API int         ptx_timing_select_mask(uint64_t mask);
+PTX_API int         ptx_timing_read_sites(int *launches, float *total_ms, int n);
 
 /* Bytes of the parameter-only tables derived once per set of weights (folded
  * BatchNorm scale/shift, per-slot bias tables PRE:212-215, folded attention-pool
  * matrices) and of the per-call scratch.  Both buffers are caller-owned. */
-size_t ptx_prep_bytes(const PtxShape *s);
-size_t ptx_workspace_bytes(const PtxShape *s);
+PTX_API size_t ptx_prep_bytes(const PtxShape *s);
+PTX_API size_t ptx_workspace_bytes(const PtxShape *s);
 
 /* A workspace must be initialised ONCE after allocation (and again after a failed ptx_forward): ptx_forward finds
  * the ownership tags, encoded bounding boxes and count accumulators zero and its kernels leave them zero -- there
  * is no clearing launch on the per-call path. */
-int ptx_workspace_init(const PtxShape *s, void *workspace, size_t ws_bytes, void *stream);
+PTX_API int ptx_workspace_init(const PtxShape *s, void *workspace, size_t ws_bytes, void *stream);
 
 /* Build the derived tables in `prep`.  lin = torch.linspace(0,1,gs) (gs floats, device);
  * it is uploaded by the caller because torch's two-sided linspace formula is part of
  * the reference's arithmetic (PRE:41).  Re-run after any parameter changes. */
-int ptx_prepare(const PtxShape *s, const PtxWeights *w, const float *lin,
+PTX_API int ptx_prepare(const PtxShape *s, const PtxWeights *w, const float *lin,
                 void *prep, size_t prep_bytes, void *stream);
 
 /* ------------------------------------------------------------------ stage entry points
@@ -179,26 +183,26 @@ int ptx_prepare(const PtxShape *s, const PtxWeights *w, const float *lin,
 
 /* PRE:37-48 init_uniform_cluster_center: per-scene min/max + gs^3 grid centres.
  * minmax (B,2,3): [b][0]=min, [b][1]=max.  centers (B,M,3). */
-int ptx_grid_centers(const float *points, int B, int N, const float *lin, int gs, float margin,
+PTX_API int ptx_grid_centers(const float *points, int B, int N, const float *lin, int gs, float margin,
                      float *minmax, float *centers, void *workspace, size_t ws_bytes, void *stream);
 
 /* pytorch3d.ops.ball_query(p1=centers, p2=points, K, radius) as called at PRE:56 / PRE:65:
  * first K points in index order with dist2 < radius^2 (fp32, no FMA).
  * idx (B,M,K) int32 pad -1; cluster (B,M,K,3) gathered xyz pad 0.0 (masked_gather,
  * PRE:627-672); pad_count (B,M) int32 = #(idx==-1) (PRE:372), may be NULL. */
-int ptx_ball_query(const float *centers, const float *points, int B, int M, int N, int K,
+PTX_API int ptx_ball_query(const float *centers, const float *points, int B, int M, int N, int K,
                    float radius, int32_t *idx, float *cluster, int32_t *pad_count, void *stream);
 
 /* nn.Linear as used throughout ProxyAttention / Mlp (PRE:221, 223, 255; timm Mlp fc1/fc2):
  * y (rows,n_out) = x (rows,n_in) w^T (n_out,n_in) + bias [-> GELU(erf) if gelu] [+ residual].
  * fp32 MFMA (v_mfma_f32_32x32x2_f32); n_in % 4 == 0, x and w 16-byte aligned. */
-int ptx_linear(const float *x, const float *w, const float *bias, const float *residual, float *y,
+PTX_API int ptx_linear(const float *x, const float *w, const float *bias, const float *residual, float *y,
                int rows, int n_out, int n_in, int gelu, void *stream);
 
 /* OffsetNetwork.forward + tanh*margin + add + clamp, PRE:58-62, 87-107.
  * centers_in (B,M,3), cluster (B,M,K,3), minmax (B,2,3) -> centers_out (B,M,3);
  * offsets_out (B,M,3) = tanh(raw)*margin, may be NULL. */
-int ptx_offset_net(const PtxShape *s, const PtxWeights *w, const void *prep,
+PTX_API int ptx_offset_net(const PtxShape *s, const PtxWeights *w, const void *prep,
                    const float *centers_in, const float *cluster, const float *minmax,
                    float *centers_out, float *offsets_out, void *stream);
 
@@ -209,7 +213,7 @@ int ptx_offset_net(const PtxShape *s, const PtxWeights *w, const void *prep,
  * tag (B,N) uint32 (every word is written; since r05 the buffer need not be cleared): low 31 bits <- 1 + last (m,k) slot that owns the
  * point (pt_replace's last-writer rule, PRE:478-495), bit 31 <- point is dropped
  * (remove_points_by_index, PRE:516-523). */
-int ptx_select_clusters(const PtxShape *s, const int32_t *idx, const float *centers,
+PTX_API int ptx_select_clusters(const PtxShape *s, const int32_t *idx, const float *centers,
                         const float *cluster, const int32_t *pad_count,
                         const int32_t *order_override,
                         int32_t *order, int32_t *picks, int32_t *keep,
@@ -217,12 +221,12 @@ int ptx_select_clusters(const PtxShape *s, const int32_t *idx, const float *cent
                         uint32_t *tag, void *stream);
 
 /* SimplifiedPointNet.forward, PRE:126-142 -> point_proxy (B,Mk,C). */
-int ptx_pointnet(const PtxShape *s, const PtxWeights *w, const void *prep, const float *kcenter,
+PTX_API int ptx_pointnet(const PtxShape *s, const PtxWeights *w, const void *prep, const float *kcenter,
                  const float *kcluster, float *point_proxy, void *stream);
 
 /* get_img_proxy, PRE:335-342 (1x1 conv + AttentionPool2d token 0 + LayerNorm)
  * img_feat (B,V,in_dim,hw) of s->img_dtype -> img_proxy (B,V,C). */
-int ptx_img_proxy(const PtxShape *s, const PtxWeights *w, const void *prep, const void *img_feat,
+PTX_API int ptx_img_proxy(const PtxShape *s, const PtxWeights *w, const void *prep, const void *img_feat,
                   float *img_proxy, void *workspace, size_t ws_bytes, void *stream);
 
 /* ProxyBlock (eval) + trailing LayerNorm + Linear head + BatchNorm1d(eval):
@@ -230,20 +234,20 @@ int ptx_img_proxy(const PtxShape *s, const PtxWeights *w, const void *prep, cons
  * which = 1: imgformer[-1]  -> transform (B,Mk,9)   PRE:450-455
  * proxy (B,Lp,C); mask (B,Lp) uint8 (1 = valid token) or NULL; guide (B,Mk,C) optional
  * copy of the normed block output (may be NULL). */
-int ptx_proxy_block(const PtxShape *s, const PtxWeights *w, const void *prep, int which,
+PTX_API int ptx_proxy_block(const PtxShape *s, const PtxWeights *w, const void *prep, int which,
                     const float *point_proxy, const float *proxy, int Lp, const uint8_t *mask,
                     float *head_out, float *guide, void *workspace, size_t ws_bytes, void *stream);
 
 /* Per-cluster affine (PRE:459-462) + pt_replace (PRE:472-498) WITHOUT the drop:
  * new_points (B,N,3) = points with every owned point replaced by
  * T_j (p - c_j) + c_j + t_j, j = owning kept cluster (tag from ptx_select_clusters). */
-int ptx_affine_scatter(const PtxShape *s, const float *points, const uint32_t *tag,
+PTX_API int ptx_affine_scatter(const PtxShape *s, const float *points, const uint32_t *tag,
                        const float *kcenter, const float *translate, const float *transform,
                        float *new_points, void *stream);
 
 /* affine + pt_replace + remove_points_by_index (PRE:459-467, 501-525), order preserving.
  * out (B,N,3) capacity; counts (B) int32 = surviving points per scene (device). */
-int ptx_affine_compact(const PtxShape *s, const float *points, const uint32_t *tag,
+PTX_API int ptx_affine_compact(const PtxShape *s, const float *points, const uint32_t *tag,
                        const float *kcenter, const float *translate, const float *transform,
                        float *out, int32_t *counts, void *workspace, size_t ws_bytes, void *stream);
 
@@ -256,8 +260,8 @@ int ptx_affine_compact(const PtxShape *s, const float *points, const uint32_t *t
  * every (scene, head) in four slices on four work-groups, merged by the last to arrive (what the forward uses when a call
  * has few scenes), which needs scratch for tickets + partial results.  scratch: ptx_proxy_attention_scratch_bytes() bytes
  * for the impl passed (0 and 2: B*Lp*C floats). */
-size_t ptx_proxy_attention_scratch_bytes(int B, int n, int Lp, int heads, int C, int impl);
-int ptx_proxy_attention(const float *qkv, const float *pt, const uint8_t *mask, float *out, float *scratch, int B, int n,
+PTX_API size_t ptx_proxy_attention_scratch_bytes(int B, int n, int Lp, int heads, int C, int impl);
+PTX_API int ptx_proxy_attention(const float *qkv, const float *pt, const uint8_t *mask, float *out, float *scratch, int B, int n,
                         int Lp, int heads, int C, int impl, void *stream);
 
 /* Whole forward, PRE:424-469, enqueued on `stream` (the side streams of `ctx` fork the
@@ -278,7 +282,7 @@ typedef struct PtxDebug {
     uint32_t *tag;
 } PtxDebug;
 
-int ptx_forward(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, const void *prep, const float *lin,
+PTX_API int ptx_forward(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, const void *prep, const float *lin,
                 const float *points, const float *const *points_list, const float *text_feats,
                 const uint8_t *text_mask, const void *img_feat, const int32_t *order_override,
                 const float *centers_override,
@@ -297,7 +301,7 @@ typedef struct PtxForwardOpts {
     int32_t compute_dtype;
     int32_t reserved[5];
 } PtxForwardOpts;
-int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, const void *prep, const float *lin,
+PTX_API int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, const void *prep, const float *lin,
                    const float *points, const float *const *points_list, const float *text_feats,
                    const uint8_t *text_mask, const void *img_feat, const int32_t *order_override,
                    const float *centers_override,
@@ -307,7 +311,7 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
 /* Host-side spin until counts_host[0..B) (pinned host memory, preset to -1 by the caller) are all
  * >= 0, or timeout_us elapses.  Returns 0 when the counts are there, PTX_ETIMEOUT otherwise
  * (the caller then falls back to a stream synchronise, which also surfaces device faults). */
-int ptx_wait_counts(const int32_t *counts_host, int B, int64_t timeout_us);
+PTX_API int ptx_wait_counts(const int32_t *counts_host, int B, int64_t timeout_us);
 
 /* ------------------------------------------------------------------ multi-view depth ingest
  * What the reference's data pipeline computes on the host between the decoded depth maps and the (N,3) cloud handed to
@@ -327,10 +331,10 @@ int ptx_wait_counts(const int32_t *counts_host, int B, int64_t timeout_us);
  * global2ego with rows permuted by piv (P A = L U, unit lower); aug = NULL or 13 floats rot_mat_T (3,3) | scale | trans;
  * points (N,3); bbox_enc (6) uint32 or NULL = the cloud's bounding box in ptx_forward_ex's encoding (cleared here);
  * status (1) int32 device: bit 0 set if any sel[j] was out of range (that point is written as 0). */
-size_t ptx_ingest_workspace_bytes(int V, int H, int W);
-int ptx_ingest_index(const void *depth, int depth_dtype, int V, int H, int W, void *workspace, size_t ws_bytes,
+PTX_API size_t ptx_ingest_workspace_bytes(int V, int H, int W);
+PTX_API int ptx_ingest_index(const void *depth, int depth_dtype, int V, int H, int W, void *workspace, size_t ws_bytes,
                      int32_t *view_counts, void *stream);
-int ptx_ingest_gather(const void *depth, int depth_dtype, float depth_shift, int V, int H, int W, const float *inv_intrinsic,
+PTX_API int ptx_ingest_gather(const void *depth, int depth_dtype, float depth_shift, int V, int H, int W, const float *inv_intrinsic,
                       const float *lu, const int32_t *piv, const int64_t *sel, int N, const float *aug, float *points,
                       uint32_t *bbox_enc, int32_t *status, const void *workspace, size_t ws_bytes, void *stream);
 
@@ -347,8 +351,8 @@ int ptx_ingest_gather(const void *depth, int depth_dtype, float depth_shift, int
  * Rows written == PTX_VOX_BROKEN (0x7fffffff): a tile of the single-pass emit gave up waiting for the tiles in front of it
  * (2^24 polls); rows, inverse and the count of that call are invalid. */
 #define PTX_VOX_BROKEN 0x7fffffff
-size_t ptx_voxel_workspace_bytes(int B, int Ncap);
-int ptx_voxelize(const float *points, const int32_t *counts, int B, int Ncap, float voxel_size, int32_t *coords,
+PTX_API size_t ptx_voxel_workspace_bytes(int B, int Ncap);
+PTX_API int ptx_voxelize(const float *points, const int32_t *counts, int B, int Ncap, float voxel_size, int32_t *coords,
                  float *feats, int32_t *inverse, int32_t *nvox_overflow, void *workspace, size_t ws_bytes, void *stream);
 
 /* ------------------------------------------------------------------ image feature -> point sampling
@@ -361,8 +365,8 @@ int ptx_voxelize(const float *points, const int32_t *counts, int B, int Ncap, fl
  * 3D augmentation of apply_3d_transformation, composed by the host) or NULL; image transform scale -> crop -> flip
  * (flip: x = ori_w - x); pad_h / pad_w: padded image size.  workspace: ptx_point_sample_workspace_bytes() bytes (one
  * channels-last copy of the feature maps).  valid_num (N) int32 optional. */
-size_t ptx_point_sample_workspace_bytes(int V, int C, int H, int W);
-int ptx_point_sample(const float *points, int N, const void *feats, int feat_dtype, int V, int C, int H, int W,
+PTX_API size_t ptx_point_sample_workspace_bytes(int V, int C, int H, int W);
+PTX_API int ptx_point_sample(const float *points, int N, const void *feats, int feat_dtype, int V, int C, int H, int W,
                      const float *proj, const float *pre, float scale_w, float scale_h, float crop_w, float crop_h, int flip,
                      float ori_w, float pad_h, float pad_w, int bilinear, float *out, int32_t *valid_num, void *workspace,
                      size_t ws_bytes, void *stream);
@@ -380,48 +384,48 @@ int ptx_point_sample(const float *points, int N, const void *feats, int feat_dty
  * channels-first image features: a_dtype / b_dtype 0 fp32, 1 bf16, 2 fp16); z = z1 * inner + z2, one stride per batch
  * digit.  ksplit > 1: K is cut into slices whose partial products land c_sk elements apart (summed by the caller with
  * ptx_op_colsum) -- weight gradients contract over every slot / token of the batch with a tiny M x N. */
-int ptx_op_gemm(const void *A, const void *B, float *C, int M, int N, int K, long a_rs, long a_cs, long b_rs, long b_cs,
+PTX_API int ptx_op_gemm(const void *A, const void *B, float *C, int M, int N, int K, long a_rs, long a_cs, long b_rs, long b_cs,
                 long c_rs, long c_cs, int batch, int inner, long a_s1, long a_s2, long b_s1, long b_s2, long c_s1, long c_s2,
                 int a_dtype, int b_dtype, float alpha, int accumulate, int ksplit, long c_sk, void *stream);
 /* out (cols,rows) = in (rows,cols)^T */
-int ptx_op_transpose(const float *in, int rows, int cols, float *out, void *stream);
+PTX_API int ptx_op_transpose(const float *in, int rows, int cols, float *out, void *stream);
 /* out[n] (+)= scale * sum_r f(x[r][n]), accumulated in double; mode 0: x, 1: x*y, 2: x*x, 3: (x - y[n])^2 with y a
  * per-column vector (bias / LayerNorm / BatchNorm parameter gradients, batch statistics) */
-int ptx_op_colsum(const float *x, const float *y, int R, int N, int mode, float scale, int accumulate, float *out,
+PTX_API int ptx_op_colsum(const float *x, const float *y, int R, int N, int mode, float scale, int accumulate, float *out,
                   double *scratch /* nsplit * N doubles */, int nsplit, void *stream);
 /* op 0: a+b  1: a*s  2: gelu(a)  3: b*gelu'(a)  4: relu(a)  5: b*(a>0)  6: a+bias[col]  7: a+s*b  8: a*b */
-int ptx_op_eltwise(int op, const float *a, const float *b, float s, long n, int ncol, float *y, void *stream);
+PTX_API int ptx_op_eltwise(int op, const float *a, const float *b, float s, long n, int ncol, float *y, void *stream);
 /* y = x * keep / (1-p), keep = hash(seed, i / group) >= p: Dropout (group 1) / DropPath (group = elements per sample);
  * the backward pass is the same call on dy */
-int ptx_op_dropout(const float *x, long n, long group, float p, uint64_t seed, float *y, void *stream);
+PTX_API int ptx_op_dropout(const float *x, long n, long group, float p, uint64_t seed, float *y, void *stream);
 /* LayerNorm over C (+ optional per-slot bias table add[(row % add_rows)], PRE:215-217); stats (R,2) = mean, rstd */
-int ptx_op_layernorm_fwd(const float *x, const float *w, const float *b, const float *add, int add_rows, int R, int C,
+PTX_API int ptx_op_layernorm_fwd(const float *x, const float *w, const float *b, const float *add, int add_rows, int R, int C,
                          float eps, float *y, float *stats, void *stream);
-int ptx_op_layernorm_bwd(const float *x, const float *w, const float *dy, const float *stats, int R, int C, float *dx,
+PTX_API int ptx_op_layernorm_bwd(const float *x, const float *w, const float *dy, const float *stats, int R, int C, float *dx,
                          float *xhat, void *stream);
 /* BatchNorm over the rows of (R,C) with batch statistics: mean = colsum / R, centred sum of squares (colsum mode 3) ->
  * mean / rstd (+ running-stat update with momentum, unbiased variance) -> apply (optionally fused ReLU); backward in
  * three steps (see train_ops.hip) */
-int ptx_op_bn_stats(const float *mean, const float *sumsq_centred, int C, long R, float eps, float momentum, float *mean_rstd,
+PTX_API int ptx_op_bn_stats(const float *mean, const float *sumsq_centred, int C, long R, float eps, float momentum, float *mean_rstd,
                     float *run_mean, float *run_var, void *stream);
-int ptx_op_bn_apply(const float *x, const float *mean_rstd, const float *w, const float *b, long R, int C, int relu, float *y,
+PTX_API int ptx_op_bn_apply(const float *x, const float *mean_rstd, const float *w, const float *b, long R, int C, int relu, float *y,
                     void *stream);
-int ptx_op_bn_bwd_prep(const float *x, const float *y, const float *dy, const float *mean_rstd, long R, int C, int relu,
+PTX_API int ptx_op_bn_bwd_prep(const float *x, const float *y, const float *dy, const float *mean_rstd, long R, int C, int relu,
                        float *g, float *gx, void *stream);
-int ptx_op_bn_bwd_dx(const float *x, const float *g, const float *mean_rstd, const float *w, const float *dbeta,
+PTX_API int ptx_op_bn_bwd_dx(const float *x, const float *g, const float *mean_rstd, const float *w, const float *dbeta,
                      const float *dgamma, long R, int C, float *dx, void *stream);
 /* softmax over the last dim of (rows, L); mask (B,L) uint8 (1 = valid) fills -1e9 (PRE:247), row r -> scene r / rows_per_scene */
-int ptx_op_softmax_fwd(const float *s, const uint8_t *mask, long rows, int L, long rows_per_scene, float *p, void *stream);
-int ptx_op_softmax_bwd(const float *p, const float *dp, const uint8_t *mask, long rows, int L, long rows_per_scene, float *ds,
+PTX_API int ptx_op_softmax_fwd(const float *s, const uint8_t *mask, long rows, int L, long rows_per_scene, float *p, void *stream);
+PTX_API int ptx_op_softmax_bwd(const float *p, const float *dp, const uint8_t *mask, long rows, int L, long rows_per_scene, float *ds,
                        void *stream);
 /* OffsetNetwork / SimplifiedPointNet pieces (PRE:87-107, 126-142): slot inputs [rel | p] with padded slots zeroed,
  * pooling over the K slots (mode 0 mean, 1 max), tanh * margin + add + clamp (dcoef = d centre / d raw) */
-int ptx_op_slot_inputs(const float *center, const float *cluster, const int32_t *src, long nclus, int K, float *x6,
+PTX_API int ptx_op_slot_inputs(const float *center, const float *cluster, const int32_t *src, long nclus, int K, float *x6,
                        uint8_t *padmask, void *stream);
-int ptx_op_slot_inputs_bwd(const float *dx6, const uint8_t *padmask, long nclus, int K, float *dcenter, void *stream);
-int ptx_op_slot_pool(const float *h, long nclus, int K, int C, int mode, float *out, int32_t *arg, void *stream);
-int ptx_op_slot_pool_bwd(const float *dout, const int32_t *arg, long nclus, int K, int C, int mode, float *dh, void *stream);
-int ptx_op_offset_apply(const float *c0, const float *raw, const float *minmax, long nclus, int M, float margin, float *cout,
+PTX_API int ptx_op_slot_inputs_bwd(const float *dx6, const uint8_t *padmask, long nclus, int K, float *dcenter, void *stream);
+PTX_API int ptx_op_slot_pool(const float *h, long nclus, int K, int C, int mode, float *out, int32_t *arg, void *stream);
+PTX_API int ptx_op_slot_pool_bwd(const float *dout, const int32_t *arg, long nclus, int K, int C, int mode, float *dh, void *stream);
+PTX_API int ptx_op_offset_apply(const float *c0, const float *raw, const float *minmax, long nclus, int M, float margin, float *cout,
                         float *dcoef, void *stream);
 /* The same networks fused (csrc/slotnet_train.hip): slot inputs -> Conv2d(6,C,1) -> BatchNorm2d (batch statistics over all
  * nclus*K slots, running statistics updated) -> ReLU -> mean (maxpool 0) / max (1, first arg-max in arg) over the K slots,
@@ -429,37 +433,37 @@ int ptx_op_offset_apply(const float *c0, const float *raw, const float *minmax, 
  * center (nclus,3), cluster (nclus,K,3); out (nclus,C); mean_rstd (2,C) is saved for the backward; stat_tmp (2,C) scratch;
  * scratch: ptx_op_slotnet_scratch_bytes(C).  Backward: dout (nclus,C) -> dconv_w (C,6), dconv_b (C), dbeta_dgamma (2,C),
  * dcenter (nclus,3) or NULL. */
-size_t ptx_op_slotnet_scratch_bytes(int C);
-int ptx_op_slotnet_fwd(const float *center, const float *cluster, long nclus, int K, int C, const float *conv_w,
+PTX_API size_t ptx_op_slotnet_scratch_bytes(int C);
+PTX_API int ptx_op_slotnet_fwd(const float *center, const float *cluster, long nclus, int K, int C, const float *conv_w,
                        const float *conv_b, const float *bn_w, const float *bn_b, float eps, float momentum, float *run_mean,
                        float *run_var, int maxpool, float *out, int32_t *arg, float *mean_rstd, float *stat_tmp, void *scratch,
                        size_t scratch_bytes, void *stream);
-int ptx_op_slotnet_bwd(const float *center, const float *cluster, long nclus, int K, int C, const float *conv_w,
+PTX_API int ptx_op_slotnet_bwd(const float *center, const float *cluster, long nclus, int K, int C, const float *conv_w,
                        const float *conv_b, const float *bn_w, const float *bn_b, const float *mean_rstd, int maxpool,
                        const int32_t *arg, const float *dout, float *dconv_w, float *dconv_b, float *dbeta_dgamma,
                        float *dcenter, void *scratch, size_t scratch_bytes, void *stream);
 /* per-slot bias table of ProxyAttention (PRE:212-215) and its parameter gradients */
-int ptx_op_slotbias_fwd(const float *pb, const float *pc, const float *pr, int Mk, int s, int C, float *table, void *stream);
-int ptx_op_slotbias_bwd(const float *dtable, int Mk, int s, int C, float *dpb, float *dpc, float *dpr, void *stream);
+PTX_API int ptx_op_slotbias_fwd(const float *pb, const float *pc, const float *pr, int Mk, int s, int C, float *table, void *stream);
+PTX_API int ptx_op_slotbias_bwd(const float *dtable, int Mk, int s, int C, float *dpb, float *dpc, float *dpr, void *stream);
 /* rows of the kept clusters: src[b*Mk+j] = b*M + order[b][keep[b][j]]; gather / scatter of (rows,C) by src */
-int ptx_op_keep_rows(const int32_t *order, const int32_t *keep, int B, int M, int Mt, int Mk, int32_t *src, void *stream);
-int ptx_op_rows_gather(const float *x, const int32_t *src, long rows, int C, float *y, void *stream);
-int ptx_op_rows_scatter(const float *dy, const int32_t *src, long rows, int C, float *dx, void *stream);
+PTX_API int ptx_op_keep_rows(const int32_t *order, const int32_t *keep, int B, int M, int Mt, int Mk, int32_t *src, void *stream);
+PTX_API int ptx_op_rows_gather(const float *x, const int32_t *src, long rows, int C, float *y, void *stream);
+PTX_API int ptx_op_rows_scatter(const float *dy, const int32_t *src, long rows, int C, float *dx, void *stream);
 /* output position of every input point after remove_points_by_index (PRE:516-523), -1 = dropped, + survivor counts */
-int ptx_op_out_positions(const uint32_t *tag, int B, int N, int32_t *tile_counts, int32_t *opos, int32_t *counts, void *stream);
+PTX_API int ptx_op_out_positions(const uint32_t *tag, int B, int N, int32_t *tile_counts, int32_t *opos, int32_t *counts, void *stream);
 /* gradients of the per-cluster affine + pt_replace (PRE:459-465): every valid slot whose target point survives receives
  * that point's output gradient (index_put_ backward gathers; duplicates included) */
-int ptx_op_affine_bwd(const float *dout, const int32_t *opos, const int32_t *kidx, const float *kcluster,
+PTX_API int ptx_op_affine_bwd(const float *dout, const int32_t *opos, const int32_t *kidx, const float *kcluster,
                       const float *kcenter, const float *transform, int B, int N, int Mk, int K, float *dtranslate,
                       float *dtransform, float *dkcenter, void *stream);
 /* the same with one gradient per scene (the module returns a LIST of (n_b,3) tensors, PRE:467): douts [host] = B <= 32 device
  * pointers, NULL where a scene's output received no gradient */
-int ptx_op_affine_bwd_list(const float *const *douts, const int32_t *opos, const int32_t *kidx, const float *kcluster,
+PTX_API int ptx_op_affine_bwd_list(const float *const *douts, const int32_t *opos, const int32_t *kidx, const float *kcluster,
                            const float *kcenter, const float *transform, int B, int N, int Mk, int K, float *dtranslate,
                            float *dtransform, float *dkcenter, void *stream);
 /* AttentionPool2d tokens (PRE:155-157): token 0 = mean of the pixel tokens, then + positional embedding; backward of the mean */
-int ptx_op_tokens_finish(float *tok, const float *pos, int nimg, int hw, int C, void *stream);
-int ptx_op_tokens_finish_bwd(float *dtok, int nimg, int hw, int C, void *stream);
+PTX_API int ptx_op_tokens_finish(float *tok, const float *pos, int nimg, int hw, int C, void *stream);
+PTX_API int ptx_op_tokens_finish_bwd(float *dtok, int nimg, int hw, int C, void *stream);
 
 /* ---- one ProxyBlock of the training step as two calls (csrc/train_fused.hip)
  * ProxyBlock in train mode (PRE:273-276: x + DropPath(attn(norm1(x) [+ slot bias], proxy)), x + DropPath(mlp(norm2(x))))
@@ -498,24 +502,24 @@ typedef struct {
     float *grad[PTX_TB_NPARAM];                /* shaped like param[] */
     const float *dx_add;                       /* optional (R, C): added into dx (the other block's gradient of the same point proxies) */
 } PtxTrainBlock;
-int ptx_train_block_sizes(const PtxTrainBlock *a, size_t *save_floats, size_t *tmp_fwd_floats, size_t *tmp_bwd_floats);
-int ptx_train_block_fwd(const PtxTrainBlock *a, void *stream);
-int ptx_train_block_bwd(const PtxTrainBlock *a, void *stream);
+PTX_API int ptx_train_block_sizes(const PtxTrainBlock *a, size_t *save_floats, size_t *tmp_fwd_floats, size_t *tmp_bwd_floats);
+PTX_API int ptx_train_block_fwd(const PtxTrainBlock *a, void *stream);
+PTX_API int ptx_train_block_bwd(const PtxTrainBlock *a, void *stream);
 /* the attention core alone (train._ProxyAttnCore): qkv (B*n,3C), pt (B*L,C) -> o (B*n,C), saving P1 (B,heads,L,n),
  * PV (B,heads,L,hd), P2 (B,heads,n,L); backward -> dqkv, dpt; tmp: ptx_train_attn_tmp_floats() floats.  Returns
  * PTX_EINVAL when the shape is outside the fused range (the caller falls back to the generic products). */
-size_t ptx_train_attn_tmp_floats(int B, int n, int L, int heads, int C);
-int ptx_train_attn_fwd(const float *qkv, const float *pt, const uint8_t *mask, int B, int n, int L, int heads, int C,
+PTX_API size_t ptx_train_attn_tmp_floats(int B, int n, int L, int heads, int C);
+PTX_API int ptx_train_attn_fwd(const float *qkv, const float *pt, const uint8_t *mask, int B, int n, int L, int heads, int C,
                        float p_drop, uint64_t seed, float *P1, float *PV, float *P2, float *o, void *stream);
-int ptx_train_attn_bwd(const float *qkv, const float *pt, const uint8_t *mask, int B, int n, int L, int heads, int C,
+PTX_API int ptx_train_attn_bwd(const float *qkv, const float *pt, const uint8_t *mask, int B, int n, int L, int heads, int C,
                        float p_drop, uint64_t seed, const float *P1, const float *PV, const float *P2, const float *dO,
                        float *dqkv, float *dpt, float *tmp, size_t tmp_floats, void *stream);
 
 /* backward of a narrow Linear without bias, y (R, nout <= 9) = x (R, C) w^T (the offset network's channel_mapper, PRE:75; the
  * blocks' heads use the same kernel inside ptx_train_block_bwd): dx = (dt * coef) w, dw = (dt * coef)^T x; coef (R, nout) or NULL;
  * tmp: ptx_op_head_bwd_tmp_floats() floats (per-chunk partials of dw, summed in chunk order) */
-size_t ptx_op_head_bwd_tmp_floats(int R, int C, int nout);
-int ptx_op_head_bwd(const float *dt, const float *coef, const float *x, const float *w, int R, int C, int nout, float *dx, float *dw,
+PTX_API size_t ptx_op_head_bwd_tmp_floats(int R, int C, int nout);
+PTX_API int ptx_op_head_bwd(const float *dt, const float *coef, const float *x, const float *w, int R, int C, int nout, float *dx, float *dw,
                     float *tmp, size_t tmp_floats, void *stream);
 
 /* ---- AttentionPool2d in train mode without materialised pixel tokens (csrc/train_img.hip; PRE:144-177, 338)
@@ -543,9 +547,9 @@ typedef struct {
     const float *dproxy;
     float *dcw, *dcb, *dlnw, *dlnb;
 } PtxTrainImgPool;
-int ptx_train_imgpool_sizes(const PtxTrainImgPool *a, size_t *save_floats, size_t *tmp_fwd_floats, size_t *tmp_bwd_floats);
-int ptx_train_imgpool_fwd(const PtxTrainImgPool *a, void *stream);
-int ptx_train_imgpool_bwd(const PtxTrainImgPool *a, void *stream);
+PTX_API int ptx_train_imgpool_sizes(const PtxTrainImgPool *a, size_t *save_floats, size_t *tmp_fwd_floats, size_t *tmp_bwd_floats);
+PTX_API int ptx_train_imgpool_fwd(const PtxTrainImgPool *a, void *stream);
+PTX_API int ptx_train_imgpool_bwd(const PtxTrainImgPool *a, void *stream);
 
 #ifdef __cplusplus
 }

@@ -349,7 +349,8 @@ def loss_weights(b: int, n: int) -> np.ndarray:
 def forward_train(sd_np: Dict[str, np.ndarray], *, grid_size: int, dynamic_drop_radio: float, num_sub: int,
                   num_heads: int, text_blocks: int, img_blocks: int, points: np.ndarray, text_feats: np.ndarray,
                   text_mask: np.ndarray, img_feat: np.ndarray, centers_override: Optional[np.ndarray] = None,
-                  backward: bool = True, num_threads: Optional[int] = 1, float64: bool = False) -> Dict[str, object]:
+                  backward: bool = True, num_threads: Optional[int] = 1, float64: bool = False,
+                  timing_only: bool = False) -> Dict[str, object]:
     """One training step of the reference module without the optimiser: train-mode forward (batch-statistics
     BatchNorm2d / BatchNorm1d with running-stat update, PRE:74, 114, 329-330; Dropout / DropPath at rate 0),
     loss = sum_b <out_b, loss_weights(b)>, backward through torch autograd.  The index steps are the C functions of
@@ -358,8 +359,13 @@ def forward_train(sd_np: Dict[str, np.ndarray], *, grid_size: int, dynamic_drop_
     (same formulas; the index half stays the fp32 C code): the gradients are then accurate far beyond what two fp32
     evaluations agree on, which is what the GPU gradients are held against.  Returns outputs, intermediates, ``grads``
     (name -> array, inputs as ``input.text_feats`` / ``input.img_feat``), ``none_grads`` and the updated buffers."""
-    if num_threads is not None:
-        torch.set_num_threads(num_threads)                        # index_put_ with duplicates: single thread (H1)
+    # index_put_ with duplicate targets (PRE:495) is last-writer-wins only single-threaded (SURVEY H1): this oracle
+    # refuses any other setting rather than return an order-dependent scatter (oracle.forward's scatter is the C loop,
+    # which is why ITS num_threads is free)
+    # (``timing_only=True``: bench.py's cpu_baseline leg, which reads no values).
+    if num_threads not in (None, 1) and not timing_only:
+        raise ValueError("forward_train is deterministic with one torch thread only (index_put_, SURVEY H1)")
+    torch.set_num_threads(num_threads if timing_only and num_threads else 1)
     ft = torch.float64 if float64 else torch.float32
     sd = {k: (_t(v).clone().to(ft) if np.asarray(v).dtype.kind == "f" else _t(v).clone()) for k, v in sd_np.items()}
     params = {k: v.requires_grad_(True) for k, v in sd.items()

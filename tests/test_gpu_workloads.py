@@ -35,6 +35,8 @@ def _compare(cfg, scene_ids, img_dtype, atol=1e-4, inject=True):
     m = m.cuda()
     pts, text, mask, img = make_scene_batch(cfg, scene_ids=scene_ids)
     img_t = torch.from_numpy(img).to(img_dtype)
+    # threads only speed up the float half (torch GEMMs): the eval oracle's scatter is the single-threaded C loop, so the
+    # last-writer rule (H1) does not depend on this; forward_train (torch index_put_) refuses anything but one thread
     ref = oracle.forward(sd, **oracle_kwargs(cfg), points=pts, text_feats=text, text_mask=mask,
                          img_feat=img_t.float().numpy(), num_threads=min(16, os.cpu_count() or 1))
     if inject:

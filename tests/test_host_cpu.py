@@ -29,6 +29,15 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         getattr(lib, s)
     assert lib.ptx_abi_version() == _abi.ABI_VERSION
+    # ... and NOTHING else: -fvisibility=hidden + csrc/exports.map keep the C++ internals and the kernel
+    # handles out of the dynamic symbol table of both builds of the library
+    import subprocess
+    here = os.path.join(ROOT, "proxytransformation_amd")
+    for name in ("libproxyt_hip.so", "libproxyt_hip_testhooks.so"):
+        out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(here, name)], check=True, capture_output=True,
+                             text=True).stdout
+        exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+        assert exported == sorted(syms), (name, sorted(set(exported) ^ set(syms))[:10])
 
 
 def test_the_switchboard_of_the_product_library_is_four_variables():
