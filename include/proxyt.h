@@ -139,7 +139,10 @@ PTX_API int ptx_context_check(PtxContext *ctx);
  * of a loop, before results leave the process, at teardown); the Python module does so in check(), close() / __del__ and at
  * interpreter exit.  A C caller that sees PTX_EGATE must ptx_workspace_init its workspace again (the clean-on-entry words of
  * the failed forward cannot be trusted).  A fork's bound is PTX_GATE_TIMEOUT_MS (default 30 s: it covers everything the caller
- * queued ahead of the forward), a join's twice that (it may sit through a fork that runs into its bound). */
+ * queued ahead of the forward), a join's twice that (it may sit through a fork that runs into its bound).
+ * Lifetime: the `stream` handle of the context's latest ptx_forward is synchronised here (and by the ptx_forward / ptx_context_check
+ * that reports a failure): it must still be alive -- check BEFORE destroying a stream a forward was issued on.  A context that has
+ * run no forward drains only its own streams. */
 PTX_API int ptx_context_sync_check(PtxContext *ctx);
 PTX_API int ptx_context_gates(const PtxContext *ctx);
 

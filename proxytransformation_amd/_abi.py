@@ -12,9 +12,11 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# PTX_LIBRARY=testhooks selects the in-tree build with the stream gates' fault-injection hooks compiled in (csrc/Makefile:
-# libproxyt_hip_testhooks.so; only tests/test_gpu_host.py's gate-failure workers ask for it).  Nothing else can be loaded.
-LIB_PATH = os.path.join(_HERE, "libproxyt_hip_testhooks.so" if os.environ.get("PTX_LIBRARY") == "testhooks" else "libproxyt_hip.so")
+# The product library.  The in-tree build with the stream gates' fault-injection hooks compiled in (csrc/Makefile:
+# libproxyt_hip_testhooks.so) is reachable only through the explicit test-only call ``use_test_hooks_library()`` below, made by
+# tests/test_gpu_host.py's gate-failure workers BEFORE anything is loaded -- no environment variable can swap the library of a
+# process.  Nothing else can be loaded.
+LIB_PATH = os.path.join(_HERE, "libproxyt_hip.so")
 ABI_VERSION = 11
 
 c_float_p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
@@ -184,6 +186,15 @@ SIGNATURES.update({
 })
 
 _lib: Optional[C.CDLL] = None
+
+
+def use_test_hooks_library() -> None:
+    """TEST ONLY: make this process load libproxyt_hip_testhooks.so (same C ABI + PTX_GATE_FAULT / PTX_GATE_TRAP).  Must be called
+    before the first ``lib()``; raises once the product library is loaded."""
+    global LIB_PATH
+    if _lib is not None:
+        raise RuntimeError("use_test_hooks_library(): a library is already loaded in this process")
+    LIB_PATH = os.path.join(_HERE, "libproxyt_hip_testhooks.so")
 
 
 def lib() -> C.CDLL:

@@ -257,6 +257,7 @@ struct PtxContext {
     bool probed = false; hipStream_t probed_st = nullptr;   // the caller stream the concurrency probe was run against
     bool lo_ok = false;                  // ... and the low-priority stream runs beside both (the slot tags may leave the chain)
     hipStream_t last_st = nullptr;       // caller stream of the latest forward (drained before the poison word is cleared)
+    bool have_last = false;              // ... valid only once a forward has run (a null handle would mean the default stream)
     uint64_t gate_ticks = 0, probe_ticks = 0; int gate_trap = 0;
     std::mutex mu;                       // held for the whole enqueue section of a forward
 };
@@ -421,7 +422,7 @@ static int gate_check(PtxContext *c)
     *reinterpret_cast<volatile uint32_t *>(c->gate_err) = 0u;
     // the streams may still be running the poisoned forward (its k_affine has to see the word): drain them, then clear
     (void)hipStreamSynchronize(c->st);
-    (void)hipStreamSynchronize(c->last_st);
+    if (c->have_last) (void)hipStreamSynchronize(c->last_st);
     (void)hipMemset(c->gate + 48, 0, 4);
     set_error("stream gate timed out at the %s of forward #%u: the two chains of that forward were not ordered and its outputs "
               "were set to NaN; this context now orders its streams with events (PTX_GATE=0 selects them from the start)",
@@ -849,7 +850,8 @@ int ptx_context_sync_check(PtxContext *ctx)
 {
     PTX_REQUIRE(ctx != nullptr, "ptx_context_sync_check: null context");
     std::lock_guard<std::mutex> lk(ctx->mu);
-    PTX_HIP(hipStreamSynchronize(ctx->last_st));             // (a null handle is the default stream: torch's current stream by default)
+    // the caller's stream of the latest forward must still be alive (proxyt.h); no forward yet: nothing of the caller's to drain
+    if (ctx->have_last) PTX_HIP(hipStreamSynchronize(ctx->last_st));
     PTX_HIP(hipStreamSynchronize(ctx->st));
     PTX_HIP(hipStreamSynchronize(ctx->lo));
     return gate_check(ctx);
@@ -1135,7 +1137,7 @@ int ptx_forward_ex(PtxContext *ctx, const PtxShape *s, const PtxWeights *w, cons
     const bool capturing = cap_status != hipStreamCaptureStatusNone;
     if (!capturing) {
         PTX_TRY(gate_check(side));                              // a gate of an EARLIER forward timed out: reported here, once
-        side->last_st = st;
+        side->last_st = st; side->have_last = true;
         if (side->gates_on && (!side->probed || side->probed_st != st)) PTX_TRY(gate_probe(side, st));
     }
     // Which chain stays on the caller's stream (no cross-queue hop on the path the step waits for) depends on the shape.  Estimates in

@@ -120,11 +120,26 @@ class MultiViewIngest:
     class _Slot:
         __slots__ = ("key", "ws", "counts", "counts_np", "stage", "stage_np", "stage_dev", "copied")
 
+    _MAX_SLOT_SETS = 4      # (thread, stream) pairs served concurrently; the least recently used set is retired (module._MAX_LANES)
+
     def _slot(self, b: int, V: int, H: int, W: int, N: int, dev, stream: int) -> "MultiViewIngest._Slot":
         # one set of slots per (thread, stream): two calls on different streams or from different threads (prefetch threads, serving
-        # lanes) must not share a workspace, a staging buffer or the -1 preset of the pinned counts
-        per = self.__dict__.setdefault("_slots", {})
-        slots = per.setdefault((threading.get_ident(), stream), [])
+        # lanes) must not share a workspace, a staging buffer or the -1 preset of the pinned counts.  The table is an
+        # LRU of at most _MAX_SLOT_SETS sets guarded by a lock (short-lived prefetch threads would otherwise pile up
+        # pinned + device memory for the life of the object); a retired set's stream is drained first, its buffers go back to torch.
+        with self.__dict__.setdefault("_slots_lock", threading.Lock()):
+            per = self.__dict__.setdefault("_slots", {})
+            skey = (threading.get_ident(), stream)
+            slots = per.pop(skey, None)
+            if slots is None:
+                slots = []
+                while len(per) >= self._MAX_SLOT_SETS:
+                    old_key = next(iter(per))
+                    for sl in per.pop(old_key):
+                        if sl is not None and sl.copied is not None:
+                            sl.copied.synchronize()
+                    torch.cuda.synchronize(dev)      # kernels of the retired set may still read its workspace / staging twin
+            per[skey] = slots                        # most recently used last
         while len(slots) <= b:
             slots.append(None)
         key = (V, H, W, N, str(dev))

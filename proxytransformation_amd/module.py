@@ -162,10 +162,24 @@ _MAX_LANES = 4                       # streams served concurrently by one module
 # Every live module is known to the interpreter-exit hook below: a forward whose join gate failed after forward() returned (outputs
 # NaN, csrc/api.hip "gates") must not let the process end quietly with exit code 0 when it was the LAST forward of a loop.
 _LIVE_MODULES = weakref.WeakSet()
+_ORPHAN_LANES: list = []
 
 
 def _exit_check():
+    """Interpreter-exit hook.  When a failure was never reported it ends the process with ``os._exit(70)``: a HARD exit -- an atexit
+    handler cannot change the exit status any other way, and a silent 0 is the worse outcome.  atexit runs handlers last-in
+    first-out and this one is registered at import of the package, so handlers registered later (process-group teardown, loggers)
+    have already run; stdout / stderr are flushed here; anything else buffered at that point is lost (documented in INTEGRATION.md)."""
     failed = []
+    while _ORPHAN_LANES:                # lanes of modules that were collected inside a stream capture (__del__)
+        lane = _ORPHAN_LANES.pop()
+        try:
+            err = lane.sync_check()
+            if err:
+                failed.append(err)
+            lane.release()
+        except Exception:
+            pass
     for mod in list(_LIVE_MODULES):
         try:
             mod.check()
@@ -445,6 +459,11 @@ class ProxyTransformationNormReverse(nn.Module):
                 old_key = next(iter(self._lanes))
                 old = self._lanes.pop(old_key)
                 old.stream.synchronize()           # its workspace may still be in use
+                # a join gate of the retired lane's last forward may have failed after that forward returned: the error must
+                # outlive the context that holds it -- check() / close() / the exit hook report it
+                err = old.sync_check()
+                if err:
+                    self.__dict__.setdefault("_pending_errors", []).append(err)
                 old.release()
             lane = self._lanes[key] = _Lane(tstream)
         else:
@@ -465,7 +484,9 @@ class ProxyTransformationNormReverse(nn.Module):
         by the next ``forward`` on the same stream, by ``check()`` (which drains the streams the module used), by ``close()``, when
         the module is garbage-collected (a warning) and at interpreter exit (exit code 70).  A loop that does not set
         ``sync_outputs`` should call ``check()`` once behind its last forward."""
-        errs = [e for e in (lane.sync_check() for lane in list(self._lanes.values())) if e]
+        errs = self.__dict__.get("_pending_errors") or []     # failures found while a lane was retired (_lane)
+        self.__dict__["_pending_errors"] = []
+        errs = errs + [e for e in (lane.sync_check() for lane in list(self._lanes.values())) if e]
         if errs:
             raise RuntimeError("ptx_forward: " + " | ".join(errs))
 
@@ -477,13 +498,32 @@ class ProxyTransformationNormReverse(nn.Module):
             self._release_lanes()
 
     def __del__(self):
+        # A finaliser runs at any collection point, also inside a torch.cuda.graph capture, where the drain of check() /
+        # ptx_context_destroy would invalidate the capture.  There it only POLLS the pinned error words
+        # (ptx_context_check, no synchronise) and parks the lanes on a module-level list that the exit hook drains, checks and
+        # releases; outside a capture it is check() (a drain that ptx_context_destroy would perform anyway) + release.
         try:
-            try:
-                self.check()
-            except RuntimeError as e:
-                import warnings
-                warnings.warn(f"{type(self).__name__} collected with an unreported failure: {e}", RuntimeWarning)
-            self._release_lanes()
+            capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+            if capturing:
+                lib = _abi.lib()
+                errs = list(self.__dict__.get("_pending_errors") or [])
+                lanes = self.__dict__.get("_lanes") or {}
+                self.__dict__["_lanes"] = {}
+                for lane in lanes.values():
+                    if lane.ctx is not None and lane.unchecked and lib.ptx_context_check(lane.ctx) != 0:
+                        errs.append(lib.ptx_last_error().decode())
+                        lane.unchecked = False
+                    _ORPHAN_LANES.append(lane)
+                if errs:
+                    raise RuntimeError(" | ".join(errs))
+            else:
+                try:
+                    self.check()
+                finally:
+                    self._release_lanes()
+        except RuntimeError as e:
+            import warnings
+            warnings.warn(f"{type(self).__name__} collected with an unreported failure: {e}", RuntimeWarning)
         except Exception:          # interpreter shutdown: modules may already be torn down
             pass
 

@@ -356,6 +356,9 @@ def test_launch_count_with_stream_gates():
 _GATE_WORKER = r"""
 import os, sys, hashlib, torch
 sys.path.insert(0, %r)
+if os.environ.get("GATE_TEST_LIBRARY") == "testhooks":          # read by THIS script, not by the package: the product has no such switch
+    from proxytransformation_amd import _abi
+    _abi.use_test_hooks_library()
 from proxytransformation_amd.synth import PreshapeConfig, make_scene_batch
 from tests.util import build_module
 if os.environ.get("GATE_TEST_SHAPE", "image") == "cluster":      # the clustering chain owns the caller's stream ("cgate" words)
@@ -426,7 +429,7 @@ def _run_gate_worker(tmp_path, expect_rc=0, **env_extra):
     script.write_text(_GATE_WORKER % ROOT)
     env = dict(os.environ, **env_extra)
     if "PTX_GATE_FAULT" in env_extra:       # the fault-injection hooks exist in the test-hooks build of the library only
-        env["PTX_LIBRARY"] = "testhooks"
+        env["GATE_TEST_LIBRARY"] = "testhooks"
     r = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == expect_rc, (r.returncode, r.stderr[-3000:])
     out = {"STDERR": [r.stderr]}
@@ -570,7 +573,7 @@ def test_product_library_has_no_fault_injection_hook(tmp_path):
     script = tmp_path / "gate_worker.py"
     script.write_text(_GATE_WORKER % ROOT)
     env = dict(os.environ, PTX_GATE_FAULT="join", PTX_GATE_TIMEOUT_MS="30")
-    env.pop("PTX_LIBRARY", None)
+    env.pop("GATE_TEST_LIBRARY", None)
     r = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     calls = [ln for ln in r.stdout.splitlines() if ln.startswith("CALL")]
