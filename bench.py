@@ -93,6 +93,9 @@ def parse():
                     help="the roofline kernel is bracketed by HIP events on every n-th measured step (each event record costs "
                          "the stream ~6 us of idle between two kernels; 1 = every step)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (nccl = RCCL)")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="BASELINE configs[3] as a pipeline: depth maps -> ingest -> neck -> 1 cm voxels -> four levels of image-feature "
+                         "sampling, chained on one stream (proxytransformation_amd/pipeline.py); use with --config cfg4_room")
     ap.add_argument("--share-gpu", action="store_true",
                     help="test aid for 1-GPU boxes: every rank uses cuda:0 (with --backend gloo); numbers are meaningless")
     return ap.parse_args()
@@ -440,8 +443,126 @@ def passes_report(cfg, B, us, dt_bytes, p_max=None, step_s=None):
     return rep
 
 
+def pipeline_bench(args, cfg, device):
+    """BASELINE configs[3] ("EmbodiedScan mv-grounding config, full pipeline on 1xMI355X") as ONE chained call per step: B scenes of
+    V = 50 synthetic 480 x 640 depth maps -> MultiViewIngest(100 000) -> forward(..., bbox=) with the shipped configuration's weights and
+    fp32 features -> module.quantize(0.01) -> MinkResNet's four level coordinate sets -> batch_point_sample on the four 2D-backbone
+    levels (DET:385-448, CFG:105-142).  Prints one JSON line with a `pipeline` object (ms per stage, ms total, scenes/s)."""
+    import numpy as np
+    from proxytransformation_amd.pipeline import MINK_RESNET_STRIDES, GroundingFeaturePrefix
+    from proxytransformation_amd.synth import FPN_LEVELS, make_depth_scene
+    B = args.scenes_per_gpu or 6
+    mod, sd = build_module(cfg, device)
+    V = cfg.V
+    scenes_np = [make_depth_scene(cfg.seed_base + 50 + b, V=V) for b in range(B)]
+    scenes = [dict(sc, depth_img=torch.from_numpy(sc["depth_img"].view(np.int16)).to(device).view(torch.uint16)) for sc in scenes_np]
+    g = torch.Generator(device=device)
+    g.manual_seed(cfg.seed_base)
+    feats = [torch.randn((B, V, c, s_, s_), generator=g, device=device) for c, s_ in FPN_LEVELS]
+    text = {"text_feats": torch.randn((B, cfg.L, cfg.embed_dim), generator=g, device=device),
+            "text_token_mask": torch.ones((B, cfg.L), dtype=torch.bool, device=device)}
+    pipe = GroundingFeaturePrefix(mod, n_points=cfg.N)
+    with torch.no_grad():
+        for i in range(3):
+            res = pipe(scenes, text, feats, rng=np.random.RandomState(i))
+        torch.cuda.synchronize()
+        mod.check()
+        # (a) the pixel draws of the two PointSample stages precomputed, as a dataloader worker would hand them over (the reference draws
+        # them in its num_workers=6 loader processes, CFG:146): the chained call is device work + enqueue only
+        pre = [dict(sc, choices=res.ingested.sel[b]) for b, sc in enumerate(scenes)]
+        for i in range(args.warmup):
+            pipe(pre, text, feats)
+        torch.cuda.synchronize()
+        blocks = []
+        for r in range(max(1, args.repeats)):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                res = pipe(pre, text, feats)
+            torch.cuda.synchronize()
+            blocks.append((time.perf_counter() - t0) / args.steps)
+        el = sorted(blocks)[len(blocks) // 2]
+        # per-stage times: events on the caller's stream between the stages (they perturb the chain a little: separate calls)
+        stage = {}
+        for i in range(max(5, args.steps // 2)):
+            r_ = pipe(pre, text, feats, time_stages=True)
+            for k, v in r_.stage_ms.items():
+                stage.setdefault(k, []).append(v)
+        stage = {k: round(sorted(v)[len(v) // 2], 4) for k, v in stage.items()}
+        # (b) the same call drawing the pixels itself on the host (np.random.choice per view + per scene, in the reference's order)
+        t0 = time.perf_counter()
+        nb = max(2, args.steps // 4)
+        for i in range(nb):
+            pipe(scenes, text, feats, rng=np.random.RandomState(i))
+        torch.cuda.synchronize()
+        el_draw = (time.perf_counter() - t0) / nb
+        mod.check()
+    depth_bytes = B * V * 480 * 640 * 2
+    img_bytes = sum(int(f.numel()) * 4 for f in feats[-1:])
+    nvox = int(res.coordinates.shape[0])
+    lvl_rows = [sum(int(c.shape[0]) for c in lc) for lc in res.level_coords]
+    alg = depth_bytes + img_bytes + B * (60 * cfg.N + 40 * cfg.M * cfg.num_sub) + B * cfg.N * 12 + nvox * 28 + \
+        sum(n * (12 + 4 * FPN_LEVELS[li][0]) for li, n in enumerate(lvl_rows))
+    line = dict(metric="scenes/sec (100k pts, 256 clusters, 64 proxies)", value=round(B / el, 2), unit="scenes/s", n_gpus=1,
+                steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * el, 4), higher_is_better=True, scaling="weak",
+                vs_baseline=None, dtype="f32", data="synthetic",
+                config=dict(workload=f"{cfg.name} PIPELINE (BASELINE configs[3]): {B} scenes x {V} views of 480x640 uint16 depth -> ingest "
+                                     f"{cfg.N} pts -> neck gs={cfg.grid_size} (M'={cfg.M_keep}, {cfg.text_blocks}+{cfg.img_blocks} blocks, "
+                                     f"fp32 features) -> 1 cm voxels -> levels {MINK_RESNET_STRIDES} -> point sampling on "
+                                     f"{[c for c, _ in FPN_LEVELS]}-channel maps", scenes_per_gpu=B, img_feat_dtype="f32"),
+                pipeline=dict(ms_total=round(1e3 * el, 4), scenes_per_s=round(B / el, 2), ms_blocks=[round(1e3 * x, 4) for x in blocks],
+                              ms_per_stage=stage,
+                              with_host_pixel_draws=dict(ms_total=round(1e3 * el_draw, 3), scenes_per_s=round(B / el_draw, 2),
+                                                         what="the call draws the PointSample indices itself (np.random.choice per view and "
+                                                              "per scene on the host, the reference's order): dataloader-worker work in the "
+                                                              "reference (CFG:146 num_workers=6)"),
+                              voxel_rows=nvox, level_rows=lvl_rows, surviving_points=sum(int(o.shape[0]) for o in res.points),
+                              what="ms_total: wall clock of `steps` chained calls between device synchronises / steps, pixel draws "
+                                   "precomputed; ms_per_stage: HIP events between the stages of separate calls (median)"),
+                roofline=dict(bound="hbm", kernel="whole chain", achieved=round(alg / el / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                              frac=round(alg / el / 1e9 / HBM_PEAK_GBS, 4), traffic=None, algorithmic_bytes_per_launch=alg,
+                              what="depth maps (2 B/pixel) + one read of img_features[-1] + the neck's point side (60 N + 40 M K per "
+                                   "scene) + voxel pass (12 N in, 28 B per row out) + level points and sampled features written; the "
+                                   "chain is ~60 dependent launches: latency-bound, not a bandwidth figure"))
+    if not args.no_cpu_baseline:
+        try:
+            from oracle import oracle
+            from proxytransformation_amd.pipeline import projection_matrices
+            threads = min(os.cpu_count() or 1, 32)
+            sc = scenes_np[0]
+            t0 = time.perf_counter()
+            depth = sc["depth_img"].astype(np.float32) / np.float32(1000.0)
+            ing = oracle.ingest(depth, sc["depth_cam2img"], sc["extrinsic"], cfg.N, rng=np.random.RandomState(0), num_threads=threads)
+            f_last = feats[-1][:1].cpu().numpy()
+            ref = oracle.forward(sd, grid_size=cfg.grid_size, dynamic_drop_radio=cfg.dynamic_drop_radio, num_sub=cfg.num_sub,
+                                 num_heads=cfg.num_heads, text_blocks=cfg.text_blocks, img_blocks=cfg.img_blocks, points=ing["points"][None],
+                                 text_feats=text["text_feats"][:1].cpu().numpy(), text_mask=text["text_token_mask"][:1].cpu().numpy(),
+                                 img_feat=f_last, num_threads=threads)
+            rc, _, _ = oracle.voxelize(ref["outputs"], 0.01)
+            P = projection_matrices(sc["depth2img"])
+            for li, s_ in enumerate(MINK_RESNET_STRIDES):
+                lp = oracle.level_coordinates(rc, 1, s_)[0].astype(np.float32) * np.float32(0.01)
+                oracle.point_sample(lp, feats[li][0].cpu().numpy(), P, scale=(0.75, 1.0), pad_hw=(480.0, 480.0))
+            el_cpu = time.perf_counter() - t0
+            line["cpu_baseline"] = dict(value=round(1.0 / el_cpu, 4), unit="scenes/s", cores=threads, kind="port",
+                                        sample=f"ONE scene through the oracle chain (ingest -> forward -> voxelize -> levels -> point_sample; "
+                                               f"includes the device-to-host copies of its feature maps) on {threads} of {os.cpu_count()} host threads")
+        except Exception as e:
+            line["cpu_baseline"] = dict(value=None, error=repr(e))
+    else:
+        line["cpu_baseline"] = None
+    print(json.dumps(line))
+
+
 def main():
     args = parse()
+    if args.pipeline:
+        assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path to measure)"
+        if args.gpus != 1:
+            raise SystemExit("--pipeline is a single-GPU line (scenes are independent: N ranks = N replicas)")
+        device = torch.device("cuda", 0)
+        torch.cuda.set_device(device)
+        return pipeline_bench(args, CONFIGS[args.config], device)
     if args.gpus > 1 and "RANK" not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher -- one rank per GPU over RCCL, same flags
         import socket

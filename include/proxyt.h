@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PTX_ABI_VERSION 11
+#define PTX_ABI_VERSION 12
 
 /* The library is built with -fvisibility=hidden: the entry points below are its ONLY dynamic symbols
  * (tests/test_host_cpu.py::test_library_exports_every_declared_symbol asserts "these and nothing else"). */
@@ -357,6 +357,12 @@ PTX_API int ptx_ingest_gather(const void *depth, int depth_dtype, float depth_sh
 PTX_API size_t ptx_voxel_workspace_bytes(int B, int Ncap);
 PTX_API int ptx_voxelize(const float *points, const int32_t *counts, int B, int Ncap, float voxel_size, int32_t *coords,
                  float *feats, int32_t *inverse, int32_t *nvox_overflow, void *workspace, size_t ws_bytes, void *stream);
+/* ABI 12.  ptx_voxelize + `scene_end` (B int32, device memory or device-mapped pinned host memory preset to -1; NULL = ptx_voxelize):
+ * scene_end[b] = rows written for scenes 0..b, published with system scope by the last tile of scene b -- what a caller needs to
+ * split the rows per scene (ME's decomposed_coordinates, DET:391-392, 429-430) without reading the scene column back. */
+PTX_API int ptx_voxelize_ex(const float *points, const int32_t *counts, int B, int Ncap, float voxel_size, int32_t *coords,
+                    float *feats, int32_t *inverse, int32_t *nvox_overflow, int32_t *scene_end, void *workspace, size_t ws_bytes,
+                    void *stream);
 
 /* ------------------------------------------------------------------ image feature -> point sampling
  * batch_point_sample (models/layers/fusion_layers/point_fusion.py:208-313) as called at detectors/

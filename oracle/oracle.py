@@ -463,6 +463,22 @@ def voxelize(outs, voxel_size: float = 0.01):
     return coords[rows], feats[rows], [inverse[sizes[b]:sizes[b + 1]] for b in range(len(outs))]
 
 
+def level_coordinates(coords, n_scenes: int, stride: int):
+    """Coordinates of a MinkowskiEngine level of output tensor stride ``stride`` over the voxel rows ``coords`` (Nv,4) int32
+    (MinkResNet, backbones/mink_resnet.py:57-78: four stages at tensor strides 8 / 16 / 32 / 64; DET:398, 429-430 read
+    ``x[level].decomposed_coordinates[idx]``): a strided ME layer maps a coordinate c to ``floor(c / stride) * stride`` and keeps
+    one row per distinct result -- independent of the layer's weights.  ME is not vendored (parity unpinned, like ``voxelize``):
+    row order pinned to first occurrence.  Returns a list of (n_b, 3) int32 arrays."""
+    coords = np.asarray(coords, np.int32)
+    out = []
+    for b in range(n_scenes):
+        c = coords[coords[:, 0] == b, 1:]
+        lv = np.floor_divide(c, stride) * stride
+        _, first = np.unique(lv, axis=0, return_index=True)
+        out.append(lv[np.sort(first)].astype(np.int32))
+    return out
+
+
 # --------------------------------------------------------------------------
 # image feature -> point sampling after the backbone (SURVEY 8f N3)
 # --------------------------------------------------------------------------

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # tests/test_gpu_host.py's gate-failure workers BEFORE anything is loaded -- no environment variable can swap the library of a
 # process.  Nothing else can be loaded.
 LIB_PATH = os.path.join(_HERE, "libproxyt_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 c_float_p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 
@@ -139,6 +139,7 @@ SIGNATURES.update({
     "ptx_ingest_gather": (_I, [_P, _I, _F, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _Z, _P]),
     "ptx_voxel_workspace_bytes": (_Z, [_I, _I]),
     "ptx_voxelize": (_I, [_P, _P, _I, _I, _F, _P, _P, _P, _P, _P, _Z, _P]),
+    "ptx_voxelize_ex": (_I, [_P, _P, _I, _I, _F, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "ptx_point_sample_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "ptx_point_sample": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _F, _F, _F, _F, _I, _F, _F, _F, _I, _P, _P, _P, _Z, _P]),
     "ptx_op_gemm": (_I, [_P, _P, _P, _I, _I, _I, _L, _L, _L, _L, _L, _L, _I, _I, _L, _L, _L, _L, _L, _L, _I, _I, _F, _I, _I, _L, _P]),

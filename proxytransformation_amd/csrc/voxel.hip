@@ -28,6 +28,7 @@ struct VoxArgs {
     unsigned long long *keys; uint32_t *owner; int32_t *first; int32_t *slot_of; int32_t *row_of_slot; unsigned long long *tile_word;
     unsigned int mask;
     int32_t *coords; float *feats; int32_t *inverse; int32_t *overflow; int32_t *nvox_overflow;
+    int32_t *scene_end;                    // optional (ptx_voxelize_ex): rows written up to and including scene b
 };
 
 __device__ __forceinline__ bool vox_key(const VoxArgs &a, int b, int i, int (&v)[3], unsigned long long &key)
@@ -140,6 +141,10 @@ __global__ __launch_bounds__(256) void k_vox_emit(VoxArgs a)
         // to -1: the host spins on it with ptx_wait_counts instead of draining the stream); rows first: the count releases them
         __hip_atomic_store(a.nvox_overflow + 1, __hip_atomic_load(a.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    // the last tile of a scene knows where the scene's rows end (ptx_voxelize_ex; system scope like the total: the buffer may be
+    // device-mapped pinned host memory that the host polls)
+    if (a.scene_end != nullptr && tid == 0 && tile == ntiles - 1)
+        __hip_atomic_store(a.scene_end + b, base + total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const unsigned long long lt = (1ull << lane) - 1ull;
     int run = base;
 #pragma unroll
@@ -216,6 +221,14 @@ size_t ptx_voxel_workspace_bytes(int B, int Ncap)
 int ptx_voxelize(const float *points, const int32_t *counts, int B, int Ncap, float voxel_size, int32_t *coords,
                  float *feats, int32_t *inverse, int32_t *nvox_overflow, void *workspace, size_t ws_bytes, void *stream)
 {
+    return ptx_voxelize_ex(points, counts, B, Ncap, voxel_size, coords, feats, inverse, nvox_overflow, nullptr, workspace, ws_bytes,
+                           stream);
+}
+
+int ptx_voxelize_ex(const float *points, const int32_t *counts, int B, int Ncap, float voxel_size, int32_t *coords,
+                    float *feats, int32_t *inverse, int32_t *nvox_overflow, int32_t *scene_end, void *workspace, size_t ws_bytes,
+                    void *stream)
+{
     PTX_REQUIRE(points && counts && coords && feats && nvox_overflow && workspace, "ptx_voxelize: null argument");
     PTX_REQUIRE(B >= 1 && B <= 64 && Ncap >= 1 && (long)B * Ncap <= (1l << 30) && voxel_size > 0.0f,
                 "ptx_voxelize: B=%d Ncap=%d voxel_size=%g", B, Ncap, voxel_size);
@@ -228,7 +241,7 @@ int ptx_voxelize(const float *points, const int32_t *counts, int B, int Ncap, fl
               reinterpret_cast<unsigned long long *>(ws + L.keys), reinterpret_cast<uint32_t *>(ws + L.owner),
               reinterpret_cast<int32_t *>(ws + L.first), reinterpret_cast<int32_t *>(ws + L.slot_of), reinterpret_cast<int32_t *>(ws + L.row_of_slot),
               reinterpret_cast<unsigned long long *>(ws + L.tile_word), L.slots - 1, coords, feats, inverse,
-              reinterpret_cast<int32_t *>(ws + L.overflow), nvox_overflow};
+              reinterpret_cast<int32_t *>(ws + L.overflow), nvox_overflow, scene_end};
     PTX_HIP(hipMemsetAsync(ws + L.zero_begin, 0, L.zero_bytes, st));
     const dim3 per_point(cdiv(Ncap, 256), B), per_tile(cdiv(Ncap, kTilePts), B);
     hipLaunchKernelGGL(k_vox_insert, per_point, dim3(256), 0, st, a);

@@ -206,7 +206,7 @@ class MultiViewIngest:
             ext = np.asarray(sc["extrinsic"], dtype=np.float32).reshape(V, 4, 4)
             lus, pivs = zip(*(lu_factor_4x4(ext[v]) for v in range(V)))
             aug = sc.get("aug")
-            if sl.copied is not None:
+            if sl.copied is not None and not sl.copied.query():
                 sl.copied.synchronize()                          # the previous call's copy out of the staging buffer (long done)
             o_sel, o_small = 0, (8 * N + 15) // 16 * 16          # 16-byte aligned tables
             o_piv = o_small + 4 * (32 * V + 16)

@@ -858,14 +858,18 @@ class ProxyTransformationNormReverse(nn.Module):
                 ("text_trans_norm", self.text_trans_norm), ("img_trans_norm", self.img_trans_norm))
 
     @torch.no_grad()
-    def quantize(self, outs: List[torch.Tensor], voxel_size: float = 0.01, return_inverse: bool = False):
+    def quantize(self, outs: List[torch.Tensor], voxel_size: float = 0.01, return_inverse: bool = False,
+                 return_scene_rows: bool = False):
         """What the reference's detector does with this module's output next (detectors/
         sparse_featfusion_grounder_preshape.py:388-397, ``use_xyz_feat``): ``ME.utils.batch_sparse_collate([(p / voxel_size,
         p) ...])`` + ``ME.SparseTensor`` -- coordinates ``(Nv,4) int32 = (scene, floor(p / voxel_size))`` and features
         ``(Nv,3)``, one row per occupied voxel (the first point of a voxel in (scene, point) order; MinkowskiEngine's own
         choice is unspecified).  ``outs`` = the list ``forward`` returned (views of one padded buffer are used in place,
         anything else is packed).  Runs on the current stream; the host waits only for the row count, which the last kernel
-        publishes through pinned memory (the tensors' contents are stream-ordered like any torch result)."""
+        publishes through pinned memory (the tensors' contents are stream-ordered like any torch result).
+
+        ``return_scene_rows=True`` appends ``ends`` (list of B ints): the rows of scene b are ``[ends[b-1], ends[b])`` -- what
+        ``x.decomposed_coordinates`` (DET:391-392, 429-430) splits by; published through the same pinned words as the count."""
         lib = _abi.lib()
         B = len(outs)
         dev = outs[0].device
@@ -892,7 +896,7 @@ class ProxyTransformationNormReverse(nn.Module):
                 raise RuntimeError(f"quantize: unsupported size B={B}, N={Ncap}")
             q = lane.quant = dict(key=qkey, ws=torch.empty((nbytes,), dtype=torch.uint8, device=dev),
                                   counts_h=torch.empty((max(B, 1),), dtype=torch.int32).pin_memory(),
-                                  info=torch.empty((2,), dtype=torch.int32).pin_memory())
+                                  info=torch.empty((2 + max(B, 1),), dtype=torch.int32).pin_memory())
             q["info_np"] = q["info"].numpy()
         q["counts_h"][:B] = torch.tensor(n, dtype=torch.int32)
         counts = torch.empty((B,), dtype=torch.int32, device=dev)
@@ -901,12 +905,13 @@ class ProxyTransformationNormReverse(nn.Module):
         feats = torch.empty((B * Ncap, 3), dtype=torch.float32, device=dev)
         inverse = torch.empty((B, Ncap), dtype=torch.int32, device=dev) if return_inverse else None
         q["info_np"][:] = -1
-        _abi.check(lib.ptx_voxelize(buf.data_ptr(), counts.data_ptr(), B, Ncap, float(voxel_size), coords.data_ptr(),
-                                    feats.data_ptr(), _ptr(inverse), q["info"].data_ptr(), q["ws"].data_ptr(), q["ws"].numel(),
-                                    tstream.cuda_stream), "ptx_voxelize")
-        if lib.ptx_wait_counts(q["info"].data_ptr(), 2, _COUNTS_TIMEOUT_US) != 0:
+        _abi.check(lib.ptx_voxelize_ex(buf.data_ptr(), counts.data_ptr(), B, Ncap, float(voxel_size), coords.data_ptr(),
+                                       feats.data_ptr(), _ptr(inverse), q["info"].data_ptr(), q["info"].data_ptr() + 8,
+                                       q["ws"].data_ptr(), q["ws"].numel(), tstream.cuda_stream), "ptx_voxelize")
+        if lib.ptx_wait_counts(q["info"].data_ptr(), 2 + B, _COUNTS_TIMEOUT_US) != 0:
             tstream.synchronize()
-        nvox, overflow = (int(x) for x in q["info_np"])
+        nvox, overflow = (int(x) for x in q["info_np"][:2])
+        ends = q["info_np"][2:2 + B].tolist()
         if nvox < 0:
             raise RuntimeError("ptx_voxelize finished without publishing its row count")
         if nvox == 0x7fffffff:           # PTX_VOX_BROKEN: a tile of the emit pass gave up waiting for the tiles in front of it
@@ -919,6 +924,8 @@ class ProxyTransformationNormReverse(nn.Module):
         res = (coords[:nvox], feats[:nvox])
         if return_inverse:
             res += ([inverse[b, : n[b]] for b in range(B)],)
+        if return_scene_rows:
+            res += (ends,)
         return res
 
     @torch.no_grad()

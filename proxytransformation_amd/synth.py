@@ -24,7 +24,8 @@ from typing import Dict, Tuple
 import numpy as np
 
 __all__ = [
-    "PreshapeConfig", "CONFIGS", "make_scene_batch", "fill_tensor", "fill_state_dict",
+    "PreshapeConfig", "CONFIGS", "make_scene_batch", "fill_tensor", "fill_state_dict", "make_depth_scene",
+    "FPN_LEVELS",
 ]
 
 
@@ -121,6 +122,68 @@ def make_scene_batch(cfg: PreshapeConfig, scene_ids=None, *, mask_scene: int = 1
         if int(sid) == mask_scene and cfg.L >= 3:
             mask[j, cfg.L - cfg.L // 3:] = False
     return points, text, mask, img
+
+
+# --------------------------------------------------------------------------
+# synthetic multi-view depth scenes (BASELINE configs[3]: the shipped pipeline, CFG:105-142)
+# --------------------------------------------------------------------------
+#: (channels, side) of the 2D backbone's four output levels for a 480 x 480 input: mmdet ResNet-50 with base_channels=16
+#: (CFG:28-39) has stage widths 64 / 128 / 256 / 512 at strides 4 / 8 / 16 / 32; the last one is the neck's img_feat (DET:385)
+FPN_LEVELS = ((64, 120), (128, 60), (256, 30), (512, 15))
+
+
+def make_depth_scene(seed: int, V: int = 50, H: int = 480, W: int = 640, extent=(7.0, 5.0, 3.0), *, as_u16: bool = True,
+                     hole_rate: float = 0.08):
+    """One synthetic RGB-D scan of a box-shaped room of size ``extent`` (metres, one corner at the origin): ``V`` pinhole cameras at
+    random poses inside the room look at its walls / floor / ceiling through "room-sized frusta" -- every pixel's depth is the
+    distance (along the optical axis) to the first surface its ray meets, shortened inside smooth random blobs (furniture) and
+    zero (invalid, like a sensor hole) for ``hole_rate`` of the pixels.  Back-projected through ``depth_cam2img`` and the
+    global2cam ``extrinsic`` the pixels land inside ``[0, extent]`` -- the (7, 5, 3) m regime of SURVEY 8d.
+
+    Returns a dict shaped like what the reference's loading transforms hand on (mv_3dvg_dataset.py:535-553,
+    transforms/multiview.py:140-190): ``depth_img`` (V,H,W) uint16 raw (``depth_shift`` 1000) or float32 metres,
+    ``depth_cam2img`` (4,4), ``depth2img = dict(extrinsic=[V x (4,4) global2cam], intrinsic=[V x (4,4) cam2img])`` and an
+    ``img_meta`` for a 480 x 640 image resized to 480 x 480 (CFG:114: ``scale_factor`` (0.75, 1.0))."""
+    rng = np.random.default_rng(seed)
+    ex = np.asarray(extent, np.float64)
+    fx = fy = 577.0 * W / 640.0
+    cx, cy = (W - 1) / 2.0, (H - 1) / 2.0
+    K = np.eye(4, dtype=np.float32)
+    K[0, 0], K[1, 1], K[0, 2], K[1, 2] = fx, fy, cx, cy
+    us, vs = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32))
+    dc = np.stack([(us - cx) / fx, (vs - cy) / fy, np.ones_like(us)], -1).astype(np.float32)         # (H,W,3), z = 1
+    depth = np.empty((V, H, W), np.float32)
+    extr = []
+    for v in range(V):
+        pos = ex * (0.15 + 0.7 * rng.random(3))
+        yaw, pitch = 2 * np.pi * rng.random(), 0.5 * (rng.random() - 0.5)
+        fwd = np.array([np.cos(yaw) * np.cos(pitch), np.sin(yaw) * np.cos(pitch), np.sin(pitch)])
+        right = np.cross(fwd, [0.0, 0.0, 1.0])
+        right /= np.linalg.norm(right)
+        down = np.cross(fwd, right)
+        R = np.stack([right, down, fwd], 1)                                   # cam2global rotation (columns = camera axes)
+        dw = dc @ R.T.astype(np.float32)                                      # ray directions in the room's frame
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t = np.full((H, W), np.inf, np.float32)
+            for a in range(3):
+                da = dw[..., a]
+                ta = np.where(da > 0, (ex[a] - pos[a]) / da, np.where(da < 0, (0.0 - pos[a]) / da, np.inf))
+                t = np.minimum(t, ta.astype(np.float32))
+        # furniture: a few smooth blobs in the image plane pull the surface towards the camera
+        for _ in range(4):
+            bu, bv, br = W * rng.random(), H * rng.random(), (0.08 + 0.15 * rng.random()) * W
+            w = np.exp(-(((us - bu) ** 2 + (vs - bv) ** 2) / (2 * br * br))).astype(np.float32)
+            t = t * (1.0 - np.float32(0.45 * rng.random()) * w)
+        t[rng.random((H, W)) < hole_rate] = 0.0
+        depth[v] = t
+        c2g = np.eye(4)
+        c2g[:3, :3], c2g[:3, 3] = R, pos
+        extr.append(np.linalg.inv(c2g).astype(np.float32))
+    raw = np.clip(np.rint(depth * 1000.0), 0, 65535).astype(np.uint16)
+    img_meta = dict(scale_factor=(480.0 / W, 480.0 / H), img_shape=(480, 480), flip=False)
+    return dict(depth_img=raw if as_u16 else raw.astype(np.float32) / np.float32(1000.0), depth_shift=1000.0, depth_cam2img=K,
+                depth2img=dict(extrinsic=extr, intrinsic=[K.copy() for _ in range(V)]), extrinsic=np.stack(extr),
+                img_meta=img_meta)
 
 
 # --------------------------------------------------------------------------

@@ -1,0 +1,168 @@
+"""The training step under the reference's ONLY parallel strategy (VERDICT r05 "next" #2): ``DistributedDataParallel`` with
+``find_unused_parameters=True`` (configs/grounding/proxy-tiblock33-gs12-wbias-ddr0.6-clip.py:246, configs/default_runtime.py:15
+``launcher`` / ``dist_cfg``, tools/train.py:93-105; mmengine wraps the model in ``MMDistributedDataParallel``, a subclass that
+forwards to ``DistributedDataParallel.forward``).
+
+Two processes share cuda:0 over gloo (the 1-GPU box; with the nccl backend the same code runs over RCCL).  Each rank wraps the
+module, takes DIFFERENT scenes and steps; every live gradient must equal the mean of the two single-process gradients, the 36
+parameters of the dead blocks stay ``None`` -- which is what ``find_unused_parameters=True`` is in the config for -- a
+second step works, with ``static_graph`` off and on, with the image block beside the text block on the side stream
+(``train._BLOCKS_APART``) and without, and through 100 steps with allocator churn between them: the one autograd node hands
+gradients across a side stream in its backward (train.py ``_TrainStep.backward``), and the reducer copies them into its buckets on
+the autograd stream right behind it."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_WORKER = r'''
+import os, sys, torch, numpy as np
+import torch.distributed as dist
+from torch.nn.parallel import DistributedDataParallel as DDP
+sys.path.insert(0, %r)
+from proxytransformation_amd import MODELS, train
+from proxytransformation_amd.synth import PreshapeConfig, fill_state_dict, make_scene_batch
+from oracle import oracle
+
+OUT = %r
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+static_graph = os.environ["DDP_STATIC"] == "1"
+train._BLOCKS_APART = os.environ["DDP_APART"] == "1"
+soak = int(os.environ.get("DDP_SOAK", "0"))
+dist.init_process_group("gloo", rank=rank, world_size=world)
+torch.cuda.set_device(0)
+dev = torch.device("cuda:0")
+cfg = PreshapeConfig("ddp", B=2, N=6000, grid_size=5, dynamic_drop_radio=0.6, L=9, V=4, text_blocks=2, img_blocks=2, seed_base=9400)
+kw = dict(cfg.module_kwargs(), drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.0)
+m = MODELS.build(dict(type="ProxyTransformationNormReverse", **kw))
+m.load_state_dict({k: torch.from_numpy(v) for k, v in fill_state_dict(m.state_dict()).items()})
+m = m.cuda().train()
+ids = [2 * rank, 2 * rank + 1]                                   # every rank trains on its own scenes
+pts, text, mask, img = make_scene_batch(cfg, scene_ids=ids)
+t = lambda a: torch.from_numpy(a).to(dev)
+args = ([t(p) for p in pts], {"text_feats": t(text), "text_token_mask": t(mask)}, t(img))
+
+def loss_of(outs):
+    return sum((o * torch.from_numpy(oracle.loss_weights(b, o.shape[0])).to(o.device)).sum() for b, o in enumerate(outs))
+
+def grads(mod):
+    return {k: (None if p.grad is None else p.grad.detach().clone()) for k, p in mod.named_parameters()}
+
+# the single-process step of this rank's scenes (no wrapper): what the mean is taken of
+loss_of(m(*args)).backward()
+torch.cuda.synchronize()
+local = grads(m)
+buffers0 = {k: v.detach().clone() for k, v in m.named_buffers()}
+for p in m.parameters():
+    p.grad = None
+m.load_state_dict({k: torch.from_numpy(v) for k, v in fill_state_dict(m.state_dict()).items()})   # running statistics back to the start
+
+ddp = DDP(m, device_ids=[0], find_unused_parameters=True, static_graph=static_graph)
+steps = []
+for it in range(2):
+    for p in m.parameters():
+        p.grad = None
+    loss_of(ddp(*args)).backward()
+    torch.cuda.synchronize()
+    steps.append(grads(m))
+m.check()
+ok_soak = True
+if soak:
+    # allocator churn between and inside the steps: blocks of every size freed and re-used while the side stream's gradients are in
+    # flight -- a hand-over that is not ordered before the reducer's bucket copies shows up as a gradient that differs
+    g = torch.Generator().manual_seed(rank)
+    junk = []
+    want = steps[1]
+    for it in range(soak):
+        for p in m.parameters():
+            p.grad = None
+        junk = [torch.empty(int(torch.randint(1, 1 << 22, (1,), generator=g)), device=dev) for _ in range(8)]
+        out = ddp(*args)
+        del junk[::2]
+        junk.append(torch.full((1 << 20,), float(it), device=dev))
+        loss_of(out).backward()
+        junk = [torch.empty(int(torch.randint(1, 1 << 20, (1,), generator=g)), device=dev).fill_(1.0) for _ in range(4)]
+        got = grads(m)
+        for k, v in want.items():
+            if (v is None) != (got[k] is None) or (v is not None and not torch.equal(v, got[k])):
+                ok_soak = False
+                print("SOAK MISMATCH", it, k, flush=True)
+                break
+        if not ok_soak:
+            break
+    torch.cuda.synchronize()
+    m.check()
+torch.save(dict(local={k: (None if v is None else v.cpu()) for k, v in local.items()},
+                steps=[{k: (None if v is None else v.cpu()) for k, v in s.items()} for s in steps], ok_soak=ok_soak,
+                buffers={k: v.cpu() for k, v in m.named_buffers()}), os.path.join(OUT, f"rank{rank}.pt"))
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def _launch(tmp_path, static_graph, apart, soak=0):
+    script = tmp_path / "ddp_worker.py"
+    script.write_text(_WORKER % (ROOT, str(tmp_path)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               DDP_STATIC="1" if static_graph else "0", DDP_APART="1" if apart else "0", DDP_SOAK=str(soak))
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        out, _ = p.communicate(timeout=900)
+        outs.append(out)
+        assert p.returncode == 0, out[-4000:]
+    return [torch.load(tmp_path / f"rank{r}.pt") for r in range(2)], outs
+
+
+def _check(res):
+    r0, r1 = res
+    names = sorted(r0["local"])
+    dead = [k for k in names if r0["local"][k] is None]
+    live = [k for k in names if r0["local"][k] is not None]
+    # text_blocks = img_blocks = 2: block 0 of each list and its norm are dead: 2 x (16 + 2) = 36 parameters
+    assert len(dead) == 36 and all(k.startswith(("textformer.0.", "imgformer.0.", "text_norm.0.", "img_norm.0.")) for k in dead)
+    assert [k for k in names if r1["local"][k] is None] == dead
+    for step in (0, 1):
+        for k in dead:
+            assert r0["steps"][step][k] is None and r1["steps"][step][k] is None, f"dead parameter {k} received a gradient"
+        for k in live:
+            want = (r0["local"][k].double() + r1["local"][k].double()) / 2
+            for r in (r0, r1):
+                got = r["steps"][step][k]
+                assert got is not None, f"step {step}: {k} has no gradient"
+                scale = float(want.abs().max()) + 1e-30
+                err = float((got.double() - want).abs().max()) / scale
+                assert err <= 1e-6, f"step {step}: {k}: |ddp - mean of the single-process gradients| / max = {err:.3e}"
+        # both ranks hold the same averaged gradient, bit for bit
+        for k in live:
+            assert torch.equal(r0["steps"][step][k], r1["steps"][step][k]), k
+    # broadcast_buffers (DDP's default): rank 0's running statistics are what both ranks end with
+    for k in r0["buffers"]:
+        assert torch.equal(r0["buffers"][k], r1["buffers"][k]), k
+
+
+@pytest.mark.parametrize("apart", [True, False], ids=["blocks-apart", "blocks-in-line"])
+@pytest.mark.parametrize("static_graph", [False, True], ids=["dynamic", "static-graph"])
+def test_training_step_under_ddp_averages_the_gradients(tmp_path, static_graph, apart):
+    res, _ = _launch(tmp_path, static_graph, apart)
+    _check(res)
+
+
+def test_ddp_steps_with_allocator_churn(tmp_path):
+    """100 wrapped steps with blocks of every size allocated and freed around them: every step's gradients equal the first's bit
+    for bit on both ranks (the step is bit-reproducible, tests/test_gpu_train.py)."""
+    res, outs = _launch(tmp_path, False, True, soak=100)
+    _check(res)
+    assert res[0]["ok_soak"] and res[1]["ok_soak"], outs

@@ -287,3 +287,25 @@ def test_module_copies_drop_the_host_caches():
     buf.seek(0)
     m3 = torch.load(buf, weights_only=False)
     assert list(m3.state_dict()) == list(m.state_dict()) and m3._wstruct is None
+
+
+def test_pipeline_host_pieces():
+    """The host-side pieces of the configs[3] chain (proxytransformation_amd/pipeline.py), no GPU: the synthetic depth scan
+    back-projects into its room through the ORACLE's ingest, projection matrices are intrinsic @ extrinsic, the oracle's level
+    coordinates are the distinct floor(c / s) * s in first-occurrence order (negative coordinates floor, not truncate)."""
+    from oracle import oracle
+    from proxytransformation_amd.pipeline import MINK_RESNET_STRIDES, projection_matrices
+    from proxytransformation_amd.synth import FPN_LEVELS, make_depth_scene
+    sc = make_depth_scene(11, V=3, H=120, W=160)
+    assert sc["depth_img"].dtype == np.uint16 and sc["depth_img"].shape == (3, 120, 160)
+    depth = sc["depth_img"].astype(np.float32) / np.float32(sc["depth_shift"])
+    r = oracle.ingest(depth, sc["depth_cam2img"], sc["extrinsic"], 5000, rng=np.random.RandomState(0))
+    assert (r["points"] > -5e-3).all() and (r["points"] < np.array([7, 5, 3], np.float32) + 5e-3).all()
+    P = projection_matrices(sc["depth2img"])
+    assert P.shape == (3, 4, 4) and np.allclose(P[1], sc["depth2img"]["intrinsic"][1] @ sc["depth2img"]["extrinsic"][1])
+    # a point of view 0 projects back into view 0's image with positive depth
+    q = P[0] @ np.append(r["points"][0], 1.0)
+    assert MINK_RESNET_STRIDES == (8, 16, 32, 64) and [c for c, _ in FPN_LEVELS] == [64, 128, 256, 512]
+    coords = np.array([[0, 9, -1, 17], [0, 15, -8, 23], [0, 16, -9, 0], [1, 9, -1, 17], [1, 1, 1, 1]], np.int32)
+    lv = oracle.level_coordinates(coords, 2, 8)
+    assert np.array_equal(lv[0], [[8, -8, 16], [16, -16, 0]]) and np.array_equal(lv[1], [[8, -8, 16], [0, 0, 0]])
