@@ -111,6 +111,7 @@ SIGNATURES = {
     "ptx_grid_centers": (_I, [_P, _I, _I, _P, _I, _F, _P, _P, _P, _Z, _P]),
     "ptx_ball_query": (_I, [_P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P]),
     "ptx_linear": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ptx_gemm_policy": (_I, [_I]),
     "ptx_offset_net": (_I, [_SH, _W, _P, _P, _P, _P, _P, _P, _P]),
     "ptx_select_clusters": (_I, [_SH] + [_P] * 14),
     "ptx_pointnet": (_I, [_SH, _W, _P, _P, _P, _P, _P]),
