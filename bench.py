@@ -93,6 +93,8 @@ def parse():
                     help="the roofline kernel is bracketed by HIP events on every n-th measured step (each event record costs "
                          "the stream ~6 us of idle between two kernels; 1 = every step)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (nccl = RCCL)")
+    ap.add_argument("--gemm-policy", type=int, default=None,
+                    help="ptx_gemm_policy: 128x128 tiles in a launch from which the 128x128-tile GEMM is used (0 = never, 1 = whenever legal; default: the library's 256)")
     ap.add_argument("--pipeline", action="store_true",
                     help="BASELINE configs[3] as a pipeline: depth maps -> ingest -> neck -> 1 cm voxels -> four levels of image-feature "
                          "sampling, chained on one stream (proxytransformation_amd/pipeline.py); use with --config cfg4_room")
@@ -596,6 +598,8 @@ def main():
     mod, sd = build_module(cfg, device)
     inputs = InputSets(cfg, B, max(1, args.sets), rank, world, device, tdt)
     lib = _abi.lib()
+    if args.gemm_policy is not None:
+        lib.ptx_gemm_policy(args.gemm_policy)
     names = [lib.ptx_kernel_name(i).decode() for i in range(lib.ptx_kernel_count())]
     if args.time_kernel not in names:
         raise SystemExit(f"--time-kernel must be one of {names}")

@@ -201,11 +201,12 @@ PTX_API int ptx_ball_query(const float *centers, const float *points, int B, int
  * fp32 MFMA (v_mfma_f32_32x32x2_f32); n_in % 4 == 0, x and w 16-byte aligned. */
 PTX_API int ptx_linear(const float *x, const float *w, const float *bias, const float *residual, float *y,
                int rows, int n_out, int n_in, int gelu, void *stream);
-/* ABI 12.  Tile policy of the split-operand GEMMs behind every nn.Linear of the path (csrc/gemm.hip): problems whose every group
- * has at least `min_rows_128` rows (and K a multiple of 256) run on 128 x 128 tiles (k_gemm128x), smaller ones on 64 x 64 tiles /
- * the latency-regime kernel.  Default 4096; 0 = never; 1 = whenever the shape allows it (tests); < 0 = query.  Returns the previous
- * value.  Process-wide, relaxed: results do not depend on it beyond the summation order of an fp32-equivalent product. */
-PTX_API int ptx_gemm_policy(int min_rows_128);
+/* ABI 12.  Tile policy of the split-operand GEMMs behind every nn.Linear of the path (csrc/gemm.hip): a launch (all its groups
+ * together) of at least `min_tiles_128` tiles of 128 x 128 outputs, with K a multiple of 256, runs on 128 x 128 tiles (k_gemm128x),
+ * anything else on 64 x 64 tiles / the latency-regime kernel.  Default 256 (one tile per CU); 0 = never; 1 = whenever the shape
+ * allows it (tests); < 0 = query.  Returns the previous value.  Process-wide, relaxed: results do not depend on it beyond the
+ * summation order of an fp32-equivalent product. */
+PTX_API int ptx_gemm_policy(int min_tiles_128);
 
 /* OffsetNetwork.forward + tanh*margin + add + clamp, PRE:58-62, 87-107.
  * centers_in (B,M,3), cluster (B,M,K,3), minmax (B,2,3) -> centers_out (B,M,3);

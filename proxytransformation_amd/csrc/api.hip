@@ -947,7 +947,7 @@ int ptx_linear(const float *x, const float *w, const float *bias, const float *r
     return launch_gemm(g, static_cast<hipStream_t>(stream));
 }
 
-int ptx_gemm_policy(int min_rows_128) { return gemm_policy(min_rows_128); }
+int ptx_gemm_policy(int min_tiles_128) { return gemm_policy(min_tiles_128); }
 
 int ptx_offset_net(const PtxShape *s, const PtxWeights *w, const void *prep, const float *centers_in,
                    const float *cluster, const float *minmax, float *centers_out, float *offsets_out,

@@ -299,7 +299,7 @@ struct GemmBatch {
     GateRef tail_gate;
 };
 int launch_gemm(const GemmBatch &gb, hipStream_t st, int compute_dtype = 0);     // 1: plain bf16 operands where supported
-int gemm_policy(int min_rows_128);      // ptx_gemm_policy
+int gemm_policy(int min_tiles_128);      // ptx_gemm_policy
 
 struct LnProb { const float *x; float *y; const float *w; const float *b; const float *add; int R, add_rows; };
 struct LnBatch { LnProb p[2]; int n; int C; float eps; };

@@ -348,6 +348,19 @@ __global__ __launch_bounds__(256) void k_gemm64x(GemmBatch gb)
 // half, 16 B each, rows consecutive) covers 256 consecutive bytes, and the 8-byte stash writes of 16 consecutive lanes (four rows
 // x both halves x two quads) hit sixteen distinct even banks: both conflict-free by construction (cf. xswz for the 64-B rows).
 constexpr int kYHalf = 128 * 16 + 64, kYPlane = 2 * kYHalf, kYBuf = 6 * kYPlane;     // 2112 / 4224 / 25344 bytes
+// lab knobs (scratch/g128_variants.py builds the library with other values; the product uses the defaults)
+#ifndef PTX_G128_NM
+#define PTX_G128_NM 8          // macro steps in the written-out body
+#endif
+#ifndef PTX_G128_ORDER
+#define PTX_G128_ORDER 0       // 0: the six terms go term by term over the four accumulators; 1: accumulator by accumulator
+#endif
+#ifndef PTX_G128_SWZ
+#define PTX_G128_SWZ 0         // 1: XCD-aware tile order (k_gemm128x)
+#endif
+#ifndef PTX_G128_PIPE
+#define PTX_G128_PIPE 1        // 1: sched_group_barrier interleave of a step (reads, then MFMA + VALU + DS-write groups): +3-5 %
+#endif
 
 #define PTX_Y_FETCH(S, m_)                                                                 \
     do {                                                                                   \
@@ -386,11 +399,13 @@ constexpr int kYHalf = 128 * 16 + 64, kYPlane = 2 * kYHalf, kYBuf = 6 * kYPlane;
                 fa[i_][p_] = *reinterpret_cast<const bf16x8 *>(A_ + i_ * 512 + p_ * kYPlane); \
                 fw[i_][p_] = *reinterpret_cast<const bf16x8 *>(W_ + i_ * 512 + p_ * kYPlane); \
             }                                                                              \
-        if (NP == 3) {                                                                     \
+        if (NP == 3 && PTX_G128_ORDER == 0) {                                              \
             constexpr int ta_[6] = {2, 1, 0, 1, 0, 0}, tw_[6] = {0, 1, 2, 0, 1, 0};        \
             _Pragma("unroll") for (int t_ = 0; t_ < 6; ++t_)                               \
                 _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                           \
                     acc[q_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[q_ >> 1][ta_[t_]], fw[q_ & 1][tw_[t_]], acc[q_], 0, 0, 0); \
+        } else if (NP == 3) {                                                              \
+            _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) acc[q_] = mfma_split6(fa[q_ >> 1], fw[q_ & 1], acc[q_]); \
         } else {                                                                           \
             _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                               \
                 acc[q_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[q_ >> 1][0], fw[q_ & 1][0], acc[q_], 0, 0, 0); \
@@ -403,7 +418,19 @@ __global__ __launch_bounds__(256, 2) void k_gemm128x(GemmBatch gb, int nrep)
 {
     static_assert(NM >= 2 && NM % 2 == 0, "macro steps come in P / Q pairs");
     const GemmProb pr = gb.p[blockIdx.z];
-    const int row0 = blockIdx.x * 128, col0 = blockIdx.y * 128;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (PTX_G128_SWZ) {
+        // XCD-aware tile order: work-groups are dealt round-robin over the 8 XCDs (linear id mod 8), each with its own L2.  The
+        // launch order (row tile fastest) gives an XCD every 8th row tile of ONE column tile at a time, so every column tile re-reads
+        // the whole A operand from beyond the L2; here an XCD owns a contiguous range of row tiles and walks their column tiles
+        // first: an A row panel is fetched once per XCD and the (small) W operand stays L2-resident
+        const unsigned total = gridDim.x * gridDim.y, lin = blockIdx.x + gridDim.x * blockIdx.y;
+        if ((total & 7u) == 0u) {
+            const unsigned l2 = (lin & 7u) * (total >> 3) + (lin >> 3);
+            bx = (int)(l2 / gridDim.y); by = (int)(l2 % gridDim.y);
+        }
+    }
+    const int row0 = bx * 128, col0 = by * 128;
     if (row0 >= pr.R || col0 >= pr.N) return;
     __shared__ __attribute__((aligned(16))) char smem[2 * kYBuf];
     __shared__ float s_mu[128], s_rs[128];
@@ -434,14 +461,26 @@ __global__ __launch_bounds__(256, 2) void k_gemm128x(GemmBatch gb, int nrep)
     __syncthreads();
     // sub-step (m, 0): consume LDS[0], second half of set S (macro step m) -> LDS[1]
     // sub-step (m, 1): loads of macro step m + 2 -> set S (free now); consume LDS[1]; first half of set T (macro step m + 1) -> LDS[0]
+#define PTX_Y_PIPE()                                                                       \
+    do {                                                                                   \
+        if (NP != 3 || !PTX_G128_PIPE) break;                                              \
+        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);             /* fragment reads */ \
+        _Pragma("unroll") for (int g_ = 0; g_ < 12; ++g_) {                                \
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                             \
+            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);                             \
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                             \
+        }                                                                                  \
+    } while (0)
 #define PTX_Y_MACRO(S, T, u_)                                                              \
     PTX_Y_COMPUTE(0);                                                                      \
     PTX_Y_STASH(S, 1, 1);                                                                  \
+    PTX_Y_PIPE();                                                                          \
     __syncthreads();                                                                       \
     if ((u_) + 2 < NM || rep + 1 < nrep) PTX_Y_FETCH(S, mbase + (u_) + 2);                 \
     __builtin_amdgcn_sched_barrier(0);                                                     \
     PTX_Y_COMPUTE(1);                                                                      \
     if ((u_) + 1 < NM || rep + 1 < nrep) PTX_Y_STASH(T, 0, 0);                             \
+    PTX_Y_PIPE();                                                                          \
     __syncthreads();
     int mbase = 0;
     for (int rep = 0; rep < nrep; ++rep) {
@@ -454,6 +493,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm128x(GemmBatch gb, int nrep)
     }
     (void)total;
 #undef PTX_Y_MACRO
+#undef PTX_Y_PIPE
     // epilogue, one accumulator at a time (C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5));
     // its operands are requested per accumulator (64 residual registers up front would not fit beside the prefetch sets)
     float *scratch = reinterpret_cast<float *>(smem) + wid * (32 * 33);
@@ -786,11 +826,11 @@ static int launch_gemm32(const GemmBatch &gb, int rmax, int nmax, hipStream_t st
     return PTX_OK;
 }
 
-// rows from which the 128 x 128-tile kernel is used (ptx_gemm_policy: 0 = never, 1 = whenever the shape allows it)
-static std::atomic<int> g_gemm128_min_rows{4096};
-int gemm_policy(int min_rows_128)
+// 128 x 128 tiles in a launch from which k_gemm128x is used (ptx_gemm_policy: 0 = never, 1 = whenever the shape allows it)
+static std::atomic<int> g_gemm128_min_tiles{256};
+int gemm_policy(int min_tiles_128)
 {
-    return min_rows_128 < 0 ? g_gemm128_min_rows.load() : g_gemm128_min_rows.exchange(min_rows_128);
+    return min_tiles_128 < 0 ? g_gemm128_min_tiles.load() : g_gemm128_min_tiles.exchange(min_tiles_128);
 }
 
 int launch_gemm(const GemmBatch &gb_in, hipStream_t st, int compute_dtype)
@@ -831,22 +871,19 @@ int launch_gemm(const GemmBatch &gb_in, hipStream_t st, int compute_dtype)
         return PTX_OK;
     }
     constexpr int g64_min = 1024;
-    // 128 x 128 tiles (k_gemm128x): K a multiple of 256 (256 .. 4096), every problem at least g_gemm128_min_rows rows (default 4096,
-    // ptx_gemm_policy) and enough tiles for every CU
+    // 128 x 128 tiles (k_gemm128x): K a multiple of 256 (256 .. 4096) and at least g_gemm128_min_tiles tiles in the launch (default
+    // 256 = one per CU, ptx_gemm_policy).  Alone on the chip (scratch/gemm128_lab.py, profiles/r06_gemm128_lab.txt): 1.24 - 1.39 x
+    // the 64 x 64 kernel from ~380 tiles on (8192 x 768 x 256 ... 16384 x 2048 x 512: 100 -> 160 TF fp32-equivalent), even at
+    // 200 - 260 tiles, 0.65 - 0.8 x at 128 tiles (half of the CUs idle).  Groups of one launch may have any row count.
     long tiles128 = 0;
-    int rmin = 1 << 30;
-    for (int g = 0; g < gb.n; ++g) {
-        tiles128 += (long)cdiv(gb.p[g].R, 128) * cdiv(gb.p[g].N, 128);
-        rmin = gb.p[g].R < rmin ? gb.p[g].R : rmin;
-    }
-    const int min128 = g_gemm128_min_rows.load(std::memory_order_relaxed);
-    const bool use128 = gb.p[0].pg == nullptr && kmin == kmax && kmin % 256 == 0 && kmin <= 4096 && min128 > 0 && rmin >= min128 &&
-                        (tiles128 >= 256 || min128 == 1);
+    for (int g = 0; g < gb.n; ++g) tiles128 += (long)cdiv(gb.p[g].R, 128) * cdiv(gb.p[g].N, 128);
+    const int min128 = g_gemm128_min_tiles.load(std::memory_order_relaxed);
+    const bool use128 = gb.p[0].pg == nullptr && kmin == kmax && kmin % 256 == 0 && kmin <= 4096 && min128 > 0 && tiles128 >= min128;
     if (use128) {
         const dim3 grid(cdiv(rmax, 128), cdiv(nmax, 128), gb.n);
-        const int nrep = kmin / 256;
-        if (compute_dtype == 1) hipLaunchKernelGGL((k_gemm128x<8, 1>), grid, dim3(256), 0, st, gb, nrep);
-        else                    hipLaunchKernelGGL((k_gemm128x<8, 3>), grid, dim3(256), 0, st, gb, nrep);
+        const int nrep = kmin / (32 * PTX_G128_NM);
+        if (compute_dtype == 1) hipLaunchKernelGGL((k_gemm128x<PTX_G128_NM, 1>), grid, dim3(256), 0, st, gb, nrep);
+        else                    hipLaunchKernelGGL((k_gemm128x<PTX_G128_NM, 3>), grid, dim3(256), 0, st, gb, nrep);
         PTX_LAUNCHED("k_gemm128x");
         return PTX_OK;
     }

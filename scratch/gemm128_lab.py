@@ -1,10 +1,19 @@
 """r06: k_gemm128x (128 x 128 tiles) against k_gemm64x (64 x 64) through ptx_linear: error vs float64 and time per launch.
 usage: python scratch/gemm128_lab.py"""
-import sys, os, torch
+import sys, os, ctypes, torch
 sys.path.insert(0, os.getcwd())
 from proxytransformation_amd import _abi
 lib = _abi.lib()
 dev = torch.device("cuda")
+
+
+def load(path):
+    """A lab build of the library (scratch/g128_variants.py), typed like the product's."""
+    h = ctypes.CDLL(os.path.abspath(path))
+    for name in ("ptx_linear", "ptx_gemm_policy", "ptx_last_error"):
+        fn = getattr(h, name)
+        fn.restype, fn.argtypes = _abi.SIGNATURES[name]
+    return h
 
 
 def run(R, N, K, policy, reps=100, gelu=0, res=False):
@@ -38,6 +47,20 @@ def run(R, N, K, policy, reps=100, gelu=0, res=False):
     return us, 2.0 * R * N * K / us / 1e6, err
 
 
+if "--libs" in sys.argv:
+    libs = sys.argv[sys.argv.index("--libs") + 1:]
+    shapes = [(16384, 2048, 512), (16384, 512, 2048), (8192, 1024, 256), (8192, 768, 256), (4146, 1024, 256)]
+    base = {shp: run(*shp, 1) for shp in shapes}
+    print("product     " + "  ".join(f"{base[s][0]:7.1f} us {base[s][1]:6.1f} TF" for s in shapes))
+    for path in libs:
+        lib = load(path)
+        r = {shp: run(*shp, 1) for shp in shapes}
+        assert all(v[2] <= 1.0 for v in r.values()), (path, r)
+        print(f"{os.path.basename(path)[9:-3]:12s}" + "  ".join(f"{r[s][0]:7.1f} us {r[s][1]:6.1f} TF" for s in shapes), flush=True)
+    lib = _abi.lib()
+    again = {shp: run(*shp, 1) for shp in shapes}
+    print("product     " + "  ".join(f"{again[s][0]:7.1f} us {again[s][1]:6.1f} TF" for s in shapes))
+    sys.exit(0)
 shapes = [(8192, 768, 256), (8192, 256, 256), (8192, 1024, 256), (8192, 256, 1024), (16384, 1536, 512), (16384, 2048, 512),
           (16384, 512, 2048), (16384, 512, 512), (4146, 768, 256), (4146, 1024, 256), (4146, 256, 1024), (2048, 1024, 1024),
           (4100, 700, 256)]

@@ -3,6 +3,8 @@ import sys, torch
 import os; sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from proxytransformation_amd import _abi
 lib = _abi.lib()
+if os.environ.get('GEMM_POLICY'):
+    lib.ptx_gemm_policy(int(os.environ['GEMM_POLICY']))
 R, N, K, g = map(int, sys.argv[1:5])
 dev = torch.device('cuda:0')
 st = torch.cuda.current_stream().cuda_stream
