@@ -48,7 +48,11 @@ from proxytransformation_amd.synth import CONFIGS, fill_state_dict, make_scene_b
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix (v_mfma_f32_32x32x2_f32), 256 CUs
-PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
+# the ceiling of the pipe the fp32-EQUIVALENT kernels really run on: k_gemm64x / k_gemm128x / k_proxy_attn / k_mlp
+# issue six v_mfma_f32_32x32x16_bf16 per fp32-equivalent product (csrc/split3.h), so their ceiling is the dense bf16 peak / 6
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+MFMA_SPLIT_PEAK_TFLOPS = MFMA_BF16_PEAK_TFLOPS / 6.0
+PMC_FILE = os.path.join(ROOT, "profiles", "r06_pmc_traffic.json")
 
 
 def so_sha16():
@@ -405,7 +409,10 @@ def passes_report(cfg, B, us, dt_bytes, p_max=None, step_s=None):
         t = sum(us[s] for s in sites if s in us)
         f = sum(flops[s] for s in sites if s in us)
         return dict(us=round(t, 2), GFLOP=round(f / 1e9, 3), achieved_TFLOPs=round(f / t / 1e6, 2),
-                    frac_of_f32_mfma_peak=round(f / t / 1e6 / MFMA_F32_PEAK_TFLOPS, 4)) if t > 0 else None
+                    frac_of_f32_mfma_peak=round(f / t / 1e6 / MFMA_F32_PEAK_TFLOPS, 4),
+                    frac_of_bf16_split_peak=round(f / t / 1e6 / MFMA_SPLIT_PEAK_TFLOPS, 4),
+                    ceilings="fp32-equivalent FLOPs; f32 peak 157.3 TF = the fp32 matrix instruction's; split peak 416.7 TF = 2.5 PF bf16 / 6 "
+                             "(the pipe these kernels use: six bf16 MFMAs per product, csrc/split3.h)") if t > 0 else None
     rep["clustering_pass_hbm"] = hbm(["k_minmax", "k_cluster"])
     rep["clustering_pass_hbm"]["bound"] = "upper: each ball-query pass reads every point once (SURVEY 8d: 12 N + 2 x 12 N + writes)"
     if p_max is not None and "k_minmax" in us and "k_cluster" in us:

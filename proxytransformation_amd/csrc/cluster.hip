@@ -58,36 +58,140 @@ __device__ __forceinline__ void grid_centre(const uint32_t *__restrict__ mm_enc,
 // One wave scans the scene for the first K points with dist2 < r2 around (cx,cy,cz), in index order.  Hit number
 // `pos` goes to oi[pos] (point index, may be null) and oc[3 pos ..] (xyz; global or wave-private LDS); slots
 // beyond the hit count are padded with -1 / 0.0 (masked_gather, PRE:664-671).  Returns the hit count (<= K).
+//
+// r06 (VERDICT r05 "next" #5, north_star's "LDS-staged cluster tiles"): a centre that fills its K slots within a few hundred points
+// -- every benchmark distribution: P_max 2 677 at cfg2, < 1 000 in rooms -- is served best by the wave walking the scene on its
+// own (the prefix stays in L2, nothing is synchronised).  A centre that NEVER fills (sparse or clumped clouds, large extents)
+// reads all N points, and a wave on its own does that as ~N / 256 dependent round trips: 1.13 ms for four cfg2 scenes of a
+// two-blob cloud against 31 us at the benchmark distribution (profiles/r06_cluster_regimes.txt).  So: the first kBqPrivate points
+// wave-private as before; if any wave of the work-group is still short of K hits then, the WORK-GROUP stages the rest of the
+// scene through LDS in tiles of kBqTile points -- all 256 threads request the next tile with 16-byte loads while the unfinished
+// waves test the current one out of LDS (stride-3 dword reads: conflict-free), one barrier + vote per tile, until every wave has
+// its K hits or the scene ends.  Same ballot + prefix-popcount bookkeeping on the same points in the same order: bit-identical.
+constexpr int kBqPrivate = 4096;          // points every wave scans on its own first
+constexpr int kBqTile = 512;              // points per staged tile (6 KB; two buffers per work-group: with 1024-point tiles the 27 KB of
+                                          // LDS capped k_cluster at 5 work-groups per CU and cost the benchmark shape 7 %)
+constexpr int kBqTileFloats = kBqTile * 3;
+
+struct BqHits { int32_t *oi; float *oc; int K; int count; unsigned long long lt; };
+
+__device__ __forceinline__ void bq_group(BqHits &h, int j, bool valid, float px, float py, float pz, float cx, float cy, float cz,
+                                         float r2)
+{
+    const float d2 = dist2_nofma(cx, cy, cz, px, py, pz);
+    const bool hit = valid && (d2 < r2);                        // strict <
+    const unsigned long long mask = __ballot(hit);
+    const int pos = h.count + __popcll(mask & h.lt);
+    if (hit && pos < h.K) {
+        if (h.oi) h.oi[pos] = j;
+        h.oc[pos * 3] = px; h.oc[pos * 3 + 1] = py; h.oc[pos * 3 + 2] = pz;
+    }
+    h.count += __popcll(mask);
+}
+
+// `tiles`: 2 * kBqTileFloats floats of LDS shared by the work-group, or null = wave-private scan only.  With tiles != null EVERY
+// thread of the (256-thread) work-group must make this call with the same p and N (barriers inside).
 __device__ __forceinline__ int bq_scan(const float *__restrict__ p, int N, int K, float cx, float cy, float cz, float r2,
-                                       int32_t *oi, float *oc)
+                                       int32_t *oi, float *oc, float *tiles = nullptr)
 {
     const int lane = lane_id();
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    int count = 0;
-    for (int base = 0; base < N && count < K; base += 64 * kBqUnroll) {
+    BqHits h{oi, oc, K, 0, (1ull << lane) - 1ull};
+    // the staged part starts where p + 3 * start is 16-byte aligned (p is a (N,3) fp32 tensor or a row of a (B,N,3) one)
+    int n1 = N;
+    if (tiles != nullptr) {
+        // p + 3 (kBqPrivate + d) floats is 16-byte aligned for d = (p's offset in floats) mod 4:  fo + 3 d = 0 (mod 4)  <=>  d = fo
+        const int start = kBqPrivate + (int)((reinterpret_cast<uintptr_t>(p) >> 2) & 3u);
+        n1 = min(N, start);
+    }
+    for (int base = 0; base < n1 && h.count < K; base += 64 * kBqUnroll) {
         float px[kBqUnroll], py[kBqUnroll], pz[kBqUnroll];
 #pragma unroll
         for (int u = 0; u < kBqUnroll; ++u) {
             const int j = base + u * 64 + lane;
-            if (j < N) { px[u] = p[(size_t)j * 3]; py[u] = p[(size_t)j * 3 + 1]; pz[u] = p[(size_t)j * 3 + 2]; }
-            else       { px[u] = py[u] = pz[u] = 0.0f; }
+            if (j < n1) { px[u] = p[(size_t)j * 3]; py[u] = p[(size_t)j * 3 + 1]; pz[u] = p[(size_t)j * 3 + 2]; }
+            else        { px[u] = py[u] = pz[u] = 0.0f; }
         }
 #pragma unroll
         for (int u = 0; u < kBqUnroll; ++u) {
-            if (count < K) {                                   // wave-uniform
+            if (h.count < K) {                                 // wave-uniform
                 const int j = base + u * 64 + lane;
-                const float d2 = dist2_nofma(cx, cy, cz, px[u], py[u], pz[u]);
-                const bool hit = (j < N) && (d2 < r2);          // strict <
-                const unsigned long long mask = __ballot(hit);
-                const int pos = count + __popcll(mask & lt);
-                if (hit && pos < K) {
-                    if (oi) oi[pos] = j;
-                    oc[pos * 3] = px[u]; oc[pos * 3 + 1] = py[u]; oc[pos * 3 + 2] = pz[u];
-                }
-                count += __popcll(mask);
+                bq_group(h, j, j < n1, px[u], py[u], pz[u], cx, cy, cz, r2);
             }
         }
     }
+    if (tiles != nullptr && n1 < N) {                           // work-group uniform (same p, N in every thread)
+        const int tid = threadIdx.x;
+        const float *src = p + (size_t)n1 * 3;                  // 16-byte aligned
+        const int nfl = (N - n1) * 3;                           // floats left
+        constexpr int kF4 = kBqTileFloats / 4, kPer = (kF4 + 255) / 256;      // 384 float4 per tile: two per thread, the second for half of them
+        float4 nx[kPer];
+        auto fetch = [&](int t) {
+#pragma unroll
+            for (int i = 0; i < kPer; ++i) {
+                if (tid + 256 * i >= kF4) continue;
+                const int f = t * kBqTileFloats + 4 * (tid + 256 * i);
+                if (f + 3 < nfl) nx[i] = *reinterpret_cast<const float4 *>(src + f);
+                else {                                          // the ragged end: floats beyond the scene are 3e38 -- such a "point" is at an
+                    constexpr float kFar = 3.0e38f;             // infinite squared distance from every centre (inf < r2 is false)
+                    nx[i].x = f < nfl ? src[f] : kFar; nx[i].y = f + 1 < nfl ? src[f + 1] : kFar;
+                    nx[i].z = f + 2 < nfl ? src[f + 2] : kFar; nx[i].w = kFar;
+                }
+            }
+        };
+        auto stash = [&](int t) {
+#pragma unroll
+            for (int i = 0; i < kPer; ++i)
+                if (tid + 256 * i < kF4) *reinterpret_cast<float4 *>(tiles + (t & 1) * kBqTileFloats + 4 * (tid + 256 * i)) = nx[i];
+        };
+        const int ntile = (N - n1 + kBqTile - 1) / kBqTile;
+        bool any = __syncthreads_or(h.count < K);              // (also: nobody still reads `tiles` from an earlier call)
+        if (any) {
+            fetch(0);
+            stash(0);
+            __syncthreads();
+            for (int t = 0; t < ntile; ++t) {
+                if (t + 1 < ntile) fetch(t + 1);
+                if (h.count < K) {                              // wave-uniform
+                    // four groups of 64 points at a time: all twelve LDS reads first, four ballots, and the hit bookkeeping only
+                    // when one of them is non-empty -- in the regime this path exists for (centres that never fill) nearly every
+                    // group is empty, and the loop is 3 reads + 8 VALU + a compare per 64 points (the generic loop above it: ~40
+                    // instructions, r06 ISA count; the pass is bound by exactly this instruction stream: M N distance tests)
+                    const float *tl = tiles + (t & 1) * kBqTileFloats;
+                    const int tbase = n1 + t * kBqTile;
+#pragma unroll 1
+                    for (int g0 = 0; g0 < kBqTile / 64; g0 += 4) {
+                        float x[4], y[4], z[4];
+                        unsigned long long mk[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int q = (g0 + u) * 64 + lane;
+                            x[u] = tl[q * 3]; y[u] = tl[q * 3 + 1]; z[u] = tl[q * 3 + 2];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) mk[u] = __ballot(dist2_nofma(cx, cy, cz, x[u], y[u], z[u]) < r2);
+                        if ((mk[0] | mk[1] | mk[2] | mk[3]) != 0ull) {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                if (mk[u] != 0ull && h.count < K) {
+                                    const int pos = h.count + __popcll(mk[u] & h.lt);
+                                    if (((mk[u] >> lane) & 1ull) && pos < K) {
+                                        if (h.oi) h.oi[pos] = tbase + (g0 + u) * 64 + lane;
+                                        h.oc[pos * 3] = x[u]; h.oc[pos * 3 + 1] = y[u]; h.oc[pos * 3 + 2] = z[u];
+                                    }
+                                    h.count += __popcll(mk[u]);
+                                }
+                            }
+                            if (h.count >= K) break;
+                        }
+                    }
+                }
+                if (t + 1 < ntile) stash(t + 1);
+                any = __syncthreads_or(h.count < K);           // tile t + 1 visible, tile t free; anybody still short?
+                if (!any) break;
+            }
+        }
+    }
+    int count = h.count;
     if (count > K) count = K;
     for (int k = count + lane; k < K; k += 64) {               // masked_gather padding (PRE:664-671)
         if (oi) oi[k] = -1;
@@ -104,8 +208,12 @@ __global__ __launch_bounds__(256) void k_ball_query(
     float radius, int32_t *__restrict__ idx, float *__restrict__ cluster,
     int32_t *__restrict__ pad_count)
 {
+    __shared__ __attribute__((aligned(16))) float s_tiles[2 * kBqTileFloats];
     const int lane = lane_id();
     const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    // the work-group stages tiles only when its four waves scan the SAME scene (always, unless M is no multiple of 4: then the
+    // work-groups that straddle two scenes, and a ragged last one, keep the wave-private scan)
+    const bool coop = (int)blockIdx.x * 4 + 3 < BM && ((int)blockIdx.x * 4) / M == ((int)blockIdx.x * 4 + 3) / M;
     if (w >= BM) return;
     const int b = w / M, m = w - b * M;
     float cx, cy, cz;
@@ -119,7 +227,8 @@ __global__ __launch_bounds__(256) void k_ball_query(
         cx = centers[(size_t)w * 3 + 0]; cy = centers[(size_t)w * 3 + 1]; cz = centers[(size_t)w * 3 + 2];
     }
     const float r2 = __fmul_rn(radius, radius);
-    const int count = bq_scan(points.p[b], N, K, cx, cy, cz, r2, idx + (size_t)w * K, cluster + (size_t)w * K * 3);
+    const int count = bq_scan(points.p[b], N, K, cx, cy, cz, r2, idx + (size_t)w * K, cluster + (size_t)w * K * 3,
+                              coop ? s_tiles : nullptr);
     if (pad_count != nullptr && lane == 0) pad_count[w] = K - count;
 }
 
@@ -335,8 +444,12 @@ struct ClusterArgs {
 __global__ __launch_bounds__(256) void k_cluster(ClusterArgs a)
 {
     __shared__ float s_slots[4][64 * 3];
+    __shared__ __attribute__((aligned(16))) float s_tiles[2 * kBqTileFloats];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);
+    // LDS-staged tiles for centres that do not fill within kBqPrivate points: only when the four waves scan the same scene (bq_scan)
+    const bool coop = (int)blockIdx.x * 4 + 3 < a.BM && ((int)blockIdx.x * 4) / a.M == ((int)blockIdx.x * 4 + 3) / a.M;
+    float *tiles = coop ? s_tiles : nullptr;
     if (w >= a.BM) return;
     const int b = w / a.M, m = w - b * a.M;
     float mn[3], mx[3], c[3];
@@ -346,7 +459,7 @@ __global__ __launch_bounds__(256) void k_cluster(ClusterArgs a)
     const float r2 = __fmul_rn(a.radius, a.radius);
     const float *__restrict__ p = a.points.p[b];
     float *slots = s_slots[wv];
-    bq_scan(p, a.N, a.K, c[0], c[1], c[2], r2, nullptr, slots);                 // PRE:56
+    bq_scan(p, a.N, a.K, c[0], c[1], c[2], r2, nullptr, slots, tiles);          // PRE:56
     float x[6] = {0, 0, 0, 0, 0, 0};
     if (lane < a.K) {
         const float px = slots[lane * 3], py = slots[lane * 3 + 1], pz = slots[lane * 3 + 2];
@@ -368,7 +481,7 @@ __global__ __launch_bounds__(256) void k_cluster(ClusterArgs a)
     if (a.centers_override && lane < 3) nc = a.centers_override[(size_t)w * 3 + lane];
     if (lane < 3) a.centers[(size_t)w * 3 + lane] = nc;
     const float cx = PTX_LANE_F(nc, 0), cy = PTX_LANE_F(nc, 1), cz = PTX_LANE_F(nc, 2);
-    const int count = bq_scan(p, a.N, a.K, cx, cy, cz, r2, a.idx2 + (size_t)w * a.K, a.cluster2 + (size_t)w * a.K * 3);   // PRE:65
+    const int count = bq_scan(p, a.N, a.K, cx, cy, cz, r2, a.idx2 + (size_t)w * a.K, a.cluster2 + (size_t)w * a.K * 3, tiles);   // PRE:65
     if (lane == 0) a.pad_count[w] = a.K - count;
 }
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # extra bench lines kept under profiles/ (run on the GPU box after tools/profile_round.sh): scratch/final_lines.sh <tag>
-TAG=${1:-r05}; O=gpurun_out/${TAG}_final; mkdir -p $O; export TMPDIR=/tmp
+TAG=${1:-r06}; O=gpurun_out/${TAG}_final; mkdir -p $O; export TMPDIR=/tmp
 python bench.py --scenes-per-gpu 32 --no-cpu-baseline --no-passes > $O/bench_b32.json 2>/dev/null
 python bench.py --scenes-per-gpu 1 --no-cpu-baseline --no-passes > $O/bench_b1.json 2>/dev/null
 python bench.py --config cfg1 --no-cpu-baseline --no-passes > $O/bench_cfg1.json 2>/dev/null

@@ -34,13 +34,20 @@ def _i64(x):
 
 
 # ------------------------------------------------------------------ stage: grid centres + ball query
-@pytest.mark.parametrize("N,gs,extent", [(20000, 8, (12, 12, 9)), (4099, 4, (12, 12, 9)), (50, 4, (12, 12, 9)),
-                                         (5000, 4, (7, 5, 3)), (100000, 8, (40, 40, 12))])
-def test_grid_centers_and_ball_query_bit_exact(N, gs, extent):
+@pytest.mark.parametrize("N,gs,extent,dist", [
+    (20000, 8, (12, 12, 9), "uniform"), (4099, 4, (12, 12, 9), "uniform"), (50, 4, (12, 12, 9), "uniform"),
+    (5000, 4, (7, 5, 3), "uniform"), (100000, 8, (40, 40, 12), "uniform"),
+    # r06: centres that never fill -- the work-group stages the scene through LDS behind the first 4096 points (csrc/cluster.hip,
+    # bq_scan): a two-blob cloud (99 % of the centres scan all N points), N that is no multiple of 4 (the second scene's rows
+    # start 4 or 12 bytes off a 16-byte boundary: the staged part starts 1 .. 3 points later), a ragged last tile, odd grid sizes
+    # (M = 125 / 27 centres per scene: work-groups that straddle two scenes keep the wave-private scan)
+    (100000, 8, (30, 30, 30), "two_blob"), (10001, 4, (30, 30, 30), "two_blob"), (9999, 5, (30, 30, 30), "two_blob"),
+    (5130, 3, (40, 40, 12), "uniform"), (4097, 4, (30, 30, 30), "two_blob")])
+def test_grid_centers_and_ball_query_bit_exact(N, gs, extent, dist):
     from proxytransformation_amd.synth import PreshapeConfig, make_scene_batch
     from tests.gpu_util import Stages, t
     oracle = _oracle()
-    cfg = PreshapeConfig("t", B=2, N=N, grid_size=gs, dynamic_drop_radio=0.5, L=4, V=1, extent=extent, seed_base=31)
+    cfg = PreshapeConfig("t", B=2, N=N, grid_size=gs, dynamic_drop_radio=0.5, L=4, V=1, extent=extent, seed_base=31, distribution=dist)
     m, _ = _gpu_module(cfg)
     pts = make_scene_batch(cfg)[0]
     st = Stages(m, cfg.B, N, cfg.L, cfg.V)

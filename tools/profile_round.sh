@@ -6,7 +6,7 @@
 # separate runs with --kernel-trace only, FETCH_SIZE and WRITE_SIZE in different passes
 # (MI355X_MICROARCH.md: TCC slot budget; no trace domains mixed with --pmc).
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p "$O"
