@@ -369,6 +369,16 @@ PTX_API int ptx_voxelize(const float *points, const int32_t *counts, int B, int 
 PTX_API int ptx_voxelize_ex(const float *points, const int32_t *counts, int B, int Ncap, float voxel_size, int32_t *coords,
                     float *feats, int32_t *inverse, int32_t *nvox_overflow, int32_t *scene_end, void *workspace, size_t ws_bytes,
                     void *stream);
+/* ABI 12.  The coordinates of a COARSER MinkowskiEngine level over voxel rows the calls above produced -- what a strided layer of the
+ * detector's sparse backbone does to its coordinate map (backbones/mink_resnet.py:57-78: tensor strides 8 / 16 / 32 / 64), which is all
+ * the image-feature sampling behind it needs of that backbone (DET:429-430 `x[level].decomposed_coordinates[idx] * voxel_size`):
+ * coords_in (rows,4) int32 (scene, x, y, z), scene b's rows [in_scene_end[b-1], in_scene_end[b]) with in_scene_end a [host] array
+ * of B ints (read during the call); every row maps to floor(c / stride) * stride (stride: a power of two), one output row per
+ * distinct result in first-occurrence order: coords (rows,4) int32 and points (rows,3) fp32 = coordinate * voxel_size.
+ * nvox_overflow / scene_end / workspace as ptx_voxelize_ex (workspace: ptx_voxel_workspace_bytes(B, largest scene's rows)). */
+PTX_API int ptx_voxel_coarsen(const int32_t *coords_in, const int32_t *in_scene_end, int B, int stride, float voxel_size,
+                      int32_t *coords, float *points, int32_t *nvox_overflow, int32_t *scene_end, void *workspace, size_t ws_bytes,
+                      void *stream);
 
 /* ------------------------------------------------------------------ image feature -> point sampling
  * batch_point_sample (models/layers/fusion_layers/point_fusion.py:208-313) as called at detectors/

@@ -29,16 +29,34 @@ struct VoxArgs {
     unsigned int mask;
     int32_t *coords; float *feats; int32_t *inverse; int32_t *overflow; int32_t *nvox_overflow;
     int32_t *scene_end;                    // optional (ptx_voxelize_ex): rows written up to and including scene b
+    // coarsening mode (ptx_voxel_coarsen): the "points" are the integer voxel rows of a finer level -- coords_in (rows,4) int32
+    // (scene, x, y, z), scene b's rows [in_end[b-1], in_end[b]) -- and the voxel of a row is its coordinate >> shift (floor division
+    // by the power-of-two stride); the emitted row carries floor(c / s) * s and the "feature" that coordinate times voxel_size
+    const int32_t *coords_in; int shift; int32_t in_end[64];
 };
+
+__device__ __forceinline__ int vox_count(const VoxArgs &a, int b)
+{
+    return a.coords_in == nullptr ? a.counts[b] : a.in_end[b] - (b > 0 ? a.in_end[b - 1] : 0);
+}
 
 __device__ __forceinline__ bool vox_key(const VoxArgs &a, int b, int i, int (&v)[3], unsigned long long &key)
 {
-    const float *p = a.points + ((size_t)b * a.Ncap + i) * 3;
     bool ok = true;
+    if (a.coords_in != nullptr) {
+        const int32_t *c = a.coords_in + ((size_t)(b > 0 ? a.in_end[b - 1] : 0) + i) * 4;
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        v[d] = (int)floorf(__fdiv_rn(p[d], a.voxel_size));              // torch: floor(p / voxel_size), fp32
-        ok = ok && v[d] >= -kVoxBias && v[d] < kVoxBias;
+        for (int d = 0; d < 3; ++d) {
+            v[d] = c[1 + d] >> a.shift;                                   // arithmetic shift = floor division by the stride
+            ok = ok && v[d] >= -kVoxBias && v[d] < kVoxBias;
+        }
+    } else {
+        const float *p = a.points + ((size_t)b * a.Ncap + i) * 3;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            v[d] = (int)floorf(__fdiv_rn(p[d], a.voxel_size));            // torch: floor(p / voxel_size), fp32
+            ok = ok && v[d] >= -kVoxBias && v[d] < kVoxBias;
+        }
     }
     key = ((unsigned long long)b << 57) | ((unsigned long long)(v[0] + kVoxBias) << 38) |
           ((unsigned long long)(v[1] + kVoxBias) << 19) | (unsigned long long)(v[2] + kVoxBias);
@@ -60,7 +78,7 @@ __device__ __forceinline__ unsigned int vox_hash(unsigned long long k)
 __global__ __launch_bounds__(256) void k_vox_insert(VoxArgs a)
 {
     const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.counts[b]) return;
+    if (i >= vox_count(a, b)) return;
     int v[3]; unsigned long long key;
     if (!vox_key(a, b, i, v, key)) { atomicAdd(a.overflow, 1); }
     const int gi = b * a.Ncap + i;
@@ -83,7 +101,7 @@ __global__ __launch_bounds__(256) void k_vox_insert(VoxArgs a)
 // pass 2: representatives (first point of a voxel) counted and emitted in (scene, point) order, tile by tile
 __global__ __launch_bounds__(256) void k_vox_emit(VoxArgs a)
 {
-    const int b = blockIdx.y, tile = blockIdx.x, ntiles = gridDim.x, nb = a.counts[b];
+    const int b = blockIdx.y, tile = blockIdx.x, ntiles = gridDim.x, nb = vox_count(a, b);
     const int tid = threadIdx.x, lane = lane_id(), wid = tid >> 6;
     constexpr int R = kTilePts / 256;
     __shared__ int s_cnt[R][4];
@@ -158,10 +176,16 @@ __global__ __launch_bounds__(256) void k_vox_emit(VoxArgs a)
             int v[3]; unsigned long long key;
             vox_key(a, b, i, v, key);
             int32_t *c = a.coords + (size_t)row * 4;
-            *reinterpret_cast<int4 *>(c) = make_int4(b, v[0], v[1], v[2]);
-            const float *p = a.points + (size_t)gi * 3;
             float *f = a.feats + (size_t)row * 3;
-            f[0] = p[0]; f[1] = p[1]; f[2] = p[2];
+            if (a.coords_in != nullptr) {       // a coarser level: the coordinate in the finest level's units and its position
+                const int sm = 1 << a.shift, cx = v[0] * sm, cy = v[1] * sm, cz = v[2] * sm;
+                *reinterpret_cast<int4 *>(c) = make_int4(b, cx, cy, cz);
+                f[0] = __fmul_rn((float)cx, a.voxel_size); f[1] = __fmul_rn((float)cy, a.voxel_size); f[2] = __fmul_rn((float)cz, a.voxel_size);
+            } else {
+                *reinterpret_cast<int4 *>(c) = make_int4(b, v[0], v[1], v[2]);
+                const float *p = a.points + (size_t)gi * 3;
+                f[0] = p[0]; f[1] = p[1]; f[2] = p[2];
+            }
             a.row_of_slot[slot[r]] = row;
         }
         run += s_cnt[r][0] + s_cnt[r][1] + s_cnt[r][2] + s_cnt[r][3];
@@ -184,7 +208,7 @@ __global__ __launch_bounds__(256) void k_vox_inverse(VoxArgs a)
     const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
     if (i >= a.Ncap) return;
     const int gi = b * a.Ncap + i;
-    a.inverse[gi] = i < a.counts[b] ? a.row_of_slot[a.slot_of[gi]] : -1;
+    a.inverse[gi] = i < vox_count(a, b) ? a.row_of_slot[a.slot_of[gi]] : -1;
 }
 
 struct VoxLayout { size_t zero_begin, keys, owner, tile_word, overflow, zero_bytes, first, slot_of, row_of_slot, total; unsigned int slots; };
@@ -241,7 +265,7 @@ int ptx_voxelize_ex(const float *points, const int32_t *counts, int B, int Ncap,
               reinterpret_cast<unsigned long long *>(ws + L.keys), reinterpret_cast<uint32_t *>(ws + L.owner),
               reinterpret_cast<int32_t *>(ws + L.first), reinterpret_cast<int32_t *>(ws + L.slot_of), reinterpret_cast<int32_t *>(ws + L.row_of_slot),
               reinterpret_cast<unsigned long long *>(ws + L.tile_word), L.slots - 1, coords, feats, inverse,
-              reinterpret_cast<int32_t *>(ws + L.overflow), nvox_overflow, scene_end};
+              reinterpret_cast<int32_t *>(ws + L.overflow), nvox_overflow, scene_end, nullptr, 0, {}};
     PTX_HIP(hipMemsetAsync(ws + L.zero_begin, 0, L.zero_bytes, st));
     const dim3 per_point(cdiv(Ncap, 256), B), per_tile(cdiv(Ncap, kTilePts), B);
     hipLaunchKernelGGL(k_vox_insert, per_point, dim3(256), 0, st, a);
@@ -252,6 +276,40 @@ int ptx_voxelize_ex(const float *points, const int32_t *counts, int B, int Ncap,
         hipLaunchKernelGGL(k_vox_inverse, per_point, dim3(256), 0, st, a);
         PTX_LAUNCHED("k_vox_inverse");
     }
+    return PTX_OK;
+}
+
+int ptx_voxel_coarsen(const int32_t *coords_in, const int32_t *in_scene_end, int B, int stride, float voxel_size,
+                      int32_t *coords, float *points, int32_t *nvox_overflow, int32_t *scene_end, void *workspace, size_t ws_bytes,
+                      void *stream)
+{
+    PTX_REQUIRE(coords_in && in_scene_end && coords && points && nvox_overflow && workspace, "ptx_voxel_coarsen: null argument");
+    PTX_REQUIRE(B >= 1 && B <= 64 && stride >= 1 && (stride & (stride - 1)) == 0 && stride <= (1 << 16) && voxel_size > 0.0f,
+                "ptx_voxel_coarsen: B=%d stride=%d voxel_size=%g (stride: a power of two)", B, stride, voxel_size);
+    int ncap = 1, prev = 0;
+    for (int b = 0; b < B; ++b) {
+        PTX_REQUIRE(in_scene_end[b] >= prev, "ptx_voxel_coarsen: scene ends must not decrease");
+        ncap = in_scene_end[b] - prev > ncap ? in_scene_end[b] - prev : ncap;
+        prev = in_scene_end[b];
+    }
+    const VoxLayout L = vox_layout(B, ncap);
+    if (ws_bytes < L.total) { set_error("ptx_voxel_coarsen: workspace too small: %zu < %zu bytes", ws_bytes, L.total); return PTX_ENOSPACE; }
+    PTX_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "ptx_voxel_coarsen: workspace must be 256-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char *ws = static_cast<char *>(workspace);
+    VoxArgs a{nullptr, nullptr, B, ncap, voxel_size,
+              reinterpret_cast<unsigned long long *>(ws + L.keys), reinterpret_cast<uint32_t *>(ws + L.owner),
+              reinterpret_cast<int32_t *>(ws + L.first), reinterpret_cast<int32_t *>(ws + L.slot_of), reinterpret_cast<int32_t *>(ws + L.row_of_slot),
+              reinterpret_cast<unsigned long long *>(ws + L.tile_word), L.slots - 1, coords, points, nullptr,
+              reinterpret_cast<int32_t *>(ws + L.overflow), nvox_overflow, scene_end, coords_in, 0, {}};
+    while ((1 << a.shift) < stride) ++a.shift;
+    for (int b = 0; b < B; ++b) a.in_end[b] = in_scene_end[b];
+    PTX_HIP(hipMemsetAsync(ws + L.zero_begin, 0, L.zero_bytes, st));
+    const dim3 per_point(cdiv(ncap, 256), B), per_tile(cdiv(ncap, kTilePts), B);
+    hipLaunchKernelGGL(k_vox_insert, per_point, dim3(256), 0, st, a);
+    PTX_LAUNCHED("k_vox_insert");
+    hipLaunchKernelGGL(k_vox_emit, per_tile, dim3(256), 0, st, a);
+    PTX_LAUNCHED("k_vox_emit");
     return PTX_OK;
 }
 

@@ -29,7 +29,7 @@ import torch
 
 from . import _abi
 
-__all__ = ["MultiViewIngest", "IngestedBatch", "compose_choices", "lu_factor_4x4"]
+__all__ = ["MultiViewIngest", "IngestedBatch", "compose_choices", "lu_factor_4x4", "lu_factor_4x4_batch"]
 
 _DEPTH_DTYPES = {torch.float32: 0, torch.uint16: 1, torch.int16: 1}       # int16: a reinterpreted uint16 image
 
@@ -58,6 +58,29 @@ def lu_factor_4x4(a: np.ndarray):
             a[i, k] = np.float32(a[i, k] / a[k, k])
             a[i, k + 1:] = a[i, k + 1:] - a[i, k] * a[k, k + 1:]
     return a, np.asarray(rows, dtype=np.int32)
+
+
+def lu_factor_4x4_batch(a: np.ndarray):
+    """``lu_factor_4x4`` of V matrices at once, the same float32 operations in the same order (vectorised over the views: 50 views
+    x 6 scenes of Python-level 4 x 4 eliminations were 6 ms of host time per call of the shipped pipeline, r06).  a (V,4,4) ->
+    (lu (V,4,4) float32, rows (V,4) int32)."""
+    a = np.array(a, dtype=np.float32).reshape(-1, 4, 4).copy()
+    V = a.shape[0]
+    ar = np.arange(V)
+    rows = np.tile(np.arange(4, dtype=np.int32), (V, 1))
+    for k in range(4):
+        p = k + np.argmax(np.abs(a[:, k:, k]), axis=1)
+        if np.any(a[ar, p, k] == 0.0):
+            raise ValueError("singular global2ego matrix")
+        swap = p != k
+        if swap.any():
+            i_s, p_s = ar[swap], p[swap]
+            tmp = a[i_s, k].copy(); a[i_s, k] = a[i_s, p_s]; a[i_s, p_s] = tmp
+            rk = rows[i_s, k].copy(); rows[i_s, k] = rows[i_s, p_s]; rows[i_s, p_s] = rk
+        for i in range(k + 1, 4):
+            a[:, i, k] = a[:, i, k] / a[:, k, k]
+            a[:, i, k + 1:] = a[:, i, k + 1:] - a[:, i, k][:, None] * a[:, k, k + 1:]
+    return a, rows
 
 
 def compose_choices(view_counts: Sequence[int], per_view: int, n_points: int, rng=np.random):
@@ -106,12 +129,9 @@ class MultiViewIngest:
             k = np.broadcast_to(k, (V,) + k.shape)
         if k.shape[0] != V or k.shape[1] > 4 or k.shape[2] > 4:
             raise ValueError(f"depth_cam2img must be (r,c) or ({V},r,c) with r, c <= 4, got {k.shape}")
-        out = np.empty((V, 4, 4), np.float32)
-        for v in range(V):                                      # points_img2cam: pad to 4x4, invert (fp32)
-            pad = np.eye(4, dtype=np.float32)
-            pad[:k.shape[1], :k.shape[2]] = k[v].astype(np.float32)
-            out[v] = np.linalg.inv(pad)
-        return out
+        pad = np.tile(np.eye(4, dtype=np.float32), (V, 1, 1))   # points_img2cam: pad to 4x4, invert (fp32), all views in one call
+        pad[:, :k.shape[1], :k.shape[2]] = k.astype(np.float32)
+        return np.linalg.inv(pad)
 
     # per-scene-slot scratch, kept across calls (a fresh pinned buffer per scene and call is a hipHostMalloc with an
     # implicit device synchronise each): the index workspace, the pinned per-view counts the host polls, and one pinned
@@ -204,7 +224,7 @@ class MultiViewIngest:
                 raise IndexError(f"choices beyond the scene's depth != 0 pixels in scene {b}")
             inv_k = self._intrinsics(sc["depth_cam2img"], V)
             ext = np.asarray(sc["extrinsic"], dtype=np.float32).reshape(V, 4, 4)
-            lus, pivs = zip(*(lu_factor_4x4(ext[v]) for v in range(V)))
+            lus, pivs = lu_factor_4x4_batch(ext)
             aug = sc.get("aug")
             if sl.copied is not None and not sl.copied.query():
                 sl.copied.synchronize()                          # the previous call's copy out of the staging buffer (long done)
@@ -213,12 +233,12 @@ class MultiViewIngest:
             sl.stage_np[o_sel:o_sel + 8 * N].view(np.int64)[:] = sel
             small = sl.stage_np[o_small:o_small + 4 * (32 * V + 13)].view(np.float32)
             small[:16 * V] = inv_k.reshape(-1)
-            small[16 * V:32 * V] = np.stack(lus).reshape(-1)
+            small[16 * V:32 * V] = lus.reshape(-1)
             if aug is not None:
                 small[32 * V:32 * V + 9] = np.asarray(aug["rot_mat_T"], np.float32).reshape(9)
                 small[32 * V + 9] = np.float32(aug["scale"])
                 small[32 * V + 10:32 * V + 13] = np.asarray(aug["trans"], np.float32).reshape(3)
-            sl.stage_np[o_piv:o_piv + 16 * V].view(np.int32)[:] = np.stack(pivs).astype(np.int32).reshape(-1)
+            sl.stage_np[o_piv:o_piv + 16 * V].view(np.int32)[:] = pivs.astype(np.int32).reshape(-1)
             sl.stage_dev.copy_(sl.stage, non_blocking=True)
             sl.copied = torch.cuda.Event()
             sl.copied.record(st)

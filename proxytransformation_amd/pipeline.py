@@ -14,8 +14,8 @@ MinkowskiEngine ResNet are out of scope): reference lines on the left,
 sparse CNN and is NOT rebuilt.  The only thing the point sampling needs from it are the COORDINATES of its four output levels, and
 those do not depend on its weights: a strided MinkowskiEngine layer maps a coordinate c to floor(c / s) * s for its output tensor
 stride s -- 8, 16, 32, 64 voxels for the four stages -- and keeps one row per distinct result.  ``level_coordinates`` produces exactly
-that set (rows in first-occurrence order; ME's own row order is unspecified) by running the quantisation kernel again on the integer
-voxel rows; the features that travel with them in the reference are the backbone's and stay out.
+that set (rows in first-occurrence order; ME's own row order is unspecified) by running the quantisation kernels on the integer voxel
+rows (``ptx_voxel_coarsen``); the features that travel with them in the reference are the backbone's and stay out.
 
 Nothing in ``__call__`` synchronises the device: the host waits only for small integers the kernels publish through pinned memory
 (per-view pixel counts, survivor counts, voxel row counts) -- the list LENGTHS the reference obtains with blocking ``.item()`` /
@@ -29,6 +29,7 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 import torch
 
+from . import _abi
 from .fusion import batch_point_sample, reverse_3d_flow
 from .ingest import IngestedBatch, MultiViewIngest
 
@@ -66,21 +67,53 @@ def projection_matrices(depth2img: dict) -> np.ndarray:
     return out
 
 
-def level_coordinates(module, coordinates: torch.Tensor, scene_rows: Sequence[int], stride: int):
-    """Coordinates of a MinkowskiEngine level of tensor stride ``stride`` over the voxel rows ``coordinates`` (Nv,4): per scene the
-    distinct ``floor(c / stride) * stride`` in first-occurrence order (see the module docstring).  Returns a list of B (n_b,3) int32
-    tensors.  The integer rows go through the quantisation kernel as exact fp32 values (|c| < 2^18, stride a power of two: the
-    kernel's ``floor(c / stride)`` is exact)."""
-    if stride < 1 or stride & (stride - 1):
-        raise ValueError(f"stride must be a power of two (got {stride})")
+class _CoarsenScratch:
+    """Workspace + pinned count words of ``level_coordinates`` (one per pipeline object and stream, reused across calls)."""
+
+    def __init__(self, B: int, ncap: int, dev):
+        lib = _abi.lib()
+        nbytes = lib.ptx_voxel_workspace_bytes(B, ncap)
+        if nbytes == 0:
+            raise RuntimeError(f"level_coordinates: unsupported size B={B}, rows per scene={ncap}")
+        self.key = (B, ncap, str(dev))
+        self.ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        self.info = torch.empty((2 + B,), dtype=torch.int32).pin_memory()
+        self.info_np = self.info.numpy()
+
+
+def level_coordinates(coordinates: torch.Tensor, scene_rows: Sequence[int], stride: int, voxel_size: float, scratch: dict = None):
+    """Coordinates of a MinkowskiEngine level of tensor stride ``stride`` over the voxel rows ``coordinates`` (Nv,4) of a finer level
+    (``scene_rows[b]`` = end of scene b's rows): per scene the distinct ``floor(c / stride) * stride`` in first-occurrence order (module
+    docstring), and their positions ``coordinate * voxel_size`` (DET:429-430) -- one call of ``ptx_voxel_coarsen`` (csrc/voxel.hip: the
+    quantisation kernels on integer rows).  Returns ``(coords (n,4) int32, points (n,3) fp32, ends)``; the host waits only for the row
+    counts, which the kernel publishes through pinned memory."""
+    import ctypes
+    lib = _abi.lib()
     B = len(scene_rows)
-    cf = coordinates[:, 1:].to(torch.float32)
+    dev = coordinates.device
     lo = [0] + list(scene_rows[:-1])
-    per_scene = [cf[lo[b]:scene_rows[b]] for b in range(B)]
-    rows, _, ends = module.quantize(per_scene, float(stride), return_scene_rows=True)
-    lvl = rows[:, 1:] * stride
-    lo = [0] + ends[:-1]
-    return [lvl[lo[b]:ends[b]] for b in range(B)]
+    ncap = max(max(e - l for e, l in zip(scene_rows, lo)), 1)
+    cap = 1 << (ncap - 1).bit_length()                             # workspace sized for the next power of two: reused across levels / calls
+    scratch = {} if scratch is None else scratch
+    st = torch.cuda.current_stream(dev)
+    sc = scratch.get(st.cuda_stream)
+    if sc is None or sc.key[0] != B or sc.key[1] < cap or sc.key[2] != str(dev):
+        sc = scratch[st.cuda_stream] = _CoarsenScratch(B, cap, dev)
+    total = int(scene_rows[-1])
+    out_c = torch.empty((total, 4), dtype=torch.int32, device=dev)
+    out_p = torch.empty((total, 3), dtype=torch.float32, device=dev)
+    ends_in = (ctypes.c_int32 * B)(*[int(e) for e in scene_rows])
+    sc.info_np[:] = -1
+    _abi.check(lib.ptx_voxel_coarsen(coordinates.data_ptr(), ends_in, B, int(stride), float(voxel_size), out_c.data_ptr(), out_p.data_ptr(),
+                                     sc.info.data_ptr(), sc.info.data_ptr() + 8, sc.ws.data_ptr(), sc.ws.numel(), st.cuda_stream),
+               "ptx_voxel_coarsen")
+    if lib.ptx_wait_counts(sc.info.data_ptr(), 2 + B, 20_000_000) != 0:
+        st.synchronize()
+    n, overflow = int(sc.info_np[0]), int(sc.info_np[1])
+    if n < 0 or n == 0x7fffffff or overflow:
+        raise RuntimeError(f"ptx_voxel_coarsen failed (rows {n}, overflow {overflow})")
+    ends = sc.info_np[2:2 + B].tolist()
+    return out_c[:n], out_p[:n], ends
 
 
 class GroundingFeaturePrefix:
@@ -100,6 +133,7 @@ class GroundingFeaturePrefix:
         self.level_strides = tuple(int(s) for s in level_strides)
         self.coord_type = coord_type
         self._stage = None              # pinned staging of the per-scene projection matrices / reverse 3D flows + device twin
+        self._coarsen = {}              # per stream: workspace + pinned count words of level_coordinates
 
     def _upload_matrices(self, scenes, dev, st):
         """Projection matrices (V,4,4) and the reverse 3D augmentation flow (3,4) of every scene through ONE pinned staging buffer and
@@ -153,11 +187,13 @@ class GroundingFeaturePrefix:
         coords, feats, ends = self.preshape.quantize(outs, self.voxel_size, return_scene_rows=True)   # N2, DET:388-397
         mark("quantize")
         res = PrefixOutput(ingested=batch, points=outs, coordinates=coords, features=feats, scene_rows=ends)
-        vs = np.float32(self.voxel_size)
+        cur_c, cur_e = coords, ends
         for s in self.level_strides:                                                       # DET:398, 429-430 (coordinates only)
-            lc = level_coordinates(self.preshape, coords, ends, s)
-            res.level_coords.append(lc)
-            res.level_points.append([c.to(torch.float32) * float(vs) for c in lc])
+            # every level from the one below it: floor(floor(c / 8) * 8 / 16) = floor(c / 16), on ever fewer rows
+            cur_c, pts_l, cur_e = level_coordinates(cur_c, cur_e, s, self.voxel_size, self._coarsen)
+            lo = [0] + cur_e[:-1]
+            res.level_coords.append([cur_c[lo[b]:cur_e[b], 1:] for b in range(len(cur_e))])
+            res.level_points.append([pts_l[lo[b]:cur_e[b]] for b in range(len(cur_e))])
         mark("levels")
         B = len(scenes)
         for b, sc in enumerate(scenes):                                                    # N3, DET:402-448
