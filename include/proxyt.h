@@ -576,6 +576,66 @@ PTX_API int ptx_train_imgpool_sizes(const PtxTrainImgPool *a, size_t *save_float
 PTX_API int ptx_train_imgpool_fwd(const PtxTrainImgPool *a, void *stream);
 PTX_API int ptx_train_imgpool_bwd(const PtxTrainImgPool *a, void *stream);
 
+/* ---- the whole training step as ONE call per direction (ABI 12, csrc/train_step.hip; VERDICT r05 "next" #4)
+ * Train-mode forward of the module (PRE:424-469 with batch-statistics BatchNorm, Dropout / DropPath) and its whole backward, each
+ * enqueued by one call: the index half (grid centres, both ball queries, selection, tags, output positions), the two slot networks,
+ * the folded attention pool with c_proj + norm_img, the two ProxyBlocks with their heads, and the affine apply with compaction --
+ * what proxytransformation_amd/train.py's one-node step used to chain from Python with ~35 library calls and ~60 allocations.
+ * The host side keeps the autograd node and the ALLOCATIONS: the library carves every intermediate out of caller-owned arenas
+ * whose sizes and named offsets ptx_train_step_layout() reports (a pure function of the shape fields).
+ *
+ * caller fills: shape; points (B,N,3) stacked; lin; text_feats / text_mask; off / enc / map_w; ip (sizes, img, parameters, tail
+ * parameters); tb / ib (sizes, scalars, seeds, mask, parameters, running statistics -- x / proxy / out / save / tmp are set by the
+ * library); ws (the lane workspace: ptx_workspace_bytes / _init, for the compaction); out (B,N,3); counts_host (B int32, pinned);
+ * arena_fwd; the optional side stream with four events (fork / join / pp / counts; any hipEvent_t, used in that role only inside
+ * the two calls).  The forward copies the per-scene survivor counts to counts_host and records ev_counts behind the copy: wait for
+ * that event, then out[b, :counts[b]] are scene b's rows (PRE:467).  ptx_train_step_bwd additionally takes douts (a [host] array of
+ * B device pointers to the gradients of those rows), optional gradients of kcenter / translate / transform (return_transforms),
+ * arena_bwd, grads (layout.grads_floats floats: every parameter gradient at layout.grad_off[...], shaped like the parameter) and
+ * dtext (B*L,C) / dimg (in img's storage type) or NULL.  Gradient slots of the offset network's BatchNorm are [bias | weight]. */
+typedef struct PtxTrainSlotNet {               /* Conv2d(6,W,1) + BatchNorm2d(W) of OffsetNetwork / SimplifiedPointNet (PRE:72-76, 112-116) */
+    const float *conv_w, *conv_b, *bn_w, *bn_b;
+    float *run_mean, *run_var;
+    float eps, momentum;
+    int32_t W;
+} PtxTrainSlotNet;
+enum { PTX_TS_OFF_CONV_W = 0, PTX_TS_OFF_CONV_B, PTX_TS_OFF_BN_W, PTX_TS_OFF_BN_B, PTX_TS_MAP_W,
+       PTX_TS_ENC_CONV_W, PTX_TS_ENC_CONV_B, PTX_TS_ENC_BN_W, PTX_TS_ENC_BN_B,
+       PTX_TS_IP0,                              /* wc bc pos wq bq wk bk wv bv cw cb lnw lnb */
+       PTX_TS_TB0 = PTX_TS_IP0 + 13,            /* PTX_TB_* order */
+       PTX_TS_IB0 = PTX_TS_TB0 + PTX_TB_NPARAM,
+       PTX_TS_NGRAD = PTX_TS_IB0 + PTX_TB_NPARAM };
+typedef struct PtxTrainStepLayout {
+    size_t arena_fwd_bytes, arena_bwd_bytes, grads_floats;
+    /* byte offsets of named regions of the forward arena (tests / return_transforms read them) */
+    size_t idx2, order, picks, keep, kidx, drop_idx, centers, translate, transform, point_proxy, img_proxy, kcenter, opos;
+    int64_t grad_off[PTX_TS_NGRAD];             /* float offsets into `grads`; -1: parameter absent (qkv bias) */
+} PtxTrainStepLayout;
+typedef struct PtxTrainStep {
+    PtxShape shape;
+    const float *points, *lin, *centers_override;
+    const int32_t *order_override;
+    const float *text_feats; const uint8_t *text_mask;
+    PtxTrainSlotNet off, enc;
+    const float *map_w;                         /* Conv1d(256,3,1,bias=False) weight (3,256) */
+    PtxTrainImgPool ip;
+    PtxTrainBlock tb, ib;
+    void *ws; size_t ws_bytes;
+    float *out; int32_t *counts_host;
+    void *arena_fwd; size_t arena_fwd_bytes;
+    void *side_stream; void *ev_fork, *ev_join, *ev_pp, *ev_counts;
+    int32_t blocks_apart;                       /* the image block beside the text block on the side stream (forward and backward) */
+    /* backward */
+    const float *const *douts;
+    const float *g_kcenter, *g_translate, *g_transform;
+    void *arena_bwd; size_t arena_bwd_bytes;
+    float *grads; size_t grads_floats;
+    float *dtext; void *dimg;
+} PtxTrainStep;
+PTX_API int ptx_train_step_layout(const PtxTrainStep *a, PtxTrainStepLayout *out);
+PTX_API int ptx_train_step_fwd(const PtxTrainStep *a, void *stream);
+PTX_API int ptx_train_step_bwd(const PtxTrainStep *a, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -87,6 +87,35 @@ class PtxTrainImgPool(C.Structure):
                [(n, C.c_void_p) for n in ("proxy", "dproxy", "dcw", "dcb", "dlnw", "dlnb")]
 
 
+class PtxTrainSlotNet(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("conv_w", "conv_b", "bn_w", "bn_b", "run_mean", "run_var")] + \
+               [("eps", C.c_float), ("momentum", C.c_float), ("W", C.c_int32)]
+
+
+TS_NGRAD = 9 + 13 + 2 * len(TB_PARAMS)           # PTX_TS_NGRAD
+TS_IP0, TS_TB0, TS_IB0 = 9, 9 + 13, 9 + 13 + len(TB_PARAMS)
+
+
+class PtxTrainStepLayout(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in ("arena_fwd_bytes", "arena_bwd_bytes", "grads_floats", "idx2", "order", "picks", "keep", "kidx",
+                                           "drop_idx", "centers", "translate", "transform", "point_proxy", "img_proxy", "kcenter",
+                                           "opos")] + [("grad_off", C.c_int64 * TS_NGRAD)]
+
+
+class PtxTrainStep(C.Structure):
+    _fields_ = [("shape", PtxShape), ("points", C.c_void_p), ("lin", C.c_void_p), ("centers_override", C.c_void_p),
+                ("order_override", C.c_void_p), ("text_feats", C.c_void_p), ("text_mask", C.c_void_p),
+                ("off", PtxTrainSlotNet), ("enc", PtxTrainSlotNet), ("map_w", C.c_void_p),
+                ("ip", PtxTrainImgPool), ("tb", PtxTrainBlock), ("ib", PtxTrainBlock),
+                ("ws", C.c_void_p), ("ws_bytes", C.c_size_t), ("out", C.c_void_p), ("counts_host", C.c_void_p),
+                ("arena_fwd", C.c_void_p), ("arena_fwd_bytes", C.c_size_t),
+                ("side_stream", C.c_void_p), ("ev_fork", C.c_void_p), ("ev_join", C.c_void_p), ("ev_pp", C.c_void_p),
+                ("ev_counts", C.c_void_p), ("blocks_apart", C.c_int32),
+                ("douts", C.c_void_p), ("g_kcenter", C.c_void_p), ("g_translate", C.c_void_p), ("g_transform", C.c_void_p),
+                ("arena_bwd", C.c_void_p), ("arena_bwd_bytes", C.c_size_t), ("grads", C.c_void_p), ("grads_floats", C.c_size_t),
+                ("dtext", C.c_void_p), ("dimg", C.c_void_p)]
+
+
 class PtxForwardOpts(C.Structure):
     _fields_ = [("bbox_enc", C.c_void_p), ("compute_dtype", C.c_int32), ("reserved", C.c_int32 * 5)]
 
@@ -181,6 +210,9 @@ SIGNATURES.update({
     "ptx_train_imgpool_sizes": (_I, [C.POINTER(PtxTrainImgPool), C.POINTER(_Z), C.POINTER(_Z), C.POINTER(_Z)]),
     "ptx_train_imgpool_fwd": (_I, [C.POINTER(PtxTrainImgPool), _P]),
     "ptx_train_imgpool_bwd": (_I, [C.POINTER(PtxTrainImgPool), _P]),
+    "ptx_train_step_layout": (_I, [C.POINTER(PtxTrainStep), C.POINTER(PtxTrainStepLayout)]),
+    "ptx_train_step_fwd": (_I, [C.POINTER(PtxTrainStep), _P]),
+    "ptx_train_step_bwd": (_I, [C.POINTER(PtxTrainStep), _P]),
     "ptx_op_head_bwd_tmp_floats": (_Z, [_I, _I, _I]),
     "ptx_op_head_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _Z, _P]),
     "ptx_train_attn_tmp_floats": (_Z, [_I, _I, _I, _I, _I]),

@@ -43,6 +43,7 @@ _FUSED_IMG = True        # AttentionPool2d on its folded form (ptx_train_imgpool
 _SIDE_STREAM = True      # the image branch on a side stream beside the index half
 _BLOCKS_APART = True     # one-node step: the image block on the side stream too, beside the text block (forward and backward)
 _ONE_NODE = True         # the float half as ONE autograd node (_TrainStep)
+_C_STEP = True           # r06: the one node's two bodies behind ONE library call each (ptx_train_step_fwd / _bwd, csrc/train_step.hip)
 _IMG_FIRST = True        # one-node step: the image branch enqueued in front of the clustering half (profiles/r04_train_ab.txt)
 _IMG_POS = 1             # per-operator graph: where the image branch is enqueued -- 0 first, 1 after the selection, 2 before the
                          # text block, 3 after it
@@ -982,7 +983,7 @@ def forward_train(mod, points: List[torch.Tensor], text_feats, text_mask, img_fe
         st8 = dict(args=(mod, points, text_mask, shape, ws, order_override), seeds=seeds)
         if getattr(mod, "_train_live", None) is None:
             mod._train_live = live_params(mod)              # dropped with the layout check (module.invalidate_weights)
-        res = _TrainStep.apply(st8, text_feats, img_feat, *mod._train_live)
+        res = (_TrainStepC if _C_STEP else _TrainStep).apply(st8, text_feats, img_feat, *mod._train_live)
         aux = st8["aux"]
         # the per-cluster transforms are OUTPUTS of the node: a regulariser on module.forward(..., return_transforms=True)'s
         # kcenter / translate / transform reaches the parameters, as it did through the per-operator graph
@@ -1356,6 +1357,194 @@ class _TrainStep(torch.autograd.Function):
         dtext = dtf2.view(tf_shape).to(tf_dtype) if ctx.needs_input_grad[1] else None
         dimg = dimg.view(img_shape) if (dimg is not None and ctx.needs_input_grad[2]) else None
         return (None, dtext, dimg, *[G.get(i) for i in pids])
+
+
+# --------------------------------------------------------------------------- the one node with its bodies in C++ (r06)
+# _TrainStep above runs ~35 library calls and ~60 allocations per step from Python; its host time (0.6 ms of Python around 0.5 ms
+# inside the library) was what a box with a slow host ran the step at.  Here the node keeps the autograd plumbing and the
+# ALLOCATIONS -- one arena per direction, the output buffer, one gradient buffer -- and each direction is ONE call: the library
+# carves every intermediate out of the arenas (ptx_train_step_layout names the offsets) and enqueues the same launches in the same
+# order on the same two streams.  Same kernels, same bits: tests/test_gpu_train.py holds both forms to the same fixtures.
+class _Aux(dict):
+    """The step's intermediates as views of the forward arena, made on first access (tests / return_transforms read a few)."""
+
+    def __init__(self, arena, spec):
+        super().__init__()
+        self._arena, self._spec = arena, spec
+
+    def __missing__(self, k):
+        off, shape, dt = self._spec[k]
+        n = 1
+        for d in shape:
+            n *= d
+        v = self._arena[off:off + n * 4].view(dt).view(shape)
+        self[k] = v
+        return v
+
+    def __contains__(self, k):
+        return k in self._spec or dict.__contains__(self, k)
+
+
+def _cstep_static(mod, S, dev):
+    """Per weights-generation pieces of the C step: the canonical parameter list (PTX_TS_* order), the ctypes struct with its
+    constant fields, four events, the pinned count words."""
+    cs = S.get("cstep")
+    if cs is None or cs["dev"] != str(dev):
+        off, enc = S["off"], S["enc"]
+        bn, ebn = S["bn"], S["ebn"]
+        canon = [off.mlp[0].weight, off.mlp[0].bias, bn.weight, bn.bias, S["oh"], enc.mlp[0].weight, enc.mlp[0].bias, ebn.weight,
+                 ebn.bias, *S["ip_par"], *S["tb"][5], *S["ib"][5]]
+        assert len(canon) == _abi.TS_NGRAD
+        st = _abi.PtxTrainStep()
+        evs = []
+        for _ in range(4):
+            e = torch.cuda.Event()
+            e.record()                                   # torch creates the hipEvent on first use
+            evs.append(e)
+        cs = S["cstep"] = dict(dev=str(dev), canon=canon, st=st, ev=evs, layouts={}, pin={},
+                               slot_of={id(p_): i for i, p_ in enumerate(canon) if p_ is not None})
+        st.ev_fork, st.ev_join, st.ev_pp, st.ev_counts = (e.cuda_event for e in evs)
+    return cs
+
+
+def _cstep_fill(mod, S, cs, shape, pts, text2, text_mask, img3, seeds, ws, order_override, side):
+    """Everything of the struct that can change between steps (pointers are re-read every step: a swapped storage must be seen)."""
+    st = cs["st"]
+    st.shape = shape
+    st.points, st.lin = _p(pts), _p(mod._train_lin(pts.device))
+    co = mod._centers_override
+    keep = []
+    if co is not None:
+        co = co.to(device=pts.device, dtype=_F32).reshape(-1, 3).contiguous()
+        keep.append(co)
+    oo = None if order_override is None else order_override.to(device=pts.device, dtype=torch.int32).contiguous()
+    keep.append(oo)
+    st.centers_override, st.order_override = _p(co), _p(oo)
+    st.text_feats, st.text_mask = _p(text2), _p(text_mask)
+    bn, ebn = S["bn"], S["ebn"]
+    for sn, par, run, b_ in ((st.off, S["off_par"], S["off_run"], bn), (st.enc, S["enc_par"], S["enc_run"], ebn)):
+        sn.conv_w, sn.conv_b, sn.bn_w, sn.bn_b = (_p(t) for t in par)
+        sn.run_mean, sn.run_var = _p(run[0]), _p(run[1])
+        sn.eps, sn.momentum, sn.W = b_.eps, b_.momentum, par[0].shape[0]
+    st.map_w = _p(S["oh"])
+    ip, ipp = st.ip, S["ip_par"]
+    nimg, Cin, hw = img3.shape
+    ip.nimg, ip.Cin, ip.hw, ip.C, ip.heads = nimg, Cin, hw, mod.embed_dim, mod.num_heads
+    ip.img_dtype = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[img3.dtype]
+    ip.img = _p(img3)
+    (ip.wc, ip.bc, ip.pos, ip.wq, ip.bq, ip.wk, ip.bk, ip.wv, ip.bv, ip.cw, ip.cb, ip.lnw, ip.lnb) = (_p(t) for t in ipp)
+    ip.ln_eps = S["norm_img"].eps
+    B, Mk = shape.B, shape.Mk
+    for blk, bm, L_, sd, mask in ((st.tb, S["tb"], shape.L, seeds[0], text_mask), (st.ib, S["ib"], shape.V, seeds[1], None)):
+        cfg, par = _block_cfg(mod, *bm[:4], B, Mk, L_, sd, bm[4], bm[5])
+        (blk.B, blk.n, blk.L, blk.C, blk.H, blk.heads, blk.s, blk.nout, blk.eps1, blk.eps2, blk.eps3, blk.bn_eps, blk.bn_momentum,
+         blk.p_attn, blk.p_drop, blk.p_path, sds) = cfg[:17]
+        blk.compute_dtype = cfg[17]
+        for i, v in enumerate(sds):
+            blk.seed[i] = v & 0xFFFFFFFFFFFFFFFF
+        for i, t in enumerate(par):
+            blk.param[i] = _p(t)
+        blk.bn_run_mean, blk.bn_run_var = _p(bm[6][0]), _p(bm[6][1])
+    st.ws, st.ws_bytes = _p(ws), ws.numel()
+    st.side_stream = None if side is None else side.cuda_stream
+    st.blocks_apart = 1 if (side is not None and _BLOCKS_APART) else 0
+    return st, keep
+
+
+class _TrainStepC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, st8, text_feats, img_feat, *params):
+        mod, points, text_mask, shape, ws, order_override = st8["args"]
+        lib = _abi.lib()
+        dev = points[0].device
+        B, N = len(points), points[0].shape[0]
+        C, Mk = mod.embed_dim, shape.Mk
+        pts = torch.stack(points) if all([p.dtype == _F32 for p in points]) else torch.stack([p.to(_F32) for p in points])
+        S = _static(mod)
+        cs = _cstep_static(mod, S, dev)
+        V, L = img_feat.shape[1], text_feats.shape[1]
+        img3 = _c(img_feat).view(B * V, mod.input_dim, mod.img_spacial_dim ** 2)
+        tf2 = _c(text_feats.to(_F32)).view(B * L, C)
+        main = torch.cuda.current_stream(dev)
+        side = _side_stream(mod, dev) if _SIDE_STREAM else None
+        st, keep = _cstep_fill(mod, S, cs, shape, pts, tf2, text_mask, img3, st8["seeds"], ws, order_override, side)
+        lkey = (B, N, L, V, img3.dtype, st.tb.param[_abi.TB_PARAMS.index("qkv_b")] is None)
+        lay = cs["layouts"].get(lkey)
+        if lay is None:
+            lay = _abi.PtxTrainStepLayout()
+            _ck(lib.ptx_train_step_layout(ctypes.byref(st), ctypes.byref(lay)), "ptx_train_step_layout")
+            cs["layouts"][lkey] = lay
+        arena = torch.empty((lay.arena_fwd_bytes,), dtype=torch.uint8, device=dev)
+        out = torch.empty((B, N, 3), dtype=_F32, device=dev)
+        pin = cs["pin"].get(B)
+        if pin is None:
+            pin = cs["pin"][B] = torch.empty((B,), dtype=torch.int32, pin_memory=True)
+        ev_counts = cs["ev"][3]
+        ev_counts.synchronize()                                  # an earlier step's copy into the same pinned words
+        st.out, st.counts_host = _p(out), pin.data_ptr()
+        st.arena_fwd, st.arena_fwd_bytes = _p(arena), arena.numel()
+        if side is not None:
+            arena.record_stream(side)
+        _ck(lib.ptx_train_step_fwd(ctypes.byref(st), main.cuda_stream), "ptx_train_step_fwd")
+        ev_counts.synchronize()                                  # the list lengths of PRE:467
+        n_keep = pin.tolist()
+        Kd, M, K = shape.Mt - Mk, mod.num_cluster, shape.K
+        i32 = torch.int32
+        spec = dict(idx2=(lay.idx2, (B, M, K), i32), order=(lay.order, (B, shape.Mt), i32), picks=(lay.picks, (B, Kd), i32),
+                    keep=(lay.keep, (B, Mk), i32), kidx=(lay.kidx, (B, Mk, K), i32), drop_idx=(lay.drop_idx, (B, Kd * K), i32),
+                    centers=(lay.centers, (B * M, 3), _F32), translate=(lay.translate, (B * Mk, 3), _F32),
+                    transform=(lay.transform, (B * Mk, 9), _F32), point_proxy=(lay.point_proxy, (B * Mk, C), _F32),
+                    img_proxy=(lay.img_proxy, (B * V, C), _F32), kcenter=(lay.kcenter, (B * Mk, 3), _F32), opos=(lay.opos, (B, N), i32))
+        aux = st8["aux"] = _Aux(arena, spec)
+        ctx.set_materialize_grads(False)
+        ctx.keep = (arena, pts, tf2, img3, text_mask, ws, keep, params)      # everything the backward's raw pointers refer to
+        ctx.cs, ctx.lay, ctx.side, ctx.n_out = cs, lay, side, B
+        ctx.meta = (text_feats.shape, text_feats.dtype, img_feat.shape, B * L, C)
+        ctx.step = (mod, S, shape, st8["seeds"], order_override)
+        outs = tuple(out[b, : n_keep[b]] for b in range(B))
+        return (*outs, aux["kcenter"].detach(), aux["translate"].detach(), aux["transform"].detach())
+
+    @staticmethod
+    def backward(ctx, *douts):
+        lib = _abi.lib()
+        arena, pts, tf2, img3, text_mask, ws, keep, params = ctx.keep
+        cs, lay, side, B = ctx.cs, ctx.lay, ctx.side, ctx.n_out
+        mod, S, shape, seeds, order_override = ctx.step
+        tf_shape, tf_dtype, img_shape, BL, C = ctx.meta
+        dev = arena.device
+        main = torch.cuda.current_stream(dev)
+        # the struct is shared by every step of this module: fill it again for THIS step (another forward may have run in between)
+        st, keep2 = _cstep_fill(mod, S, cs, shape, pts, tf2, text_mask, img3, seeds, ws, order_override, side)
+        st.arena_fwd, st.arena_fwd_bytes = _p(arena), arena.numel()
+        gs = [None if g is None else _c(g) for g in douts[:B]]
+        ptrs = (ctypes.c_void_p * B)(*[_p(g) for g in gs])
+        st.douts = ctypes.addressof(ptrs)
+        extra = [None if g is None else _c(g.to(_F32)) for g in douts[B:B + 3]]
+        st.g_kcenter, st.g_translate, st.g_transform = (_p(g) for g in extra)
+        arena_b = torch.empty((lay.arena_bwd_bytes,), dtype=torch.uint8, device=dev)
+        grads = torch.empty((lay.grads_floats,), dtype=_F32, device=dev)
+        dtext = torch.empty((BL, C), dtype=_F32, device=dev) if ctx.needs_input_grad[1] else None
+        dimg = torch.empty_like(img3) if ctx.needs_input_grad[2] else None
+        st.arena_bwd, st.arena_bwd_bytes, st.grads, st.grads_floats = _p(arena_b), arena_b.numel(), _p(grads), grads.numel()
+        st.dtext, st.dimg = _p(dtext), _p(dimg)
+        if side is not None:
+            for t in (arena_b, grads, dimg):
+                if t is not None:
+                    t.record_stream(side)
+        _ck(lib.ptx_train_step_bwd(ctypes.byref(st), main.cuda_stream), "ptx_train_step_bwd")
+        slot_of, canon, goff = cs["slot_of"], cs["canon"], lay.grad_off
+        out = []
+        for p_ in params:
+            i = slot_of.get(id(p_))
+            if i is None or goff[i] < 0:
+                out.append(None)
+                continue
+            n = p_.numel()
+            g = grads[goff[i]:goff[i] + n]
+            out.append(g if p_.dim() == 1 else g.view(p_.shape))
+        dt_ = None if dtext is None else dtext.view(tf_shape).to(tf_dtype)
+        di_ = None if dimg is None else dimg.view(img_shape)
+        return (None, dt_, di_, *out)
 
 
 def live_params(mod):

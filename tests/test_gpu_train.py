@@ -338,7 +338,8 @@ def test_training_step_matches_the_reference_capture():
 
 
 @pytest.mark.parametrize("case", ["f32", "bf16_blocks3", "embed512_f16", "f32_graph", "f32_unfused", "heads4_f32", "embed512_heads16_f32",
-                                  "f32_blocks_serial", "f32_one_stream", "in128_side13_f32", "in1024_side12_bf16"])
+                                  "f32_blocks_serial", "f32_one_stream", "in128_side13_f32", "in1024_side12_bf16",
+                                  "f32_python_bodies", "f32_python_bodies_serial"])
 def test_training_step_matches_the_oracle_on_fresh_scenes(case, monkeypatch):
     """The default path (the whole float half as one autograd node over the fused kernels, the image block on the side stream
     beside the text block) and its fallbacks: the same fused kernels chained as separate autograd nodes (f32_graph), one launch
@@ -349,6 +350,10 @@ def test_training_step_matches_the_oracle_on_fresh_scenes(case, monkeypatch):
     from tests.gpu_util import t
     if case == "f32_graph":
         monkeypatch.setattr(T, "_ONE_NODE", False)
+    if case.startswith("f32_python_bodies"):     # r06: the default runs both bodies of the one node in C++ (csrc/train_step.hip); this is
+        monkeypatch.setattr(T, "_C_STEP", False)  # the same node with its bodies in Python (train._TrainStep), kept as the readable form
+        if case.endswith("serial"):
+            monkeypatch.setattr(T, "_BLOCKS_APART", False)
     if case == "f32_blocks_serial":
         monkeypatch.setattr(T, "_BLOCKS_APART", False)
     if case == "f32_one_stream":
@@ -582,7 +587,7 @@ def test_swapped_parameter_objects_are_seen_by_the_training_step():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("form", ["one_node", "graph", "one_node_transforms"])
+@pytest.mark.parametrize("form", ["one_node", "graph", "one_node_transforms", "one_node_python_bodies"])
 def test_training_steps_hold_no_memory_between_them(monkeypatch, form):
     """r05 regression: the one-node step returned the very tensor objects its tape holds, which made each step's activations
     unreachable-but-alive (a cycle through the autograd node that Python's collector cannot see): 190 MiB per step at the
@@ -592,6 +597,7 @@ def test_training_steps_hold_no_memory_between_them(monkeypatch, form):
     from proxytransformation_amd import MODELS, train
     from tests.gpu_util import t
     monkeypatch.setattr(train, "_ONE_NODE", form != "graph")
+    monkeypatch.setattr(train, "_C_STEP", form != "one_node_python_bodies")
     cfg = PreshapeConfig("leak", B=2, N=6000, grid_size=5, dynamic_drop_radio=0.5, L=6, V=3, seed_base=8990)
     m = MODELS.build(dict(type="ProxyTransformationNormReverse", **cfg.module_kwargs()))
     m.load_state_dict({k: torch.from_numpy(v) for k, v in fill_state_dict(m.state_dict()).items()})

@@ -309,3 +309,29 @@ def test_pipeline_host_pieces():
     coords = np.array([[0, 9, -1, 17], [0, 15, -8, 23], [0, 16, -9, 0], [1, 9, -1, 17], [1, 1, 1, 1]], np.int32)
     lv = oracle.level_coordinates(coords, 2, 8)
     assert np.array_equal(lv[0], [[8, -8, 16], [16, -16, 0]]) and np.array_equal(lv[1], [[8, -8, 16], [0, 0, 0]])
+
+
+def test_ctypes_structs_match_the_header(tmp_path):
+    """Every struct that crosses the C ABI by pointer: size and the offset of every field as gcc lays out include/proxyt.h must
+    equal what ctypes lays out for proxytransformation_amd/_abi.py (a field added on one side only would shift everything behind
+    it silently)."""
+    from proxytransformation_amd import _abi
+    structs = {"PtxShape": _abi.PtxShape, "PtxTrainBlock": _abi.PtxTrainBlock, "PtxTrainImgPool": _abi.PtxTrainImgPool,
+               "PtxTrainSlotNet": _abi.PtxTrainSlotNet, "PtxTrainStepLayout": _abi.PtxTrainStepLayout, "PtxTrainStep": _abi.PtxTrainStep,
+               "PtxForwardOpts": _abi.PtxForwardOpts, "PtxWeights": _abi.PtxWeights, "PtxBlock": _abi.PtxBlock}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(ROOT, "include", "proxyt.h")}"', "int main(void) {"]
+    for name, cls in structs.items():
+        lines.append(f'printf("{name} %zu\\n", sizeof({name}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'printf("{name}.{fname} %zu\\n", offsetof({name}, {fname}));')
+    lines += ['printf("NGRAD %d\\n", (int)PTX_TS_NGRAD);', "return 0; }"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-o", str(exe), str(src)], check=True)
+    out = dict(ln.split() for ln in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for name, cls in structs.items():
+        assert int(out[name]) == ctypes.sizeof(cls), (name, out[name], ctypes.sizeof(cls))
+        for fname, _ in cls._fields_:
+            assert int(out[f"{name}.{fname}"]) == getattr(cls, fname).offset, f"{name}.{fname}"
+    assert int(out["NGRAD"]) == _abi.TS_NGRAD
