@@ -63,6 +63,26 @@ def main():
         traffic[dt] = {k: {"fetch_bytes": fetch[k] * 2048.0, "write_bytes": write.get(k, 0.0) * 1024.0,
                            "raw_FETCH_SIZE": fetch[k], "raw_WRITE_SIZE": write.get(k)}
                        for k in sorted(fetch) if k.startswith("k_") or "k_" in k}
+    # matrix-pipe occupancy at 32 scenes per GPU (profile_round.sh step 4): SQ_VALU_MFMA_BUSY_CYCLES sums the busy cycles of all 1024
+    # SIMDs' matrix pipes, SQ_BUSY_CYCLES the busy cycles of the 32 SQs (one per shader engine), so
+    #   mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES / 32 * 1024)
+    # is the share of the launch during which an average SIMD's matrix pipe was executing (VERDICT r05 "next" #3)
+    files = glob.glob(os.path.join(odir, "pmc_mfma_b32", "**", "*counter_collection.csv"), recursive=True)
+    acc = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
+    for fn in files:
+        for r in csv.DictReader(open(fn)):
+            a = acc[short(r["Kernel_Name"])][r["Counter_Name"]]
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+    mf = {}
+    for k, c in acc.items():
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "SQ_BUSY_CYCLES" in c and any(t in k for t in ("k_gemm", "k_proxy_attn", "k_mlp", "k_attn32")):
+            busy, sq = c["SQ_VALU_MFMA_BUSY_CYCLES"][1] / c["SQ_VALU_MFMA_BUSY_CYCLES"][0], c["SQ_BUSY_CYCLES"][1] / c["SQ_BUSY_CYCLES"][0]
+            mf[k] = {"SQ_VALU_MFMA_BUSY_CYCLES": busy, "SQ_BUSY_CYCLES": sq, "mfma_busy_frac": round(busy / (sq / 32.0 * 1024.0), 4) if sq else None,
+                     "launches": c["SQ_BUSY_CYCLES"][0]}
+    if mf:
+        traffic["mfma_at_32_scenes"] = {"what": "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES / 32 * 1024): share of the launch an average "
+                                                "SIMD's matrix pipe was busy (cfg2, 32 scenes per GPU, bf16 features)", "kernels": dict(sorted(mf.items()))}
     json.dump(traffic, open(os.path.join(odir, f"{tag}_pmc_traffic.json"), "w"), indent=1)
 
 
