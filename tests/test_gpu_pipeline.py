@@ -210,3 +210,52 @@ def test_pipeline_at_the_shipped_shape():
         for li in range(4):
             assert torch.equal(res2.points_imgfeats[b][li], res.points_imgfeats[b][li])
     assert set(res2.stage_ms) == {"ingest", "preshape", "quantize", "levels", "point_sample", "total"}
+
+
+def test_pipeline_with_the_training_pipelines_3d_augmentation():
+    """The TRAIN pipeline (CFG:105-124) adds GlobalRotScaleTrans behind the aggregation: the ingest applies it to the cloud
+    (``aug``), and the image-feature sampling has to undo it before projecting (``img_meta['transformation_3d_flow']`` = R, S, T;
+    apply_3d_transformation(reverse=True), point_fusion.py:20-107) -- in the chained call the per-scene reverse flows travel with
+    the projection matrices through one pinned staging buffer.  Ingest against the oracle (same draws, <= 1e-5); sampled features
+    against the oracle's step-by-step reverse flow + point_sample: the composed (3,4) affine of the product differs from the
+    step-by-step fp32 flow by ~1e-6 m, which moves a handful of points across a nearest-pixel boundary -- rows that agree must
+    agree to 1e-5, and at most 1 % may differ."""
+    from oracle import oracle
+    base = CONFIGS["cfg4_room"]
+    cfg = PreshapeConfig("pipe_aug", B=2, N=20000, grid_size=base.grid_size, dynamic_drop_radio=base.dynamic_drop_radio,
+                         L=base.L, V=6, text_blocks=3, img_blocks=3, extent=base.extent, seed_base=7500)
+    m, sd = build_module(cfg)
+    m = m.cuda()
+    scenes_np, scenes, text_dict, feats = _inputs(cfg, 2, 6, 7500)
+    for b, (sn, sc) in enumerate(zip(scenes_np, scenes)):
+        a = 0.06 * (b + 1)
+        rot_T = np.array([[np.cos(a), np.sin(a), 0], [-np.sin(a), np.cos(a), 0], [0, 0, 1]], np.float32)
+        aug = dict(rot_mat_T=rot_T, scale=np.float32(1.05 - 0.1 * b), trans=np.array([0.1, -0.05, 0.08], np.float32))
+        meta = dict(sn["img_meta"], transformation_3d_flow=["R", "S", "T"], pcd_rotation=rot_T, pcd_scale_factor=float(aug["scale"]),
+                    pcd_trans=aug["trans"])
+        for d in (sn, sc):
+            d["aug"], d["img_meta"] = aug, meta
+    pipe = GroundingFeaturePrefix(m, n_points=cfg.N)
+    pipe(scenes, text_dict, feats, rng=np.random.RandomState(1))
+    torch.cuda.synchronize()
+    with _count_synchronises() as calls:
+        res = pipe(scenes, text_dict, feats, rng=np.random.RandomState(1))
+    assert calls == [], calls
+    torch.cuda.synchronize()
+    rs = np.random.RandomState(1)
+    for b, sc in enumerate(scenes_np):
+        depth = sc["depth_img"].astype(np.float32) / np.float32(sc["depth_shift"])
+        ref = oracle.ingest(depth, sc["depth_cam2img"], sc["extrinsic"], cfg.N, rng=rs, aug=sc["aug"])
+        assert np.array_equal(res.ingested.sel[b], ref["sel"])
+        assert_close(res.ingested.points[b].cpu().numpy(), ref["points"], atol=1e-5, what=f"augmented cloud, scene {b}")
+        sf = sc["img_meta"]["scale_factor"]
+        for li in range(4):
+            lp = res.level_points[li][b].cpu().numpy()
+            back = oracle.reverse_3d_points(lp, sc["img_meta"], "DEPTH")
+            want, nvalid = oracle.point_sample(back, feats[li][b].cpu().numpy(), projection_matrices(sc["depth2img"]),
+                                               scale=(sf[0], sf[1]), pad_hw=(480.0, 480.0), ori_w=480.0)
+            got = res.points_imgfeats[b][li].cpu().numpy()
+            row_err = np.abs(got - want).max(axis=1) if len(lp) else np.zeros(0)
+            differ = row_err > 1e-5
+            assert differ.mean() <= 0.01, (b, li, float(differ.mean()))
+            assert (nvalid > 0).mean() > 0.2

@@ -62,3 +62,36 @@ def test_voxelize_properties_at_the_benchmark_size():
         assert np.all(np.diff(first[mine]) > 0)                              # rows in point order
     with pytest.raises(RuntimeError, match="outside"):
         m.quantize([o * 1e4 for o in outs], 0.01)
+
+
+def test_coarsen_matches_the_restatement():
+    """ptx_voxel_coarsen (pipeline.level_coordinates) on hand-made voxel rows: negative coordinates floor (not truncate), an EMPTY
+    scene in the middle, strides 1 .. 64, rows in first-occurrence order, positions = coordinate * voxel_size in fp32 -- against
+    oracle.level_coordinates; and chained (level from the level below) equals coarsening the finest level directly."""
+    from oracle import oracle
+    from proxytransformation_amd.pipeline import level_coordinates
+    rng = np.random.default_rng(5)
+    n = [5000, 0, 3001]
+    rows = np.concatenate([np.concatenate([np.full((k, 1), b, np.int32), rng.integers(-700, 900, (k, 3)).astype(np.int32)], 1)
+                           for b, k in enumerate(n)])
+    # distinct rows per scene (the input of a coarsening is a set of voxels)
+    keep = np.sort(np.unique(rows, axis=0, return_index=True)[1])
+    rows = rows[keep]
+    ends = np.cumsum(np.bincount(rows[:, 0], minlength=3)).tolist()
+    dev = torch.device("cuda:0")
+    rows_t = torch.from_numpy(rows).to(dev)
+    scratch = {}
+    prev_c, prev_e = rows_t, ends
+    for stride in (1, 2, 8, 16, 64):
+        want = oracle.level_coordinates(rows, 3, stride)
+        for src_c, src_e in ((rows_t, ends), (prev_c, prev_e)):             # from the finest level / from the level below
+            c, p, e = level_coordinates(src_c, src_e, stride, 0.01, scratch)
+            lo = [0] + e[:-1]
+            for b in range(3):
+                got = c[lo[b]:e[b]].cpu().numpy()
+                assert (got[:, 0] == b).all() and np.array_equal(got[:, 1:], want[b]), (stride, b)
+                assert np.array_equal(p[lo[b]:e[b]].cpu().numpy(), want[b].astype(np.float32) * np.float32(0.01))
+            assert e[1] == e[0]                                              # the empty scene stays empty
+        prev_c, prev_e = c, e
+    with pytest.raises(RuntimeError, match="power of two"):
+        level_coordinates(rows_t, ends, 12, 0.01, scratch)
