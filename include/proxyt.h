@@ -391,6 +391,10 @@ PTX_API int ptx_voxel_coarsen(const int32_t *coords_in, const int32_t *in_scene_
  * (flip: x = ori_w - x); pad_h / pad_w: padded image size.  workspace: ptx_point_sample_workspace_bytes() bytes (one
  * channels-last copy of the feature maps).  valid_num (N) int32 optional. */
 PTX_API size_t ptx_point_sample_workspace_bytes(int V, int C, int H, int W);
+/* ABI 12: the channels-last copy of the feature maps alone (what ptx_point_sample does first), e.g. on another stream while the
+ * points are still being produced; ptx_point_sample(feats = NULL, ...) then samples from the prepared workspace. */
+PTX_API int ptx_point_sample_prepare(const void *feats, int feat_dtype, int V, int C, int H, int W, void *workspace, size_t ws_bytes,
+                             void *stream);
 PTX_API int ptx_point_sample(const float *points, int N, const void *feats, int feat_dtype, int V, int C, int H, int W,
                      const float *proj, const float *pre, float scale_w, float scale_h, float crop_w, float crop_h, int flip,
                      float ori_w, float pad_h, float pad_w, int bilinear, float *out, int32_t *valid_num, void *workspace,

@@ -172,6 +172,7 @@ SIGNATURES.update({
     "ptx_voxelize_ex": (_I, [_P, _P, _I, _I, _F, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "ptx_voxel_coarsen": (_I, [_P, _P, _I, _I, _F, _P, _P, _P, _P, _P, _Z, _P]),
     "ptx_point_sample_workspace_bytes": (_Z, [_I, _I, _I, _I]),
+    "ptx_point_sample_prepare": (_I, [_P, _I, _I, _I, _I, _I, _P, _Z, _P]),
     "ptx_point_sample": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _F, _F, _F, _F, _I, _F, _F, _F, _I, _P, _P, _P, _Z, _P]),
     "ptx_op_gemm": (_I, [_P, _P, _P, _I, _I, _I, _L, _L, _L, _L, _L, _L, _I, _I, _L, _L, _L, _L, _L, _L, _I, _I, _F, _I, _I, _L, _P]),
     "ptx_op_transpose": (_I, [_P, _I, _I, _P, _P]),

@@ -176,12 +176,26 @@ size_t ptx_point_sample_workspace_bytes(int V, int C, int H, int W)
     return align_up((size_t)V * C * H * W * sizeof(float), 256);
 }
 
+/* the channels-last copy alone (ABI 12): what ptx_point_sample does first.  A caller that knows the feature maps before it knows the
+ * points (the detector: the 2D backbone runs before the neck) makes the copies early, on another stream, and samples with feats = NULL */
+int ptx_point_sample_prepare(const void *feats, int feat_dtype, int V, int C, int H, int W, void *workspace, size_t ws_bytes, void *stream)
+{
+    PTX_REQUIRE(feats && workspace && V >= 1 && C >= 1 && C <= 64 * kPsMaxQ && H >= 1 && W >= 1 && feat_dtype >= 0 && feat_dtype <= 2,
+                "ptx_point_sample_prepare: V=%d C=%d (<= %d) H=%d W=%d dtype=%d", V, C, 64 * kPsMaxQ, H, W, feat_dtype);
+    const size_t need = ptx_point_sample_workspace_bytes(V, C, H, W);
+    if (ws_bytes < need) { set_error("ptx_point_sample_prepare: workspace too small: %zu < %zu bytes", ws_bytes, need); return PTX_ENOSPACE; }
+    hipLaunchKernelGGL(k_feat_transpose, dim3(cdiv(H * W, 32), cdiv(C, 32), V), dim3(256), 0, static_cast<hipStream_t>(stream), feats,
+                       feat_dtype, C, H * W, static_cast<float *>(workspace));
+    PTX_LAUNCHED("k_feat_transpose");
+    return PTX_OK;
+}
+
 int ptx_point_sample(const float *points, int N, const void *feats, int feat_dtype, int V, int C, int H, int W,
                      const float *proj, const float *pre, float scale_w, float scale_h, float crop_w, float crop_h, int flip,
                      float ori_w, float pad_h, float pad_w, int bilinear, float *out, int32_t *valid_num, void *workspace,
                      size_t ws_bytes, void *stream)
 {
-    PTX_REQUIRE(points && feats && proj && out && workspace, "ptx_point_sample: null argument");
+    PTX_REQUIRE(points && proj && out && workspace, "ptx_point_sample: null argument");       // feats == NULL: workspace prepared
     PTX_REQUIRE(N >= 1 && V >= 1 && C >= 1 && C <= 64 * kPsMaxQ && H >= 1 && W >= 1 && feat_dtype >= 0 && feat_dtype <= 2 &&
                 pad_h > 0.0f && pad_w > 0.0f, "ptx_point_sample: N=%d V=%d C=%d (<= %d) H=%d W=%d dtype=%d", N, V, C,
                 64 * kPsMaxQ, H, W, feat_dtype);
@@ -189,8 +203,10 @@ int ptx_point_sample(const float *points, int N, const void *feats, int feat_dty
     if (ws_bytes < need) { set_error("ptx_point_sample: workspace too small: %zu < %zu bytes", ws_bytes, need); return PTX_ENOSPACE; }
     hipStream_t st = static_cast<hipStream_t>(stream);
     float *featT = static_cast<float *>(workspace);
-    hipLaunchKernelGGL(k_feat_transpose, dim3(cdiv(H * W, 32), cdiv(C, 32), V), dim3(256), 0, st, feats, feat_dtype, C, H * W, featT);
-    PTX_LAUNCHED("k_feat_transpose");
+    if (feats != nullptr) {
+        hipLaunchKernelGGL(k_feat_transpose, dim3(cdiv(H * W, 32), cdiv(C, 32), V), dim3(256), 0, st, feats, feat_dtype, C, H * W, featT);
+        PTX_LAUNCHED("k_feat_transpose");
+    }
     PsArgs a{points, N, featT, V, C, H, W, proj, pre, scale_w, scale_h, crop_w, crop_h, flip, ori_w, pad_h, pad_w, out, valid_num, bilinear ? 1 : 0};
     hipLaunchKernelGGL(k_point_sample, dim3(cdiv(N, 4)), dim3(256), 0, st, a);
     PTX_LAUNCHED("k_point_sample");

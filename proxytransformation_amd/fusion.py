@@ -67,7 +67,8 @@ def batch_point_sample(img_meta: Optional[dict], img_features: torch.Tensor, poi
                        coord_type: str = "DEPTH", img_scale_factor=1.0, img_crop_offset=0.0, img_flip: bool = False,
                        img_pad_shape: Sequence[int] = (480, 640), img_shape: Sequence[int] = (480, 640),
                        aligned: bool = False, padding_mode: str = "zeros", align_corners: bool = True,
-                       valid_flag: bool = True, pre_transform: Optional[torch.Tensor] = None) -> torch.Tensor:
+                       valid_flag: bool = True, pre_transform: Optional[torch.Tensor] = None,
+                       prepared: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Same arguments as the reference function.  img_features (V,C,H,W) on the GPU (fp32 / bf16 / fp16), points (N,3)
     fp32, proj_mat (V,4,4) = intrinsic @ extrinsic.  Returns (N,C) fp32.
 
@@ -75,7 +76,8 @@ def batch_point_sample(img_meta: Optional[dict], img_features: torch.Tensor, poi
     align_corners and valid_flag as the detector passes them.  The reverse 3D augmentation of
     ``apply_3d_transformation`` (point_fusion.py:20-107) is composed from ``img_meta['transformation_3d_flow']``
     (``reverse_3d_flow``; the training pipeline's GlobalRotScaleTrans records 'R', 'S', 'T') unless an explicit
-    ``pre_transform`` (3,4) is given."""
+    ``pre_transform`` (3,4) is given.  ``prepared``: the workspace ``prepare_features(img_features)`` returned (the channels-last copy
+    made earlier, e.g. on another stream): the call then only samples."""
     if padding_mode != "zeros" or not align_corners or not valid_flag:
         raise NotImplementedError("HIP path: padding_mode='zeros', align_corners=True, valid_flag=True "
                                   "(the call at sparse_featfusion_grounder_preshape.py:428-444)")
@@ -100,14 +102,65 @@ def batch_point_sample(img_meta: Optional[dict], img_features: torch.Tensor, poi
     nbytes = lib.ptx_point_sample_workspace_bytes(V, C, H, W)
     if nbytes == 0:
         raise RuntimeError(f"unsupported feature shape {tuple(img_features.shape)} (C <= 512)")
-    ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    if prepared is not None:
+        if prepared.numel() < nbytes or prepared.device != dev:
+            raise RuntimeError("prepared: not the workspace of prepare_features() for these feature maps")
+        ws, feats_ptr = prepared, None
+    else:
+        ws, feats_ptr = torch.empty((nbytes,), dtype=torch.uint8, device=dev), feats.data_ptr()
     sw, sh = _pair(img_scale_factor, dev)
     cw, ch = _pair(img_crop_offset, dev)
     pre = None if pre_transform is None else pre_transform.detach().to(device=dev, dtype=torch.float32).contiguous()
-    _abi.check(lib.ptx_point_sample(pts.data_ptr(), N, feats.data_ptr(), _DT[feats.dtype], V, C, H, W, proj.data_ptr(),
+    _abi.check(lib.ptx_point_sample(pts.data_ptr(), N, feats_ptr, _DT[feats.dtype], V, C, H, W, proj.data_ptr(),
                                     None if pre is None else pre.data_ptr(), sw, sh, cw, ch, 1 if img_flip else 0,
                                     float(img_shape[1]), float(img_pad_shape[0]), float(img_pad_shape[1]), 1 if aligned else 0,
                                     out.data_ptr(),
                                     None, ws.data_ptr(), ws.numel(), torch.cuda.current_stream(dev).cuda_stream),
                "ptx_point_sample")
     return out
+
+
+def prepare_features(img_features: torch.Tensor) -> torch.Tensor:
+    """The channels-last copy of one sample's feature maps (V,C,H,W) that ``batch_point_sample`` gathers from, made on the CURRENT
+    stream: returns the workspace to pass as ``prepared=``.  The detector knows the feature maps (2D backbone) long before it knows
+    the points (neck + sparse backbone): ``pipeline.GroundingFeaturePrefix`` makes these copies on a side stream beside the ingest."""
+    if not img_features.is_cuda:
+        raise RuntimeError("prepare_features (HIP) needs GPU tensors: there is no CPU path")
+    if img_features.dtype not in _DT:
+        img_features = img_features.float()
+    feats = img_features.contiguous()
+    V, C, H, W = feats.shape
+    lib = _abi.lib()
+    nbytes = lib.ptx_point_sample_workspace_bytes(V, C, H, W)
+    if nbytes == 0:
+        raise RuntimeError(f"unsupported feature shape {tuple(feats.shape)} (C <= 512)")
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=feats.device)
+    _abi.check(lib.ptx_point_sample_prepare(feats.data_ptr(), _DT[feats.dtype], V, C, H, W, ws.data_ptr(), ws.numel(),
+                                            torch.cuda.current_stream(feats.device).cuda_stream), "ptx_point_sample_prepare")
+    return ws
+
+
+def prepare_features_many(maps) -> list:
+    """``prepare_features`` for a list of (V,C,H,W) feature maps with ONE allocation (the pipeline prepares scenes x levels maps at the
+    start of a call: 24 allocations + calls were 0.3 ms of host time in front of the ingest).  Returns one workspace view per map."""
+    lib = _abi.lib()
+    maps = [m if m.dtype in _DT else m.float() for m in maps]
+    maps = [m.contiguous() for m in maps]
+    sizes = []
+    for m in maps:
+        if not m.is_cuda:
+            raise RuntimeError("prepare_features (HIP) needs GPU tensors: there is no CPU path")
+        V, C, H, W = m.shape
+        n = lib.ptx_point_sample_workspace_bytes(V, C, H, W)
+        if n == 0:
+            raise RuntimeError(f"unsupported feature shape {tuple(m.shape)} (C <= 512)")
+        sizes.append(n)                                   # multiples of 256 bytes
+    dev = maps[0].device
+    flat = torch.empty((sum(sizes),), dtype=torch.uint8, device=dev)
+    views = list(flat.split_with_sizes(sizes))
+    st = torch.cuda.current_stream(dev).cuda_stream
+    for m, ws in zip(maps, views):
+        V, C, H, W = m.shape
+        _abi.check(lib.ptx_point_sample_prepare(m.data_ptr(), _DT[m.dtype], V, C, H, W, ws.data_ptr(), ws.numel(), st),
+                   "ptx_point_sample_prepare")
+    return views

@@ -205,6 +205,18 @@ class MultiViewIngest:
             _abi.check(lib.ptx_ingest_index(depth.data_ptr(), _DEPTH_DTYPES[depth.dtype], V, H, W, sl.ws.data_ptr(), sl.ws.numel(),
                                             sl.counts.data_ptr(), st.cuda_stream), "ptx_ingest_index")
             work.append((depth, sl))
+        # the per-view matrices of ALL scenes in two batched numpy calls (inverse intrinsics, LU factors of global2ego): per scene they
+        # were ~0.2 ms of Python between the launches of a chained call (r06: the ingest was host-bound at 0.3 ms per scene)
+        Vs = [int(d.shape[0]) for d, _ in work]
+        ks = [np.asarray(sc["depth_cam2img"].cpu() if isinstance(sc["depth_cam2img"], torch.Tensor) else sc["depth_cam2img"]) for sc in scenes]
+        if len(set(Vs)) == 1 and all(k.shape == ks[0].shape for k in ks):
+            stack = np.concatenate([np.broadcast_to(k, (Vs[0],) + k.shape) if k.ndim == 2 else k for k in ks])
+            inv_all = self._intrinsics(stack, Vs[0] * B)
+        else:
+            inv_all = np.concatenate([self._intrinsics(k, V) for k, V in zip(ks, Vs)])
+        ext_all = np.concatenate([np.asarray(sc["extrinsic"], dtype=np.float32).reshape(V, 4, 4) for sc, V in zip(scenes, Vs)])
+        lus_all, pivs_all = lu_factor_4x4_batch(ext_all)
+        voff = np.concatenate([[0], np.cumsum(Vs)])
         sels, vcs = [], []
         for b, (sc, (depth, sl)) in enumerate(zip(scenes, work)):           # 2. host RNG, 3. gather
             V, H, W = depth.shape
@@ -222,9 +234,7 @@ class MultiViewIngest:
                 raise ValueError(f"choices must be ({N},), got {sel.shape}")
             if sel.min() < 0 or sel.max() >= int(vc.sum()):      # checked where the counts are: no device round trip for it
                 raise IndexError(f"choices beyond the scene's depth != 0 pixels in scene {b}")
-            inv_k = self._intrinsics(sc["depth_cam2img"], V)
-            ext = np.asarray(sc["extrinsic"], dtype=np.float32).reshape(V, 4, 4)
-            lus, pivs = lu_factor_4x4_batch(ext)
+            inv_k, lus, pivs = inv_all[voff[b]:voff[b + 1]], lus_all[voff[b]:voff[b + 1]], pivs_all[voff[b]:voff[b + 1]]
             aug = sc.get("aug")
             if sl.copied is not None and not sl.copied.query():
                 sl.copied.synchronize()                          # the previous call's copy out of the staging buffer (long done)

@@ -30,7 +30,7 @@ import numpy as np
 import torch
 
 from . import _abi
-from .fusion import batch_point_sample, reverse_3d_flow
+from .fusion import batch_point_sample, prepare_features_many, reverse_3d_flow
 from .ingest import IngestedBatch, MultiViewIngest
 
 __all__ = ["GroundingFeaturePrefix", "PrefixOutput", "level_coordinates", "projection_matrices", "MINK_RESNET_STRIDES"]
@@ -126,7 +126,7 @@ class GroundingFeaturePrefix:
     (B,V,C_l,H_l,W_l); the LAST one feeds the neck (DET:385)."""
 
     def __init__(self, preshape, n_points: int = 100000, voxel_size: float = 0.01,
-                 level_strides: Sequence[int] = MINK_RESNET_STRIDES, coord_type: str = "DEPTH"):
+                 level_strides: Sequence[int] = MINK_RESNET_STRIDES, coord_type: str = "DEPTH", overlap_feature_layout: bool = True):
         self.preshape = preshape
         self.ingest = MultiViewIngest(n_points)
         self.voxel_size = float(voxel_size)
@@ -134,6 +134,11 @@ class GroundingFeaturePrefix:
         self.coord_type = coord_type
         self._stage = None              # pinned staging of the per-scene projection matrices / reverse 3D flows + device twin
         self._coarsen = {}              # per stream: workspace + pinned count words of level_coordinates
+        #: the channels-last copies of the feature maps that the sampling gathers from (~1 ms of HBM traffic at the shipped shape) are
+        #: made on a side stream at the START of the call, beside the ingest -- whose per-scene host work leaves the GPU idle --
+        #: and joined in front of the sampling (events, no host wait); False: inside each sampling call, on the caller's stream
+        self.overlap_feature_layout = overlap_feature_layout
+        self._side = None
 
     def _upload_matrices(self, scenes, dev, st):
         """Projection matrices (V,4,4) and the reverse 3D augmentation flow (3,4) of every scene through ONE pinned staging buffer and
@@ -179,6 +184,16 @@ class GroundingFeaturePrefix:
                 e.record(st)
                 marks.append((name, e))
         mark("start")
+        prepared = None
+        if self.overlap_feature_layout:
+            if self._side is None or self._side.device != dev:
+                self._side = torch.cuda.Stream(device=dev)
+            self._side.wait_stream(st)                       # the feature maps were produced on the caller's stream
+            nl = len(self.level_strides)
+            with torch.cuda.stream(self._side):
+                flat = prepare_features_many([img_features[li][b] for b in range(len(scenes)) for li in range(nl)])
+            flat[0].record_stream(st)                        # ONE allocation under the side stream, consumed on the caller's
+            prepared = [flat[b * nl:(b + 1) * nl] for b in range(len(scenes))]
         proj_t, flow_t = self._upload_matrices(scenes, dev, st)
         batch = self.ingest(scenes, rng=rng)                                               # N4
         mark("ingest")
@@ -196,6 +211,8 @@ class GroundingFeaturePrefix:
             res.level_points.append([pts_l[lo[b]:cur_e[b]] for b in range(len(cur_e))])
         mark("levels")
         B = len(scenes)
+        if prepared is not None:
+            st.wait_stream(self._side)
         for b, sc in enumerate(scenes):                                                    # N3, DET:402-448
             meta = sc.get("img_meta") or {}
             proj = proj_t[b]
@@ -206,7 +223,7 @@ class GroundingFeaturePrefix:
                     img_scale_factor=meta.get("scale_factor", (1.0, 1.0))[:2] if "scale_factor" in meta else 1.0,
                     img_crop_offset=meta.get("img_crop_offset", 0.0), img_flip=bool(meta.get("flip", False)),
                     img_pad_shape=tuple(img_pad_shape), img_shape=tuple(meta.get("img_shape", img_pad_shape))[:2],
-                    aligned=False, pre_transform=flow_t[b]))
+                    aligned=False, pre_transform=flow_t[b], prepared=None if prepared is None else prepared[b][li]))
             res.points_imgfeats.append(per_level)
         mark("point_sample")
         assert len(res.points_imgfeats) == B

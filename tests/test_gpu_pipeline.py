@@ -1,7 +1,8 @@
 """BASELINE configs[3] as a PIPELINE (VERDICT r05 "next" #1): synthetic multi-view depth maps -> MultiViewIngest (N4) -> the neck
 with the shipped configuration's weights and the ingested bounding boxes -> module.quantize (N2, 1 cm voxels) -> the coordinates of
 MinkResNet's four output levels -> fusion.batch_point_sample on the four 2D-backbone levels (N3), chained by
-``pipeline.GroundingFeaturePrefix`` on ONE stream (detectors/sparse_featfusion_grounder_preshape.py:385-448,
+``pipeline.GroundingFeaturePrefix`` on the caller's stream -- the channels-last copies of the feature maps run on a side stream beside
+the ingest and are joined by an event -- (detectors/sparse_featfusion_grounder_preshape.py:385-448,
 configs/grounding/proxy-tiblock33-gs12-wbias-ddr0.6-clip.py:105-142).
 
 Held against the oracle chain STAGE BY STAGE -- every oracle stage consumes what the GPU's previous stage produced, so that a float
@@ -187,6 +188,14 @@ def test_pipeline_reduced_size_vs_the_oracle_chain():
     m, sd, pipe, scenes_np, scenes, text_dict, feats, res = _run_chain(cfg, 2, 8, 7300)
     _check_stagewise(cfg, m, sd, scenes_np, text_dict, feats, res, 7300, which=[0, 1])
     _check_properties(cfg, scenes_np, res)
+    # the channels-last copies of the feature maps on the caller's stream (inside each sampling call) instead of on the side stream
+    # beside the ingest: the same bits
+    pipe1 = GroundingFeaturePrefix(m, n_points=cfg.N, overlap_feature_layout=False)
+    res1 = pipe1(scenes, text_dict, feats, rng=np.random.RandomState(7300))
+    assert torch.equal(res1.coordinates, res.coordinates)
+    for b in range(2):
+        for li in range(4):
+            assert torch.equal(res1.points_imgfeats[b][li], res.points_imgfeats[b][li])
     # float32 depth maps in metres (LoadDepthFromFile's output) give the same clouds as the raw uint16 ones
     m2, _, _, _, _, _, _, res2 = _run_chain(cfg, 2, 8, 7300, as_u16=False)
     for a, b in zip(res.ingested.points, res2.ingested.points):
