@@ -5,8 +5,9 @@
 // ones proxytransformation_amd/train.py's one-node step called one ctypes call at a time) from C++, with every intermediate carved
 // out of two caller-owned arenas.  r05's host anatomy of a step (scratch/train_hostprof6.py): 0.49 ms inside the library for 35 calls,
 // 0.14 ms in 60 torch.empty, ~0.6 ms of Python in the two bodies around them -- on a box whose host is the limit the step ran at the
-// host's pace (2.0 - 2.3 ms against 1.7 ms of GPU time).  The order of the launches, the two streams and their events are those of
-// train.py's _TrainStep (image branch first on the side stream, the image block beside the text block, the backward mirrored).
+// host's pace (2.0 - 2.3 ms against 1.7 ms of GPU time).  The launches, the two streams and their events are those of train.py's
+// _TrainStep (image branch on the side stream, the image block beside the text block, the backward mirrored); the ORDER in which the
+// two streams are fed follows the kernel timeline of a step (profiles/r06_train_timeline.txt): see the comments at the two places.
 #include <hip/hip_runtime.h>
 
 #include "common.h"
@@ -182,12 +183,15 @@ int ptx_train_step_fwd(const PtxTrainStep *ap, void *stream)
     hipEvent_t ev_fork = static_cast<hipEvent_t>(a.ev_fork), ev_join = static_cast<hipEvent_t>(a.ev_join),
                ev_pp = static_cast<hipEvent_t>(a.ev_pp), ev_counts = static_cast<hipEvent_t>(a.ev_counts);
     void *A = a.arena_fwd;
-    // ---- image branch first, on the side stream: it needs nothing from the clustering half (PRE:449-450)
+    // ---- enqueue ORDER (r06, from the kernel timeline of a step, profiles/r06_train_timeline.txt): the caller's stream carries the
+    // chain the forward waits for (both ball queries, 0.2 ms of sequential farthest-point picks, the slot networks), so its first
+    // dozen launches go out first; the image branch (PRE:449-450: it needs nothing from the clustering half and is ready 0.3 ms
+    // before its consumer) follows on the side stream, and the output positions + the early copy of the list lengths -- needed by
+    // the affine apply and the backward only -- run there too, off the chain
     PtxTrainImgPool ip = a.ip;
     ip.save = at<float>(A, L.ip_save); ip.save_floats = L.ip_save_f; ip.tmp = at<float>(A, L.ip_tmp); ip.tmp_floats = L.ip_tmp_f;
     if (ip.cw != nullptr) { ip.proxy = at<float>(A, L.img_proxy); ip.o = nullptr; } else { ip.o = at<float>(A, L.img_proxy); }
-    if (side) PTX_TRY(record_wait(ev_fork, main, side));
-    PTX_TRY(ptx_train_imgpool_fwd(&ip, side ? side : main));
+    if (side) PTX_TRY(record_wait(ev_fork, main, side));                // everything the caller queued before the step
     // ---- index half, part 1 + offset network (PRE:55-62)
     float *c0 = at<float>(A, L.c0), *minmax = at<float>(A, L.minmax);
     PTX_TRY(ptx_grid_centers(a.points, B, N, a.lin, s.grid_size, s.margin, minmax, c0, at<void>(A, L.enc_scratch),
@@ -207,11 +211,15 @@ int ptx_train_step_fwd(const PtxTrainStep *ap, void *stream)
     PTX_TRY(ptx_select_clusters(&s, at<int32_t>(A, L.idx2), cdet, at<float>(A, L.cl2), at<int32_t>(A, L.pad), a.order_override,
                                 at<int32_t>(A, L.order), at<int32_t>(A, L.picks), at<int32_t>(A, L.keep), at<float>(A, L.kcenter_i),
                                 at<float>(A, L.kcluster), at<int32_t>(A, L.kidx), at<int32_t>(A, L.drop_idx), at<uint32_t>(A, L.tag), main));
+    // ---- side stream: image branch, then (behind the selection's tags) output positions + the list lengths of PRE:467, copied out
+    // now and awaited by the host after everything is enqueued
+    hipStream_t aux = side ? side : main;
+    PTX_TRY(ptx_train_imgpool_fwd(&ip, aux));
+    if (side) PTX_TRY(record_wait(ev_pp, main, side));                   // the tags are final
     PTX_TRY(ptx_op_out_positions(at<uint32_t>(A, L.tag), B, N, at<int32_t>(A, L.tile_counts), at<int32_t>(A, L.opos),
-                                 at<int32_t>(A, L.counts), main));
-    // the list lengths of PRE:467: copied out now, awaited by the host after everything is enqueued
-    PTX_HIP(hipMemcpyAsync(a.counts_host, at<int32_t>(A, L.counts), (size_t)B * 4, hipMemcpyDeviceToHost, main));
-    PTX_HIP(hipEventRecord(ev_counts, main));
+                                 at<int32_t>(A, L.counts), aux));
+    PTX_HIP(hipMemcpyAsync(a.counts_host, at<int32_t>(A, L.counts), (size_t)B * 4, hipMemcpyDeviceToHost, aux));
+    PTX_HIP(hipEventRecord(ev_counts, aux));
     PTX_TRY(ptx_op_keep_rows(at<int32_t>(A, L.order), at<int32_t>(A, L.keep), B, M, Mt, Mk, at<int32_t>(A, L.src), main));
     // ---- float half (PRE:437-455)
     float *kcenter = at<float>(A, L.kcenter), *pp = at<float>(A, L.pp);
@@ -284,12 +292,18 @@ int ptx_train_step_bwd(const PtxTrainStep *ap, void *stream)
     const bool apart = side != nullptr && a.blocks_apart != 0;
     float *dpp;
     if (apart) {
-        // image block AND image branch on the side stream, beside the text block's backward on the caller's stream
+        // image block AND image branch beside the text block's backward on the caller's stream
+        // (enqueue order, r06: the text block's backward goes out BEFORE the image pool's -- enqueued behind the side stream's ~55
+        //  launches the caller's stream sat idle for the 0.2 ms the host needed for them, with 0.7 ms of its own chain still to come)
+        // (measured and NOT kept, r06, profiles/r06_train_fanout_ab.txt: the blocks' parameter-gradient tails -- a quarter of each
+        //  block, needed by nobody downstream -- on a third stream and the image pool's backward on a fourth, started when the image
+        //  block's dproxy is final: 1.66 -> 1.87 ms.  Kernels of four streams side by side stretch far beyond fair sharing on this
+        //  stack, as the lanes of the eval path did)
         PTX_TRY(record_wait(ev_fork, main, side));
         PTX_TRY(ptx_train_block_bwd(&ib, side));
         PTX_HIP(hipEventRecord(ev_pp, side));
-        PTX_TRY(ptx_train_imgpool_bwd(&ip, side));
         PTX_TRY(ptx_train_block_bwd(&tb, main));
+        PTX_TRY(ptx_train_imgpool_bwd(&ip, side));
         PTX_HIP(hipStreamWaitEvent(main, ev_pp, 0));
         dpp = at<float>(D, L.dpp);
         PTX_TRY(ptx_op_eltwise(0, tb.dx, ib.dx, 0.0f, R * C, 1, dpp, main));
