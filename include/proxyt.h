@@ -203,7 +203,8 @@ PTX_API int ptx_linear(const float *x, const float *w, const float *bias, const 
                int rows, int n_out, int n_in, int gelu, void *stream);
 /* ABI 12.  Tile policy of the split-operand GEMMs behind every nn.Linear of the path (csrc/gemm.hip): a launch (all its groups
  * together) of at least `min_tiles_128` tiles of 128 x 128 outputs, with K a multiple of 256, runs on 128 x 128 tiles (k_gemm128x),
- * anything else on 64 x 64 tiles / the latency-regime kernel.  Default 256 (one tile per CU); 0 = never; 1 = whenever the shape
+ * anything else on 64 x 64 tiles / the latency-regime kernel (between 1 and 1.5 x `min_tiles_128` tiles the large tile is taken only
+ * for K >= 512).  Default 256 (one tile per CU); 0 = never; 1 = whenever the shape
  * allows it (tests); < 0 = query.  Returns the previous value.  Process-wide, relaxed: results do not depend on it beyond the
  * summation order of an fp32-equivalent product. */
 PTX_API int ptx_gemm_policy(int min_tiles_128);

@@ -878,7 +878,11 @@ int launch_gemm(const GemmBatch &gb_in, hipStream_t st, int compute_dtype)
     long tiles128 = 0;
     for (int g = 0; g < gb.n; ++g) tiles128 += (long)cdiv(gb.p[g].R, 128) * cdiv(gb.p[g].N, 128);
     const int min128 = g_gemm128_min_tiles.load(std::memory_order_relaxed);
-    const bool use128 = gb.p[0].pg == nullptr && kmin == kmax && kmin % 256 == 0 && kmin <= 4096 && min128 > 0 && tiles128 >= min128;
+    // (at exactly one tile per CU the large tile only pays when a tile carries enough work: 2 x 8192 x 256 x 256 -- the blocks' proj at
+    //  32 scenes, 256 tiles of K = 256 -- takes 37 us on 128 x 128 tiles and 31 on 64 x 64; from 1.5 tiles per CU on, or with K >= 512,
+    //  it is ahead: profiles/r06_gemm128_lab.txt)
+    const bool enough = tiles128 >= min128 && (min128 == 1 || 2 * tiles128 >= 3 * (long)min128 || kmin >= 512);
+    const bool use128 = gb.p[0].pg == nullptr && kmin == kmax && kmin % 256 == 0 && kmin <= 4096 && min128 > 0 && enough;
     if (use128) {
         const dim3 grid(cdiv(rmax, 128), cdiv(nmax, 128), gb.n);
         const int nrep = kmin / (32 * PTX_G128_NM);

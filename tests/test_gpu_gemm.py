@@ -116,7 +116,7 @@ def test_default_policy_picks_the_tile_by_launch_size():
     from proxytransformation_amd import _abi
     lib = _abi.lib()
     assert lib.ptx_gemm_policy(-1) == 256
-    x, w = _operands(8192, 512, 256, 11, False)          # 64 x 4 = 256 tiles: the 128 x 128 kernel
+    x, w = _operands(8192, 768, 256, 11, False)          # 64 x 6 = 384 tiles = 1.5 per CU: the 128 x 128 kernel
     y_big = _linear(x, w)
     prev = lib.ptx_gemm_policy(0)
     try:
