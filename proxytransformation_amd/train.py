@@ -1388,8 +1388,12 @@ class _Aux(dict):
 def _cstep_static(mod, S, dev):
     """Per weights-generation pieces of the C step: the canonical parameter list (PTX_TS_* order), the ctypes struct with its
     constant fields, four events, the pinned count words."""
-    cs = S.get("cstep")
-    if cs is None or cs["dev"] != str(dev):
+    # one set per (device, caller's stream): the struct, the events and the pinned count words belong to the steps of ONE stream
+    # (a module trained on two streams in turn must not share them -- the Python-bodied node keys its pinned words the same way)
+    key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
+    table = S.setdefault("cstep", {})
+    cs = table.get(key)
+    if cs is None:
         off, enc = S["off"], S["enc"]
         bn, ebn = S["bn"], S["ebn"]
         canon = [off.mlp[0].weight, off.mlp[0].bias, bn.weight, bn.bias, S["oh"], enc.mlp[0].weight, enc.mlp[0].bias, ebn.weight,
@@ -1401,7 +1405,7 @@ def _cstep_static(mod, S, dev):
             e = torch.cuda.Event()
             e.record()                                   # torch creates the hipEvent on first use
             evs.append(e)
-        cs = S["cstep"] = dict(dev=str(dev), canon=canon, st=st, ev=evs, layouts={}, pin={},
+        cs = table[key] = dict(dev=str(dev), canon=canon, st=st, ev=evs, layouts={}, pin={},
                                slot_of={id(p_): i for i, p_ in enumerate(canon) if p_ is not None})
         st.ev_fork, st.ev_join, st.ev_pp, st.ev_counts = (e.cuda_event for e in evs)
     return cs

@@ -7,9 +7,4 @@ for pol in 0 256 1; do
   timeout 600 python bench.py --gemm-policy $pol --config cfg5 --scenes-per-gpu 16 --steps 10 --warmup 3 --repeats 3 --setup-forwards 6 --no-cpu-baseline --no-passes > $O/cfg5_pol${pol}_$rep.json 2> $O/cfg5_pol${pol}_$rep.err
   timeout 300 python bench.py --gemm-policy $pol --config cfg4_room --scenes-per-gpu 6 --no-cpu-baseline --no-passes > $O/cfg4_pol${pol}_$rep.json 2> $O/cfg4_pol${pol}_$rep.err
 done; done
-python - <<'PY'
-import json, glob, os
-O = os.environ.get("O", "")
-for f in sorted(glob.glob(os.path.join("gpurun_out", os.path.basename(os.getcwd()) and "", "*"))): pass
-PY
 python $R/scratch/r06_policy_digest.py $O
