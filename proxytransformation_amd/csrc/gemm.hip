@@ -344,6 +344,8 @@ __global__ __launch_bounds__(256) void k_gemm64x(GemmBatch gb)
 // rows r and r + 64 at k = 4 q and 4 q + 16 of both operands -- eight float4 per macro step in one of two register sets (P / Q);
 // sub-step (m, 0) consumes LDS[0] while the second half of macro step m is split into LDS[1], sub-step (m, 1) consumes LDS[1]
 // while the first half of macro step m + 1 goes to LDS[0] and the loads of macro step m + 2 are issued into the set m just freed.
+// (Measured and not kept, r06: half register sets -- each k half fetched ONE 16-k step ahead, 32 prefetch registers instead of 64, 168
+// VGPRs, THREE work-groups per CU -- 2 - 8 % slower at every shape: profiles/r06_gemm128_lab.txt.)
 // LDS layout per plane: [k half hh][row][8 bf16] with 64 B of padding between the halves -- a fragment read (16 lanes of one
 // half, 16 B each, rows consecutive) covers 256 consecutive bytes, and the 8-byte stash writes of 16 consecutive lanes (four rows
 // x both halves x two quads) hit sixteen distinct even banks: both conflict-free by construction (cf. xswz for the 64-B rows).
@@ -491,9 +493,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm128x(GemmBatch gb, int nrep)
         }
         mbase += NM;
     }
-    (void)total;
 #undef PTX_Y_MACRO
 #undef PTX_Y_PIPE
+    (void)total;
     // epilogue, one accumulator at a time (C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5));
     // its operands are requested per accumulator (64 residual registers up front would not fit beside the prefetch sets)
     float *scratch = reinterpret_cast<float *>(smem) + wid * (32 * 33);
