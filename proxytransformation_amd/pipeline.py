@@ -19,7 +19,9 @@ rows (``ptx_voxel_coarsen``); the features that travel with them in the referenc
 
 Nothing in ``__call__`` synchronises the device: the host waits only for small integers the kernels publish through pinned memory
 (per-view pixel counts, survivor counts, voxel row counts) -- the list LENGTHS the reference obtains with blocking ``.item()`` /
-``nonzero`` / ``unique`` calls -- and every stage is enqueued on the caller's current stream.
+``nonzero`` / ``unique`` calls -- and every stage is enqueued on the caller's current stream; only the channels-last copies of the
+feature maps that the sampling gathers from (they do not depend on the points) run on a side stream beside the ingest, forked and
+joined by events (``overlap_feature_layout=False``: on the caller's stream as well).
 """
 from __future__ import annotations
 
@@ -132,7 +134,7 @@ class GroundingFeaturePrefix:
         self.voxel_size = float(voxel_size)
         self.level_strides = tuple(int(s) for s in level_strides)
         self.coord_type = coord_type
-        self._stage = None              # pinned staging of the per-scene projection matrices / reverse 3D flows + device twin
+        self._stage = {}                # per stream: pinned staging of the per-scene projection matrices / reverse 3D flows + device twin
         self._coarsen = {}              # per stream: workspace + pinned count words of level_coordinates
         #: the channels-last copies of the feature maps that the sampling gathers from (~1 ms of HBM traffic at the shipped shape) are
         #: made on a side stream at the START of the call, beside the ingest -- whose per-scene host work leaves the GPU idle --
@@ -146,10 +148,10 @@ class GroundingFeaturePrefix:
         projs = [projection_matrices(sc["depth2img"]) for sc in scenes]
         flows = [reverse_3d_flow(sc.get("img_meta") or {}, self.coord_type) for sc in scenes]
         n = sum(p.size for p in projs) + 12 * len(scenes)
-        stg = self._stage
+        stg = self._stage.get(st.cuda_stream)           # per stream: the device twin is overwritten in stream order
         if stg is None or stg["host"].numel() < n or stg["dev"].device != dev:
-            stg = self._stage = dict(host=torch.empty((n,), dtype=torch.float32).pin_memory(),
-                                     dev=torch.empty((n,), dtype=torch.float32, device=dev), done=None)
+            stg = self._stage[st.cuda_stream] = dict(host=torch.empty((n,), dtype=torch.float32).pin_memory(),
+                                                     dev=torch.empty((n,), dtype=torch.float32, device=dev), done=None)
             stg["np"] = stg["host"].numpy()
         if stg["done"] is not None and not stg["done"].query():
             stg["done"].synchronize()                  # the previous call's copy out of the staging buffer (long done)
