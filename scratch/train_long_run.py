@@ -49,7 +49,7 @@ class TimedEvent(torch.cuda.Event):
         TimedEvent.waited += time.perf_counter() - t
 
 
-for k, (buf, ev) in list(mod._train_pin.items()):
+for k, (buf, ev) in list((mod._train_pin or {}).items()):      # (the Python-bodied node's pinned words; the C step keeps its own)
     mod._train_pin[k] = (buf, TimedEvent())
 GC = {"t": 0.0, "n": [0, 0, 0], "t0": 0.0}
 
